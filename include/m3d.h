@@ -1,0 +1,142 @@
+/* m3d.h — C ABI of libm3d.so: the MI355X (gfx950) implementation of the 3D detection hot path of
+ * MeowMeowLady/InstanceSeg-Without-Voxelwise-Labeling.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer named d_* is a DEVICE pointer (HBM), caller-allocated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous on it
+ *     and never synchronises the device, so calls may be captured into a hipGraph;
+ *   - return value: M3D_OK (0) or a negative M3D_E* code; nothing ever calls exit()
+ *     (the reference's launchers print and exit(-1): roi_align_kernel_3d.cu:165-169);
+ *   - re-entrant, no global mutable state; scratch memory comes from the caller (`d_ws`, sized by the
+ *     matching *_workspace_bytes()).
+ * Paths in comments are relative to the reference repository.
+ */
+#ifndef M3D_H_
+#define M3D_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3D_OK 0
+#define M3D_EINVAL (-1)   /* bad argument (shape, NULL pointer, unsupported size) */
+#define M3D_ELAUNCH (-2)  /* hipLaunch / runtime error (hipGetLastError) */
+#define M3D_EWORKSPACE (-3) /* workspace too small */
+#define M3D_EUNSUPPORTED (-4)
+
+int m3d_version(void);
+const char* m3d_error_string(int code);
+/* Last HIP runtime error text seen by this thread (for M3D_ELAUNCH). */
+const char* m3d_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RoIAlign 3D.  Replaces roi_align_forward_cuda_3d / roi_align_backward_cuda_3d
+ * (lib/modeling/roi_xfrom/roi_align_3d/src/roi_align_cuda_3d.h:1-5, .c:7-83; kernels
+ * src/roi_align_kernel_3d.cu:81-151, 238-338).
+ * features [batch,channels,slices,height,width] fp32; rois [num_rois,roi_cols] fp32, roi_cols must be 7
+ * (batch,x1,y1,z1,x2,y2,z2) else M3D_EINVAL (the reference returns 0, roi_align_cuda_3d.c:19-22);
+ * output [num_rois,channels,AS,AH,AW] as allocated by functions/roi_align_3d.py:24, written in the
+ * reference kernel's (n,c,ph,pw,ps) memory order (roi_align_kernel_3d.cu:87-91).  Caller allocates
+ * (and, for backward, zero-fills) the outputs exactly like functions/roi_align_3d.py:24,41-42.
+ * ------------------------------------------------------------------------------------------------------- */
+int m3d_roi_align3d_forward(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
+                            int sampling_ratio, const float* d_features, int batch, int channels, int slices,
+                            int height, int width, const float* d_rois, int num_rois, int roi_cols,
+                            float* d_output, void* stream);
+int m3d_roi_align3d_backward(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
+                             int sampling_ratio, const float* d_top_grad, const float* d_rois, int num_rois,
+                             int roi_cols, float* d_bottom_grad, int batch, int channels, int slices, int height,
+                             int width, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Greedy 3D NMS.  Replaces utils.cython_nms_3d.nms_3d / nms_3d_volume
+ * (lib/utils/cython_nms_3d.pyx:39-96, 102-159; wrappers lib/utils/boxes_3d.py:364-374).
+ * d_dets [n,7] fp32 rows (x1,y1,z1,x2,y2,z2,score).  Visiting order: descending score (by_volume=0) or
+ * descending volume (by_volume=1), ties in descending input index.  d_keep receives the surviving INPUT
+ * indices in ascending order (np.where(suppressed == 0)[0], pyx:96); *d_num_keep their count.
+ * fp32 arithmetic, `ovr >= thresh`, bit-exact with the reference.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t m3d_nms3d_workspace_bytes(int n);
+int m3d_nms3d(const float* d_dets, int n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep,
+              void* d_ws, size_t ws_bytes, void* stream);
+
+/* N x K IoU matrix.  Replaces utils.cython_bbox_3d.bbox_overlaps_3d (lib/utils/cython_bbox_3d.pyx:32-80).
+ * d_boxes [n,6], d_query [k,6] fp32 -> d_out [n,k] fp32 (fp32 intersection, fp64 union and divide). */
+int m3d_bbox_overlaps3d(const float* d_boxes, int n, const float* d_query, int k, float* d_out, void* stream);
+
+/* Box decode + clip.  Replaces utils.boxes_3d.bbox_transform_3d / clip_tiled_boxes_3d
+ * (lib/utils/boxes_3d.py:167-225, 144-163).  d_boxes [n,6] fp32, d_deltas [n,6*classes] fp32,
+ * weights[6] host doubles, xform_clip = cfg.BBOX_XFORM_CLIP; d_out [n,6*classes].
+ * If clip_slices > 0 the result is also clipped to [0,dim-1] (x:width, y:height, z:slices). */
+int m3d_bbox_transform3d(const float* d_boxes, const float* d_deltas, int n, int classes, const double* weights,
+                         double xform_clip, double clip_slices, double clip_height, double clip_width,
+                         float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RPN proposal generation for one image, fully on device.  Replaces GenerateProposalsOp_3d.forward /
+ * proposals_for_one_image / _filter_boxes_3d (lib/modeling/generate_proposals_3d.py:19-192), which in the
+ * reference copies scores and deltas to the host (:58-63).
+ * d_scores [A,S,H,W] fp32 (post-sigmoid), d_deltas [6A,S,H,W] fp32, anchors[A*6] host doubles
+ * (generate_anchors_3d), im_info = (slices,height,width,scale) host doubles.
+ * Outputs (capacity post_nms_topN, or pre_nms_topN when post <= 0): d_rois [R,7] fp32 (batch column =
+ * batch_index), d_probs [R] fp32, d_keep_idx [R] int64 = flat index into (S,H,W,A) (:160,174-175),
+ * *d_num = R.  Top-N tie rule: descending score, ties ascending flat index.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t m3d_generate_proposals3d_workspace_bytes(int A, int S, int H, int W, int pre_nms_topN);
+int m3d_generate_proposals3d(const float* d_scores, const float* d_deltas, int A, int S, int H, int W,
+                             const double* anchors, double feat_stride, const double* im_info,
+                             int pre_nms_topN, int post_nms_topN, float nms_thresh, double min_size,
+                             double xform_clip, int batch_index, float* d_rois, float* d_probs,
+                             int64_t* d_keep_idx, int32_t* d_num, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3D convolution (cross-correlation), NCDHW fp32, stride 1, zero padding k/2, dilation 1, groups 1 — what
+ * torch.nn.Conv3d computes for every conv of lib/modeling/DSN.py:19-36 and lib/modeling/rpn_heads.py:54-61.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, LDS-staged halo tiles, no im2col buffer.
+ *
+ * Weights are packed once (m3d_conv3d_pack_weights) into the MFMA A-fragment order; `mode` selects
+ *   M3D_W_PLAIN     W                       (forward conv)
+ *   M3D_W_RELU      relu(W)                 (PRM norm conv, lib/prm/peak_backprop_3d.py:41-42)
+ *   M3D_W_DGRAD     flip + transpose W      (backward-data of a stride-1 same conv)
+ *   M3D_W_DGRAD_RELU flip + transpose relu(W) (PRM backward, peak_backprop_3d.py:16-18 via autograd)
+ * Forward computes, per output element:  y = conv(x - in_offset, Wp) ; y = y*scale[c] + shift[c] (if given;
+ * bias and eval-mode BatchNorm fold into scale/shift) ; y = max(y,0) (if relu) ; y *= mul[..] (if d_mul given:
+ * same shape as the output; the PRM PreHook product).  Padding voxels stay 0 after the offset subtraction.
+ * ------------------------------------------------------------------------------------------------------- */
+enum { M3D_W_PLAIN = 0, M3D_W_RELU = 1, M3D_W_DGRAD = 2, M3D_W_DGRAD_RELU = 3 };
+size_t m3d_conv3d_packed_weight_bytes(int cin, int cout, int k, int mode);
+int m3d_conv3d_pack_weights(const float* d_weight /*[cout,cin,k,k,k]*/, int cin, int cout, int k, int mode,
+                            float* d_packed, void* stream);
+int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                       int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
+                       const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
+
+/* MaxPool3d(kernel 2, stride 2, floor) forward with argmax (lib/modeling/DSN.py:21,26,32) and its
+ * backward (gradient routed to the argmax voxel; first maximum in z,y,x scan order wins, as PyTorch). */
+int m3d_maxpool3d_2x_forward(const float* d_in, float* d_out, uint8_t* d_argmax /*may be NULL*/, int batch_channels,
+                             int depth, int height, int width, void* stream);
+int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, float* d_grad_in,
+                              int batch_channels, int depth, int height, int width, void* stream);
+
+/* Global minimum of a device fp32 array into d_out[0] (the `input.min()` offset of
+ * lib/prm/peak_backprop_3d.py:38); stays on device so the PRM convs never synchronise with the host. */
+size_t m3d_reduce_min_workspace_bytes(void);
+int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Per-RoI 2D-Otsu binarisation.  Replaces otsu.otsu_py_2d_fast (tools/otsu.py:199-284) for uint16 inputs
+ * (the callers normalise to uint16: tools/binarization_soma.py:85-91, binarization_nuclei.py:110-121).
+ * A batch of `num_rois` independent crops: crop r occupies voxels [offsets[r], offsets[r+1]) of d_image /
+ * d_prm / d_mask.  d_kb receives (k, b_max) per RoI; status[r] != 0 marks "no separating line".
+ * ------------------------------------------------------------------------------------------------------- */
+size_t m3d_otsu2d_workspace_bytes(int num_rois, int max_gray_range);
+int m3d_otsu2d_batch(const uint16_t* d_image, const uint16_t* d_prm, const int64_t* d_offsets, int num_rois,
+                     int max_gray_range, uint8_t* d_mask, int32_t* d_kb, int32_t* d_status, void* d_ws,
+                     size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3D_H_ */

@@ -1,0 +1,636 @@
+// 3D box operations for gfx950: greedy NMS, IoU matrix, box decode/clip, RPN proposal generation.
+//
+// Reference semantics: lib/utils/cython_nms_3d.pyx:39-159, lib/utils/cython_bbox_3d.pyx:32-80,
+// lib/utils/boxes_3d.py:144-225, lib/modeling/generate_proposals_3d.py:19-192.
+// Everything here is integer/index work on top of a handful of fp32 expressions whose operation order is
+// the contract with the reference: this file is compiled with -ffp-contract=off and uses IEEE divides.
+//
+// NMS design: (1) volumes + a rank sort (O(N^2) compares, embarrassingly parallel, gives a deterministic
+// total order incl. the tie rule), (2) upper-triangular 64x64 IoU bitmask tiles, (3) one workgroup walks
+// the rows in 64-row chunks staged in LDS: a scalar 64-step loop resolves the diagonal tile, then all
+// lanes OR the surviving rows into the "removed" bitmap, (4) flags are mapped back to input order and
+// compacted with a block scan.  N <= 16384.
+#include "m3d_common.h"
+
+namespace {
+
+constexpr int kMaxNms = 16384;
+
+__device__ inline float fmax32(float a, float b) { return a >= b ? a : b; }   // cython_nms_3d.pyx:30-31
+__device__ inline float fmin32(float a, float b) { return a <= b ? a : b; }   // cython_nms_3d.pyx:33-34
+
+__device__ inline bool key_before(float ka, int ia, float kb, int ib) {
+  // true if (ka, ia) is visited before (kb, ib): descending key, ties in descending index
+  // ("argsort()[::-1]" under the build's stable-sort rule, SURVEY 8c caveat i)
+  if (ka > kb) return true;
+  if (ka < kb) return false;
+  return ia > ib;
+}
+
+struct SBox { float x1, y1, z1, x2, y2, z2, vol, pad; };
+
+// ---- (1) volumes + keys ------------------------------------------------------------------------------
+__global__ void nms_prepare_kernel(const float* __restrict__ dets, int n_max, const int* __restrict__ d_n, int by_volume,
+                                   float* __restrict__ vol, float* __restrict__ key) {
+  const int n = d_n ? *d_n : n_max;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* d = dets + 7 * (size_t)i;
+  float a = d[3] - d[0]; a = a + 1.0f;      // pyx:48, NumPy fp32 left-to-right
+  float b = d[4] - d[1]; b = b + 1.0f;
+  float c = d[5] - d[2]; c = c + 1.0f;
+  float ab = a * b;
+  float v = ab * c;
+  vol[i] = v;
+  key[i] = by_volume ? v : d[6];
+}
+
+// ---- rank sort: order[rank] = i ; sorted boxes -----------------------------------------------------
+__global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ dets, const float* __restrict__ vol,
+                                                       const float* __restrict__ key, int n_max, const int* __restrict__ d_n,
+                                                       int* __restrict__ order, SBox* __restrict__ sboxes) {
+  __shared__ float skey[256];
+  const int n = d_n ? *d_n : n_max;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const float ki = i < n ? key[i] : 0.f;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    skey[threadIdx.x] = j < n ? key[j] : 0.f;
+    __syncthreads();
+    const int m = min(256, n - j0);
+    if (i < n)
+      for (int t = 0; t < m; ++t) rank += key_before(skey[t], j0 + t, ki, i) ? 1 : 0;
+    __syncthreads();
+  }
+  if (i < n) {
+    order[rank] = i;
+    const float* d = dets + 7 * (size_t)i;
+    SBox s{d[0], d[1], d[2], d[3], d[4], d[5], vol[i], 0.f};
+    sboxes[rank] = s;
+  }
+}
+
+// ---- (2) IoU bitmask over sorted boxes: mask[i*nblk + cb] bit t <=> box (cb*64+t) is suppressed by i ----
+__global__ __launch_bounds__(64) void nms_mask_kernel(const SBox* __restrict__ sboxes, int n_max, const int* __restrict__ d_n,
+                                                      float thresh, int nblk, unsigned long long* __restrict__ mask) {
+  const int n = d_n ? *d_n : n_max;
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (rb * 64 >= n || cb * 64 >= n) return;
+  const int i = rb * 64 + threadIdx.x;
+  if (cb < rb) {
+    if (i < n) mask[(size_t)i * nblk + cb] = 0ull;
+    return;
+  }
+  __shared__ SBox cols[64];
+  const int jc = cb * 64 + threadIdx.x;
+  if (jc < n) cols[threadIdx.x] = sboxes[jc];
+  __syncthreads();
+  if (i >= n) return;
+  const SBox bi = sboxes[i];
+  unsigned long long bits = 0ull;
+  const int m = min(64, n - cb * 64);
+  for (int t = 0; t < m; ++t) {
+    const int j = cb * 64 + t;
+    if (j <= i) continue;
+    const SBox bj = cols[t];
+    const float xx1 = fmax32(bi.x1, bj.x1), yy1 = fmax32(bi.y1, bj.y1), zz1 = fmax32(bi.z1, bj.z1);   // pyx:82-87
+    const float xx2 = fmin32(bi.x2, bj.x2), yy2 = fmin32(bi.y2, bj.y2), zz2 = fmin32(bi.z2, bj.z2);
+    float w = xx2 - xx1; w = w + 1.0f; w = fmax32(0.0f, w);                                             // pyx:88-90
+    float h = yy2 - yy1; h = h + 1.0f; h = fmax32(0.0f, h);
+    float s = zz2 - zz1; s = s + 1.0f; s = fmax32(0.0f, s);
+    float inter = w * h; inter = inter * s;                                                            // pyx:91
+    float uni = bi.vol + bj.vol; uni = uni - inter;
+    const float ovr = inter / uni;                                                                     // pyx:92
+    if (ovr >= thresh) bits |= 1ull << t;                                                              // pyx:93
+  }
+  mask[(size_t)i * nblk + cb] = bits;
+}
+
+// ---- (3)+(4) sequential resolve + compaction; ONE workgroup of 1024 threads ---------------------------
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int* __restrict__ order,
+                                                        int n_max, const int* __restrict__ d_n, int nblk_alloc,
+                                                        int64_t* __restrict__ keep, int32_t* __restrict__ num_keep,
+                                                        unsigned char* __restrict__ flag /* [n] scratch, input order */,
+                                                        int keep_limit) {
+  extern __shared__ unsigned long long lds[];   // [64 rows][nblk] chunk + removed[nblk] + misc
+  const int n = d_n ? *d_n : n_max;
+  const int nblk = (n + 63) / 64;
+  unsigned long long* chunk = lds;
+  unsigned long long* removed = lds + (size_t)64 * nblk_alloc;
+  __shared__ unsigned long long kept_word;
+  __shared__ int scan_tmp[1024];
+  __shared__ int scan_base;
+  for (int w = threadIdx.x; w < nblk; w += blockDim.x) removed[w] = 0ull;
+  __syncthreads();
+  for (int c = 0; c < nblk; ++c) {
+    const int rows = min(64, n - c * 64);
+    // stage rows [c*64, c*64+rows) x words [c, nblk)
+    const int wcount = nblk - c;
+    for (int e = threadIdx.x; e < rows * wcount; e += blockDim.x) {
+      const int r = e / wcount, w = c + e % wcount;
+      chunk[(size_t)r * nblk_alloc + w] = mask[(size_t)(c * 64 + r) * nblk_alloc + w];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long rem = removed[c], kept = 0ull;
+      for (int b = 0; b < rows; ++b) {
+        if (!((rem >> b) & 1ull)) {
+          kept |= 1ull << b;
+          rem |= chunk[(size_t)b * nblk_alloc + c];
+        }
+      }
+      removed[c] = rem;
+      kept_word = kept;
+    }
+    __syncthreads();
+    const unsigned long long kept = kept_word;
+    for (int w = c + 1 + threadIdx.x; w < nblk; w += blockDim.x) {
+      unsigned long long acc = removed[w];
+      unsigned long long kk = kept;
+      while (kk) {
+        const int b = __ffsll((long long)kk) - 1;
+        kk &= kk - 1;
+        acc |= chunk[(size_t)b * nblk_alloc + w];
+      }
+      removed[w] = acc;
+    }
+    // flags in input order for this chunk
+    if (threadIdx.x < rows) flag[order[c * 64 + threadIdx.x]] = (unsigned char)((kept >> threadIdx.x) & 1ull);
+    __syncthreads();
+  }
+  // compaction in ascending input index (np.where(suppressed == 0)[0], pyx:96)
+  if (threadIdx.x == 0) scan_base = 0;
+  __threadfence_block();
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int f = (i < n) ? flag[i] : 0;
+    scan_tmp[threadIdx.x] = f;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+      int v = threadIdx.x >= off ? scan_tmp[threadIdx.x - off] : 0;
+      __syncthreads();
+      scan_tmp[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int pos = scan_base + scan_tmp[threadIdx.x] - f;
+    if (f && (keep_limit <= 0 || pos < keep_limit)) keep[pos] = i;
+    __syncthreads();
+    if (threadIdx.x == 1023) scan_base += scan_tmp[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *num_keep = (keep_limit > 0 && scan_base > keep_limit) ? keep_limit : scan_base;
+}
+
+struct NmsWs {
+  float* vol; float* key; int* order; SBox* sboxes; unsigned long long* mask; unsigned char* flag;
+};
+
+size_t nms_ws_bytes(int n) {
+  const size_t nblk = (n + 63) / 64;
+  size_t b = 0;
+  b += m3d::align_up(sizeof(float) * n, 256) * 2;
+  b += m3d::align_up(sizeof(int) * n, 256);
+  b += m3d::align_up(sizeof(SBox) * n, 256);
+  b += m3d::align_up(sizeof(unsigned long long) * n * nblk, 256);
+  b += m3d::align_up((size_t)n, 256);
+  return b + 256;
+}
+
+NmsWs nms_carve(void* ws, int n) {
+  const size_t nblk = (n + 63) / 64;
+  char* p = (char*)m3d::align_up((size_t)ws, 256);
+  NmsWs w;
+  w.vol = (float*)p; p += m3d::align_up(sizeof(float) * n, 256);
+  w.key = (float*)p; p += m3d::align_up(sizeof(float) * n, 256);
+  w.order = (int*)p; p += m3d::align_up(sizeof(int) * n, 256);
+  w.sboxes = (SBox*)p; p += m3d::align_up(sizeof(SBox) * n, 256);
+  w.mask = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * n * nblk, 256);
+  w.flag = (unsigned char*)p;
+  return w;
+}
+
+// n_max: capacity (host); d_n: optional device count (<= n_max).
+int nms_launch(const float* d_dets, int n_max, const int* d_n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep,
+               void* d_ws, size_t ws_bytes, int keep_limit, hipStream_t st) {
+  if (n_max < 0 || n_max > kMaxNms) return n_max < 0 ? M3D_EINVAL : M3D_EUNSUPPORTED;
+  if (!d_num_keep) return M3D_EINVAL;
+  if (n_max == 0) {
+    (void)hipMemsetAsync(d_num_keep, 0, sizeof(int32_t), st);   // boxes_3d.py:366-367
+    return m3d::check_launch("nms3d(empty)");
+  }
+  if (!d_dets || !d_keep || !d_ws) return M3D_EINVAL;
+  if (ws_bytes < nms_ws_bytes(n_max)) return M3D_EWORKSPACE;
+  const NmsWs w = nms_carve(d_ws, n_max);
+  const int nblk = (n_max + 63) / 64;
+  hipLaunchKernelGGL(nms_prepare_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, n_max, d_n, by_volume, w.vol, w.key);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, w.vol, w.key, n_max, d_n, w.order,
+                     w.sboxes);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, st, w.sboxes, n_max, d_n, thresh, nblk, w.mask);
+  const size_t lds = sizeof(unsigned long long) * ((size_t)64 * nblk + nblk);
+  if (lds > 150 * 1024) return M3D_EUNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), lds, st, w.mask, w.order, n_max, d_n, nblk, d_keep, d_num_keep,
+                     w.flag, keep_limit);
+  return m3d::check_launch("nms3d");
+}
+
+// ---- IoU matrix (cython_bbox_3d.pyx:32-80; C typing per lib/utils/cython_bbox_3d.c:2042,2105,2288) -------------
+__global__ __launch_bounds__(256) void overlaps_kernel(const float* __restrict__ boxes, int N, const float* __restrict__ query,
+                                                       int K, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)N * K) return;
+  const int n = (int)(e / K), k = (int)(e % K);
+  const float* b = boxes + 6 * (size_t)n;
+  const float* q = query + 6 * (size_t)k;
+  float r = 0.f;                                                          // pyx:46
+  const float box_volume = (float)((((double)(q[3] - q[0]) + 1.0) * ((double)(q[4] - q[1]) + 1.0)) *
+                                   ((double)(q[5] - q[2]) + 1.0));         // pyx:52-56
+  const float iw = (float)((double)(fmin32(b[3], q[3]) - fmax32(b[0], q[0])) + 1.0);   // pyx:58-61
+  if (iw > 0) {
+    const float ih = (float)((double)(fmin32(b[4], q[4]) - fmax32(b[1], q[1])) + 1.0);
+    if (ih > 0) {
+      const float is = (float)((double)(fmin32(b[5], q[5]) - fmax32(b[2], q[2])) + 1.0);
+      if (is > 0) {
+        float inter = iw * ih; inter = inter * is;
+        const double uv = ((((double)(b[3] - b[0]) + 1.0) * ((double)(b[4] - b[1]) + 1.0)) * ((double)(b[5] - b[2]) + 1.0) +
+                           (double)box_volume) - (double)inter;            // pyx:73-78
+        r = (float)((double)inter / uv);                                   // pyx:79
+      }
+    }
+  }
+  out[e] = r;
+}
+
+// ---- decode + clip (boxes_3d.py:167-225, 144-163; NumPy-2 promotion: dw/dh/ds path in fp64) --------------------
+struct XformParams { double w[6]; double clip; double cs, ch, cw; };
+
+__device__ inline void decode_one(const float* b, const float* d, const XformParams& p, float* o) {
+  float w = b[3] - b[0]; w = w + 1.0f;                                    // :177-179
+  float h = b[4] - b[1]; h = h + 1.0f;
+  float s = b[5] - b[2]; s = s + 1.0f;
+  const float hw = 0.5f * w, hh = 0.5f * h, hs = 0.5f * s;
+  const float cx = b[0] + hw, cy = b[1] + hh, cz = b[2] + hs;             // :180-182
+  const float dx = d[0] / (float)p.w[0], dy = d[1] / (float)p.w[1], dz = d[2] / (float)p.w[2];   // :185-190
+  const float dwf = d[3] / (float)p.w[3], dhf = d[4] / (float)p.w[4], dsf = d[5] / (float)p.w[5];
+  const double dw = fmin((double)dwf, p.clip), dh = fmin((double)dhf, p.clip), ds = fmin((double)dsf, p.clip);   // :193-195
+  float px = dx * w; px = px + cx;                                        // :197-199
+  float py = dy * h; py = py + cy;
+  float pz = dz * s; pz = pz + cz;
+  const double pw = exp(dw) * (double)w, ph = exp(dh) * (double)h, ps = exp(ds) * (double)s;   // :200-202
+  o[0] = (float)((double)px - 0.5 * pw);                                  // :213-223
+  o[1] = (float)((double)py - 0.5 * ph);
+  o[2] = (float)((double)pz - 0.5 * ps);
+  o[3] = (float)(((double)px + 0.5 * pw) - 1.0);
+  o[4] = (float)(((double)py + 0.5 * ph) - 1.0);
+  o[5] = (float)(((double)pz + 0.5 * ps) - 1.0);
+  if (p.cs > 0) {                                                         // clip_tiled_boxes_3d :152-162
+    const double hi[6] = {p.cw - 1, p.ch - 1, p.cs - 1, p.cw - 1, p.ch - 1, p.cs - 1};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (o[c] == o[c]) {   // NaN propagates in NumPy
+        double v = (double)o[c];
+        v = v < hi[c] ? v : hi[c];
+        v = v > 0.0 ? v : 0.0;
+        o[c] = (float)v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(const float* __restrict__ boxes, const float* __restrict__ deltas, int n,
+                                                        int classes, XformParams p, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * classes) return;
+  const int i = e / classes;
+  float o[6];
+  decode_one(boxes + 6 * (size_t)i, deltas + 6 * (size_t)e, p, o);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) out[6 * (size_t)e + c] = o[c];
+}
+
+// ======================================================================================================
+// RPN proposals (generate_proposals_3d.py:19-192)
+// ======================================================================================================
+// 64-bit selection key: high word = fp32 score bits (scores are probabilities >= 0, so the unsigned
+// bit pattern orders like the value; negatives/NaN are mapped to keep a total order), low word =
+// ~flat_index so that among equal scores the SMALLER flat (S,H,W,A) index is the larger key.
+__device__ inline unsigned int score_bits(float s) {
+  unsigned int u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float bits_score(unsigned int b) {
+  return __uint_as_float((b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b);
+}
+__device__ inline unsigned long long make_key(float s, unsigned int flat) {
+  return ((unsigned long long)score_bits(s) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+}
+
+struct SelState {           // device-resident radix-select state
+  unsigned long long prefix;   // selected high bits so far
+  unsigned int remaining;      // how many still to take inside the current prefix bucket
+  unsigned int done;           // 1 once every element with the prefix is selected
+  unsigned int hist[256];
+  unsigned int count;          // compaction cursor
+  unsigned int nvalid;         // after the filter
+};
+
+// memory index m = a*SHW + pos  <->  flat index f = pos*A + a  (generate_proposals_3d.py:121,129)
+__global__ __launch_bounds__(256) void sel_hist_kernel(const float* __restrict__ scores, int A, int SHW, int pass, SelState* st) {
+  __shared__ unsigned int h[256];
+  if (st->done) return;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int shift = 56 - 8 * pass;
+  const unsigned long long prefix = st->prefix;
+  const long long total = (long long)A * SHW;
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long long)gridDim.x * blockDim.x) {
+    const unsigned int a = (unsigned int)(m / SHW), pos = (unsigned int)(m % SHW);
+    const unsigned long long key = make_key(scores[m], pos * (unsigned int)A + a);
+    if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&h[(unsigned int)(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void sel_pick_kernel(int pass, SelState* st) {
+  if (threadIdx.x != 0 || st->done) return;
+  const int shift = 56 - 8 * pass;
+  unsigned int rem = st->remaining;
+  unsigned int total = 0;
+  for (int d = 0; d < 256; ++d) total += st->hist[d];
+  if (total <= rem) {           // everything under the prefix is selected (also covers total elements <= K)
+    st->done = 1;
+    // prefix stays: lower bits zero => threshold = prefix
+  } else {
+    for (int d = 255; d >= 0; --d) {
+      const unsigned int c = st->hist[d];
+      if (c >= rem) { st->prefix |= (unsigned long long)d << shift; break; }
+      rem -= c;
+    }
+    st->remaining = rem;
+    if (pass == 7) st->done = 1;
+  }
+  for (int d = 0; d < 256; ++d) st->hist[d] = 0;
+}
+
+__global__ void sel_init_kernel(SelState* st, unsigned int k) {
+  if (threadIdx.x == 0) { st->prefix = 0; st->remaining = k; st->done = 0; st->count = 0; st->nvalid = 0; }
+  if (threadIdx.x < 256) st->hist[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void sel_compact_kernel(const float* __restrict__ scores, int A, int SHW, SelState* st,
+                                                          unsigned long long* __restrict__ keys, unsigned int cap) {
+  const unsigned long long thr = st->prefix;
+  const long long total = (long long)A * SHW;
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long long)gridDim.x * blockDim.x) {
+    const unsigned int a = (unsigned int)(m / SHW), pos = (unsigned int)(m % SHW);
+    const unsigned long long key = make_key(scores[m], pos * (unsigned int)A + a);
+    if (key >= thr) {
+      const unsigned int slot = atomicAdd(&st->count, 1u);
+      if (slot < cap) keys[slot] = key;
+    }
+  }
+}
+
+// rank sort of the (distinct) selected keys, descending
+__global__ __launch_bounds__(256) void sel_rank_kernel(const unsigned long long* __restrict__ keys, const SelState* st,
+                                                       unsigned int cap, unsigned long long* __restrict__ sorted) {
+  __shared__ unsigned long long sk[256];
+  const unsigned int n = min(st->count, cap);
+  const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const unsigned long long ki = i < n ? keys[i] : 0ull;
+  unsigned int rank = 0;
+  for (unsigned int j0 = 0; j0 < n; j0 += 256) {
+    sk[threadIdx.x] = (j0 + threadIdx.x < n) ? keys[j0 + threadIdx.x] : 0ull;
+    __syncthreads();
+    const unsigned int m = min(256u, n - j0);
+    for (unsigned int t = 0; t < m; ++t) rank += sk[t] > ki ? 1u : 0u;
+    __syncthreads();
+  }
+  if (i < n) sorted[rank] = ki;
+}
+
+struct PropParams {
+  double anchors[6 * 64];   // A <= 64
+  double stride, im_s, im_h, im_w, im_scale, min_size;
+  XformParams xf;
+  int A, S, H, W, batch_index;
+};
+
+// decode + clip + filter for the sorted candidates; one thread each
+__global__ __launch_bounds__(256) void prop_decode_kernel(const unsigned long long* __restrict__ sorted, const SelState* st,
+                                                          unsigned int cap, const float* __restrict__ deltas, PropParams p,
+                                                          float* __restrict__ boxes /*[cap,6]*/, unsigned char* __restrict__ valid) {
+  const unsigned int n = min(st->count, cap);
+  const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long key = sorted[i];
+  const unsigned int flat = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+  const int a = flat % p.A;
+  const int pos = flat / p.A;
+  const int w = pos % p.W, h = (pos / p.W) % p.H, s = pos / (p.W * p.H);
+  const double sx = (double)w * p.stride, sy = (double)h * p.stride, sz = (double)s * p.stride;   // :68-77
+  const double* an = p.anchors + 6 * a;
+  float b[6] = {(float)(an[0] + sx), (float)(an[1] + sy), (float)(an[2] + sz),                      // :88, boxes_3d.py:175
+                (float)(an[3] + sx), (float)(an[4] + sy), (float)(an[5] + sz)};
+  const size_t SHW = (size_t)p.S * p.H * p.W;
+  float d[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) d[c] = deltas[(size_t)(a * 6 + c) * SHW + pos];                      // :121
+  float o[6];
+  decode_one(b, d, p.xf, o);                                                                      // :149,154
+#pragma unroll
+  for (int c = 0; c < 6; ++c) boxes[6 * (size_t)i + c] = o[c];
+  // _filter_boxes_3d :180-192 (y/z centres use the x-side `ss`: reference behaviour, kept)
+  const double ms = p.min_size * p.im_scale;
+  float ss = o[3] - o[0]; ss = ss + 1.0f;
+  const float half = ss / 2.0f;
+  const float xc = o[0] + half, yc = o[1] + half, zc = o[2] + half;
+  valid[i] = ((double)ss >= ms && (double)xc < p.im_w && (double)yc < p.im_h && (double)zc < p.im_s) ? 1 : 0;
+}
+
+// ordered compaction of valid candidates into dets [n,7] + flat index; ONE workgroup
+__global__ __launch_bounds__(1024) void prop_compact_kernel(const unsigned long long* __restrict__ sorted, SelState* st,
+                                                            unsigned int cap, const float* __restrict__ boxes,
+                                                            const unsigned char* __restrict__ valid, float* __restrict__ dets,
+                                                            int64_t* __restrict__ flat_idx) {
+  __shared__ int tmp[1024];
+  __shared__ int base_s;
+  const unsigned int n = min(st->count, cap);
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (unsigned int b0 = 0; b0 < n; b0 += 1024) {
+    const unsigned int i = b0 + threadIdx.x;
+    const int f = (i < n) ? valid[i] : 0;
+    tmp[threadIdx.x] = f;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int v = (int)threadIdx.x >= off ? tmp[threadIdx.x - off] : 0;
+      __syncthreads();
+      tmp[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (f) {
+      const int pos = base_s + tmp[threadIdx.x] - 1;
+      const unsigned long long key = sorted[i];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dets[7 * (size_t)pos + c] = boxes[6 * (size_t)i + c];
+      dets[7 * (size_t)pos + 6] = bits_score((unsigned int)(key >> 32));
+      flat_idx[pos] = (int64_t)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) base_s += tmp[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st->nvalid = (unsigned int)base_s;
+}
+
+__global__ __launch_bounds__(256) void prop_gather_kernel(const float* __restrict__ dets, const int64_t* __restrict__ flat_idx,
+                                                          const int64_t* __restrict__ keep, const int32_t* __restrict__ num_keep,
+                                                          int batch_index, float* __restrict__ rois, float* __restrict__ probs,
+                                                          int64_t* __restrict__ keep_idx, int32_t* __restrict__ d_num) {
+  const int n = *num_keep;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *d_num = n;
+  if (i >= n) return;
+  const int64_t k = keep[i];
+  rois[7 * (size_t)i + 0] = (float)batch_index;                           // :98-100
+#pragma unroll
+  for (int c = 0; c < 6; ++c) rois[7 * (size_t)i + 1 + c] = dets[7 * (size_t)k + c];
+  probs[i] = dets[7 * (size_t)k + 6];
+  keep_idx[i] = flat_idx[k];                                              // :160,174-175
+}
+
+// all candidates kept (nms_thresh <= 0): identity keep list
+__global__ void prop_iota_kernel(const SelState* st, int limit, int64_t* keep, int32_t* num_keep) {
+  int n = (int)st->nvalid;
+  if (limit > 0 && n > limit) n = limit;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) keep[i] = i;
+  if (threadIdx.x == 0) *num_keep = n;
+}
+
+struct PropWs {
+  SelState* st; unsigned long long* keys; unsigned long long* sorted; float* boxes; unsigned char* valid; float* dets;
+  int64_t* flat_idx; int64_t* keep; int32_t* num_keep; void* nms_ws; size_t nms_bytes;
+};
+
+size_t prop_ws_bytes(int K) {
+  size_t b = 256;
+  b += m3d::align_up(sizeof(SelState), 256);
+  b += m3d::align_up(sizeof(unsigned long long) * K, 256) * 2;
+  b += m3d::align_up(sizeof(float) * 6 * K, 256);
+  b += m3d::align_up((size_t)K, 256);
+  b += m3d::align_up(sizeof(float) * 7 * K, 256);
+  b += m3d::align_up(sizeof(int64_t) * K, 256) * 2;
+  b += 256;
+  b += nms_ws_bytes(K);
+  return b;
+}
+
+PropWs prop_carve(void* ws, int K) {
+  char* p = (char*)m3d::align_up((size_t)ws, 256);
+  PropWs w;
+  w.st = (SelState*)p; p += m3d::align_up(sizeof(SelState), 256);
+  w.keys = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * K, 256);
+  w.sorted = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * K, 256);
+  w.boxes = (float*)p; p += m3d::align_up(sizeof(float) * 6 * K, 256);
+  w.valid = (unsigned char*)p; p += m3d::align_up((size_t)K, 256);
+  w.dets = (float*)p; p += m3d::align_up(sizeof(float) * 7 * K, 256);
+  w.flat_idx = (int64_t*)p; p += m3d::align_up(sizeof(int64_t) * K, 256);
+  w.keep = (int64_t*)p; p += m3d::align_up(sizeof(int64_t) * K, 256);
+  w.num_keep = (int32_t*)p; p += 256;
+  w.nms_ws = p; w.nms_bytes = nms_ws_bytes(K);
+  return w;
+}
+
+}  // namespace
+
+M3D_API size_t m3d_nms3d_workspace_bytes(int n) { return n <= 0 ? 256 : nms_ws_bytes(n); }
+
+M3D_API int m3d_nms3d(const float* d_dets, int n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep, void* d_ws,
+                      size_t ws_bytes, void* stream) {
+  return nms_launch(d_dets, n, nullptr, thresh, by_volume, d_keep, d_num_keep, d_ws, ws_bytes, 0, m3d::as_stream(stream));
+}
+
+M3D_API int m3d_bbox_overlaps3d(const float* d_boxes, int n, const float* d_query, int k, float* d_out, void* stream) {
+  if (n < 0 || k < 0) return M3D_EINVAL;
+  if ((long long)n * k == 0) return M3D_OK;
+  if (!d_boxes || !d_query || !d_out) return M3D_EINVAL;
+  const long long total = (long long)n * k;
+  hipLaunchKernelGGL(overlaps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, m3d::as_stream(stream), d_boxes, n,
+                     d_query, k, d_out);
+  return m3d::check_launch("bbox_overlaps3d");
+}
+
+M3D_API int m3d_bbox_transform3d(const float* d_boxes, const float* d_deltas, int n, int classes, const double* weights,
+                                 double xform_clip, double clip_slices, double clip_height, double clip_width, float* d_out,
+                                 void* stream) {
+  if (n < 0 || classes <= 0 || !weights) return M3D_EINVAL;
+  if (n == 0) return M3D_OK;                                              // boxes_3d.py:172-173
+  if (!d_boxes || !d_deltas || !d_out) return M3D_EINVAL;
+  XformParams p;
+  for (int i = 0; i < 6; ++i) p.w[i] = weights[i];
+  p.clip = xform_clip; p.cs = clip_slices; p.ch = clip_height; p.cw = clip_width;
+  hipLaunchKernelGGL(transform_kernel, dim3((n * classes + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_boxes, d_deltas,
+                     n, classes, p, d_out);
+  return m3d::check_launch("bbox_transform3d");
+}
+
+M3D_API size_t m3d_generate_proposals3d_workspace_bytes(int A, int S, int H, int W, int pre_nms_topN) {
+  long long total = (long long)A * S * H * W;
+  long long K = (pre_nms_topN <= 0 || pre_nms_topN >= total) ? total : pre_nms_topN;
+  if (K <= 0) K = 1;
+  return prop_ws_bytes((int)K);
+}
+
+M3D_API int m3d_generate_proposals3d(const float* d_scores, const float* d_deltas, int A, int S, int H, int W,
+                                     const double* anchors, double feat_stride, const double* im_info, int pre_nms_topN,
+                                     int post_nms_topN, float nms_thresh, double min_size, double xform_clip, int batch_index,
+                                     float* d_rois, float* d_probs, int64_t* d_keep_idx, int32_t* d_num, void* d_ws,
+                                     size_t ws_bytes, void* stream) {
+  if (A <= 0 || A > 64 || S <= 0 || H <= 0 || W <= 0 || !anchors || !im_info) return M3D_EINVAL;
+  if (!d_scores || !d_deltas || !d_rois || !d_probs || !d_keep_idx || !d_num || !d_ws) return M3D_EINVAL;
+  const long long total = (long long)A * S * H * W;
+  if (total >= 0xFFFFFFFFll) return M3D_EUNSUPPORTED;
+  const long long Kll = (pre_nms_topN <= 0 || pre_nms_topN >= total) ? total : pre_nms_topN;   // :135
+  if (Kll > kMaxNms) return M3D_EUNSUPPORTED;
+  const int K = (int)Kll;
+  if (ws_bytes < prop_ws_bytes(K)) return M3D_EWORKSPACE;
+  hipStream_t st = m3d::as_stream(stream);
+  const PropWs w = prop_carve(d_ws, K);
+  const int SHW = S * H * W;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(256), 0, st, w.st, (unsigned)K);
+  for (int pass = 0; pass < 8; ++pass) {
+    hipLaunchKernelGGL(sel_hist_kernel, dim3(grid), dim3(256), 0, st, d_scores, A, SHW, pass, w.st);
+    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(64), 0, st, pass, w.st);
+  }
+  hipLaunchKernelGGL(sel_compact_kernel, dim3(grid), dim3(256), 0, st, d_scores, A, SHW, w.st, w.keys, (unsigned)K);
+  hipLaunchKernelGGL(sel_rank_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w.keys, w.st, (unsigned)K, w.sorted);
+  PropParams p;
+  for (int i = 0; i < 6 * A; ++i) p.anchors[i] = anchors[i];
+  p.stride = feat_stride; p.im_s = im_info[0]; p.im_h = im_info[1]; p.im_w = im_info[2]; p.im_scale = im_info[3];
+  p.min_size = min_size; p.A = A; p.S = S; p.H = H; p.W = W; p.batch_index = batch_index;
+  for (int i = 0; i < 6; ++i) p.xf.w[i] = 1.0;                            // :149-150
+  p.xf.clip = xform_clip; p.xf.cs = im_info[0]; p.xf.ch = im_info[1]; p.xf.cw = im_info[2];   // :154
+  hipLaunchKernelGGL(prop_decode_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w.sorted, w.st, (unsigned)K, d_deltas, p,
+                     w.boxes, w.valid);
+  hipLaunchKernelGGL(prop_compact_kernel, dim3(1), dim3(1024), 0, st, w.sorted, w.st, (unsigned)K, w.boxes, w.valid, w.dets,
+                     w.flat_idx);
+  int rc = m3d::check_launch("generate_proposals3d(select/decode)");
+  if (rc != M3D_OK) return rc;
+  if (nms_thresh > 0) {                                                   // :167-171
+    rc = nms_launch(w.dets, K, (const int*)&w.st->nvalid, nms_thresh, 0, w.keep, w.num_keep, w.nms_ws, w.nms_bytes,
+                    post_nms_topN, st);
+    if (rc != M3D_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(prop_iota_kernel, dim3(1), dim3(256), 0, st, w.st, 0, w.keep, w.num_keep);
+  }
+  hipLaunchKernelGGL(prop_gather_kernel, dim3((K + 255) / 256), dim3(256), 0, st, w.dets, w.flat_idx, w.keep, w.num_keep,
+                     batch_index, d_rois, d_probs, d_keep_idx, d_num);
+  return m3d::check_launch("generate_proposals3d");
+}

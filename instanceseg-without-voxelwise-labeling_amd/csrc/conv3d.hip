@@ -1,0 +1,462 @@
+// 3D convolution for gfx950 as an fp32 MFMA implicit GEMM (no im2col buffer).
+//
+// What it replaces: the cuDNN-backed torch.nn.Conv3d calls of lib/modeling/DSN.py:19-36,57-68 and
+// lib/modeling/rpn_heads.py:54-61,94-98 (forward), and — with M3D_W_RELU / M3D_W_DGRAD_RELU weight packs —
+// the norm conv and the backward-data conv of lib/prm/peak_backprop_3d.py:16-18,37-44.
+//
+// GEMM view (per batch item):  Out[co][v] = sum_{ci,tap} Wt[co][ci][tap] * In[ci][v + tap]
+//   MFMA v_mfma_f32_32x32x2_f32:  D[i][j] += A[i][k] * B[k][j],  i = 32 output channels (A = weights),
+//   j = 32 voxels (B = input, XB consecutive x times 32/XB rows of y), k = 2 input channels at one tap.
+//   Accumulator layout puts j on the lane, so every accumulator register is a 128-byte (XB=32) run of
+//   consecutive x for one output channel: NCDHW stores are coalesced without any transpose.
+//
+// Data movement: the fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD (the f32 vector rate), so the
+// kernel is MFMA-issue bound by construction; per K-step a wave needs only (ROWS + NCB) ds_read_b32 for
+// ROWS*NCB MFMAs.  A workgroup (4 waves) stages, per chunk of CC input channels, the halo tile
+// [CC][TZ+2p][TY+2p][TX+2p] and the matching pre-packed weight slab into LDS.  The next chunk's global
+// loads are issued into registers BEFORE the current chunk's MFMA loop and written to LDS after it
+// (issue-early / write-late), so HBM/L2 latency hides under the matrix pipe.
+//
+// All B-fragment addresses are "one per-lane base VGPR + compile-time immediate": the tap loop is fully
+// unrolled and the (ci pair, dz, dy, dx) offsets fold into the ds_read offset field.
+#include "m3d_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------------
+// Weight packing.  Packed layout: Wp[cpair][cb][tap][lane]  (lane 0..63; cpair = input-channel pair)
+//   value = Wsrc[co = cb*32 + (lane & 31)][ci = 2*cpair + (lane >> 5)][tap]   (0 outside)
+// A workgroup that owns NCB consecutive cb reads, per channel pair, one contiguous NCB*K3*64-float run, so
+// the chunk size CC (channels staged per barrier) is a pure kernel choice, not a packing property.
+// For the k=5 / Cin=1 stem the K index is the tap itself: Wp[cb][pair][lane] = W[co][0][tap = 2*pair + (lane>>5)].
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cin, int cout, int k, int mode,
+                                                           float* __restrict__ wp, int ncb, int npair) {
+  const int k3 = k * k * k;
+  const long long total = (long long)npair * ncb * k3 * 64;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63);
+    long long t = e >> 6;
+    const int tap = (int)(t % k3); t /= k3;
+    const int cb = (int)(t % ncb); t /= ncb;
+    const int cpair = (int)t;
+    const int co = cb * 32 + (lane & 31);
+    const int ci = 2 * cpair + (lane >> 5);
+    // logical conv: out channels `cout_l`, in channels `cin_l`
+    const bool dgrad = (mode == M3D_W_DGRAD || mode == M3D_W_DGRAD_RELU);
+    const int cout_l = dgrad ? cin : cout, cin_l = dgrad ? cout : cin;
+    float v = 0.f;
+    if (co < cout_l && ci < cin_l) {
+      // dgrad of a stride-1 "same" conv = conv with W'[co'][ci'][tap'] = W[ci'][co'][k3-1-tap']
+      v = dgrad ? w[((size_t)ci * cin + co) * k3 + (k3 - 1 - tap)] : w[((size_t)co * cin + ci) * k3 + tap];
+      if ((mode == M3D_W_RELU || mode == M3D_W_DGRAD_RELU) && v < 0.f) v = 0.f;   // peak_backprop_3d.py:41
+    }
+    wp[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, int cout, int k3, int mode,
+                                                        float* __restrict__ wp, int npair) {
+  const int ncb = (cout + 31) / 32;
+  const int total = ncb * npair * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int lane = e & 63;
+    const int pair = (e >> 6) % npair;
+    const int cb = (e >> 6) / npair;
+    const int co = cb * 32 + (lane & 31);
+    const int tap = 2 * pair + (lane >> 5);
+    float v = 0.f;
+    if (co < cout && tap < k3) {
+      v = w[(size_t)co * k3 + tap];
+      if (mode == M3D_W_RELU && v < 0.f) v = 0.f;
+    }
+    wp[e] = v;
+  }
+}
+
+struct Epilogue {
+  const float* scale;   // per output channel or null
+  const float* shift;   // per output channel or null
+  const float* mul;     // same shape as out, or null
+  const float* in_off;  // 1 float (device) or null
+  int relu;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// Generic k in {1,3} kernel.
+//   XB   : x extent of a 32-voxel block (32, 16 or 8);  YB = 32 / XB rows of y per block
+//   ROWS : voxel blocks per wave (stacked along y);  NCB : 32-channel output blocks per workgroup
+//   WZ, WY: wave grid inside the workgroup (WZ * WY == 4); tile = XB x (WY*ROWS*YB) x WZ voxels
+// ------------------------------------------------------------------------------------------------------
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+struct Cfg {
+  static constexpr int P = K / 2;
+  static constexpr int K3 = K * K * K;
+  static constexpr int YB = 32 / XB;
+  static constexpr int TX = XB, TY = WY * ROWS * YB, TZ = WZ;
+  static constexpr int HX = TX + 2 * P, HY = TY + 2 * P, HZ = TZ + 2 * P;
+  static constexpr int CS = HX * HY * HZ;                 // per-channel LDS stride (floats)
+  static constexpr int IN_ELEMS = CC * CS;
+  static constexpr int W_SEG = NCB * K3 * 64;              // floats per channel pair for this workgroup
+  static constexpr int W_ELEMS = (CC / 2) * W_SEG;
+  static constexpr int NI = (IN_ELEMS + 255) / 256;       // input staging registers per thread
+  static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;   // weight staging float4 per thread
+  static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS;
+  static_assert(WZ * WY == 4, "4 waves per workgroup");
+  static_assert(W_SEG % 4 == 0, "weights staged as float4");
+};
+
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                          float* __restrict__ out, int cin, int cout, int D, int H, int W,
+                                                          int tiles_x, int tiles_y, int tiles_z, int ncb_total, Epilogue ep) {
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY>;
+  extern __shared__ float lds[];
+  float* lds_in = lds;
+  float* lds_w = lds + C::IN_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wz = wave / WY, wy = wave % WY;
+
+  // block -> (cout tile, x tile, y tile, z tile), batch = blockIdx.y
+  int bid = blockIdx.x;
+  const int co_tiles = (ncb_total + NCB - 1) / NCB;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int tz = bid;
+  const int b = blockIdx.y;
+  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const size_t DHW = (size_t)D * H * W;
+  const float* in_b = in + (size_t)b * cin * DHW;
+  const float in_off = ep.in_off ? *ep.in_off : 0.f;
+
+  // ---- per-thread staging descriptors (constant across chunks except for the channel base) ----
+  int goff[C::NI];          // offset inside one channel-chunk of the input, or -1 for padding / out of tile
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int e = tid + i * 256;
+    int g = -2;             // -2: beyond the tile (no LDS write at all)
+    if (e < C::IN_ELEMS) {
+      const int ci = e / C::CS;
+      const int r = e % C::CS;
+      const int hz = r / (C::HY * C::HX), hy = (r / C::HX) % C::HY, hx = r % C::HX;
+      const int z = z0 + hz - C::P, y = y0 + hy - C::P, x = x0 + hx - C::P;
+      const bool ok = (z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+      g = ok ? (int)(ci * DHW + ((size_t)z * H + y) * W + x) : -1;   // channel-chunk fits in int (checked on host)
+    }
+    goff[i] = g;
+  }
+
+  float rin[C::NI];
+  float4 rw[C::NW4];
+  const int nchunk = (cin + CC - 1) / CC;
+  const float4* wp4 = reinterpret_cast<const float4*>(wp);
+  const size_t w_pair_stride4 = (size_t)ncb_total * C::K3 * 64 / 4;      // one channel pair, all cout blocks
+  const size_t w_tile_off4 = (size_t)cot * NCB * C::K3 * 64 / 4;
+  // valid float4 per channel pair for this cout tile (the last tile may have fewer than NCB blocks)
+  const int ncb_here = min(NCB, ncb_total - cot * NCB);
+  const int seg4_here = ncb_here * C::K3 * 64 / 4;
+  const int npair_total = (cin + 1) / 2;
+
+  auto prefetch = [&](int chunk) {
+    const float* src = in_b + (size_t)chunk * CC * DHW;
+    const int cvalid = min(CC, cin - chunk * CC);          // channels present in this chunk
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {
+      float v = 0.f;
+      const int g = goff[i];
+      if (g >= 0 && ((tid + i * 256) / C::CS) < cvalid) v = src[g] - in_off;
+      rin[i] = v;
+    }
+    const float4* ws = wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4;
+#pragma unroll
+    for (int i = 0; i < C::NW4; ++i) {
+      const int e = tid + i * 256;
+      const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
+      const bool ok = (e < C::W_ELEMS / 4) & (o < seg4_here) & (chunk * (CC / 2) + pr < npair_total);
+      rw[i] = ok ? ws[(size_t)pr * w_pair_stride4 + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i)
+      if (goff[i] != -2) lds_in[tid + i * 256] = rin[i];
+    float4* lw4 = reinterpret_cast<float4*>(lds_w);
+#pragma unroll
+    for (int i = 0; i < C::NW4; ++i) {
+      const int e = tid + i * 256;
+      if (e < C::W_ELEMS / 4) lw4[e] = rw[i];
+    }
+  };
+
+  f32x16 acc[NCB][ROWS];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[c][r][g] = 0.f;
+
+  // per-lane LDS base (floats) of the B fragment for row block r = 0, tap (0,0,0), pair 0
+  const int jx = (lane & 31) % XB, jy = (lane & 31) / XB;
+  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HX) + (wy * ROWS * C::YB + jy) * C::HX + jx;
+
+  prefetch(0);
+  commit();
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    if (chunk + 1 < nchunk) prefetch(chunk + 1);
+#pragma unroll
+    for (int tap = 0; tap < C::K3; ++tap) {
+      const int dz = tap / (K * K), dy = (tap / K) % K, dx = tap % K;
+#pragma unroll
+      for (int pair = 0; pair < CC / 2; ++pair) {
+        float bf[ROWS], af[NCB];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          bf[r] = lds_in[b_base + r * C::YB * C::HX + pair * 2 * C::CS + dz * (C::HY * C::HX) + dy * C::HX + dx];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) af[c] = lds_w[pair * C::W_SEG + (c * C::K3 + tap) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (chunk + 1 < nchunk) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: y = acc*scale + shift ; relu ; * mul ; coalesced NCDHW stores ----
+  const int z = z0 + wz;
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int x = x0 + jx;
+      const int y = y0 + (wy * ROWS + r) * C::YB + jy;
+      if (x < W && y < H && z < D) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+          if (co < cout) {
+            float v = acc[c][r][g];
+            if (ep.scale) v = v * ep.scale[co];
+            if (ep.shift) v = v + ep.shift[co];
+            if (ep.relu) v = v > 0.f ? v : 0.f;
+            const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
+            if (ep.mul) v = v * ep.mul[o];
+            out[o] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Stem kernel: k = 5, Cin = 1 (conv1a, DSN.py:19).  K index = tap (125 -> 63 pairs).  The two halves of
+// a wave read taps 2p and 2p+1; their LDS distance is +1 inside an x run, HX-4 at a dx wrap, and
+// HY*HX-4*HX-4 at a dy wrap: three per-lane base registers, every other offset is an immediate.
+// Tile: 32 x (ROWS*WY) x WZ voxels, all (<=32*NCB) output channels.
+// ------------------------------------------------------------------------------------------------------
+template <int ROWS, int NCB, int WZ, int WY>
+__global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                           float* __restrict__ out, int cout, int D, int H, int W, int tiles_x,
+                                                           int tiles_y, Epilogue ep) {
+  constexpr int K = 5, P = 2, K3 = 125, NPAIR = 63;
+  constexpr int TX = 32, TY = ROWS * WY, TZ = WZ;
+  constexpr int HX = TX + 4, HY = TY + 4, HZ = TZ + 4;
+  constexpr int IN_ELEMS = HX * HY * HZ;
+  constexpr int IN_PAD = IN_ELEMS + 8;
+  constexpr int W_ELEMS = NCB * NPAIR * 64;
+  extern __shared__ float lds[];
+  float* lds_in = lds;
+  float* lds_w = lds + IN_PAD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wz = wave / WY, wy = wave % WY;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int tz = bid;
+  const int b = blockIdx.y;
+  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+  const size_t DHW = (size_t)D * H * W;
+  const float* in_b = in + (size_t)b * DHW;
+  const float in_off = ep.in_off ? *ep.in_off : 0.f;
+  for (int e = tid; e < IN_PAD; e += 256) {
+    float v = 0.f;
+    if (e < IN_ELEMS) {
+      const int hz = e / (HY * HX), hy = (e / HX) % HY, hx = e % HX;
+      const int z = z0 + hz - P, y = y0 + hy - P, x = x0 + hx - P;
+      if ((z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W)) v = in_b[((size_t)z * H + y) * W + x] - in_off;
+    }
+    lds_in[e] = v;
+  }
+  for (int e = tid; e < W_ELEMS; e += 256) lds_w[e] = wp[e];
+  __syncthreads();
+
+  f32x16 acc[NCB][ROWS];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[c][r][g] = 0.f;
+
+  const int jx = lane & 31;
+  const int base0 = wz * (HY * HX) + (wy * ROWS) * HX + jx;
+  const int hi = lane >> 5;
+  const int baseA = base0 + hi * 1;
+  const int baseB = base0 + hi * (HX - 4);
+  const int baseC = base0 + hi * (HY * HX - 4 * HX - 4);
+#pragma unroll
+  for (int pair = 0; pair < NPAIR; ++pair) {
+    const int tap = 2 * pair;
+    const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
+    const int imm = dz * (HY * HX) + dy * HX + dx;
+    // which delta takes tap -> tap+1
+    const int base = (dx < 4) ? baseA : ((dy < 4) ? baseB : baseC);
+    float bf[ROWS], af[NCB];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) bf[r] = lds_in[base + r * HX + imm];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) af[c] = lds_w[(c * NPAIR + pair) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
+  }
+  (void)K; (void)K3;
+  const int z = z0 + wz;
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int x = x0 + jx, y = y0 + wy * ROWS + r;
+      if (x < W && y < H && z < D) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+          if (co < cout) {
+            float v = acc[c][r][g];
+            if (ep.scale) v = v * ep.scale[co];
+            if (ep.shift) v = v + ep.shift[co];
+            if (ep.relu) v = v > 0.f ? v : 0.f;
+            const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
+            if (ep.mul) v = v * ep.mul[o];
+            out[o] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, Epilogue ep,
+               hipStream_t st) {
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY>;
+  const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
+  const int ncb_total = (cout + 31) / 32;
+  const int co_tiles = (ncb_total + NCB - 1) / NCB;
+  const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
+  if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
+  const size_t lds = sizeof(float) * C::LDS_FLOATS;
+  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(256), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
+                     tiles_z, ncb_total, ep);
+  return m3d::check_launch("conv3d_mfma");
+}
+
+}  // namespace
+
+M3D_API size_t m3d_conv3d_packed_weight_bytes(int cin, int cout, int k, int mode) {
+  const bool dgrad = (mode == M3D_W_DGRAD || mode == M3D_W_DGRAD_RELU);
+  const int cin_l = dgrad ? cout : cin, cout_l = dgrad ? cin : cout;
+  if (k == 5 && cin_l == 1) return sizeof(float) * (size_t)((cout_l + 31) / 32) * 63 * 64;
+  const size_t npair = (cin_l + 1) / 2, ncb = (cout_l + 31) / 32;
+  return sizeof(float) * npair * ncb * (size_t)(k * k * k) * 64;
+}
+
+M3D_API int m3d_conv3d_pack_weights(const float* d_weight, int cin, int cout, int k, int mode, float* d_packed, void* stream) {
+  if (!d_weight || !d_packed || cin <= 0 || cout <= 0 || mode < 0 || mode > 3) return M3D_EINVAL;
+  const bool dgrad = (mode == M3D_W_DGRAD || mode == M3D_W_DGRAD_RELU);
+  const int cin_l = dgrad ? cout : cin, cout_l = dgrad ? cin : cout;
+  hipStream_t st = m3d::as_stream(stream);
+  if (k == 5 && cin_l == 1) {
+    if (dgrad) return M3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(pack_stem_kernel, dim3(64), dim3(256), 0, st, d_weight, cout, 125, mode, d_packed, 63);
+    return m3d::check_launch("pack_stem");
+  }
+  if (k != 1 && k != 3) return M3D_EUNSUPPORTED;
+  const int npair = (cin_l + 1) / 2, ncb = (cout_l + 31) / 32;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(1024), dim3(256), 0, st, d_weight, cin, cout, k, mode, d_packed, ncb, npair);
+  return m3d::check_launch("pack_weights");
+}
+
+M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                               int height, int width, int k, const float* d_in_offset, const float* d_scale,
+                               const float* d_shift, int relu, const float* d_mul, void* stream) {
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
+    return M3D_EINVAL;
+  const size_t DHW = (size_t)depth * height * width;
+  if (DHW * 32 >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // int offsets inside a channel chunk
+  hipStream_t st = m3d::as_stream(stream);
+  Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu};
+  if (k == 5) {
+    if (cin != 1 || cout > 64) return M3D_EUNSUPPORTED;
+    constexpr int ROWS = 8, WZ = 4, WY = 1;
+    const int tiles_x = (width + 31) / 32, tiles_y = (height + ROWS * WY - 1) / (ROWS * WY), tiles_z = (depth + WZ - 1) / WZ;
+    const long long blocks = (long long)tiles_x * tiles_y * tiles_z;
+    if (blocks > 0x7FFFFFFFll || batch > 65535) return M3D_EUNSUPPORTED;
+    if (cout <= 32) {
+      constexpr int NCB = 1;
+      const size_t lds = sizeof(float) * (36 * (ROWS * WY + 4) * (WZ + 4) + 8 + NCB * 63 * 64);
+      hipLaunchKernelGGL((conv3d_stem5_kernel<ROWS, NCB, WZ, WY>), dim3((unsigned)blocks, batch), dim3(256), lds, st, d_in,
+                         d_packed, d_out, cout, depth, height, width, tiles_x, tiles_y, ep);
+    } else {
+      constexpr int NCB = 2, R2 = 4;
+      const int ty2 = (height + R2 - 1) / R2;
+      const long long blocks2 = (long long)tiles_x * ty2 * tiles_z;
+      const size_t lds = sizeof(float) * (36 * (R2 + 4) * (WZ + 4) + 8 + NCB * 63 * 64);
+      hipLaunchKernelGGL((conv3d_stem5_kernel<R2, NCB, WZ, WY>), dim3((unsigned)blocks2, batch), dim3(256), lds, st, d_in,
+                         d_packed, d_out, cout, depth, height, width, tiles_x, ty2, ep);
+    }
+    return m3d::check_launch("conv3d_stem5");
+  }
+  if (k == 3) {
+    // Tile choice: keep >= ~2 workgroups per CU in flight; prefer big tiles (more MFMAs per staged byte).
+    const long long vox = (long long)batch * DHW;
+    const int ncb_total = (cout + 31) / 32;
+    if (width >= 24) {
+      const long long wg_big = (vox / 512) * ((ncb_total + 1) / 2);
+      if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      const long long wg_mid = (vox / 256) * ((ncb_total + 1) / 2);
+      if (wg_mid >= 256) return launch_cfg<3, 4, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      return launch_cfg<3, 4, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    }
+    if (width >= 12) {
+      const long long wg = (vox / 256) * ((ncb_total + 1) / 2);
+      if (wg >= 512) return launch_cfg<3, 4, 16, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      return launch_cfg<3, 4, 16, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    }
+    return launch_cfg<3, 4, 8, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  }
+  if (k == 1) {
+    if (width >= 24) return launch_cfg<1, 32, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    if (width >= 12) return launch_cfg<1, 32, 16, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    return launch_cfg<1, 32, 8, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  }
+  return M3D_EUNSUPPORTED;
+}

@@ -1,0 +1,25 @@
+// Shared helpers for libm3d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/m3d.h"
+
+#define M3D_API extern "C" __attribute__((visibility("default")))
+
+namespace m3d {
+extern thread_local char g_last_hip_error[256];
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s: %s", what, hipGetErrorString(e));
+    return M3D_ELAUNCH;
+  }
+  return M3D_OK;
+}
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int kWave = 64;
+}  // namespace m3d

@@ -1,0 +1,118 @@
+// MaxPool3d(2,2) forward/backward and small reductions for gfx950 (HBM-bound elementwise work).
+// Reference call sites: lib/modeling/DSN.py:21,26,32 (nn.MaxPool3d(2, 2, padding=0), floor mode) and
+// lib/prm/peak_backprop_3d.py:38 (input.min()).
+#include "m3d_common.h"
+
+namespace {
+
+// one thread per output voxel; window scanned in (z,y,x) order, first maximum wins (PyTorch semantics;
+// NaN propagates: a NaN beats everything once seen).
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           uint8_t* __restrict__ argmax, long long total, int D, int H, int W,
+                                                           int OD, int OH, int OW) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % OW);
+    long long t = e / OW;
+    const int oy = (int)(t % OH); t /= OH;
+    const int oz = (int)(t % OD);
+    const long long bc = t / OD;
+    const float* p = in + ((bc * D + 2 * oz) * H + 2 * oy) * (long long)W + 2 * ox;
+    float best = p[0];
+    int bi = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const float v = p[((q >> 2) * H + ((q >> 1) & 1)) * (long long)W + (q & 1)];
+      if (v > best || (v != v && best == best)) { best = v; bi = q; }
+    }
+    out[e] = best;
+    if (argmax) argmax[e] = (uint8_t)bi;
+  }
+}
+
+// gradient routed to the argmax voxel; every input voxel belongs to at most one window => plain stores.
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ gout, const uint8_t* __restrict__ argmax,
+                                                           float* __restrict__ gin, long long total_in, int D, int H, int W,
+                                                           int OD, int OH, int OW) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total_in; e += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % W);
+    long long t = e / W;
+    const int y = (int)(t % H); t /= H;
+    const int z = (int)(t % D);
+    const long long bc = t / D;
+    const int ox = x >> 1, oy = y >> 1, oz = z >> 1;
+    float g = 0.f;
+    if (ox < OW && oy < OH && oz < OD) {
+      const long long o = ((bc * OD + oz) * OH + oy) * (long long)OW + ox;
+      const int q = ((z & 1) << 2) | ((y & 1) << 1) | (x & 1);
+      if (argmax[o] == q) g = gout[o];
+    }
+    gin[e] = g;
+  }
+}
+
+__device__ inline float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// two-stage min reduction; partial[blocks] then final (x.min(), peak_backprop_3d.py:38)
+__global__ __launch_bounds__(256) void min_partial_kernel(const float* __restrict__ in, long long n, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  float v = INFINITY;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    v = fminf(v, in[e]);
+  v = wave_min(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void min_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  __shared__ float sm[4];
+  float v = INFINITY;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) v = fminf(v, partial[e]);
+  v = wave_min(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
+}
+
+inline unsigned grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+M3D_API int m3d_maxpool3d_2x_forward(const float* d_in, float* d_out, uint8_t* d_argmax, int batch_channels, int depth,
+                                     int height, int width, void* stream) {
+  if (!d_in || !d_out || batch_channels <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
+  const int OD = depth / 2, OH = height / 2, OW = width / 2;
+  const long long total = (long long)batch_channels * OD * OH * OW;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, m3d::as_stream(stream), d_in, d_out, d_argmax,
+                     total, depth, height, width, OD, OH, OW);
+  return m3d::check_launch("maxpool3d_2x_forward");
+}
+
+M3D_API int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, float* d_grad_in, int batch_channels,
+                                      int depth, int height, int width, void* stream) {
+  if (!d_grad_out || !d_argmax || !d_grad_in || batch_channels <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
+  const int OD = depth / 2, OH = height / 2, OW = width / 2;
+  const long long total = (long long)batch_channels * depth * height * width;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, m3d::as_stream(stream), d_grad_out, d_argmax,
+                     d_grad_in, total, depth, height, width, OD, OH, OW);
+  return m3d::check_launch("maxpool3d_2x_backward");
+}
+
+M3D_API size_t m3d_reduce_min_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+M3D_API int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_in || !d_out || !d_ws || n <= 0) return M3D_EINVAL;
+  if (ws_bytes < 1024 * sizeof(float)) return M3D_EWORKSPACE;
+  long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(min_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream), d_in, (long long)n,
+                     (float*)d_ws);
+  hipLaunchKernelGGL(min_final_kernel, dim3(1), dim3(256), 0, m3d::as_stream(stream), (const float*)d_ws, (int)blocks, d_out);
+  return m3d::check_launch("reduce_min");
+}

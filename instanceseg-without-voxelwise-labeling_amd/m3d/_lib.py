@@ -1,0 +1,49 @@
+"""ctypes loader for libm3d.so (include/m3d.h).  Fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libm3d.so")
+
+M3D_OK = 0
+_lib = None
+
+SYMBOLS = [
+    "m3d_version", "m3d_error_string", "m3d_last_hip_error",
+    "m3d_roi_align3d_forward", "m3d_roi_align3d_backward",
+    "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
+    "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
+    "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_pack_weights", "m3d_conv3d_forward",
+    "m3d_maxpool3d_2x_forward", "m3d_maxpool3d_2x_backward",
+    "m3d_reduce_min_workspace_bytes", "m3d_reduce_min",
+    "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch",
+]
+
+
+class M3DError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M3DError("libm3d.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C instanceseg-without-voxelwise-labeling_amd/csrc`. There is no CPU fallback."
+                           % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.m3d_error_string.restype = C.c_char_p
+        L.m3d_last_hip_error.restype = C.c_char_p
+        for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
+                  "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_otsu2d_workspace_bytes"):
+            getattr(L, n).restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != M3D_OK:
+        L = lib()
+        msg = L.m3d_error_string(rc).decode()
+        hip = L.m3d_last_hip_error().decode()
+        raise M3DError("%s failed: %s (%d) %s" % (what or "m3d call", msg, rc, hip))

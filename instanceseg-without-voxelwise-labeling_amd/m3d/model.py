@@ -1,0 +1,122 @@
+"""Host-side counterpart of the reference's inference graph, running on the HIP kernels.
+
+Mirrors (reference paths): lib/modeling/DSN.py:57-68 (dsn_body), lib/modeling/rpn_heads.py:88-137
+(single_scale_rpn_outputs), lib/modeling/generate_proposals_3d.py (via m3d.generate_proposals3d),
+lib/modeling/model_builder.py:294-312 (roi_feature_transform, RoIAlign branch),
+lib/modeling/fast_rcnn_heads.py:104-117,39-47 (roi_2mlp_head, fast_rcnn_outputs),
+lib/core/test.py:194-263,806-883 (im_detect_bbox, box_results_with_nms_and_limit).
+The state-dict key layout is the reference's: Conv_Body.conv1a.weight ... Box_Outs.bbox_pred.bias.
+
+Linear layers go to rocBLAS through torch (plain library GEMMs); every other op is a libm3d.so kernel.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+BN_EPS = 1e-5   # nn.BatchNorm3d default, DSN.py:20
+
+
+def dsn_layers(stride):
+    if stride == 8:
+        return [("conv1a", "bn1a", True), ("conv2a", "bn2a", False), ("conv2b", "bn2b", True), ("conv3a", "bn3a", False),
+                ("conv3b", "bn3b", True), ("conv4a", "bn4a", False), ("conv4b", "bn4b", False)]
+    return [("conv1a", "bn1a", True), ("conv2a", "bn2a", False), ("conv2b", "bn2b", True), ("conv3a", "bn3a", False),
+            ("conv3b", "bn3b", False)]
+
+
+class DetectorM3D:
+    def __init__(self, params, cfg):
+        """params: dict of CUDA fp32 tensors with the reference's state-dict keys; cfg: object with the
+        attributes of oracle.Cfg (stride, anchors, pre/post_nms_topN, thresholds, ...)."""
+        self.cfg = cfg
+        self.P = params
+        self.anchors = np.ascontiguousarray(cfg.anchors, dtype=np.float64)
+        self.body = []
+        for cname, bname, pool in dsn_layers(cfg.stride):
+            c, b = "Conv_Body." + cname, "Conv_Body." + bname
+            conv = ops.PackedConv3d(params[c + ".weight"])
+            scale = (params[b + ".weight"] / torch.sqrt(params[b + ".running_var"] + BN_EPS)).contiguous()
+            shift = ((params[c + ".bias"] - params[b + ".running_mean"]) * scale + params[b + ".bias"]).contiguous()
+            self.body.append((conv, scale, shift, pool))
+        self.rpn_conv = ops.PackedConv3d(params["RPN.RPN_conv.weight"])
+        self.rpn_conv_bias = params["RPN.RPN_conv.bias"].contiguous()
+        self.A = params["RPN.RPN_cls_score.weight"].shape[0]
+        # the two 1x1x1 heads share their input: one conv with A + 6A output channels (rpn_heads.py:96-98)
+        w = torch.cat([params["RPN.RPN_cls_score.weight"], params["RPN.RPN_bbox_pred.weight"]], 0).contiguous()
+        self.rpn_heads = ops.PackedConv3d(w)
+        self.rpn_heads_bias = torch.cat([params["RPN.RPN_cls_score.bias"], params["RPN.RPN_bbox_pred.bias"]]).contiguous()
+        self.has_head = "Box_Head.fc1.weight" in params
+
+    # ---- lib/modeling/DSN.py:57-68
+    def conv_body(self, x):
+        for conv, scale, shift, pool in self.body:
+            x = conv(x, scale=scale, shift=shift, relu=True)
+            if pool:
+                x = ops.maxpool3d_2x(x)
+        return x
+
+    # ---- lib/modeling/rpn_heads.py:94-116
+    def rpn(self, feat):
+        h = self.rpn_conv(feat, shift=self.rpn_conv_bias, relu=True)
+        o = self.rpn_heads(h, shift=self.rpn_heads_bias)
+        logits, deltas = o[:, :self.A], o[:, self.A:]
+        return torch.sigmoid(logits), deltas.contiguous()
+
+    def proposals(self, prob, deltas, im_info):
+        c = self.cfg
+        return ops.generate_proposals3d(prob[0].contiguous(), deltas[0], self.anchors, float(c.stride), im_info,
+                                        c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
+
+    # ---- lib/modeling/fast_rcnn_heads.py:104-117,39-47
+    def box_head(self, feat, rois):
+        c, P = self.cfg, self.P
+        x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
+        x = x.view(x.shape[0], -1)
+        x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"]))
+        x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc2.weight"], P["Box_Head.fc2.bias"]))
+        cls = torch.softmax(torch.nn.functional.linear(x, P["Box_Outs.cls_score.weight"], P["Box_Outs.cls_score.bias"]), dim=1)
+        bbox = torch.nn.functional.linear(x, P["Box_Outs.bbox_pred.weight"], P["Box_Outs.bbox_pred.bias"])
+        return cls, bbox
+
+    # ---- lib/core/test.py:806-883 (device-side; SOFT_NMS / BBOX_VOTE off)
+    def box_results_with_nms_and_limit(self, scores, boxes, scores_keep_idx=None):
+        c = self.cfg
+        cls_boxes = [torch.zeros((0, 7), device=scores.device) for _ in range(c.num_classes)]
+        cls_keep = [torch.zeros((0,), dtype=torch.int64, device=scores.device) for _ in range(c.num_classes)]
+        for j in range(1, c.num_classes):
+            inds = torch.nonzero(scores[:, j] > c.score_thresh).squeeze(1)           # :836
+            dets_j = torch.cat([boxes[inds, j * 6:(j + 1) * 6], scores[inds, j:j + 1]], 1).float().contiguous()
+            keep = ops.nms3d(dets_j, c.nms)                                          # :851
+            cls_boxes[j] = dets_j[keep]
+            if scores_keep_idx is not None:
+                cls_keep[j] = scores_keep_idx[inds][keep]
+        if c.detections_per_im > 0:                                                  # :869-878 (cap semantics)
+            image_scores = torch.cat([cls_boxes[j][:, -1] for j in range(1, c.num_classes)])
+            if image_scores.numel() > c.detections_per_im:
+                image_thresh = torch.sort(image_scores)[0][-c.detections_per_im]
+                for j in range(1, c.num_classes):
+                    keep = torch.nonzero(cls_boxes[j][:, -1] >= image_thresh).squeeze(1)
+                    cls_boxes[j] = cls_boxes[j][keep]
+                    if scores_keep_idx is not None:
+                        cls_keep[j] = cls_keep[j][keep]
+        im_results = torch.cat([cls_boxes[j] for j in range(1, c.num_classes)], 0)
+        return im_results[:, -1], im_results[:, :-1], cls_boxes, cls_keep
+
+    # ---- one tile, detection only: model_builder.py:151-240 + core/test.py:194-263
+    def detect_tile(self, data, im_info=None):
+        c = self.cfg
+        S, H, W = data.shape[-3:]
+        if im_info is None:
+            im_info = np.array([S, H, W, 1.0], np.float64)
+        feat = self.conv_body(data)
+        prob, deltas = self.rpn(feat)
+        rois, probs, keep_idx = self.proposals(prob, deltas, im_info)
+        out = dict(feat=feat, rpn_prob=prob, rpn_deltas=deltas, rois=rois, roi_probs=probs, keep_idx=keep_idx)
+        if not self.has_head or rois.shape[0] == 0:
+            return out
+        cls, bbox = self.box_head(feat, rois)
+        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
+        sc, bx, cls_boxes, cls_keep = self.box_results_with_nms_and_limit(cls, pred, keep_idx)
+        out.update(cls=cls, bbox=bbox, pred_boxes=pred, det_scores=sc, det_boxes=bx, cls_boxes=cls_boxes, cls_keep=cls_keep)
+        return out

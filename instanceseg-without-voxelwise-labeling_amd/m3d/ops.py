@@ -1,0 +1,213 @@
+"""Tensor-level wrappers over the C ABI (include/m3d.h).  Every function takes/returns torch CUDA tensors and
+launches on the current torch stream; none of them synchronises unless the result size is data dependent."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, M3DError
+
+BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
+
+__all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
+           "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
+           "otsu2d_batch", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+
+W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise M3DError("m3d ops need CUDA (ROCm) tensors; there is no CPU path")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t):
+    return t.contiguous().float() if (t.dtype != torch.float32 or not t.is_contiguous()) else t
+
+
+# ------------------------------------------------------------------ RoIAlign3D
+def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio):
+    _need_gpu(features, rois)
+    features, rois = _f32c(features), _f32c(rois)
+    B, Cc, S, H, W = features.shape
+    R = rois.shape[0]
+    out = torch.zeros((R, Cc, AS, AH, AW), dtype=torch.float32, device=features.device)   # roi_align_3d.py:24
+    check(lib().m3d_roi_align3d_forward(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
+                                        _ptr(features), B, Cc, S, H, W, _ptr(rois), R, int(rois.shape[1]) if rois.dim() == 2 else 0,
+                                        _ptr(out), _stream()), "roi_align3d_forward")
+    return out
+
+
+def roi_align3d_backward(top_grad, rois, feature_size, AS, AH, AW, spatial_scale, sampling_ratio):
+    _need_gpu(top_grad, rois)
+    top_grad, rois = _f32c(top_grad), _f32c(rois)
+    B, Cc, S, H, W = feature_size
+    grad = torch.zeros((B, Cc, S, H, W), dtype=torch.float32, device=top_grad.device)      # roi_align_3d.py:41-42
+    check(lib().m3d_roi_align3d_backward(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
+                                         _ptr(top_grad), _ptr(rois), rois.shape[0], int(rois.shape[1]), _ptr(grad),
+                                         B, Cc, S, H, W, _stream()), "roi_align3d_backward")
+    return grad
+
+
+# ------------------------------------------------------------------ NMS / IoU / decode
+def nms3d(dets, thresh, by_volume=False):
+    """dets [N,7] fp32 CUDA -> int64 CUDA tensor of kept input indices (ascending)."""
+    _need_gpu(dets)
+    dets = _f32c(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=dets.device)
+    if dets.dim() != 2 or dets.shape[1] != 7:
+        raise ValueError("dets must be [N,7]")
+    keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    wsb = lib().m3d_nms3d_workspace_bytes(n)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dets.device)
+    check(lib().m3d_nms3d(_ptr(dets), n, C.c_float(np.float32(thresh)), int(bool(by_volume)), _ptr(keep), _ptr(num),
+                          _ptr(ws), C.c_size_t(wsb), _stream()), "nms3d")
+    return keep[:int(num.item())]
+
+
+def bbox_overlaps3d(boxes, query):
+    _need_gpu(boxes, query)
+    boxes, query = _f32c(boxes), _f32c(query)
+    out = torch.empty((boxes.shape[0], query.shape[0]), dtype=torch.float32, device=boxes.device)
+    check(lib().m3d_bbox_overlaps3d(_ptr(boxes), boxes.shape[0], _ptr(query), query.shape[0], _ptr(out), _stream()),
+          "bbox_overlaps3d")
+    return out
+
+
+def bbox_transform3d(boxes, deltas, weights=(1.,) * 6, clip_to=None, xform_clip=BBOX_XFORM_CLIP):
+    """boxes [N,6], deltas [N,6k] -> [N,6k]; clip_to=(slices,height,width) fuses clip_tiled_boxes_3d."""
+    _need_gpu(boxes, deltas)
+    boxes, deltas = _f32c(boxes), _f32c(deltas)
+    n, k = boxes.shape[0], deltas.shape[1] // 6
+    out = torch.empty_like(deltas)
+    w = (C.c_double * 6)(*[float(x) for x in weights])
+    cs, ch, cw = (0., 0., 0.) if clip_to is None else [float(v) for v in clip_to]
+    check(lib().m3d_bbox_transform3d(_ptr(boxes), _ptr(deltas), n, k, w, C.c_double(xform_clip), C.c_double(cs),
+                                     C.c_double(ch), C.c_double(cw), _ptr(out), _stream()), "bbox_transform3d")
+    return out
+
+
+def generate_proposals3d(scores, deltas, anchors, feat_stride, im_info, pre_nms_topN, post_nms_topN, nms_thresh,
+                         min_size=0.0, batch_index=0, xform_clip=BBOX_XFORM_CLIP):
+    """scores [A,S,H,W], deltas [6A,S,H,W] CUDA fp32; anchors [A,6] float64 numpy.
+    Returns (rois [R,7] f32, probs [R,1] f32, keep_idx [R] i64) on device."""
+    _need_gpu(scores, deltas)
+    scores, deltas = _f32c(scores), _f32c(deltas)
+    A, S, H, W = scores.shape
+    assert deltas.shape == (6 * A, S, H, W)
+    total = A * S * H * W
+    K = total if (pre_nms_topN <= 0 or pre_nms_topN >= total) else pre_nms_topN
+    cap = K
+    dev = scores.device
+    rois = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    probs = torch.empty((cap,), dtype=torch.float32, device=dev)
+    kidx = torch.empty((cap,), dtype=torch.int64, device=dev)
+    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    wsb = lib().m3d_generate_proposals3d_workspace_bytes(A, S, H, W, int(pre_nms_topN))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    anc = np.ascontiguousarray(anchors, dtype=np.float64)
+    info = np.ascontiguousarray(im_info, dtype=np.float64)
+    check(lib().m3d_generate_proposals3d(_ptr(scores), _ptr(deltas), A, S, H, W, anc.ctypes.data_as(C.c_void_p),
+                                         C.c_double(feat_stride), info.ctypes.data_as(C.c_void_p), int(pre_nms_topN),
+                                         int(post_nms_topN), C.c_float(np.float32(nms_thresh)), C.c_double(min_size),
+                                         C.c_double(xform_clip), int(batch_index), _ptr(rois), _ptr(probs), _ptr(kidx),
+                                         _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()), "generate_proposals3d")
+    r = int(num.item())
+    return rois[:r], probs[:r].unsqueeze(1), kidx[:r]
+
+
+# ------------------------------------------------------------------ conv / pool
+class PackedConv3d:
+    """A Conv3d weight packed once into MFMA A-fragment order (m3d_conv3d_pack_weights)."""
+
+    def __init__(self, weight, mode=W_PLAIN):
+        _need_gpu(weight)
+        weight = _f32c(weight)
+        self.cout_w, self.cin_w, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert weight.shape[2] == weight.shape[3] == weight.shape[4]
+        self.mode = mode
+        dgrad = mode in (W_DGRAD, W_DGRAD_RELU)
+        self.cin = self.cout_w if dgrad else self.cin_w      # logical conv this pack implements
+        self.cout = self.cin_w if dgrad else self.cout_w
+        nbytes = lib().m3d_conv3d_packed_weight_bytes(self.cin_w, self.cout_w, self.k, mode)
+        self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=weight.device)
+        check(lib().m3d_conv3d_pack_weights(_ptr(weight), self.cin_w, self.cout_w, self.k, mode, _ptr(self.packed), _stream()),
+              "conv3d_pack_weights")
+
+    def __call__(self, x, scale=None, shift=None, relu=False, in_offset=None, mul=None, out=None):
+        _need_gpu(x)
+        x = _f32c(x)
+        B, Cin, D, H, W = x.shape
+        if Cin != self.cin:
+            raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
+        if out is None:
+            out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
+        for t in (scale, shift):
+            if t is not None:
+                assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.cout and t.is_contiguous()
+        if mul is not None:
+            assert mul.shape == out.shape and mul.is_contiguous() and mul.dtype == torch.float32
+        check(lib().m3d_conv3d_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, self.k,
+                                       _ptr(in_offset), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(mul), _stream()),
+              "conv3d_forward")
+        return out
+
+
+def maxpool3d_2x(x, return_argmax=False):
+    _need_gpu(x)
+    x = _f32c(x)
+    B, Cc, D, H, W = x.shape
+    out = torch.empty((B, Cc, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    am = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if return_argmax else None
+    check(lib().m3d_maxpool3d_2x_forward(_ptr(x), _ptr(out), _ptr(am), B * Cc, D, H, W, _stream()), "maxpool3d_2x_forward")
+    return (out, am) if return_argmax else out
+
+
+def maxpool3d_2x_backward(grad_out, argmax, in_shape):
+    _need_gpu(grad_out, argmax)
+    grad_out = _f32c(grad_out)
+    B, Cc, D, H, W = in_shape
+    gin = torch.empty(in_shape, dtype=torch.float32, device=grad_out.device)
+    check(lib().m3d_maxpool3d_2x_backward(_ptr(grad_out), _ptr(argmax), _ptr(gin), B * Cc, D, H, W, _stream()),
+          "maxpool3d_2x_backward")
+    return gin
+
+
+def reduce_min(x):
+    _need_gpu(x)
+    x = _f32c(x)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    wsb = lib().m3d_reduce_min_workspace_bytes()
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    check(lib().m3d_reduce_min(_ptr(x), C.c_int64(x.numel()), _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min")
+    return out
+
+
+# ------------------------------------------------------------------ Otsu 2D
+def otsu2d_batch(image, prm, offsets, max_gray_range=4096):
+    """image, prm: flat uint16 CUDA tensors (crops concatenated); offsets int64 [R+1] CUDA.
+    Returns (mask uint8 flat, kb int32 [R,2], status int32 [R])."""
+    _need_gpu(image, prm, offsets)
+    assert image.dtype == torch.uint16 and prm.dtype == torch.uint16 and offsets.dtype == torch.int64
+    R = offsets.numel() - 1
+    mask = torch.empty(image.shape, dtype=torch.uint8, device=image.device)
+    kb = torch.zeros((R, 2), dtype=torch.int32, device=image.device)
+    status = torch.zeros((R,), dtype=torch.int32, device=image.device)
+    wsb = lib().m3d_otsu2d_workspace_bytes(R, int(max_gray_range))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=image.device)
+    check(lib().m3d_otsu2d_batch(_ptr(image), _ptr(prm), _ptr(offsets), R, int(max_gray_range), _ptr(mask), _ptr(kb),
+                                 _ptr(status), _ptr(ws), C.c_size_t(wsb), _stream()), "otsu2d_batch")
+    return mask, kb, status

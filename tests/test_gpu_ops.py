@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/m3d.h) against the CPU oracle and the golden
+fixtures generated from the reference.  Bit-exact for integer/index work; fp32 conv within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m3d():
+    import m3d as _m
+    assert torch.cuda.is_available()
+    return _m
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------ NMS
+def test_nms_golden_bit_exact(m3d, golden):
+    g = golden("nms")
+    for i in range(int(g["ncases"])):
+        dets, thr = g["dets%d" % i], float(g["thr%d" % i])
+        assert np.array_equal(m3d.nms3d(dev(dets), thr).cpu().numpy(), g["keep%d" % i]), i
+        if "keepvol%d" % i in g:
+            assert np.array_equal(m3d.nms3d(dev(dets), thr, by_volume=True).cpu().numpy(), g["keepvol%d" % i]), i
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 3000, 9000])
+def test_nms_vs_oracle_random_and_ties(m3d, n):
+    rs = np.random.RandomState(n)
+    c = rs.uniform(0, 100, (n, 3)); s = rs.uniform(4, 40, (n, 3))
+    b = np.hstack((c - s / 2, c + s / 2))
+    sc = np.round(rs.uniform(0, 1, n), 2)            # many exact score ties -> exercises the tie rule
+    dets = np.hstack((b, sc[:, None])).astype(np.float32)
+    for thr in (0.15, 0.5):
+        assert np.array_equal(m3d.nms3d(dev(dets), thr).cpu().numpy(), O.nms_3d(dets, thr))
+    assert np.array_equal(m3d.nms3d(dev(dets), 0.3, by_volume=True).cpu().numpy(), O.nms_3d_volume(dets, 0.3))
+
+
+def test_nms_empty_and_idempotent(m3d):
+    assert m3d.nms3d(torch.zeros((0, 7), device="cuda"), 0.3).numel() == 0
+    rs = np.random.RandomState(5)
+    c = rs.uniform(0, 60, (500, 3)); s = rs.uniform(4, 30, (500, 3))
+    dets = np.hstack((c - s / 2, c + s / 2, rs.permutation(500)[:, None] / 500.)).astype(np.float32)
+    k1 = m3d.nms3d(dev(dets), 0.2).cpu().numpy()
+    k2 = m3d.nms3d(dev(dets[k1]), 0.2).cpu().numpy()
+    assert np.array_equal(k2, np.arange(len(k1)))       # survivors do not suppress each other
+
+
+# ------------------------------------------------------------------ IoU / decode
+def test_overlaps(m3d, golden):
+    g = golden("overlaps")
+    assert np.array_equal(m3d.bbox_overlaps3d(dev(g["boxes"]), dev(g["query"])).cpu().numpy(), g["out"])
+    rs = np.random.RandomState(1)
+    a = rs.uniform(0, 50, (300, 6)).astype(np.float32); a[:, 3:] += a[:, :3]
+    q = rs.uniform(0, 50, (77, 6)).astype(np.float32); q[:, 3:] += q[:, :3]
+    assert np.array_equal(m3d.bbox_overlaps3d(dev(a), dev(q)).cpu().numpy(), O.bbox_overlaps_3d(a, q))
+
+
+def test_bbox_transform(m3d, golden):
+    g = golden("boxes")
+    t1 = m3d.bbox_transform3d(dev(g["boxes"]), dev(g["d1"])).cpu().numpy()
+    t2 = m3d.bbox_transform3d(dev(g["boxes"]), dev(g["d2"]), tuple(g["w2"])).cpu().numpy()
+    # device exp() vs NumPy exp(): fp64 last-ulp differences can move the fp32 rounding -> 1 fp32 ulp
+    for got, ref in ((t1, g["t1"]), (t2, g["t2"])):
+        assert np.allclose(got, ref, rtol=2e-7, atol=1e-5)
+        assert (got == ref).mean() > 0.98
+    c2 = m3d.bbox_transform3d(dev(g["boxes"]), dev(g["d2"]), tuple(g["w2"]), clip_to=(64, 200, 200)).cpu().numpy()
+    assert np.allclose(c2, g["c2"], rtol=2e-7, atol=1e-5)
+    assert c2.min() >= 0 and c2[:, 0::6].max() <= 199 and c2[:, 2::6].max() <= 63
+
+
+# ------------------------------------------------------------------ proposals
+@pytest.mark.parametrize("tag,sizes,ratios", [
+    ("n", (10, 27, 33, 38, 42, 46, 50), [[1.0, 0.5], [0.5, 0.5], [2., 0.5], [0.2, 0.5], [3., 2.]]),
+    ("s", (10, 12, 14, 16, 18, 20, 22, 24, 28, 30, 34, 36, 38, 40), [[1.0, 1.0]])])
+def test_generate_proposals_golden(m3d, golden, tag, sizes, ratios):
+    g = golden("proposals")
+    stride = float(g[tag + "_stride"])
+    anchors = O.generate_anchors_3d(stride, sizes, ratios)
+    rois, probs, kidx = m3d.generate_proposals3d(dev(g[tag + "_scores"][0]), dev(g[tag + "_deltas"][0]), anchors, stride,
+                                                 g[tag + "_im_info"][0], int(g["pre"]), int(g["post"]), float(g[tag + "_thr"]))
+    assert np.array_equal(kidx.cpu().numpy(), g[tag + "_keep_idx"])
+    assert np.array_equal(probs.cpu().numpy(), g[tag + "_probs"])
+    assert np.allclose(rois.cpu().numpy(), g[tag + "_rois"], rtol=2e-7, atol=1e-5)
+
+
+def test_generate_proposals_vs_oracle_full_size_with_ties(m3d):
+    rs = np.random.RandomState(3)
+    A, S, H, W = 35, 16, 16, 16                         # config[1]/[2] size: 143 360 anchors
+    cfg = O.Cfg()
+    sc = rs.uniform(0, 1, (A, S, H, W)).astype(np.float32)
+    sc[rs.uniform(0, 1, sc.shape) > 0.995] = 1.0        # saturated sigmoid: exact ties at the top
+    dl = (rs.randn(6 * A, S, H, W) * 0.2).astype(np.float32)
+    info = np.array([128., 128., 128., 1.0])
+    r0, p0, k0 = O.generate_proposals_3d(sc, dl, info, cfg.anchors, 8, 1000, 1000, 0.15, 0)
+    r1, p1, k1 = m3d.generate_proposals3d(dev(sc), dev(dl), cfg.anchors, 8., info, 1000, 1000, 0.15)
+    assert np.array_equal(k1.cpu().numpy(), k0)
+    assert np.array_equal(p1.cpu().numpy(), p0)
+    assert np.allclose(r1.cpu().numpy(), r0, rtol=2e-7, atol=1e-5)
+    # properties: scores sorted descending, boxes inside the image
+    p = p1.cpu().numpy().ravel()
+    assert np.all(p[:-1] >= p[1:])
+    r = r1.cpu().numpy()
+    assert r[:, 1:].min() >= 0 and r[:, 1:].max() <= 127
+
+
+# ------------------------------------------------------------------ RoIAlign3D
+@pytest.mark.parametrize("shape,R,res,ratio", [((1, 8, 8, 8, 8), 5, 7, 2), ((2, 16, 6, 9, 11), 33, 7, 2),
+                                                ((1, 4, 5, 6, 7), 9, 3, 0), ((1, 256, 16, 16, 16), 200, 7, 2)])
+def test_roi_align_forward_bit_exact(m3d, shape, R, res, ratio):
+    rs = np.random.RandomState(R)
+    f = rs.randn(*shape).astype(np.float32)
+    B, _, S, H, W = shape
+    c = rs.uniform(-8, 8 * max(S, H, W) + 8, (R, 3)); s = rs.uniform(1, 60, (R, 3))
+    rois = np.hstack((rs.randint(0, B, (R, 1)), c - s / 2, c + s / 2)).astype(np.float32)
+    rois[0, 4:] = rois[0, 1:4] - 3          # malformed (x2 < x1)
+    rois[1, 1:] = 4000.                     # fully outside
+    got = m3d.roi_align3d_forward(dev(f), dev(rois), res, res, res, 0.125, ratio).cpu().numpy()
+    ref = O.roi_align_3d_forward(f, rois, res, res, res, 0.125, ratio)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_roi_align_bad_cols_and_empty(m3d):
+    f = torch.zeros((1, 2, 4, 4, 4), device="cuda")
+    with pytest.raises(m3d.M3DError):
+        m3d.roi_align3d_forward(f, torch.zeros((3, 5), device="cuda"), 7, 7, 7, 0.125, 2)   # roi_align_cuda_3d.c:19-22
+    assert m3d.roi_align3d_forward(f, torch.zeros((0, 7), device="cuda"), 7, 7, 7, 0.125, 2).shape == (0, 2, 7, 7, 7)
+
+
+def test_roi_align_backward(m3d):
+    rs = np.random.RandomState(9)
+    shape = (2, 6, 5, 7, 8)
+    rois = np.array([[1, 4, 4, 4, 40, 36, 30], [0, 0, 0, 0, 20, 20, 20], [0, -20, 3, 5, 70, 44, 39]], np.float32)
+    top = rs.rand(3, 6, 3, 3, 3).astype(np.float32)
+    got = m3d.roi_align3d_backward(dev(top), dev(rois), shape, 3, 3, 3, 0.125, 2).cpu().numpy()
+    ref = O.roi_align_3d_backward(top, rois, shape, 3, 3, 3, 0.125, 2)
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-6)      # float atomics: order differs (as in the reference)
+
+
+# ------------------------------------------------------------------ conv / pool
+def _conv_case(m3d, B, cin, cout, D, H, W, k, seed, **kw):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) * (2.0 / (cin * k ** 3)) ** 0.5
+    conv = m3d.PackedConv3d(w.cuda())
+    y = conv(x.cuda(), **kw).cpu()
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, k // 2)
+    return y, ref
+
+
+@pytest.mark.parametrize("B,cin,cout,D,H,W,k", [
+    (1, 1, 32, 8, 16, 40, 5), (1, 32, 64, 8, 12, 32, 3), (1, 64, 64, 9, 13, 33, 3), (2, 64, 128, 8, 8, 32, 3),
+    (1, 128, 128, 6, 16, 16, 3), (1, 128, 256, 4, 8, 16, 3), (1, 256, 256, 5, 6, 7, 3), (1, 256, 245, 4, 16, 16, 1),
+    (1, 128, 98, 3, 10, 40, 1), (1, 3, 5, 4, 5, 6, 3), (1, 1, 20, 6, 7, 9, 5), (1, 256, 256, 2, 25, 25, 3)])
+def test_conv3d_forward_vs_fp64(m3d, B, cin, cout, D, H, W, k):
+    y, ref = _conv_case(m3d, B, cin, cout, D, H, W, k, seed=cin * 7 + k)
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-4, err                                  # north_star: fp32 convs within 1e-4 relative
+    assert err < 5e-6                                       # exact-fp32 MFMA: expect ~1e-6
+
+
+def test_conv3d_matches_oracle_direct_and_epilogue(m3d):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 6, 5, 9, 34, generator=g)
+    w = torch.randn(40, 6, 3, 3, 3, generator=g) * 0.1
+    sc = torch.rand(40, generator=g) + 0.5
+    sh = torch.randn(40, generator=g)
+    off = torch.tensor([x.min().item()])
+    ref = torch.from_numpy(O.conv3d_direct(x.numpy(), w.numpy(), None, in_offset=float(off), relu_w=True))
+    ref = torch.relu(ref * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    conv = m3d.PackedConv3d(w.cuda(), mode=m3d.W_RELU)
+    y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True, in_offset=off.cuda()).cpu()
+    assert (y - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+
+
+def test_conv3d_dgrad_pack(m3d):
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(48, 20, 3, 3, 3, generator=g) * 0.1
+    gy = torch.randn(1, 48, 6, 10, 32, generator=g)
+    ref = torch.nn.grad.conv3d_input((1, 20, 6, 10, 32), w.double(), gy.double(), 1, 1)
+    dg = m3d.PackedConv3d(w.cuda(), mode=m3d.W_DGRAD)
+    y = dg(gy.cuda()).cpu()
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
+def test_conv3d_linearity_full_size(m3d):
+    """Size-independent property at the BASELINE config[1] size (conv2b on 64^3): conv(a*x + y) = a*conv(x) + conv(y)."""
+    g = torch.Generator().manual_seed(7)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.03).cuda()
+    conv = m3d.PackedConv3d(w)
+    x = torch.randn(1, 64, 64, 64, 64, generator=g).cuda()
+    y = torch.randn(1, 64, 64, 64, 64, generator=g).cuda()
+    lhs = conv(2.0 * x + y)
+    rhs = 2.0 * conv(x) + conv(y)
+    assert (lhs - rhs).abs().max().item() / rhs.abs().max().item() < 1e-5
+
+
+def test_maxpool(m3d):
+    x = torch.randn(2, 5, 9, 10, 13)
+    ref, idx = torch.nn.functional.max_pool3d(x, 2, 2, return_indices=True)
+    out, am = m3d.maxpool3d_2x(x.cuda(), return_argmax=True)
+    assert torch.equal(out.cpu(), ref)
+    go = torch.randn(ref.shape)
+    gin = m3d.maxpool3d_2x_backward(go.cuda(), am, x.shape).cpu()
+    xr = x.clone().requires_grad_()
+    torch.nn.functional.max_pool3d(xr, 2, 2).backward(go)
+    assert torch.equal(gin, xr.grad)
+    assert m3d.reduce_min(x.cuda()).item() == x.min().item()
+
+
+# ------------------------------------------------------------------ Otsu 2D
+def test_otsu_golden(m3d, golden):
+    g = golden("otsu")
+    imgs = [g["img%d" % i].ravel() for i in range(6)]
+    prms = [g["prm%d" % i].ravel() for i in range(6)]
+    offs = np.concatenate(([0], np.cumsum([a.size for a in imgs]))).astype(np.int64)
+    mask, kb, status = m3d.otsu2d_batch(torch.from_numpy(np.concatenate(imgs)).cuda(), torch.from_numpy(np.concatenate(prms)).cuda(),
+                                        dev(offs))
+    mask, kb, status = mask.cpu().numpy(), kb.cpu().numpy(), status.cpu().numpy()
+    for i in range(6):
+        assert status[i] == 0
+        assert tuple(kb[i]) == tuple(g["kb%d" % i]), i
+        assert np.array_equal(mask[offs[i]:offs[i + 1]].reshape(g["mask%d" % i].shape), g["mask%d" % i]), i
+
+
+def test_otsu_vs_oracle_random(m3d):
+    rs = np.random.RandomState(4)
+    imgs, prms = [], []
+    for i in range(12):
+        shp = tuple(rs.randint(6, 40, 3))
+        zz, yy, xx = np.mgrid[0:shp[0], 0:shp[1], 0:shp[2]]
+        r = np.sqrt((zz - shp[0] / 2) ** 2 + (yy - shp[1] / 2) ** 2 + (xx - shp[2] / 2) ** 2)
+        img = (rs.uniform(300, 3000) * np.exp(-(r / rs.uniform(3, 12)) ** 2) + 100 + rs.randn(*shp) * 20).clip(0, 65535).astype(np.uint16)
+        prm = (255 * np.exp(-(r / rs.uniform(3, 10)) ** 2) * rs.uniform(0.6, 1.0, shp)).astype(np.uint8)
+        a, b = (O.normalize_soma if i % 2 == 0 else O.normalize_nuclei)(img, prm)
+        imgs.append(a); prms.append(b)
+    offs = np.concatenate(([0], np.cumsum([a.size for a in imgs]))).astype(np.int64)
+    mask, kb, status = m3d.otsu2d_batch(torch.from_numpy(np.concatenate([a.ravel() for a in imgs])).cuda(),
+                                        torch.from_numpy(np.concatenate([a.ravel() for a in prms])).cuda(), dev(offs), 8192)
+    mask, kb = mask.cpu().numpy(), kb.cpu().numpy()
+    for i in range(12):
+        m, k, b = O.otsu_py_2d_fast(imgs[i], prms[i])
+        assert (k, b) == tuple(kb[i]), i
+        assert np.array_equal(mask[offs[i]:offs[i + 1]].reshape(m.shape), m), i
