@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the 3D detection hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload backbone|detect]
+
+A "step" is one pass of the hot path over one batch of synthetic 1x128x128x128 volumes already resident in
+HBM.  Workloads (BASELINE.json configs):
+  backbone  configs[1]: dsn_body forward (7 convs + BN + ReLU + 3 max-pools) on one 128^3 volume per rank
+  detect    configs[2]-style: full detection-mode tile (backbone, RPN, on-device proposals, RoIAlign3D,
+            box head, decode, NMS) on one 128^3 volume per rank
+Rank 0 prints ONE JSON line: metric voxels/s (whole job), plus `roofline` for the dominant kernel (the
+conv2b MFMA implicit-GEMM launch, timed live with HIP events on the launch stream) and `cpu_baseline`
+(the oracle's torch-CPU restatement of the same workload on the host cores, rank 0, bounded sample).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); volumes are independent, so ranks share
+nothing on the data path ("weak" scaling); detect mode ends with the single all_gather of padded detections
+(SURVEY 8e).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+VOL = 128
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz, no xf32 on gfx950
+
+
+def synth_volume(i, size=VOL):
+    """SURVEY 8d synthetic nuclei-style volume: N(100,10) background + 40 Gaussian blobs, uint16, then norm1."""
+    rng = np.random.RandomState(1234 + i)
+    v = rng.normal(100, 10, (size, size, size)).astype(np.float32)
+    zz, yy, xx = np.mgrid[0:size, 0:size, 0:size].astype(np.float32)
+    for _ in range(40):
+        c = rng.uniform(0, size, 3)
+        s = rng.uniform(4, 8)
+        a = rng.uniform(300, 900)
+        r = int(4 * s)
+        z0, z1 = max(0, int(c[0]) - r), min(size, int(c[0]) + r + 1)
+        y0, y1 = max(0, int(c[1]) - r), min(size, int(c[1]) + r + 1)
+        x0, x1 = max(0, int(c[2]) - r), min(size, int(c[2]) + r + 1)
+        d2 = (zz[z0:z1, y0:y1, x0:x1] - c[0]) ** 2 + (yy[z0:z1, y0:y1, x0:x1] - c[1]) ** 2 + (xx[z0:z1, y0:y1, x0:x1] - c[2]) ** 2
+        v[z0:z1, y0:y1, x0:x1] += a * np.exp(-d2 / (2 * s * s))
+    v = np.clip(v, 0, 65535).astype(np.uint16).astype(np.float32)
+    m = v > 0
+    return ((v - v[m].mean()) / v[m].std()).astype(np.float32)    # norm1, lib/utils/blob.py:179-184
+
+
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box shows 256 logical
+    CPUs but grants a 16-core share per GPU), else the affinity mask."""
+    if "M3D_CPU_THREADS" in os.environ:
+        return int(os.environ["M3D_CPU_THREADS"])
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def conv_flops(cin, cout, k, vox):
+    return 2.0 * cin * cout * k ** 3 * vox
+
+
+def backbone_flops(size):
+    v = size ** 3
+    L = [(1, 32, 5, v), (32, 64, 3, v // 8), (64, 64, 3, v // 8), (64, 128, 3, v // 64), (128, 128, 3, v // 64),
+         (128, 256, 3, v // 512), (256, 256, 3, v // 512)]
+    return sum(conv_flops(*l) for l in L)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import m3d
+    from m3d.model import DetectorM3D
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O   # parameter generator + CPU baseline only (never on the measured GPU path)
+
+    cfg = O.Cfg()
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=(args.workload == "detect"))
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    vol = torch.from_numpy(synth_volume(rank)).view(1, 1, VOL, VOL, VOL).cuda()
+
+    # dominant kernel SYMBOL: conv3d_mfma_kernel<3,2,32,4,2,4,1> — launched twice per step (conv2a 32->64 and
+    # conv2b 64->64 on 64^3 voxels: 28.99 + 57.98 GFLOP), 51 % of the backbone FLOPs.
+    # rocprofv3 --stats reports one average per symbol, so the roofline is quoted per launch of the symbol.
+    dom_layers = (1, 2)
+    dom_flops = (conv_flops(32, 64, 3, (VOL // 2) ** 3) + conv_flops(64, 64, 3, (VOL // 2) ** 3)) / 2.0
+    dom_ev = []
+
+    def step(timed):
+        x = vol
+        for li, (conv, scale, shift, pool) in enumerate(det.body):
+            if timed and li in dom_layers:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                x = conv(x, scale=scale, shift=shift, relu=True)
+                e1.record()
+                dom_ev.append((e0, e1))
+            else:
+                x = conv(x, scale=scale, shift=shift, relu=True)
+            if pool:
+                x = m3d.maxpool3d_2x(x)
+        if args.workload == "backbone":
+            return x
+        prob, deltas = det.rpn(x)
+        im_info = np.array([VOL, VOL, VOL, 1.0])
+        rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
+        cls, bbox = det.box_head(x, rois)
+        pred = m3d.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, cfg.bbox_reg_weights, clip_to=im_info[:3])
+        sc, bx, _, _ = det.box_results_with_nms_and_limit(cls, pred, keep_idx)
+        out = torch.zeros((cfg.detections_per_im, 7), device="cuda")
+        n = min(sc.numel(), cfg.detections_per_im)
+        out[:n, :6] = bx[:n]
+        out[:n, 6] = sc[:n]
+        if dist is not None:   # the path's one exchange step: all_gather of padded detections
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+        return out
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        dom_ms = float(np.mean([a.elapsed_time(b) for a, b in dom_ev]))
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        voxels = world * args.steps * VOL ** 3
+        res = {
+            "metric": "voxels/sec end-to-end infer_simple (128^3 vol); 3D-conv TFLOPS vs roofline",
+            "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool), 1x1x128x128x128 per rank [configs[1]]"
+                                    if args.workload == "backbone" else
+                                    "detection-mode infer tile: backbone+RPN+proposals+RoIAlign3D+2mlp head+NMS, 1x1x128^3 per rank"),
+                       "volumes_per_step": world, "net": "nuclei stride-8 dsn_body, 35 anchors",
+                       "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9,
+                       "backbone_tflops_whole_step": (backbone_flops(VOL) / (dt / args.steps) / 1e12) if args.workload == "backbone" else None},
+            "roofline": {"bound": "mfma", "kernel": "conv3d_mfma_kernel<3,2,32,4,2,4,1> (conv2a+conv2b @64^3, mean per launch)", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": dom_ms, "algorithmic_gflop_per_launch": dom_flops / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            ncpu = host_cores()
+            torch.set_num_threads(ncpu)
+            Pc = P
+            xv = vol.cpu()
+            with torch.no_grad():
+                f = O.dsn_body_forward if args.workload == "backbone" else None
+                if f is not None:
+                    f(Pc, xv, 8)     # warm-up
+                    nrep, tcpu = 0, 0.0
+                    while tcpu < 10.0 and nrep < 20:
+                        c0 = time.perf_counter()
+                        f(Pc, xv, 8)
+                        tcpu += time.perf_counter() - c0
+                        nrep += 1
+                else:
+                    O.detect_tile(Pc, cfg, xv)
+                    nrep, tcpu = 0, 0.0
+                    while tcpu < 10.0 and nrep < 10:
+                        c0 = time.perf_counter()
+                        O.detect_tile(Pc, cfg, xv)
+                        tcpu += time.perf_counter() - c0
+                        nrep += 1
+            res["cpu_baseline"] = {"value": nrep * VOL ** 3 / tcpu, "unit": "voxels/s", "cores": ncpu, "kind": "port",
+                                   "sample": "%d x the same 1x128^3 workload (oracle: torch-CPU fp32 convs + oracle C ops), "
+                                             "torch.set_num_threads(%d), %.1f s" % (nrep, ncpu, tcpu)}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-layer conv timing (HIP events) for tuning: python tools/bench_layers.py [size] [reps]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
+import torch, m3d
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+L = [("conv1a", 1, 32, 5, size), ("conv2a", 32, 64, 3, size // 2), ("conv2b", 64, 64, 3, size // 2),
+     ("conv3a", 64, 128, 3, size // 4), ("conv3b", 128, 128, 3, size // 4), ("conv4a", 128, 256, 3, size // 8),
+     ("conv4b", 256, 256, 3, size // 8), ("rpn_conv", 256, 256, 3, size // 8), ("rpn_heads", 256, 245, 1, size // 8)]
+tot_t, tot_f = 0.0, 0.0
+for name, cin, cout, k, s in L:
+    x = torch.randn(1, cin, s, s, s, device="cuda")
+    w = torch.randn(cout, cin, k, k, k, device="cuda") * 0.05
+    conv = m3d.PackedConv3d(w)
+    sc = torch.rand(cout, device="cuda"); sh = torch.rand(cout, device="cuda")
+    out = torch.empty(1, cout, s, s, s, device="cuda")
+    for _ in range(3):
+        conv(x, scale=sc, shift=sh, relu=True, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        conv(x, scale=sc, shift=sh, relu=True, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * cin * cout * k ** 3 * s ** 3
+    tot_t += ms; tot_f += fl
+    print("%-10s cin %3d cout %3d k%d %3d^3  %8.3f ms  %7.2f GFLOP  %6.2f TFLOP/s (%.1f%% of 157.3)" %
+          (name, cin, cout, k, s, ms, fl / 1e9, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
+print("TOTAL %.3f ms  %.2f GFLOP  %.2f TFLOP/s" % (tot_t, tot_f / 1e9, tot_f / tot_t / 1e9))
