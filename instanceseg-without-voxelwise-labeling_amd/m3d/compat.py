@@ -1,0 +1,247 @@
+"""Drop-in modules under the reference's own dotted names, backed by libm3d.so.
+
+    import m3d.compat; m3d.compat.install()          # before `import modeling...` / `import utils...`
+
+registers:
+  modeling.roi_xfrom.roi_align_3d.functions.roi_align_3d   RoIAlignFunction_3d          (functions/roi_align_3d.py:7-51)
+  modeling.roi_xfrom.roi_align_3d.modules.roi_align_3d     RoIAlign_3d / Avg_3d / Max_3d (modules/roi_align_3d.py:6-48)
+  utils.cython_nms_3d      nms_3d, nms_3d_volume, soft_nms_3d                            (lib/utils/cython_nms_3d.pyx)
+  utils.cython_bbox_3d     bbox_overlaps_3d                                              (lib/utils/cython_bbox_3d.pyx)
+  model.roi_pooling.functions.roi_pool / model.roi_crop.functions.roi_crop   import-compat shims (2D legacy,
+                           model_builder.py:11-12 imports them; the 3D path never calls them)
+  otsu                     otsu_py_2d_fast                                               (tools/otsu.py:199-284)
+and install_conv3d() routes qualifying torch.nn.functional.conv3d calls (fp32, CUDA, NCDHW, stride 1,
+padding k//2, dilation 1, groups 1, k in {1,3} or the 5^3/Cin=1 stem) to the MFMA kernels, forward and
+backward-data, so lib/modeling/DSN.py and lib/prm/peak_backprop_3d.py run unchanged on them.
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- RoIAlign3D
+class _RoIAlign3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, rois, AS, AH, AW, scale, ratio):
+        ctx.save_for_backward(rois)
+        ctx.cfg = (AS, AH, AW, scale, ratio, tuple(features.shape))
+        return ops.roi_align3d_forward(features, rois, AS, AH, AW, scale, ratio)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        rois, = ctx.saved_tensors
+        AS, AH, AW, scale, ratio, fshape = ctx.cfg
+        g = ops.roi_align3d_backward(grad_output.contiguous(), rois, fshape, AS, AH, AW, scale, ratio)
+        return g, None, None, None, None, None, None
+
+
+class RoIAlignFunction_3d(object):
+    """Same call shape as the reference's legacy instance-style Function:
+    RoIAlignFunction_3d(AS, AH, AW, scale, ratio)(features, rois)   (model_builder.py:311-312)."""
+
+    def __init__(self, aligned_slices, aligned_height, aligned_width, spatial_scale, sampling_ratio):
+        self.aligned_slices = int(aligned_slices)
+        self.aligned_width = int(aligned_width)
+        self.aligned_height = int(aligned_height)
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+
+    def __call__(self, features, rois):
+        if not features.is_cuda:
+            raise NotImplementedError          # functions/roi_align_3d.py:31-32
+        return _RoIAlign3dFn.apply(features, rois, self.aligned_slices, self.aligned_height, self.aligned_width,
+                                   self.spatial_scale, self.sampling_ratio)
+
+
+class RoIAlign_3d(torch.nn.Module):
+    def __init__(self, aligned_slices, aligned_height, aligned_width, spatial_scale, sampling_ratio):
+        super().__init__()
+        self.aligned_width, self.aligned_height, self.aligned_slices = int(aligned_width), int(aligned_height), int(aligned_slices)
+        self.spatial_scale, self.sampling_ratio = float(spatial_scale), int(sampling_ratio)
+
+    def _fn(self, extra):
+        return RoIAlignFunction_3d(self.aligned_slices + extra, self.aligned_height + extra, self.aligned_width + extra,
+                                   self.spatial_scale, self.sampling_ratio)
+
+    def forward(self, features, rois):
+        return self._fn(0)(features, rois)
+
+
+class RoIAlignAvg_3d(RoIAlign_3d):
+    def forward(self, features, rois):       # modules/roi_align_3d.py:30-33
+        return torch.nn.functional.avg_pool3d(self._fn(1)(features, rois), kernel_size=2, stride=1)
+
+
+class RoIAlignMax_3d(RoIAlign_3d):
+    def forward(self, features, rois):       # modules/roi_align_3d.py:45-48
+        return torch.nn.functional.max_pool3d(self._fn(1)(features, rois), kernel_size=2, stride=1)
+
+
+# ----------------------------------------------------------------------------- Cython-API box ops (NumPy in/out)
+def _check_f32_2d(a, name):
+    # Cython buffer typing `np.ndarray[np.float32_t, ndim=2]` rejects anything else with ValueError
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)" % (name, type(a).__name__))
+    if a.ndim != 2:
+        raise ValueError("Buffer has wrong number of dimensions (expected 2, got %d)" % a.ndim)
+    if a.dtype != np.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t' but got '%s'" % a.dtype)
+
+
+def nms_3d(dets, thresh):
+    _check_f32_2d(dets, "dets")
+    d = torch.from_numpy(np.ascontiguousarray(dets)).cuda()
+    return ops.nms3d(d, thresh).cpu().numpy()
+
+
+def nms_3d_volume(dets, thresh):
+    _check_f32_2d(dets, "dets")
+    d = torch.from_numpy(np.ascontiguousarray(dets)).cuda()
+    return ops.nms3d(d, thresh, by_volume=True).cpu().numpy()
+
+
+def soft_nms_3d(boxes_in, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    raise NotImplementedError(
+        "soft_nms_3d is unreachable in the reference (TEST.SOFT_NMS.ENABLED=False, core/config.py:370; the wrapper "
+        "boxes_3d.soft_nms is mis-named vs its caller core/test.py:843 and the kernel overwrites column 4 three times, "
+        "cython_nms_3d.pyx:280-282); deliberately not reproduced")
+
+
+def bbox_overlaps_3d(boxes, query_boxes):
+    _check_f32_2d(boxes, "boxes")
+    _check_f32_2d(query_boxes, "query_boxes")
+    b = torch.from_numpy(np.ascontiguousarray(boxes)).cuda()
+    q = torch.from_numpy(np.ascontiguousarray(query_boxes)).cuda()
+    return ops.bbox_overlaps3d(b, q).cpu().numpy()
+
+
+def otsu_py_2d_fast(image, prm, b_range=None):
+    """tools/otsu.py:199 signature; uint16 volumes (what both callers pass).  Returns (uint8 mask, k, b)."""
+    if b_range is not None:
+        raise NotImplementedError("b_range is never passed by the reference callers")
+    img = np.ascontiguousarray(image)
+    pr = np.ascontiguousarray(prm)
+    if img.dtype != np.uint16 or pr.dtype != np.uint16:
+        raise TypeError("otsu_py_2d_fast (HIP) takes the uint16 crops the reference callers produce")
+    offs = torch.tensor([0, img.size], dtype=torch.int64, device="cuda")
+    G = int(img.max()) - int(img.min()) + 1
+    mask, kb, status = ops.otsu2d_batch(torch.from_numpy(img.ravel()).cuda(), torch.from_numpy(pr.ravel()).cuda(), offs,
+                                        max_gray_range=max(G, 2))
+    if int(status[0]) != 0:
+        raise UnboundLocalError("local variable 'k_max' referenced before assignment")   # otsu.py:277 behaviour
+    return mask.cpu().numpy().reshape(img.shape), int(kb[0, 0]), int(kb[0, 1])
+
+
+class _Legacy2D(object):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("2D legacy op: no 3D version exists in the reference (SURVEY 8a-15)")
+
+
+# ----------------------------------------------------------------------------- F.conv3d interception
+_orig_conv3d = None
+_pack_cache = {}
+
+
+def _packed(weight, mode):
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), mode)
+    p = _pack_cache.get(key)
+    if p is None:
+        if len(_pack_cache) > 256:
+            _pack_cache.clear()
+        p = ops.PackedConv3d(weight.detach(), mode)
+        _pack_cache[key] = p
+    return p
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(weight)
+        ctx.has_bias = bias is not None
+        return _packed(weight, ops.W_PLAIN)(x, shift=bias.detach().contiguous() if bias is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, = ctx.saved_tensors
+        gx = _packed(weight, ops.W_DGRAD)(gy.contiguous()) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            raise NotImplementedError("conv3d weight/bias gradients (training) are outside the inference hot path")
+        return gx, None, None
+
+
+def _qualifies(x, weight, stride, padding, dilation, groups):
+    def tup(v):
+        return (v,) * 3 if isinstance(v, int) else tuple(v)
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 5):
+        return False
+    k = weight.shape[2]
+    if weight.shape[3] != k or weight.shape[4] != k or groups != 1:
+        return False
+    if tup(stride) != (1, 1, 1) or tup(dilation) != (1, 1, 1) or isinstance(padding, str) or tup(padding) != (k // 2,) * 3:
+        return False
+    if k in (1, 3):
+        return True
+    return k == 5 and weight.shape[1] == 1 and weight.shape[0] <= 64 and not x.requires_grad
+
+
+def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    if _qualifies(input, weight, stride, padding, dilation, groups):
+        return _Conv3dFn.apply(input.contiguous(), weight, bias)
+    return _orig_conv3d(input, weight, bias, stride, padding, dilation, groups)
+
+
+def install_conv3d():
+    global _orig_conv3d
+    if _orig_conv3d is None:
+        _orig_conv3d = torch.nn.functional.conv3d
+        torch.nn.functional.conv3d = conv3d
+
+
+def uninstall_conv3d():
+    global _orig_conv3d
+    if _orig_conv3d is not None:
+        torch.nn.functional.conv3d = _orig_conv3d
+        _orig_conv3d = None
+
+
+# ----------------------------------------------------------------------------- registration
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__m3d__ = True
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent and parent in sys.modules:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+def _pkg(name):
+    if name not in sys.modules:
+        m = _mod(name)
+        m.__path__ = []
+    return sys.modules[name]
+
+
+def install(conv3d=True):
+    """Register the drop-in modules.  Packages that already exist (the reference's `modeling`, `utils`) are kept;
+    only the native-op leaf modules are replaced."""
+    for pk in ("modeling", "modeling.roi_xfrom", "modeling.roi_xfrom.roi_align_3d",
+               "modeling.roi_xfrom.roi_align_3d.functions", "modeling.roi_xfrom.roi_align_3d.modules",
+               "utils", "model", "model.roi_pooling", "model.roi_pooling.functions", "model.roi_crop",
+               "model.roi_crop.functions"):
+        _pkg(pk)
+    _mod("modeling.roi_xfrom.roi_align_3d.functions.roi_align_3d", RoIAlignFunction_3d=RoIAlignFunction_3d)
+    _mod("modeling.roi_xfrom.roi_align_3d.modules.roi_align_3d", RoIAlign_3d=RoIAlign_3d, RoIAlignAvg_3d=RoIAlignAvg_3d,
+         RoIAlignMax_3d=RoIAlignMax_3d, RoIAlignFunction_3d=RoIAlignFunction_3d)
+    _mod("utils.cython_nms_3d", nms_3d=nms_3d, nms_3d_volume=nms_3d_volume, soft_nms_3d=soft_nms_3d)
+    _mod("utils.cython_bbox_3d", bbox_overlaps_3d=bbox_overlaps_3d)
+    _mod("model.roi_pooling.functions.roi_pool", RoIPoolFunction=_Legacy2D)
+    _mod("model.roi_crop.functions.roi_crop", RoICropFunction=_Legacy2D)
+    _mod("otsu", otsu_py_2d_fast=otsu_py_2d_fast)
+    if conv3d:
+        install_conv3d()

@@ -1,0 +1,74 @@
+"""GPU: the drop-in modules (reference dotted names) and the F.conv3d interception."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def compat():
+    import m3d.compat as c
+    c.install()
+    yield c
+    c.uninstall_conv3d()
+
+
+def test_reference_import_names(compat, golden):
+    from utils.cython_nms_3d import nms_3d, nms_3d_volume
+    from utils.cython_bbox_3d import bbox_overlaps_3d
+    from modeling.roi_xfrom.roi_align_3d.functions.roi_align_3d import RoIAlignFunction_3d
+    from model.roi_pooling.functions.roi_pool import RoIPoolFunction      # model_builder.py:11
+    from model.roi_crop.functions.roi_crop import RoICropFunction          # model_builder.py:12
+    g = golden("nms")
+    assert np.array_equal(nms_3d(g["dets8"], np.float32(g["thr8"])), g["keep8"])
+    assert nms_3d(g["dets8"], 0.3).dtype == np.int64
+    with pytest.raises(ValueError):
+        nms_3d(g["dets8"].astype(np.float64), 0.3)          # Cython buffer dtype check
+    go = golden("overlaps")
+    assert np.array_equal(bbox_overlaps_3d(go["boxes"], go["query"]), go["out"])
+    f = torch.randn(1, 4, 6, 6, 6, device="cuda", requires_grad=True)
+    rois = torch.tensor([[0, 2, 2, 2, 30, 30, 30.]], device="cuda")
+    out = RoIAlignFunction_3d(7, 7, 7, 0.125, 2)(f, rois)
+    assert np.array_equal(out.detach().cpu().numpy(),
+                          O.roi_align_3d_forward(f.detach().cpu().numpy(), rois.cpu().numpy(), 7, 7, 7, 0.125, 2))
+    out.sum().backward()
+    assert f.grad is not None and abs(f.grad.sum().item() - 4 * 343) < 1e-2
+    with pytest.raises(NotImplementedError):
+        RoIAlignFunction_3d(7, 7, 7, 0.125, 2)(f.detach().cpu(), rois.cpu())   # functions/roi_align_3d.py:31-32
+    with pytest.raises(NotImplementedError):
+        RoIPoolFunction(7, 7, 0.125)
+
+
+def test_otsu_dropin(compat, golden):
+    from otsu import otsu_py_2d_fast
+    g = golden("otsu")
+    m, k, b = otsu_py_2d_fast(g["img1"], g["prm1"])
+    assert (k, b) == tuple(g["kb1"]) and np.array_equal(m, g["mask1"])
+
+
+def test_conv3d_interception_runs_unmodified_module_code(compat):
+    """nn.Conv3d modules (as lib/modeling/DSN.py builds them) hit the MFMA kernels through F.conv3d;
+    the PRM-style pr_conv3d pattern (peak_backprop_3d.py:37-44) back-propagates through the dgrad kernel."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    conv = nn.Conv3d(8, 16, 3, 1, 1, bias=True).cuda()
+    x = torch.randn(1, 8, 6, 10, 34, device="cuda", requires_grad=True)
+    y = conv(x)
+    assert F.conv3d is compat.conv3d
+    ref = compat._orig_conv3d(x.detach().double(), conv.weight.detach().double(), conv.bias.detach().double(), 1, 1)
+    assert (y.detach().double() - ref).abs().max().item() < 1e-5
+    wpos = F.relu(conv.weight).detach()
+    n = F.conv3d(x - x.min().detach(), wpos, None, 1, 1)
+    g = torch.randn_like(n)
+    n.backward(g)
+    ref_gx = torch.nn.grad.conv3d_input(x.shape, wpos.double(), g.double(), 1, 1)
+    assert (x.grad.double() - ref_gx).abs().max().item() / ref_gx.abs().max().item() < 5e-6
+    # a non-qualifying call (stride 2) falls through to torch's own conv
+    z = F.conv3d(x.detach(), conv.weight.detach(), None, 2, 1)
+    assert z.shape[-1] == 17
