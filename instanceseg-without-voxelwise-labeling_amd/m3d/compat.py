@@ -14,6 +14,7 @@ and install_conv3d() routes qualifying torch.nn.functional.conv3d calls (fp32, C
 padding k//2, dilation 1, groups 1, k in {1,3} or the 5^3/Cin=1 stem) to the MFMA kernels, forward and
 backward-data, so lib/modeling/DSN.py and lib/prm/peak_backprop_3d.py run unchanged on them.
 """
+import importlib
 import sys
 import types
 
@@ -221,9 +222,13 @@ def _mod(name, **attrs):
 
 
 def _pkg(name):
+    """The real package when the reference's lib/ is importable, else an empty stand-in package."""
     if name not in sys.modules:
-        m = _mod(name)
-        m.__path__ = []
+        try:
+            importlib.import_module(name)
+        except Exception:
+            m = _mod(name)
+            m.__path__ = []
     return sys.modules[name]
 
 
@@ -242,6 +247,9 @@ def install(conv3d=True):
     _mod("utils.cython_bbox_3d", bbox_overlaps_3d=bbox_overlaps_3d)
     _mod("model.roi_pooling.functions.roi_pool", RoIPoolFunction=_Legacy2D)
     _mod("model.roi_crop.functions.roi_crop", RoICropFunction=_Legacy2D)
-    _mod("otsu", otsu_py_2d_fast=otsu_py_2d_fast)
+    try:                                   # tools/otsu.py also holds otsu_py / otsu_py_2d (binarization_nuclei.py:12)
+        importlib.import_module("otsu").otsu_py_2d_fast = otsu_py_2d_fast
+    except Exception:
+        _mod("otsu", otsu_py_2d_fast=otsu_py_2d_fast)
     if conv3d:
         install_conv3d()
