@@ -113,6 +113,15 @@ int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, i
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
 
+/* Same conv on a batch of cropped windows, with the PRM PreHook multiply fused: out[b,co,z,y,x] *=
+ * full[co, origin_b + (z,y,x)] - *d_full_offset, and 0 where that position lies outside the full tensor
+ * (lib/prm/peak_backprop_3d.py:16-18 restricted to each peak's receptive-field cone).
+ * d_full [cout, full_depth, full_height, full_width]; d_origins int32 [batch,3] = (z,y,x) of each window. */
+int m3d_conv3d_forward_windowed(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                int depth, int height, int width, int k, const float* d_full,
+                                const float* d_full_offset, const int32_t* d_origins, int full_depth,
+                                int full_height, int full_width, void* stream);
+
 /* MaxPool3d(kernel 2, stride 2, floor) forward with argmax (lib/modeling/DSN.py:21,26,32) and its
  * backward (gradient routed to the argmax voxel; first maximum in z,y,x scan order wins, as PyTorch). */
 int m3d_maxpool3d_2x_forward(const float* d_in, float* d_out, uint8_t* d_argmax /*may be NULL*/, int batch_channels,
@@ -124,6 +133,35 @@ int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, 
  * lib/prm/peak_backprop_3d.py:38); stays on device so the PRM convs never synchronise with the host. */
 size_t m3d_reduce_min_workspace_bytes(void);
 int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Peak-response back-propagation on cropped windows (all kept peaks of a tile as one batch).  Replaces the
+ * per-detection `class_response_maps.backward(...)` loop of lib/prm/peak_response_mapping_3d.py:157-172 and
+ * the hooks of lib/prm/peak_backprop_3d.py:8-34.  Windows are cubes in virtual coordinates (positions
+ * outside the tile are zero), d_origin* are int32 [num_peaks,3] = (z,y,x).
+ *   m3d_prm_seed      sigmoid' + the 1x1x1 RPN_cls_score conv for one-hot seeds: d_peaks int32 [P,4] =
+ *                     (anchor,s,h,w); d_prob/d_norm_cls [A,S,H,W]; d_w_cls [A,C]; d_h [C,S,H,W] (the ReLU'd
+ *                     RPN_conv output) and its min; writes d_out [P,C] (a 1^3 window per peak at (s,h,w)).
+ *   m3d_prm_prepare   upper window d_gup [P,C,U,U,U] (gradient w.r.t. this layer's post-activation output, at
+ *                     d_origin_up) -> this layer's conv-input window d_out [P,C,Wn,Wn,Wn], Wn = (pool?2:1)*U +
+ *                     2*border: max-unpool routing by d_argmax (if pool), ReLU mask (d_xnext > 0; pooled values
+ *                     if pool), * d_scale[c] (BatchNorm, may be NULL), / (|norm|+1e-10) with norm < 1e-10 -> 0.
+ *   m3d_prm_stem_dgrad backward-data of conv1a (5^3, one output channel) with relu(W), times (data - offset),
+ *                     clamp(min=0); d_out [P,Wn^3]; d_sums [P] = per-peak sum (for prm / prm.sum()).
+ *   m3d_prm_scatter   dense [P,D,H,W] = window / sum at each peak's origin (caller zero-fills d_dense).
+ * ------------------------------------------------------------------------------------------------------- */
+int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
+                 const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
+                 float* d_out, void* stream);
+int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                    int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height,
+                    int up_width, const float* d_scale, const float* d_norm, int depth, int height, int width,
+                    float* d_out, int32_t* d_origin_out, void* stream);
+int m3d_prm_stem_dgrad(const float* d_gn, const float* d_weight, const float* d_data, const float* d_data_offset,
+                       const int32_t* d_origins, int num_peaks, int channels, int win, int depth, int height,
+                       int width, float* d_out, float* d_sums, void* stream);
+int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
+                    int depth, int height, int width, float* d_dense, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Per-RoI 2D-Otsu binarisation.  Replaces otsu.otsu_py_2d_fast (tools/otsu.py:199-284) for uint16 inputs

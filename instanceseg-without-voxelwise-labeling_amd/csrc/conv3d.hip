@@ -82,7 +82,28 @@ struct Epilogue {
   const float* mul;     // same shape as out, or null
   const float* in_off;  // 1 float (device) or null
   int relu;
+  // windowed multiply (PRM PreHook on cropped peak windows): out[b,co,z,y,x] *= full[co, o_b + (z,y,x)] - *full_off,
+  // and 0 where the window position lies outside the full tensor.
+  const float* full;    // [cout, FD, FH, FW] or null
+  const float* full_off;
+  const int* origins;   // [batch, 3] (z, y, x)
+  int FD, FH, FW;
 };
+
+__device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int co, int z, int y, int x, size_t o) {
+  if (ep.scale) v = v * ep.scale[co];
+  if (ep.shift) v = v + ep.shift[co];
+  if (ep.relu) v = v > 0.f ? v : 0.f;
+  if (ep.mul) v = v * ep.mul[o];
+  if (ep.full) {
+    const int qz = ep.origins[3 * b] + z, qy = ep.origins[3 * b + 1] + y, qx = ep.origins[3 * b + 2] + x;
+    if ((qz >= 0) & (qz < ep.FD) & (qy >= 0) & (qy < ep.FH) & (qx >= 0) & (qx < ep.FW))
+      v = v * (ep.full[(((size_t)co * ep.FD + qz) * ep.FH + qy) * ep.FW + qx] - (ep.full_off ? *ep.full_off : 0.f));
+    else
+      v = 0.f;
+  }
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Generic k in {1,3} kernel.
@@ -248,13 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
         for (int g = 0; g < 16; ++g) {
           const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
           if (co < cout) {
-            float v = acc[c][r][g];
-            if (ep.scale) v = v * ep.scale[co];
-            if (ep.shift) v = v + ep.shift[co];
-            if (ep.relu) v = v > 0.f ? v : 0.f;
             const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-            if (ep.mul) v = v * ep.mul[o];
-            out[o] = v;
+            out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
           }
         }
       }
@@ -347,13 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
         for (int g = 0; g < 16; ++g) {
           const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
           if (co < cout) {
-            float v = acc[c][r][g];
-            if (ep.scale) v = v * ep.scale[co];
-            if (ep.shift) v = v + ep.shift[co];
-            if (ep.relu) v = v > 0.f ? v : 0.f;
             const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-            if (ep.mul) v = v * ep.mul[o];
-            out[o] = v;
+            out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
           }
         }
       }
@@ -405,15 +416,12 @@ M3D_API int m3d_conv3d_pack_weights(const float* d_weight, int cin, int cout, in
   return m3d::check_launch("pack_weights");
 }
 
-M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
-                               int height, int width, int k, const float* d_in_offset, const float* d_scale,
-                               const float* d_shift, int relu, const float* d_mul, void* stream) {
+static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                         int height, int width, int k, Epilogue ep, hipStream_t st) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
     return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
   if (DHW * 32 >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // int offsets inside a channel chunk
-  hipStream_t st = m3d::as_stream(stream);
-  Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu};
   if (k == 5) {
     if (cin != 1 || cout > 64) return M3D_EUNSUPPORTED;
     constexpr int ROWS = 8, WZ = 4, WY = 1;
@@ -436,22 +444,31 @@ M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* 
     return m3d::check_launch("conv3d_stem5");
   }
   if (k == 3) {
-    // Tile choice: keep >= ~2 workgroups per CU in flight; prefer big tiles (more MFMAs per staged byte).
+    // Tile choice: keep >= ~2 workgroups per CU in flight; prefer big tiles (more MFMAs per staged byte);
+    // pick the x-block (32/16/8) that wastes the fewest lanes on this width.
     const long long vox = (long long)batch * DHW;
     const int ncb_total = (cout + 31) / 32;
-    if (width >= 24) {
+    auto waste = [&](int xb) { return (double)((width + xb - 1) / xb * xb) / width; };
+    int xb = 32;
+    if (waste(16) < waste(xb) - 0.05) xb = 16;
+    if (waste(8) < waste(xb) - 0.05) xb = 8;
+    if (xb == 32) {
       const long long wg_big = (vox / 512) * ((ncb_total + 1) / 2);
       if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       const long long wg_mid = (vox / 256) * ((ncb_total + 1) / 2);
       if (wg_mid >= 256) return launch_cfg<3, 4, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
-    if (width >= 12) {
+    if (xb == 16) {
       const long long wg = (vox / 256) * ((ncb_total + 1) / 2);
       if (wg >= 512) return launch_cfg<3, 4, 16, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 16, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
-    return launch_cfg<3, 4, 8, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    {
+      const long long wg = (vox / 256) * ((ncb_total + 1) / 2);
+      if (wg >= 512) return launch_cfg<3, 4, 8, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      return launch_cfg<3, 4, 8, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    }
   }
   if (k == 1) {
     if (width >= 24) return launch_cfg<1, 32, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
@@ -459,4 +476,19 @@ M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* 
     return launch_cfg<1, 32, 8, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   }
   return M3D_EUNSUPPORTED;
+}
+
+M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                               int height, int width, int k, const float* d_in_offset, const float* d_scale,
+                               const float* d_shift, int relu, const float* d_mul, void* stream) {
+  Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu, nullptr, nullptr, nullptr, 0, 0, 0};
+  return conv_dispatch(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
+}
+
+M3D_API int m3d_conv3d_forward_windowed(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                        int depth, int height, int width, int k, const float* d_full, const float* d_full_offset,
+                                        const int32_t* d_origins, int full_depth, int full_height, int full_width, void* stream) {
+  if (!d_full || !d_origins || full_depth <= 0 || full_height <= 0 || full_width <= 0) return M3D_EINVAL;
+  Epilogue ep{nullptr, nullptr, nullptr, nullptr, 0, d_full, d_full_offset, d_origins, full_depth, full_height, full_width};
+  return conv_dispatch(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
 }

@@ -1,0 +1,247 @@
+// Peak-response back-propagation support kernels for gfx950.
+//
+// Reference: lib/prm/peak_response_mapping_3d.py:157-172 runs one full-volume autograd backward per kept
+// detection (<= 300 per tile) through the hooks of lib/prm/peak_backprop_3d.py:8-34.  A one-hot seed has a
+// bounded receptive-field cone (3^3 -> 5^3 -> 7^3 at stride 8, 16^3/18^3 at stride 4, 38^3/40^3 at stride 2,
+// 84^3 at stride 1), outside of which every gradient is exactly zero.  The build therefore back-propagates
+// all peaks of a tile as ONE batch of cropped windows: per layer a gather/"prepare" kernel (this file) turns
+// the upper window into the conv's input window — max-unpool routing, ReLU mask, BatchNorm scale and the
+// PostHook division by the norm conv (peak_backprop_3d.py:30-33) fused, reading the saved full-size forward
+// tensors at each peak's own origin — and the MFMA conv (conv3d.hip, dgrad-packed relu(W)) finishes with the
+// PreHook multiply (peak_backprop_3d.py:16-18) fused in its epilogue.  Windows live in virtual coordinates
+// (they may stick out of the tile; such positions are zero), so all peaks share one window size per layer.
+#include "m3d_common.h"
+
+namespace {
+
+constexpr float kEps = 1e-10f;   // peak_backprop_3d.py:29
+
+// ---- seed: sigmoid' and the 1x1x1 RPN_cls_score conv, whose upstream gradient has a single non-zero channel ----
+// out[p, c] = (h[c,pos] - off_h) * relu(Wcls[a,c]) * gn,  gn = s(1-s) / (|Ncls[a,pos]| + eps)  (0 if Ncls < eps)
+__global__ __launch_bounds__(256) void prm_seed_kernel(const int* __restrict__ peaks /*[P,4] a,s,h,w*/, int P,
+                                                       const float* __restrict__ prob, const float* __restrict__ ncls,
+                                                       const float* __restrict__ wcls /*[A,C]*/, const float* __restrict__ h,
+                                                       const float* __restrict__ h_off, int A, int C, int S, int H, int W,
+                                                       float* __restrict__ out /*[P,C]*/) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P * C) return;
+  const int p = e / C, c = e % C;
+  const int a = peaks[4 * p], s = peaks[4 * p + 1], hh = peaks[4 * p + 2], w = peaks[4 * p + 3];
+  const size_t pos = ((size_t)s * H + hh) * W + w, SHW = (size_t)S * H * W;
+  const float y = prob[a * SHW + pos];
+  const float g = (1.f - y) * y;                       // torch sigmoid backward: grad * (1 - y) * y
+  const float n = ncls[a * SHW + pos];
+  const float gn = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);
+  float wv = wcls[(size_t)a * C + c];
+  wv = wv > 0.f ? wv : 0.f;
+  out[e] = (h[c * SHW + pos] - *h_off) * (wv * gn);
+}
+
+// ---- prepare: upper gradient window -> G_N window of this layer ----
+struct PrepParams {
+  const float* gup;        // [P, C, U, U, U]
+  const int* origin_up;    // [P,3] origin of gup in X_{L+1} coordinates
+  const uint8_t* argmax;   // pool: [C, UD, UH, UW] argmax of the 2x2x2 windows, else null
+  const float* xnext;      // [C, UD, UH, UW]  X_{L+1} (pooled values if pool) — ReLU mask source
+  const float* scale;      // [C] BatchNorm gamma/sqrt(var+eps) or null
+  const float* norm;       // [C, D, H, W] norm conv output of this layer
+  float* out;              // [P, C, Wn, Wn, Wn]
+  int* origin_out;         // [P,3]
+  int P, C, U, Wn, border, pool;
+  int D, H, W;             // this layer's resolution
+  int UD, UH, UW;          // X_{L+1} resolution
+};
+
+__global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
+  const long long w3 = (long long)q.Wn * q.Wn * q.Wn;
+  const long long total = (long long)q.P * q.C * w3;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % q.Wn);
+    long long t = e / q.Wn;
+    const int y = (int)(t % q.Wn); t /= q.Wn;
+    const int z = (int)(t % q.Wn); t /= q.Wn;
+    const int c = (int)(t % q.C);
+    const int p = (int)(t / q.C);
+    const int m = q.pool ? 2 : 1;
+    const int oz = q.origin_up[3 * p] * m - q.border, oy = q.origin_up[3 * p + 1] * m - q.border,
+              ox = q.origin_up[3 * p + 2] * m - q.border;
+    if (c == 0 && z == 0 && y == 0 && x == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+    const int iz = z - q.border, iy = y - q.border, ix = x - q.border;     // inner (un-padded) window coords
+    const int inner = q.Wn - 2 * q.border;
+    float g = 0.f;
+    const int qz = oz + z, qy = oy + y, qx = ox + x;                       // position in this layer's tensor
+    if ((iz >= 0) & (iz < inner) & (iy >= 0) & (iy < inner) & (ix >= 0) & (ix < inner) & (qz >= 0) & (qz < q.D) & (qy >= 0) &
+        (qy < q.H) & (qx >= 0) & (qx < q.W)) {
+      const int uz = q.pool ? (iz >> 1) : iz, uy = q.pool ? (iy >> 1) : iy, ux = q.pool ? (ix >> 1) : ix;
+      const int az = q.origin_up[3 * p] + uz, ay = q.origin_up[3 * p + 1] + uy, ax = q.origin_up[3 * p + 2] + ux;
+      if ((az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) & (ax >= 0) & (ax < q.UW)) {
+        const size_t upos = (((size_t)c * q.UD + az) * q.UH + ay) * q.UW + ax;
+        g = q.gup[(((size_t)p * q.C + c) * q.U + uz) * q.U * q.U + (size_t)uy * q.U + ux];
+        if (q.pool) {
+          const int child = ((qz & 1) << 2) | ((qy & 1) << 1) | (qx & 1);
+          if (q.argmax[upos] != child) g = 0.f;                             // max-unpool routing
+        }
+        if (!(q.xnext[upos] > 0.f)) g = 0.f;                                // ReLU backward (output > 0)
+        if (q.scale) g = g * q.scale[c];                                    // eval-mode BatchNorm backward
+        const float n = q.norm[(((size_t)c * q.D + qz) * q.H + qy) * q.W + qx];
+        g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                       // PostHook, peak_backprop_3d.py:30-33
+      }
+    }
+    q.out[e] = g;
+  }
+}
+
+// ---- stem dgrad: conv1a is 1 -> 32 channels, 5^3; its backward-data has ONE output channel, so the MFMA tile
+// would be 1/32 full.  VALU direct form: out[p,v] = (data[v] - off) * sum_{c,t} relu(W)[c][t] * G[p,c][v - t + 2].
+// Each thread produces 8 consecutive x; one (dz,dy) row of 12 inputs feeds 40 FMAs.  Tile 32 x 8 x 8 voxels.
+__global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __restrict__ gn /*[P,32,Wn^3]*/,
+                                                             const float* __restrict__ w /*[32,125] raw conv1a weight*/,
+                                                             const float* __restrict__ data /*[D,H,W]*/,
+                                                             const float* __restrict__ data_off, const int* __restrict__ origins,
+                                                             int Wn, int D, int H, int W, int C, float* __restrict__ out /*[P,Wn^3]*/,
+                                                             float* __restrict__ sums /*[P]*/) {
+  constexpr int TX = 32, TY = 8, TZ = 8, HX = TX + 4, HY = TY + 4, HZ = TZ + 4;
+  __shared__ float tile[HZ * HY * HX];
+  __shared__ float wl[125];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int tiles = (Wn + TX - 1) / TX, tilesy = (Wn + TY - 1) / TY;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles; bid /= tiles;
+  const int ty = bid % tilesy; bid /= tilesy;
+  const int tz = bid;
+  const int p = blockIdx.y;
+  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
+  const int lx = (tid & 3) * 8, ly = (tid >> 2) & 7, lz = tid >> 5;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const size_t w3 = (size_t)Wn * Wn * Wn;
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+    const float* g = gn + ((size_t)p * C + c) * w3;
+    for (int e = tid; e < HZ * HY * HX; e += 256) {
+      const int hz = e / (HY * HX), hy = (e / HX) % HY, hx = e % HX;
+      const int z = z0 + hz - 2, y = y0 + hy - 2, x = x0 + hx - 2;
+      tile[e] = ((z >= 0) & (z < Wn) & (y >= 0) & (y < Wn) & (x >= 0) & (x < Wn)) ? g[((size_t)z * Wn + y) * Wn + x] : 0.f;
+    }
+    if (tid < 125) { const float v = w[c * 125 + tid]; wl[tid] = v > 0.f ? v : 0.f; }   // relu(W), peak_backprop_3d.py:41
+    __syncthreads();
+    // dgrad of a "same" conv: out[v] += Wf[t'] * G[v + t' - 2] with Wf[t'] = W[124 - t']
+#pragma unroll
+    for (int dz = 0; dz < 5; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) {
+        const float* row = tile + ((lz + dz) * HY + (ly + dy)) * HX + lx;
+        float r[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) r[i] = row[i];
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const float wv = wl[124 - ((dz * 5 + dy) * 5 + dx)];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = fmaf(wv, r[i + dx], acc[i]);
+        }
+      }
+  }
+  // PreHook multiply, clamp(min=0) (peak_response_mapping_3d.py:170), per-peak sum for the normalisation (:171)
+  const int z = z0 + lz, y = y0 + ly;
+  const int oz = origins[3 * p], oy = origins[3 * p + 1], ox = origins[3 * p + 2];
+  float local = 0.f;
+  const float off = *data_off;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int x = x0 + lx + i;
+    if (z < Wn && y < Wn && x < Wn) {
+      const int qz = oz + z, qy = oy + y, qx = ox + x;
+      float v = 0.f;
+      if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
+        v = (data[((size_t)qz * H + qy) * W + qx] - off) * acc[i];
+        v = v > 0.f ? v : 0.f;
+      }
+      out[(size_t)p * w3 + ((size_t)z * Wn + y) * Wn + x] = v;
+      local += v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = local;
+  __syncthreads();
+  if (tid == 0) atomicAdd(&sums[p], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- normalise + scatter windows into dense [P, D, H, W] maps (zero elsewhere; caller memsets) ----
+__global__ __launch_bounds__(256) void prm_scatter_kernel(const float* __restrict__ win, const float* __restrict__ sums,
+                                                          const int* __restrict__ origins, int P, int Wn, int D, int H, int W,
+                                                          float* __restrict__ dense) {
+  const long long w3 = (long long)Wn * Wn * Wn;
+  const long long total = (long long)P * w3;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % Wn);
+    long long t = e / Wn;
+    const int y = (int)(t % Wn); t /= Wn;
+    const int z = (int)(t % Wn);
+    const int p = (int)(t / Wn);
+    const int qz = origins[3 * p] + z, qy = origins[3 * p + 1] + y, qx = origins[3 * p + 2] + x;
+    if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W))
+      dense[(((size_t)p * D + qz) * H + qy) * W + qx] = win[e] / sums[p];   // prm / prm.sum()  (:171)
+  }
+}
+
+}  // namespace
+
+M3D_API int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
+                         const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
+                         float* d_out, void* stream) {
+  if (num_peaks < 0 || A <= 0 || C <= 0 || S <= 0 || H <= 0 || W <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_peaks || !d_prob || !d_norm_cls || !d_w_cls || !d_h || !d_h_offset || !d_out) return M3D_EINVAL;
+  hipLaunchKernelGGL(prm_seed_kernel, dim3((num_peaks * C + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_peaks, num_peaks,
+                     d_prob, d_norm_cls, d_w_cls, d_h, d_h_offset, A, C, S, H, W, d_out);
+  return m3d::check_launch("prm_seed");
+}
+
+M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                            int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                            const float* d_scale, const float* d_norm, int depth, int height, int width, float* d_out,
+                            int32_t* d_origin_out, void* stream) {
+  if (num_peaks < 0 || channels <= 0 || up_size <= 0 || border < 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_gup || !d_origin_up || !d_xnext || !d_norm || !d_out || !d_origin_out || (pool && !d_argmax)) return M3D_EINVAL;
+  PrepParams q;
+  q.gup = d_gup; q.origin_up = d_origin_up; q.argmax = pool ? d_argmax : nullptr; q.xnext = d_xnext; q.scale = d_scale;
+  q.norm = d_norm; q.out = d_out; q.origin_out = d_origin_out; q.P = num_peaks; q.C = channels; q.U = up_size;
+  q.Wn = (pool ? 2 : 1) * up_size + 2 * border; q.border = border; q.pool = pool ? 1 : 0;
+  q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
+  const long long total = (long long)num_peaks * channels * q.Wn * q.Wn * q.Wn;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(prm_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream), q);
+  return m3d::check_launch("prm_prepare");
+}
+
+M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_weight, const float* d_data, const float* d_data_offset,
+                               const int32_t* d_origins, int num_peaks, int channels, int win, int depth, int height, int width,
+                               float* d_out, float* d_sums, void* stream) {
+  if (num_peaks < 0 || channels <= 0 || win <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_gn || !d_weight || !d_data || !d_data_offset || !d_origins || !d_out || !d_sums || num_peaks > 65535) return M3D_EINVAL;
+  const int tx = (win + 31) / 32, ty = (win + 7) / 8, tz = (win + 7) / 8;
+  (void)hipMemsetAsync(d_sums, 0, sizeof(float) * num_peaks, m3d::as_stream(stream));
+  hipLaunchKernelGGL(prm_stem_dgrad_kernel, dim3(tx * ty * tz, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_gn, d_weight,
+                     d_data, d_data_offset, d_origins, win, depth, height, width, channels, d_out, d_sums);
+  return m3d::check_launch("prm_stem_dgrad");
+}
+
+M3D_API int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
+                            int depth, int height, int width, float* d_dense, void* stream) {
+  if (num_peaks < 0 || win <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_windows || !d_sums || !d_origins || !d_dense) return M3D_EINVAL;
+  const long long total = (long long)num_peaks * win * win * win;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(prm_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream), d_windows, d_sums,
+                     d_origins, num_peaks, win, depth, height, width, d_dense);
+  return m3d::check_launch("prm_scatter");
+}

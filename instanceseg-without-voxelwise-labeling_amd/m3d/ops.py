@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -211,3 +211,63 @@ def otsu2d_batch(image, prm, offsets, max_gray_range=4096):
     check(lib().m3d_otsu2d_batch(_ptr(image), _ptr(prm), _ptr(offsets), R, int(max_gray_range), _ptr(mask), _ptr(kb),
                                  _ptr(status), _ptr(ws), C.c_size_t(wsb), _stream()), "otsu2d_batch")
     return mask, kb, status
+
+
+# ------------------------------------------------------------------ PRM window kernels
+def conv3d_windowed(packed, x, full, full_off, origins):
+    """Batched same-conv on cropped windows + fused (full[co, origin+pos] - off) multiply (m3d_conv3d_forward_windowed)."""
+    _need_gpu(x, full, origins)
+    x = _f32c(x)
+    B, Cin, D, H, W = x.shape
+    assert Cin == packed.cin and full.shape[0] == packed.cout and full.dim() == 4 and full.is_contiguous()
+    assert origins.dtype == torch.int32 and origins.shape == (B, 3) and origins.is_contiguous()
+    out = torch.empty((B, packed.cout, D, H, W), dtype=torch.float32, device=x.device)
+    check(lib().m3d_conv3d_forward_windowed(_ptr(x), _ptr(packed.packed), _ptr(out), B, Cin, packed.cout, D, H, W, packed.k,
+                                            _ptr(full), _ptr(full_off), _ptr(origins), full.shape[1], full.shape[2],
+                                            full.shape[3], _stream()), "conv3d_forward_windowed")
+    return out
+
+
+def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off):
+    """peaks int32 [P,4] (a,s,h,w); prob/norm_cls [A,S,H,W]; w_cls [A,C]; h [C,S,H,W] -> [P,C,1,1,1]."""
+    _need_gpu(peaks, prob, norm_cls, w_cls, h, h_off)
+    P = peaks.shape[0]
+    A, S, H, W = prob.shape
+    Cc = h.shape[0]
+    out = torch.empty((P, Cc, 1, 1, 1), dtype=torch.float32, device=prob.device)
+    check(lib().m3d_prm_seed(_ptr(peaks), P, _ptr(prob), _ptr(norm_cls), _ptr(w_cls), _ptr(h), _ptr(h_off), A, Cc, S, H, W,
+                             _ptr(out), _stream()), "prm_seed")
+    return out
+
+
+def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm):
+    """gup [P,C,U,U,U]; xnext [C,UD,UH,UW]; norm [C,D,H,W] -> (window [P,C,Wn,Wn,Wn], origin int32 [P,3])."""
+    _need_gpu(gup, origin_up, xnext, norm)
+    P, Cc, U = gup.shape[0], gup.shape[1], gup.shape[2]
+    Wn = (2 if pool else 1) * U + 2 * border
+    out = torch.empty((P, Cc, Wn, Wn, Wn), dtype=torch.float32, device=gup.device)
+    oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
+    check(lib().m3d_prm_prepare(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
+                                xnext.shape[1], xnext.shape[2], xnext.shape[3], _ptr(scale), _ptr(norm), norm.shape[1],
+                                norm.shape[2], norm.shape[3], _ptr(out), _ptr(oo), _stream()), "prm_prepare")
+    return out, oo
+
+
+def prm_stem_dgrad(gn, weight, data, data_off, origins):
+    """gn [P,C,Wn,Wn,Wn]; weight [C,1,5,5,5]; data [D,H,W] -> (windows [P,Wn,Wn,Wn] clamped, sums [P])."""
+    _need_gpu(gn, weight, data, data_off, origins)
+    P, Cc, Wn = gn.shape[0], gn.shape[1], gn.shape[2]
+    out = torch.empty((P, Wn, Wn, Wn), dtype=torch.float32, device=gn.device)
+    sums = torch.empty((P,), dtype=torch.float32, device=gn.device)
+    check(lib().m3d_prm_stem_dgrad(_ptr(gn), _ptr(weight), _ptr(data), _ptr(data_off), _ptr(origins), P, Cc, Wn, data.shape[0],
+                                   data.shape[1], data.shape[2], _ptr(out), _ptr(sums), _stream()), "prm_stem_dgrad")
+    return out, sums
+
+
+def prm_scatter(windows, sums, origins, shape):
+    _need_gpu(windows, sums, origins)
+    P, Wn = windows.shape[0], windows.shape[1]
+    D, H, W = shape
+    dense = torch.zeros((P, D, H, W), dtype=torch.float32, device=windows.device)
+    check(lib().m3d_prm_scatter(_ptr(windows), _ptr(sums), _ptr(origins), P, Wn, D, H, W, _ptr(dense), _stream()), "prm_scatter")
+    return dense

@@ -1,0 +1,110 @@
+"""Peak-response mapping on the HIP kernels: host-side counterpart of PeakResponseMapping_3d.forward
+(lib/prm/peak_response_mapping_3d.py:85-193) with the per-conv rule of lib/prm/peak_backprop_3d.py:8-44.
+
+Forward: every conv runs twice, as in the reference's pr_conv3d — the response conv (bias + eval BatchNorm +
+ReLU fused in the epilogue) and the norm conv on (x - min(x)) with relu(W).  The RPN_bbox_pred norm conv the
+reference also computes (its Conv3d is patched too) is skipped: nothing back-propagates through it.
+Backward: ALL kept peaks of the tile at once, as batches of receptive-field windows (csrc/prm.hip).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .model import DetectorM3D
+
+
+class PRMEngine:
+    def __init__(self, det: DetectorM3D, peak_chunk=32):
+        self.det = det
+        self.cfg = det.cfg
+        self.peak_chunk = peak_chunk
+        P = det.P
+        self.layers = []
+        names = [c for c, _, _ in __import__("m3d.model", fromlist=["dsn_layers"]).dsn_layers(det.cfg.stride)]
+        for (conv, scale, shift, pool), cname in zip(det.body, names):
+            w = P["Conv_Body.%s.weight" % cname]
+            self.layers.append(dict(name=cname, conv=conv, scale=scale, shift=shift, pool=pool, k=w.shape[2],
+                                    norm_conv=ops.PackedConv3d(w, ops.W_RELU),
+                                    dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU), weight=w))
+        w = P["RPN.RPN_conv.weight"]
+        self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU))
+        self.w_cls = P["RPN.RPN_cls_score.weight"]
+        self.cls_norm_conv = ops.PackedConv3d(self.w_cls, ops.W_RELU)
+        self.w_cls2d = self.w_cls.reshape(self.w_cls.shape[0], self.w_cls.shape[1]).contiguous()
+
+    # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
+    def forward(self, data):
+        det = self.det
+        saved = []
+        x = data
+        for L in self.layers:
+            off = ops.reduce_min(x)
+            y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
+            n = L["norm_conv"](x, in_offset=off)
+            if L["pool"]:
+                xn, am = ops.maxpool3d_2x(y, return_argmax=True)
+            else:
+                xn, am = y, None
+            saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
+                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], weight=L["weight"]))
+            x = xn
+        feat = x
+        off = ops.reduce_min(feat)
+        h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
+        n = self.rpn["norm_conv"](feat, in_offset=off)
+        saved.append(dict(x=feat[0], off=off, n=n[0], scale=None, pool=False, argmax=None, xnext=h[0], k=3,
+                          dgrad=self.rpn["dgrad"]))
+        off_h = ops.reduce_min(h)
+        o = det.rpn_heads(h, shift=det.rpn_heads_bias)
+        prob = torch.sigmoid(o[:, :det.A]).contiguous()
+        deltas = o[:, det.A:].contiguous()
+        n_cls = self.cls_norm_conv(h, in_offset=off_h)
+        top = dict(h=h[0], off_h=off_h, n_cls=n_cls[0], prob=prob[0])
+        return feat, prob, deltas, saved, top
+
+    # ---------------------------------------------------------------- backward for a batch of peaks
+    def backward_windows(self, peaks_ashw, saved, top, data):
+        """peaks_ashw: int32 CUDA [P,4] (anchor, s, h, w).  Returns (windows [P,Wn,Wn,Wn] (un-normalised, clamped),
+        sums [P], origins int32 [P,3])."""
+        outs, sums, origs = [], [], []
+        for c0 in range(0, peaks_ashw.shape[0], self.peak_chunk):
+            pk = peaks_ashw[c0:c0 + self.peak_chunk].contiguous()
+            g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
+            origin = pk[:, 1:4].contiguous()
+            for rec in reversed(saved[1:]):
+                gn, origin = ops.prm_prepare(g, origin, rec["pool"], 1, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
+                g = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
+            rec = saved[0]                       # conv1a: 5^3, one input channel -> VALU stem dgrad
+            gn, origin = ops.prm_prepare(g, origin, rec["pool"], 2, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
+            w, s = ops.prm_stem_dgrad(gn, rec["weight"], data[0, 0], rec["off"], origin)
+            outs.append(w); sums.append(s); origs.append(origin)
+        return torch.cat(outs), torch.cat(sums), torch.cat(origs)
+
+    # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193
+    def prm_tile(self, data, peak_threshold=0.1, dense=True):
+        det, c = self.det, self.cfg
+        S, H, W = data.shape[-3:]
+        im_info = np.array([S, H, W, 1.0], np.float64)
+        feat, prob, deltas, saved, top = self.forward(data)
+        rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
+        if rois.shape[0] == 0:
+            return None, None, None, None
+        cls, bbox = det.box_head(feat, rois)
+        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
+        sc, bx, _, cls_keep = det.box_results_with_nms_and_limit(cls, pred, keep_idx)                          # :124
+        keep = cls_keep[1]                                                                                     # :125
+        A = prob.shape[1]
+        s_, h_, w_ = prob.shape[-3:]
+        a = keep % A                                  # unravel_index(idx, (B,S,H,W,A)) with B = 1 (:136-139)
+        pos = keep // A
+        peaks = torch.stack([torch.zeros_like(a), a, pos // (h_ * w_), (pos // w_) % h_, pos % w_], 1)
+        valid = sc > peak_threshold                                                                            # :161-162
+        if int(valid.sum()) == 0:
+            return None, None, None, None
+        peaks_v = peaks[valid]
+        dets = torch.cat([bx[valid], sc[valid].unsqueeze(1)], 1).double()                                      # :163
+        win, sums, origins = self.backward_windows(peaks_v[:, 1:].to(torch.int32).contiguous(), saved, top, data)
+        out = dict(crm=prob, peaks=peaks_v, dets=dets, windows=win, sums=sums, origins=origins)
+        if dense:
+            out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
+        return out
