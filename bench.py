@@ -80,12 +80,50 @@ def backbone_flops(size):
     return sum(conv_flops(*l) for l in L)
 
 
+def bench_prm(args, rank, world, dist):
+    """configs[3]: PRM_ON soma tile 1x64x160x160: forward (2 convs per layer) + batched peak back-propagation."""
+    import m3d
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    import oracle as O
+    cfg = O.Cfg.soma()
+    P = O.make_params(stride=4, num_anchors=14, mlp_dim=cfg.mlp_dim, seed=0)
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), peak_chunk=32)
+    S, H, W = 64, 160, 160
+    vol = torch.from_numpy(synth_volume(rank, 160)[:S]).reshape(1, 1, S, H, W).contiguous().cuda()
+    npk = []
+
+    def step():
+        out = eng.prm_tile(vol, dense=False)
+        npk.append(0 if out is None else int(out["peaks"].shape[0]))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # forward-only and backward-only split
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record(); eng.forward(vol); e[1].record(); torch.cuda.synchronize()
+    fwd_ms = e[0].elapsed_time(e[1])
+    if rank == 0:
+        print(json.dumps({"metric": "voxels/sec end-to-end infer_simple (PRM_ON soma tile)", "value": world * args.steps * S * H * W / dt,
+                          "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "PRM tile 1x64x160x160 soma net (stride 4, 14 anchors): PRM forward + box head + "
+                                                 "batched peak back-propagation [configs[3]]", "peaks_per_tile": npk[-1],
+                                     "prm_forward_ms": fwd_ms}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect"])
+    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect", "prm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -105,6 +143,8 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O   # parameter generator + CPU baseline only (never on the measured GPU path)
 
+    if args.workload == "prm":
+        return bench_prm(args, rank, world, dist)
     cfg = O.Cfg()
     P = O.make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=(args.workload == "detect"))
     det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)

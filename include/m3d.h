@@ -45,6 +45,14 @@ int m3d_roi_align3d_forward(int aligned_slices, int aligned_height, int aligned_
                             int sampling_ratio, const float* d_features, int batch, int channels, int slices,
                             int height, int width, const float* d_rois, int num_rois, int roi_cols,
                             float* d_output, void* stream);
+/* Same contract, but every output element is computed in the reference kernel's exact fp32 operation order
+ * (8 samples x 8 corner products, roi_align_kernel_3d.cu:73-76,128-147): bit-identical to oracle/m3d_oracle.c.
+ * m3d_roi_align3d_forward uses the algebraically equal separable form (three 1-D passes through LDS, ~4x fewer
+ * operand reads); the two agree to ~1e-6 * max|feature|. */
+int m3d_roi_align3d_forward_exact(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
+                                  int sampling_ratio, const float* d_features, int batch, int channels, int slices,
+                                  int height, int width, const float* d_rois, int num_rois, int roi_cols,
+                                  float* d_output, void* stream);
 int m3d_roi_align3d_backward(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
                              int sampling_ratio, const float* d_top_grad, const float* d_rois, int num_rois,
                              int roi_cols, float* d_bottom_grad, int batch, int channels, int slices, int height,

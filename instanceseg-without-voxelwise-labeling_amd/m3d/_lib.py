@@ -10,7 +10,7 @@ _lib = None
 
 SYMBOLS = [
     "m3d_version", "m3d_error_string", "m3d_last_hip_error",
-    "m3d_roi_align3d_forward", "m3d_roi_align3d_backward",
+    "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward",
     "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
     "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
     "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_pack_weights", "m3d_conv3d_forward", "m3d_conv3d_forward_windowed",

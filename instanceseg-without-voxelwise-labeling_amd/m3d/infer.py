@@ -1,0 +1,77 @@
+"""Counterparts of the reference's inference drivers on the HIP path.
+
+  im_detect_all   lib/core/test.py:54-177  (detection mode: pad, tile, per-tile detect, offset, cross-tile NMS)
+  infer_prm       tools/infer_simple.py:176-247 (PRM mode: per tile dets.npy + uint8 PRMs; TIFF container is a
+                  'next' row)
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops, tiling
+
+
+def im_detect_all(det, im, patch=None, overlap=100, dist=None):
+    """det: DetectorM3D; im: raw (S,H,W) volume (any dtype).  Returns cls_boxes_total: list (per class) of
+    [n,7] float32 arrays (x1,y1,z1,x2,y2,z2,score) in volume coordinates, after the cross-tile nms_3d
+    (core/test.py:159).  With `dist` initialised the tiles are sharded round-robin over ranks and their
+    detections exchanged by one all_gather (m3d.shard)."""
+    from . import shard
+    c = det.cfg
+    patch = patch or getattr(c, "in_size", (64, 200, 200))
+    vol = tiling.norm1(np.asarray(im), np.float32).astype(np.float32)          # blob.py:179-184
+    vol, pad_s = tiling.pad_slices(vol, patch[0])                             # core/test.py:79-86
+    sidx, hidx, widx = tiling.tile_grid(vol.shape, patch, overlap)
+    tiles = tiling.enumerate_tiles(sidx, hidx, widx)
+    rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    dvol = torch.from_numpy(vol).cuda()
+    local = []
+    for i in shard.partition(len(tiles), rank, world):
+        _, s, h, w = tiles[i]
+        cube = dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].contiguous()[None, None]
+        out = det.detect_tile(cube)
+        d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
+        off = torch.tensor([w, h, s - pad_s, w, h, s - pad_s, 0], dtype=torch.float32, device=d.device)   # :117-121,140-141
+        local.append(d + off)
+    padded, counts = shard.pack_detections(local, c.detections_per_im, device="cuda")
+    allt = shard.all_gather_detections(padded, counts, len(tiles), dist)
+    dets = torch.cat(allt, 0) if allt else torch.zeros((0, 7), device="cuda")
+    keep = ops.nms3d(dets.contiguous(), c.nms)                                 # :159
+    res = [np.zeros((0, 7), np.float32) for _ in range(c.num_classes)]
+    res[1] = dets[keep].cpu().numpy()
+    return res
+
+
+def infer_prm(engine, im, dataset="nuclei", patch=None, overlap=100, out_dir=None, peak_threshold=0.1):
+    """engine: PRMEngine.  Returns a list of per-tile dicts {num, start, dets (float64 [P,7]), prm_u8 (list of
+    uint8 volumes, slice padding removed)} for tiles that produced detections (infer_simple.py:209-247)."""
+    c = engine.cfg
+    patch = patch or getattr(c, "in_size", (64, 200, 200))
+    vol = tiling.norm1(np.asarray(im), np.float64)                            # :180-183
+    orig_slices = vol.shape[0]
+    vol, pad_s = tiling.pad_slices(vol, patch[0])                             # :188-195
+    sidx, hidx, widx = tiling.tile_grid(vol.shape, patch, overlap, dataset)   # :196-204
+    results = []
+    for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
+        crop = vol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].copy().astype(np.float32)   # :217
+        out = engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=peak_threshold, dense=True)
+        if out is None or out.get("dets") is None:
+            continue                                                          # :225-226
+        dets = out["dets"].cpu().numpy()
+        prm = out["prms"].cpu().numpy()
+        u8 = []
+        for ch in range(prm.shape[0]):                                        # :233-240
+            fm = tiling.quantize_u8(prm[ch])
+            if pad_s:
+                fm = fm[pad_s:pad_s + orig_slices]
+            u8.append(fm)
+        rec = dict(num=num, start=(s, h, w), dets=dets, prm_u8=u8, peaks=out["peaks"].cpu().numpy())
+        results.append(rec)
+        if out_dir is not None:                                               # :213-216,246-247
+            sp = os.path.join(out_dir, "instances", str(num))
+            os.makedirs(sp, exist_ok=True)
+            np.save(os.path.join(sp, "dets.npy"), dets)
+            np.savez_compressed(os.path.join(sp, "prms_u8.npz"), *u8)
+    return results

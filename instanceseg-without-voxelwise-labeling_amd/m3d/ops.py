@@ -36,13 +36,16 @@ def _f32c(t):
 
 
 # ------------------------------------------------------------------ RoIAlign3D
-def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio):
+def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio, exact=False):
+    """exact=True: the reference kernel's fp32 operation order (bit-identical to the oracle); default: the
+    separable fast form (same samples and weights, different summation order)."""
     _need_gpu(features, rois)
     features, rois = _f32c(features), _f32c(rois)
     B, Cc, S, H, W = features.shape
     R = rois.shape[0]
     out = torch.zeros((R, Cc, AS, AH, AW), dtype=torch.float32, device=features.device)   # roi_align_3d.py:24
-    check(lib().m3d_roi_align3d_forward(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
+    fn = lib().m3d_roi_align3d_forward_exact if exact else lib().m3d_roi_align3d_forward
+    check(fn(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
                                         _ptr(features), B, Cc, S, H, W, _ptr(rois), R, int(rois.shape[1]) if rois.dim() == 2 else 0,
                                         _ptr(out), _stream()), "roi_align3d_forward")
     return out

@@ -34,8 +34,8 @@ def test_reference_import_names(compat, golden):
     f = torch.randn(1, 4, 6, 6, 6, device="cuda", requires_grad=True)
     rois = torch.tensor([[0, 2, 2, 2, 30, 30, 30.]], device="cuda")
     out = RoIAlignFunction_3d(7, 7, 7, 0.125, 2)(f, rois)
-    assert np.array_equal(out.detach().cpu().numpy(),
-                          O.roi_align_3d_forward(f.detach().cpu().numpy(), rois.cpu().numpy(), 7, 7, 7, 0.125, 2))
+    assert np.allclose(out.detach().cpu().numpy(),
+                       O.roi_align_3d_forward(f.detach().cpu().numpy(), rois.cpu().numpy(), 7, 7, 7, 0.125, 2), atol=1e-5)
     out.sum().backward()
     assert f.grad is not None and abs(f.grad.sum().item() - 4 * 343) < 1e-2
     with pytest.raises(NotImplementedError):

@@ -1,0 +1,69 @@
+"""CPU: host-side driver logic (tiling, sharding) against the golden index lists and a 2-rank gloo run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_tiling_matches_reference_lists(golden):
+    from m3d import tiling
+    g = golden("tiling")
+    for i in range(int(g["n"])):
+        shape, patch, ov = g["shape%d" % i], g["patch%d" % i], int(g["ov%d" % i])
+        im, pad_s = tiling.pad_slices(np.zeros(shape, np.float32), patch[0])
+        assert pad_s == int(g["pad%d" % i])
+        s, h, w = tiling.tile_grid(im.shape, patch, ov)
+        assert (s, h, w) == (list(g["s%d" % i]), list(g["h%d" % i]), list(g["w%d" % i]))
+    nums = [t[0] for t in tiling.enumerate_tiles([0], [0, 100, 150], [0, 100, 150])]
+    assert nums == list(range(9))
+    assert tiling.tile_grid((96, 256, 256), (64, 160, 160), 0, "soma") == ([0, 32, 64], [0, 96], [0, 96])
+
+
+def test_norm1_and_quantize():
+    from m3d import tiling
+    import oracle as O
+    rs = np.random.RandomState(0)
+    im = rs.randint(0, 900, (5, 6, 7)).astype(np.uint16)
+    assert np.array_equal(tiling.norm1(im), O.norm1(im))
+    a = rs.rand(4, 5, 6).astype(np.float32)
+    assert np.array_equal(tiling.quantize_u8(a), O.quantize_prm_u8(a))
+    p, ps = tiling.pad_slices(np.arange(24, dtype=np.float32).reshape(2, 3, 4), 5)
+    assert ps == 1 and p.shape == (5, 3, 4) and np.array_equal(p[0], p[1]) and np.array_equal(p[-1], p[-3])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "instanceseg-without-voxelwise-labeling_amd"))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from m3d import shard
+    n_items = 5
+    mine = shard.partition(n_items, rank, world)
+    local = [torch.full((i + 1, 7), float(i)) for i in mine]      # item i has i+1 detections, all valued i
+    padded, counts = shard.pack_detections(local, cap=4)
+    out = shard.all_gather_detections(padded, counts, n_items, dist)
+    q.put((rank, [(int(t.shape[0]), float(t[0, 0])) for t in out]))
+    dist.destroy_process_group()
+
+
+def test_shard_all_gather_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    expect = [(min(i + 1, 4), float(i)) for i in range(5)]      # capped at 4, global item order restored
+    assert res[0] == expect and res[1] == expect
