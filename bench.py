@@ -160,15 +160,18 @@ def main():
     def step(timed):
         x = vol
         for li, (conv, scale, shift, pool) in enumerate(det.body):
+            fused = pool and conv.supports_pool(x.shape[-1])
+            run = (lambda t: conv.pooled(t, scale=scale, shift=shift, relu=True)) if fused else \
+                  (lambda t: conv(t, scale=scale, shift=shift, relu=True))
             if timed and li in dom_layers:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                x = conv(x, scale=scale, shift=shift, relu=True)
+                x = run(x)
                 e1.record()
                 dom_ev.append((e0, e1))
             else:
-                x = conv(x, scale=scale, shift=shift, relu=True)
-            if pool:
+                x = run(x)
+            if pool and not fused:
                 x = m3d.maxpool3d_2x(x)
         if args.workload == "backbone":
             return x

@@ -121,6 +121,15 @@ int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, i
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
 
+/* Conv + scale/shift + ReLU + MaxPool3d(2,2) fused (DSN.py:58,60-61: pool1/pool2 directly follow a conv):
+ * writes only the pooled tensor [batch,cout,D/2,H/2,W/2] (8x fewer output bytes, no separate pool pass) and,
+ * if d_argmax != NULL, the window index (z*4+y*2+x, first maximum) for the PRM un-pooling.  Supported for the
+ * 5^3 stem (cout <= 32) and k = 3 with width >= 24; otherwise M3D_EUNSUPPORTED (use conv + m3d_maxpool3d_2x). */
+int m3d_conv3d_forward_pool2(const float* d_in, const float* d_packed, float* d_out_pooled, uint8_t* d_argmax,
+                             int batch, int cin, int cout, int depth, int height, int width, int k,
+                             const float* d_in_offset, const float* d_scale, const float* d_shift, int relu,
+                             void* stream);
+
 /* Same conv on a batch of cropped windows, with the PRM PreHook multiply fused: out[b,co,z,y,x] *=
  * full[co, origin_b + (z,y,x)] - *d_full_offset, and 0 where that position lies outside the full tensor
  * (lib/prm/peak_backprop_3d.py:16-18 restricted to each peak's receptive-field cone).

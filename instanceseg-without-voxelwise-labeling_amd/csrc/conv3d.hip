@@ -21,9 +21,14 @@
 // unrolled and the (ci pair, dz, dy, dx) offsets fold into the ds_read offset field.
 #include "m3d_common.h"
 
+#ifndef M3D_STEM_ROWS
+#define M3D_STEM_ROWS 4
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------------
 // Weight packing.  Packed layout: Wp[cpair][cb][tap][lane]  (lane 0..63; cpair = input-channel pair)
@@ -88,6 +93,7 @@ struct Epilogue {
   const float* full_off;
   const int* origins;   // [batch, 3] (z, y, x)
   int FD, FH, FW;
+  uint8_t* argmax;      // fused 2x2x2 max-pool variants only: [batch, cout, D/2, H/2, W/2] or null
 };
 
 __device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int co, int z, int y, int x, size_t o) {
@@ -105,18 +111,41 @@ __device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int c
   return v;
 }
 
+
+// Fused 2x2x2 max-pool epilogue (XB = 32, four rows per wave = the 2x2 (z,y) footprint of one pooling window row).
+// v[r] is the post-activation value of row r = zz*2 + yy at this lane's x; the pooling window index is
+// q = zz*4 + yy*2 + (x&1), scanned in (z,y,x) order with "first maximum wins" like nn.MaxPool3d (DSN.py:21,26).
+__device__ inline void pool4_store(const Epilogue& ep, float* __restrict__ out, const float v[4], int lane_x, int b, int co,
+                                   int cout, int oz, int oy, int ox, int OD, int OH, int OW) {
+  float best = v[0];
+  int q = lane_x & 1;
+#pragma unroll
+  for (int r = 1; r < 4; ++r)
+    if (v[r] > best || (v[r] != v[r] && best == best)) { best = v[r]; q = r * 2 + (lane_x & 1); }
+  const float ov = __shfl_xor(best, 1, 64);
+  const int oq = __shfl_xor(q, 1, 64);
+  if (ov > best || (ov == best && oq < q) || (ov != ov && best == best)) { best = ov; q = oq; }
+  if (((lane_x & 1) == 0) & (oz < OD) & (oy < OH) & (ox < OW)) {
+    const size_t o = ((((size_t)b * cout + co) * OD + oz) * OH + oy) * OW + ox;
+    out[o] = best;
+    if (ep.argmax) ep.argmax[o] = (uint8_t)q;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Generic k in {1,3} kernel.
 //   XB   : x extent of a 32-voxel block (32, 16 or 8);  YB = 32 / XB rows of y per block
 //   ROWS : voxel blocks per wave (stacked along y);  NCB : 32-channel output blocks per workgroup
 //   WZ, WY: wave grid inside the workgroup (WZ * WY == 4); tile = XB x (WY*ROWS*YB) x WZ voxels
 // ------------------------------------------------------------------------------------------------------
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false>
 struct Cfg {
   static constexpr int P = K / 2;
   static constexpr int K3 = K * K * K;
   static constexpr int YB = 32 / XB;
-  static constexpr int TX = XB, TY = WY * ROWS * YB, TZ = WZ;
+  // rows of a wave: r -> (zz = r / RY, yy = r % RY).  POOL: 2 z-levels x 2 y-rows = one pooling footprint.
+  static constexpr int RY = POOL ? ROWS / 2 : ROWS, RZ = ROWS / RY;
+  static constexpr int TX = XB, TY = WY * RY * YB, TZ = WZ * RZ;
   static constexpr int HX = TX + 2 * P, HY = TY + 2 * P, HZ = TZ + 2 * P;
   static constexpr int CS = HX * HY * HZ;                 // per-channel LDS stride (floats)
   static constexpr int IN_ELEMS = CC * CS;
@@ -127,13 +156,14 @@ struct Cfg {
   static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS;
   static_assert(WZ * WY == 4, "4 waves per workgroup");
   static_assert(W_SEG % 4 == 0, "weights staged as float4");
+  static_assert(!POOL || (ROWS == 4 && XB == 32), "fused pool: 32-wide blocks, 2x2 rows per wave");
 };
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                           float* __restrict__ out, int cin, int cout, int D, int H, int W,
                                                           int tiles_x, int tiles_y, int tiles_z, int ncb_total, Epilogue ep) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
   extern __shared__ float lds[];
   float* lds_in = lds;
   float* lds_w = lds + C::IN_ELEMS;
@@ -145,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
 
   // block -> (cout tile, x tile, y tile, z tile), batch = blockIdx.y
   int bid = blockIdx.x;
-  const int co_tiles = (ncb_total + NCB - 1) / NCB;
+  const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
   const int cot = bid % co_tiles; bid /= co_tiles;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; bid /= tiles_y;
@@ -157,57 +187,62 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
   const float in_off = ep.in_off ? *ep.in_off : 0.f;
 
   // ---- per-thread staging descriptors (constant across chunks except for the channel base) ----
-  int goff[C::NI];          // offset inside one channel-chunk of the input, or -1 for padding / out of tile
+  // goff: offset inside one channel chunk of the input; -1 = zero padding, -2 = beyond the tile (no LDS write).
+  int goff[C::NI];
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
     const int e = tid + i * 256;
-    int g = -2;             // -2: beyond the tile (no LDS write at all)
+    int g = -2;
     if (e < C::IN_ELEMS) {
       const int ci = e / C::CS;
       const int r = e % C::CS;
       const int hz = r / (C::HY * C::HX), hy = (r / C::HX) % C::HY, hx = r % C::HX;
       const int z = z0 + hz - C::P, y = y0 + hy - C::P, x = x0 + hx - C::P;
       const bool ok = (z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
-      g = ok ? (int)(ci * DHW + ((size_t)z * H + y) * W + x) : -1;   // channel-chunk fits in int (checked on host)
+      g = ok ? (int)(ci * DHW + ((size_t)z * H + y) * W + x) : -1;   // channel chunk fits in int (checked on host)
     }
     goff[i] = g;
   }
 
   float rin[C::NI];
-  float4 rw[C::NW4];
+  f32x4 rw[C::NW4];
   const int nchunk = (cin + CC - 1) / CC;
-  const float4* wp4 = reinterpret_cast<const float4*>(wp);
-  const size_t w_pair_stride4 = (size_t)ncb_total * C::K3 * 64 / 4;      // one channel pair, all cout blocks
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  // packed weights are zero-padded to a multiple of 16 channel pairs and 2 cout blocks (conv3d_packed_dims),
+  // so the slab loads below never need a predicate.
+  const size_t w_pair_stride4 = (size_t)ncb_total * C::K3 * 64 / 4;      // one channel pair, all (padded) cout blocks
   const size_t w_tile_off4 = (size_t)cot * NCB * C::K3 * 64 / 4;
-  // valid float4 per channel pair for this cout tile (the last tile may have fewer than NCB blocks)
-  const int ncb_here = min(NCB, ncb_total - cot * NCB);
-  const int seg4_here = ncb_here * C::K3 * 64 / 4;
-  const int npair_total = (cin + 1) / 2;
 
-  auto prefetch = [&](int chunk) {
+  // Loads are unconditional (index clamped to a valid element) and carry NO arithmetic: anything applied to a
+  // loaded value here would make the compiler wait for the load before the MFMA loop.  Zero padding and the
+  // PRM input offset are applied in commit(), after the loop.
+  auto prefetch = [&](int chunk) __attribute__((always_inline)) {
     const float* src = in_b + (size_t)chunk * CC * DHW;
     const int cvalid = min(CC, cin - chunk * CC);          // channels present in this chunk
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
-      float v = 0.f;
       const int g = goff[i];
-      if (g >= 0 && ((tid + i * 256) / C::CS) < cvalid) v = src[g] - in_off;
-      rin[i] = v;
+      const bool ok = (g >= 0) & (((tid + i * 256) / C::CS) < cvalid);
+      rin[i] = src[ok ? g : 0];
     }
-    const float4* ws = wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4;
+    const f32x4* ws = wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4;
 #pragma unroll
     for (int i = 0; i < C::NW4; ++i) {
-      const int e = tid + i * 256;
+      int e = tid + i * 256;
+      if (e >= C::W_ELEMS / 4) e = C::W_ELEMS / 4 - 1;     // only the last i can overshoot (compile-time for the rest)
       const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
-      const bool ok = (e < C::W_ELEMS / 4) & (o < seg4_here) & (chunk * (CC / 2) + pr < npair_total);
-      rw[i] = ok ? ws[(size_t)pr * w_pair_stride4 + o] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = ws[(size_t)pr * w_pair_stride4 + o];
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int chunk, float* dst_in, float* dst_w) __attribute__((always_inline)) {
+    const int cvalid = min(CC, cin - chunk * CC);
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i)
-      if (goff[i] != -2) lds_in[tid + i * 256] = rin[i];
-    float4* lw4 = reinterpret_cast<float4*>(lds_w);
+    for (int i = 0; i < C::NI; ++i) {
+      const int g = goff[i];
+      const bool ok = (g >= 0) & (((tid + i * 256) / C::CS) < cvalid);
+      if (g != -2) dst_in[tid + i * 256] = ok ? rin[i] - in_off : 0.f;
+    }
+    f32x4* lw4 = reinterpret_cast<f32x4*>(dst_w);
 #pragma unroll
     for (int i = 0; i < C::NW4; ++i) {
       const int e = tid + i * 256;
@@ -225,12 +260,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
 
   // per-lane LDS base (floats) of the B fragment for row block r = 0, tap (0,0,0), pair 0
   const int jx = (lane & 31) % XB, jy = (lane & 31) / XB;
-  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HX) + (wy * ROWS * C::YB + jy) * C::HX + jx;
+  const int b_base = (lane >> 5) * C::CS + wz * C::RZ * (C::HY * C::HX) + (wy * C::RY * C::YB + jy) * C::HX + jx;
 
+  // double-buffered LDS: chunk c is computed from buffer c&1 while chunk c+1 is committed to the other one;
+  // one barrier per chunk.
   prefetch(0);
-  commit();
+  commit(0, lds_in, lds_w);
   __syncthreads();
   for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
+    const float* cur_w = cur_in + C::IN_ELEMS;
     if (chunk + 1 < nchunk) prefetch(chunk + 1);
 #pragma unroll
     for (int tap = 0; tap < C::K3; ++tap) {
@@ -240,37 +279,61 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
         float bf[ROWS], af[NCB];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
-          bf[r] = lds_in[b_base + r * C::YB * C::HX + pair * 2 * C::CS + dz * (C::HY * C::HX) + dy * C::HX + dx];
+          bf[r] = cur_in[b_base + (r / C::RY) * (C::HY * C::HX) + (r % C::RY) * C::YB * C::HX + pair * 2 * C::CS +
+                         dz * (C::HY * C::HX) + dy * C::HX + dx];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) af[c] = lds_w[pair * C::W_SEG + (c * C::K3 + tap) * 64 + lane];
+        for (int c = 0; c < NCB; ++c) af[c] = cur_w[pair * C::W_SEG + (c * C::K3 + tap) * 64 + lane];
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
       }
     }
-    __syncthreads();
     if (chunk + 1 < nchunk) {
-      commit();
-      __syncthreads();
+      float* nxt = lds + ((chunk + 1) & 1) * C::LDS_FLOATS;
+      commit(chunk + 1, nxt, nxt + C::IN_ELEMS);
     }
+    __syncthreads();
   }
 
-  // ---- epilogue: y = acc*scale + shift ; relu ; * mul ; coalesced NCDHW stores ----
-  const int z = z0 + wz;
+  // ---- epilogue: y = acc*scale + shift ; relu ; * mul ; coalesced NCDHW stores (or fused 2x2x2 max-pool) ----
+  if constexpr (POOL) {
+    const int OD = D / 2, OH = H / 2, OW = W / 2;
+    const int oz = (z0 + wz * 2) >> 1, oy = (y0 + wy * 2) >> 1, ox = (x0 + jx) >> 1;
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) {
+    for (int c = 0; c < NCB; ++c) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int x = x0 + jx;
-      const int y = y0 + (wy * ROWS + r) * C::YB + jy;
-      if (x < W && y < H && z < D) {
+      for (int g = 0; g < 16; ++g) {
+        const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+        const int coc = co < cout ? co : cout - 1;
+        float v[4];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-          if (co < cout) {
-            const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-            out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[c][r][g];
+          if (ep.scale) t = t * ep.scale[coc];
+          if (ep.shift) t = t + ep.shift[coc];
+          if (ep.relu) t = t > 0.f ? t : 0.f;
+          v[r] = t;
+        }
+        pool4_store(ep, out, v, jx, b, coc, cout, co < cout ? oz : OD, oy, ox, OD, OH, OW);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int z = z0 + wz * C::RZ + r / C::RY;
+        const int x = x0 + jx;
+        const int y = y0 + (wy * C::RY + r % C::RY) * C::YB + jy;
+        if (x < W && y < H && z < D) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+            if (co < cout) {
+              const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
+              out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
+            }
           }
         }
       }
@@ -284,15 +347,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
 // HY*HX-4*HX-4 at a dy wrap: three per-lane base registers, every other offset is an immediate.
 // Tile: 32 x (ROWS*WY) x WZ voxels, all (<=32*NCB) output channels.
 // ------------------------------------------------------------------------------------------------------
-template <int ROWS, int NCB, int WZ, int WY>
+template <int ROWS, int NCB, int WZ, int WY, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                            float* __restrict__ out, int cout, int D, int H, int W, int tiles_x,
                                                            int tiles_y, Epilogue ep) {
   constexpr int K = 5, P = 2, K3 = 125, NPAIR = 63;
-  constexpr int TX = 32, TY = ROWS * WY, TZ = WZ;
+  constexpr int RY = POOL ? ROWS / 2 : ROWS, RZ = ROWS / RY;   // rows of a wave: r -> (zz = r / RY, yy = r % RY)
+  constexpr int TX = 32, TY = RY * WY, TZ = WZ * RZ;
   constexpr int HX = TX + 4, HY = TY + 4, HZ = TZ + 4;
+  static_assert(!POOL || ROWS == 4, "fused pool: 2x2 rows per wave");
   constexpr int IN_ELEMS = HX * HY * HZ;
-  constexpr int IN_PAD = IN_ELEMS + 8;
+  constexpr int IN_PAD = (IN_ELEMS + 8 + 3) / 4 * 4;
   constexpr int W_ELEMS = NCB * NPAIR * 64;
   extern __shared__ float lds[];
   float* lds_in = lds;
@@ -308,16 +373,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
   const size_t DHW = (size_t)D * H * W;
   const float* in_b = in + (size_t)b * DHW;
   const float in_off = ep.in_off ? *ep.in_off : 0.f;
-  for (int e = tid; e < IN_PAD; e += 256) {
-    float v = 0.f;
-    if (e < IN_ELEMS) {
-      const int hz = e / (HY * HX), hy = (e / HX) % HY, hx = e % HX;
-      const int z = z0 + hz - P, y = y0 + hy - P, x = x0 + hx - P;
-      if ((z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W)) v = in_b[((size_t)z * H + y) * W + x] - in_off;
-    }
-    lds_in[e] = v;
+  // all loads of the halo tile are issued back to back (unconditional, clamped index), then written to LDS
+  constexpr int NI = (IN_PAD + 255) / 256;
+  float rin[NI];
+  bool okv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = tid + i * 256;
+    const int hz = e / (HY * HX), hy = (e / HX) % HY, hx = e % HX;
+    const int z = z0 + hz - P, y = y0 + hy - P, x = x0 + hx - P;
+    okv[i] = (e < IN_ELEMS) & (z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+    rin[i] = in_b[okv[i] ? ((size_t)z * H + y) * W + x : 0];
   }
-  for (int e = tid; e < W_ELEMS; e += 256) lds_w[e] = wp[e];
+  constexpr int NWv = (W_ELEMS / 4 + 255) / 256;
+  f32x4 rwv[NWv];
+#pragma unroll
+  for (int i = 0; i < NWv; ++i) {
+    int e = tid + i * 256;
+    if (e >= W_ELEMS / 4) e = W_ELEMS / 4 - 1;
+    rwv[i] = reinterpret_cast<const f32x4*>(wp)[e];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = tid + i * 256;
+    if (e < IN_PAD) lds_in[e] = okv[i] ? rin[i] - in_off : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NWv; ++i) {
+    const int e = tid + i * 256;
+    if (e < W_ELEMS / 4) reinterpret_cast<f32x4*>(lds_w)[e] = rwv[i];
+  }
   __syncthreads();
 
   f32x16 acc[NCB][ROWS];
@@ -329,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
       for (int g = 0; g < 16; ++g) acc[c][r][g] = 0.f;
 
   const int jx = lane & 31;
-  const int base0 = wz * (HY * HX) + (wy * ROWS) * HX + jx;
+  const int base0 = wz * RZ * (HY * HX) + (wy * RY) * HX + jx;
   const int hi = lane >> 5;
   const int baseA = base0 + hi * 1;
   const int baseB = base0 + hi * (HX - 4);
@@ -343,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
     const int base = (dx < 4) ? baseA : ((dy < 4) ? baseB : baseC);
     float bf[ROWS], af[NCB];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) bf[r] = lds_in[base + r * HX + imm];
+    for (int r = 0; r < ROWS; ++r) bf[r] = lds_in[base + (r / RY) * (HY * HX) + (r % RY) * HX + imm];
 #pragma unroll
     for (int c = 0; c < NCB; ++c) af[c] = lds_w[(c * NPAIR + pair) * 64 + lane];
 #pragma unroll
@@ -352,19 +437,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
       for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
   }
   (void)K; (void)K3;
-  const int z = z0 + wz;
+  if constexpr (POOL) {
+    const int OD = D / 2, OH = H / 2, OW = W / 2;
+    const int oz = (z0 + wz * 2) >> 1, oy = (y0 + wy * 2) >> 1, ox = (x0 + jx) >> 1;
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) {
+    for (int c = 0; c < NCB; ++c) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int x = x0 + jx, y = y0 + wy * ROWS + r;
-      if (x < W && y < H && z < D) {
+      for (int g = 0; g < 16; ++g) {
+        const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+        const int coc = co < cout ? co : cout - 1;
+        float v[4];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-          if (co < cout) {
-            const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-            out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[c][r][g];
+          if (ep.scale) t = t * ep.scale[coc];
+          if (ep.shift) t = t + ep.shift[coc];
+          if (ep.relu) t = t > 0.f ? t : 0.f;
+          v[r] = t;
+        }
+        pool4_store(ep, out, v, jx, b, coc, cout, co < cout ? oz : OD, oy, ox, OD, OH, OW);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int z = z0 + wz * RZ + r / RY;
+        const int x = x0 + jx, y = y0 + wy * RY + r % RY;
+        if (x < W && y < H && z < D) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+            if (co < cout) {
+              const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
+              out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
+            }
           }
         }
       }
@@ -372,17 +480,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
   }
 }
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false>
 int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, Epilogue ep,
                hipStream_t st) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
-  const int ncb_total = (cout + 31) / 32;
-  const int co_tiles = (ncb_total + NCB - 1) / NCB;
+  const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;   // as packed (padded to 2 blocks)
+  const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
   const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
   if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
-  const size_t lds = sizeof(float) * C::LDS_FLOATS;
-  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY>;
+  const size_t lds = sizeof(float) * 2 * C::LDS_FLOATS;   // double-buffered
+  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(256), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
@@ -396,7 +504,7 @@ M3D_API size_t m3d_conv3d_packed_weight_bytes(int cin, int cout, int k, int mode
   const bool dgrad = (mode == M3D_W_DGRAD || mode == M3D_W_DGRAD_RELU);
   const int cin_l = dgrad ? cout : cin, cout_l = dgrad ? cin : cout;
   if (k == 5 && cin_l == 1) return sizeof(float) * (size_t)((cout_l + 31) / 32) * 63 * 64;
-  const size_t npair = (cin_l + 1) / 2, ncb = (cout_l + 31) / 32;
+  const size_t npair = ((cin_l + 1) / 2 + 15) / 16 * 16, ncb = ((cout_l + 31) / 32 + 1) / 2 * 2;   // zero-padded
   return sizeof(float) * npair * ncb * (size_t)(k * k * k) * 64;
 }
 
@@ -411,35 +519,36 @@ M3D_API int m3d_conv3d_pack_weights(const float* d_weight, int cin, int cout, in
     return m3d::check_launch("pack_stem");
   }
   if (k != 1 && k != 3) return M3D_EUNSUPPORTED;
-  const int npair = (cin_l + 1) / 2, ncb = (cout_l + 31) / 32;
+  const int npair = ((cin_l + 1) / 2 + 15) / 16 * 16, ncb = ((cout_l + 31) / 32 + 1) / 2 * 2;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(1024), dim3(256), 0, st, d_weight, cin, cout, k, mode, d_packed, ncb, npair);
   return m3d::check_launch("pack_weights");
 }
 
 static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
-                         int height, int width, int k, Epilogue ep, hipStream_t st) {
+                         int height, int width, int k, Epilogue ep, hipStream_t st, bool pool = false) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
     return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
   if (DHW * 32 >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // int offsets inside a channel chunk
   if (k == 5) {
     if (cin != 1 || cout > 64) return M3D_EUNSUPPORTED;
-    constexpr int ROWS = 8, WZ = 4, WY = 1;
-    const int tiles_x = (width + 31) / 32, tiles_y = (height + ROWS * WY - 1) / (ROWS * WY), tiles_z = (depth + WZ - 1) / WZ;
-    const long long blocks = (long long)tiles_x * tiles_y * tiles_z;
-    if (blocks > 0x7FFFFFFFll || batch > 65535) return M3D_EUNSUPPORTED;
-    if (cout <= 32) {
-      constexpr int NCB = 1;
-      const size_t lds = sizeof(float) * (36 * (ROWS * WY + 4) * (WZ + 4) + 8 + NCB * 63 * 64);
-      hipLaunchKernelGGL((conv3d_stem5_kernel<ROWS, NCB, WZ, WY>), dim3((unsigned)blocks, batch), dim3(256), lds, st, d_in,
-                         d_packed, d_out, cout, depth, height, width, tiles_x, tiles_y, ep);
+    const int tiles_x = (width + 31) / 32;
+    if (batch > 65535) return M3D_EUNSUPPORTED;
+    auto lds_bytes = [](int ty, int tz, int ncb) { return sizeof(float) * ((36 * (ty + 4) * (tz + 4) + 8 + 3) / 4 * 4 + ncb * 63 * 64); };
+    if (pool) {      // tile 32 x 4 x 4, waves 2(z) x 2(y), each wave = one 2x2 (z,y) pooling footprint
+      if (cout > 32) return M3D_EUNSUPPORTED;
+      const int ty = (height + 3) / 4, tz = (depth + 3) / 4;
+      hipLaunchKernelGGL((conv3d_stem5_kernel<4, 1, 2, 2, true>), dim3((unsigned)(tiles_x * ty * tz), batch), dim3(256),
+                         lds_bytes(4, 4, 1), st, d_in, d_packed, d_out, cout, depth, height, width, tiles_x, ty, ep);
+    } else if (cout <= 32) {
+      constexpr int ROWS = M3D_STEM_ROWS;
+      const int ty = (height + ROWS - 1) / ROWS, tz = (depth + 3) / 4;
+      hipLaunchKernelGGL((conv3d_stem5_kernel<ROWS, 1, 4, 1, false>), dim3((unsigned)(tiles_x * ty * tz), batch), dim3(256),
+                         lds_bytes(ROWS, 4, 1), st, d_in, d_packed, d_out, cout, depth, height, width, tiles_x, ty, ep);
     } else {
-      constexpr int NCB = 2, R2 = 4;
-      const int ty2 = (height + R2 - 1) / R2;
-      const long long blocks2 = (long long)tiles_x * ty2 * tiles_z;
-      const size_t lds = sizeof(float) * (36 * (R2 + 4) * (WZ + 4) + 8 + NCB * 63 * 64);
-      hipLaunchKernelGGL((conv3d_stem5_kernel<R2, NCB, WZ, WY>), dim3((unsigned)blocks2, batch), dim3(256), lds, st, d_in,
-                         d_packed, d_out, cout, depth, height, width, tiles_x, ty2, ep);
+      const int ty = (height + 3) / 4, tz = (depth + 3) / 4;
+      hipLaunchKernelGGL((conv3d_stem5_kernel<4, 2, 4, 1, false>), dim3((unsigned)(tiles_x * ty * tz), batch), dim3(256),
+                         lds_bytes(4, 4, 2), st, d_in, d_packed, d_out, cout, depth, height, width, tiles_x, ty, ep);
     }
     return m3d::check_launch("conv3d_stem5");
   }
@@ -452,11 +561,15 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
     int xb = 32;
     if (waste(16) < waste(xb) - 0.05) xb = 16;
     if (waste(8) < waste(xb) - 0.05) xb = 8;
+    if (pool) {
+      if (width < 24) return M3D_EUNSUPPORTED;
+      return launch_cfg<3, 2, 32, 4, 2, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    }
     if (xb == 32) {
       const long long wg_big = (vox / 512) * ((ncb_total + 1) / 2);
       if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       const long long wg_mid = (vox / 256) * ((ncb_total + 1) / 2);
-      if (wg_mid >= 256) return launch_cfg<3, 4, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      if (wg_mid >= 256) return launch_cfg<3, 2, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
     if (xb == 16) {
@@ -470,6 +583,7 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       return launch_cfg<3, 4, 8, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
   }
+  if (pool) return M3D_EUNSUPPORTED;
   if (k == 1) {
     if (width >= 24) return launch_cfg<1, 32, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     if (width >= 12) return launch_cfg<1, 32, 16, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
@@ -481,7 +595,7 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
 M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
                                int height, int width, int k, const float* d_in_offset, const float* d_scale,
                                const float* d_shift, int relu, const float* d_mul, void* stream) {
-  Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu, nullptr, nullptr, nullptr, 0, 0, 0};
+  Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
   return conv_dispatch(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
 }
 
@@ -489,6 +603,14 @@ M3D_API int m3d_conv3d_forward_windowed(const float* d_in, const float* d_packed
                                         int depth, int height, int width, int k, const float* d_full, const float* d_full_offset,
                                         const int32_t* d_origins, int full_depth, int full_height, int full_width, void* stream) {
   if (!d_full || !d_origins || full_depth <= 0 || full_height <= 0 || full_width <= 0) return M3D_EINVAL;
-  Epilogue ep{nullptr, nullptr, nullptr, nullptr, 0, d_full, d_full_offset, d_origins, full_depth, full_height, full_width};
+  Epilogue ep{nullptr, nullptr, nullptr, nullptr, 0, d_full, d_full_offset, d_origins, full_depth, full_height, full_width, nullptr};
   return conv_dispatch(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
+}
+
+M3D_API int m3d_conv3d_forward_pool2(const float* d_in, const float* d_packed, float* d_out_pooled, uint8_t* d_argmax, int batch,
+                                     int cin, int cout, int depth, int height, int width, int k, const float* d_in_offset,
+                                     const float* d_scale, const float* d_shift, int relu, void* stream) {
+  if (depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
+  Epilogue ep{d_scale, d_shift, nullptr, d_in_offset, relu, nullptr, nullptr, nullptr, 0, 0, 0, d_argmax};
+  return conv_dispatch(d_in, d_packed, d_out_pooled, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream), true);
 }

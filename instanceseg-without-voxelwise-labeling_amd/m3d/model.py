@@ -51,9 +51,12 @@ class DetectorM3D:
     # ---- lib/modeling/DSN.py:57-68
     def conv_body(self, x):
         for conv, scale, shift, pool in self.body:
-            x = conv(x, scale=scale, shift=shift, relu=True)
-            if pool:
-                x = ops.maxpool3d_2x(x)
+            if pool and conv.supports_pool(x.shape[-1]):
+                x = conv.pooled(x, scale=scale, shift=shift, relu=True)      # conv+BN+ReLU+MaxPool in one kernel
+            else:
+                x = conv(x, scale=scale, shift=shift, relu=True)
+                if pool:
+                    x = ops.maxpool3d_2x(x)
         return x
 
     # ---- lib/modeling/rpn_heads.py:94-116

@@ -150,6 +150,23 @@ class PackedConv3d:
         check(lib().m3d_conv3d_pack_weights(_ptr(weight), self.cin_w, self.cout_w, self.k, mode, _ptr(self.packed), _stream()),
               "conv3d_pack_weights")
 
+    def supports_pool(self, width):
+        return (self.k == 5 and self.cin == 1 and self.cout <= 32) or (self.k == 3 and width >= 24)
+
+    def pooled(self, x, scale=None, shift=None, relu=False, in_offset=None, return_argmax=False):
+        """conv + scale/shift + ReLU + MaxPool3d(2,2) in one kernel (m3d_conv3d_forward_pool2)."""
+        _need_gpu(x)
+        x = _f32c(x)
+        B, Cin, D, H, W = x.shape
+        if Cin != self.cin:
+            raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
+        out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        am = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if return_argmax else None
+        check(lib().m3d_conv3d_forward_pool2(_ptr(x), _ptr(self.packed), _ptr(out), _ptr(am), B, Cin, self.cout, D, H, W,
+                                             self.k, _ptr(in_offset), _ptr(scale), _ptr(shift), int(bool(relu)), _stream()),
+              "conv3d_forward_pool2")
+        return (out, am) if return_argmax else out
+
     def __call__(self, x, scale=None, shift=None, relu=False, in_offset=None, mul=None, out=None):
         _need_gpu(x)
         x = _f32c(x)

@@ -39,12 +39,15 @@ class PRMEngine:
         x = data
         for L in self.layers:
             off = ops.reduce_min(x)
-            y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
             n = L["norm_conv"](x, in_offset=off)
-            if L["pool"]:
-                xn, am = ops.maxpool3d_2x(y, return_argmax=True)
+            if L["pool"] and L["conv"].supports_pool(x.shape[-1]):
+                xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
-                xn, am = y, None
+                y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
+                if L["pool"]:
+                    xn, am = ops.maxpool3d_2x(y, return_argmax=True)
+                else:
+                    xn, am = y, None
             saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
                               xnext=xn[0], k=L["k"], dgrad=L["dgrad"], weight=L["weight"]))
             x = xn

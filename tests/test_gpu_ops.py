@@ -278,3 +278,30 @@ def test_im_detect_all_vs_oracle(m3d):
     assert abs(len(got) - len(ref)) <= max(2, len(ref) // 20)
     matched = sum(np.abs(ref - g).max(1).min() < 1e-2 for g in got)
     assert matched >= 0.95 * len(got)
+
+
+@pytest.mark.parametrize("cin,cout,k,D,H,W", [(1, 32, 5, 8, 12, 64), (1, 20, 5, 6, 10, 34), (64, 64, 3, 8, 8, 64), (32, 48, 3, 7, 9, 33)])
+def test_conv3d_fused_pool_equals_conv_then_pool(m3d, cin, cout, k, D, H, W):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, D, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, k, k, k, generator=g) * 0.1).cuda()
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(cout, generator=g).cuda()
+    conv = m3d.PackedConv3d(w)
+    assert conv.supports_pool(W)
+    y = conv(x, scale=sc, shift=sh, relu=True)
+    ref, am_ref = m3d.maxpool3d_2x(y, return_argmax=True)
+    out, am = conv.pooled(x, scale=sc, shift=sh, relu=True, return_argmax=True)
+    # the un-fused launch may use another channel-chunk size (different fp32 summation order): 1e-5, not bitwise
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    tref, _ = torch.nn.functional.max_pool3d(y.cpu(), 2, 2, return_indices=True)
+    assert torch.allclose(out.cpu(), tref, rtol=1e-5, atol=1e-5)
+    # argmax consistency: the window element the index points at is the pooled maximum
+    B, Cc, OD, OH, OW = out.shape
+    q = am.long()
+    zz = torch.arange(OD, device="cuda").view(1, 1, OD, 1, 1) * 2 + (q >> 2)
+    yy = torch.arange(OH, device="cuda").view(1, 1, 1, OH, 1) * 2 + ((q >> 1) & 1)
+    xx = torch.arange(OW, device="cuda").view(1, 1, 1, 1, OW) * 2 + (q & 1)
+    picked = y[torch.arange(B, device="cuda").view(B, 1, 1, 1, 1), torch.arange(Cc, device="cuda").view(1, Cc, 1, 1, 1), zz, yy, xx]
+    assert torch.allclose(picked, out, rtol=1e-5, atol=1e-5)
+    assert (am == am_ref).float().mean() > 0.999

@@ -11,7 +11,10 @@ L = [("conv1a", 1, 32, 5, size), ("conv2a", 32, 64, 3, size // 2), ("conv2b", 64
      ("conv3a", 64, 128, 3, size // 4), ("conv3b", 128, 128, 3, size // 4), ("conv4a", 128, 256, 3, size // 8),
      ("conv4b", 256, 256, 3, size // 8), ("rpn_conv", 256, 256, 3, size // 8), ("rpn_heads", 256, 245, 1, size // 8)]
 tot_t, tot_f = 0.0, 0.0
+only = os.environ.get('LAYERS')
 for name, cin, cout, k, s in L:
+    if only and name not in only.split(','):
+        continue
     x = torch.randn(1, cin, s, s, s, device="cuda")
     w = torch.randn(cout, cin, k, k, k, device="cuda") * 0.05
     conv = m3d.PackedConv3d(w)
