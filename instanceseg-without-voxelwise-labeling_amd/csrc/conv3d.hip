@@ -20,6 +20,7 @@
 // All B-fragment addresses are "one per-lane base VGPR + compile-time immediate": the tap loop is fully
 // unrolled and the (ci pair, dz, dy, dx) offsets fold into the ds_read offset field.
 #include "m3d_common.h"
+#include <stdlib.h>
 
 #ifndef M3D_STEM_ROWS
 #define M3D_STEM_ROWS 4
@@ -138,8 +139,10 @@ __device__ inline void pool4_store(const Epilogue& ep, float* __restrict__ out, 
 //   ROWS : voxel blocks per wave (stacked along y);  NCB : 32-channel output blocks per workgroup
 //   WZ, WY: wave grid inside the workgroup (WZ * WY == 4); tile = XB x (WY*ROWS*YB) x WZ voxels
 // ------------------------------------------------------------------------------------------------------
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
 struct Cfg {
+  static constexpr int NT = 256 * KS;                    // threads per workgroup (KS = in-workgroup split of K)
+  static constexpr int PP = CC / 2 / KS;                  // channel pairs per chunk handled by one K-split group
   static constexpr int P = K / 2;
   static constexpr int K3 = K * K * K;
   static constexpr int YB = 32 / XB;
@@ -151,26 +154,29 @@ struct Cfg {
   static constexpr int IN_ELEMS = CC * CS;
   static constexpr int W_SEG = NCB * K3 * 64;              // floats per channel pair for this workgroup
   static constexpr int W_ELEMS = (CC / 2) * W_SEG;
-  static constexpr int NI = (IN_ELEMS + 255) / 256;       // input staging registers per thread
-  static constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;   // weight staging float4 per thread
+  static constexpr int NI = (IN_ELEMS + NT - 1) / NT;     // input staging registers per thread
+  static constexpr int NW4 = (W_ELEMS / 4 + NT - 1) / NT; // weight staging float4 per thread
   static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS;
   static_assert(WZ * WY == 4, "4 waves per workgroup");
   static_assert(W_SEG % 4 == 0, "weights staged as float4");
   static_assert(!POOL || (ROWS == 4 && XB == 32), "fused pool: 32-wide blocks, 2x2 rows per wave");
+  static_assert(KS == 1 || (KS == 2 && !POOL && CC % 4 == 0), "split-K: two groups of 4 waves");
+  static_assert(KS == 1 || 4 * NCB * ROWS * 16 * 64 <= 2 * LDS_FLOATS, "split-K reduction buffer fits the staging area");
 };
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL, int KS>
+__global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                           float* __restrict__ out, int cin, int cout, int D, int H, int W,
                                                           int tiles_x, int tiles_y, int tiles_z, int ncb_total, Epilogue ep) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
   extern __shared__ float lds[];
   float* lds_in = lds;
   float* lds_w = lds + C::IN_ELEMS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = (tid >> 6) & 3;      // position inside a K-split group
+  const int ks = tid >> 8;               // K-split group (0 when KS == 1)
   const int wz = wave / WY, wy = wave % WY;
 
   // block -> (cout tile, x tile, y tile, z tile), batch = blockIdx.y
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
   int goff[C::NI];
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
-    const int e = tid + i * 256;
+    const int e = tid + i * C::NT;
     int g = -2;
     if (e < C::IN_ELEMS) {
       const int ci = e / C::CS;
@@ -222,13 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int g = goff[i];
-      const bool ok = (g >= 0) & (((tid + i * 256) / C::CS) < cvalid);
+      const bool ok = (g >= 0) & (((tid + i * C::NT) / C::CS) < cvalid);
       rin[i] = src[ok ? g : 0];
     }
     const f32x4* ws = wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4;
 #pragma unroll
     for (int i = 0; i < C::NW4; ++i) {
-      int e = tid + i * 256;
+      int e = tid + i * C::NT;
       if (e >= C::W_ELEMS / 4) e = C::W_ELEMS / 4 - 1;     // only the last i can overshoot (compile-time for the rest)
       const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
       rw[i] = ws[(size_t)pr * w_pair_stride4 + o];
@@ -239,13 +245,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {
       const int g = goff[i];
-      const bool ok = (g >= 0) & (((tid + i * 256) / C::CS) < cvalid);
-      if (g != -2) dst_in[tid + i * 256] = ok ? rin[i] - in_off : 0.f;
+      const bool ok = (g >= 0) & (((tid + i * C::NT) / C::CS) < cvalid);
+      if (g != -2) dst_in[tid + i * C::NT] = ok ? rin[i] - in_off : 0.f;
     }
     f32x4* lw4 = reinterpret_cast<f32x4*>(dst_w);
 #pragma unroll
     for (int i = 0; i < C::NW4; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * C::NT;
       if (e < C::W_ELEMS / 4) lw4[e] = rw[i];
     }
   };
@@ -271,22 +277,38 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
     const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
     const float* cur_w = cur_in + C::IN_ELEMS;
     if (chunk + 1 < nchunk) prefetch(chunk + 1);
-#pragma unroll
-    for (int tap = 0; tap < C::K3; ++tap) {
-      const int dz = tap / (K * K), dy = (tap / K) % K, dx = tap % K;
-#pragma unroll
-      for (int pair = 0; pair < CC / 2; ++pair) {
-        float bf[ROWS], af[NCB];
+    // K loop of this chunk, software-pipelined by one step: the fragments of step s+1 are requested from LDS
+    // before the MFMAs of step s issue, so a wave with few accumulators does not sit on the LDS latency.
+    {
+      const float* in_k = cur_in + b_base + ks * (C::PP * 2 * C::CS);       // K-split group offset (0 when KS == 1)
+      const float* w_k = cur_w + ks * (C::PP * C::W_SEG) + lane;
+      constexpr int NS = C::K3 * C::PP;
+      auto load_frag = [&](int s, float (&b)[ROWS], float (&a)[NCB]) __attribute__((always_inline)) {
+        const int tap = s / C::PP, pp = s % C::PP;
+        const int dz = tap / (K * K), dy = (tap / K) % K, dx = tap % K;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
-          bf[r] = cur_in[b_base + (r / C::RY) * (C::HY * C::HX) + (r % C::RY) * C::YB * C::HX + pair * 2 * C::CS +
-                         dz * (C::HY * C::HX) + dy * C::HX + dx];
+          b[r] = in_k[(r / C::RY) * (C::HY * C::HX) + (r % C::RY) * C::YB * C::HX + pp * 2 * C::CS + dz * (C::HY * C::HX) +
+                      dy * C::HX + dx];
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) af[c] = cur_w[pair * C::W_SEG + (c * C::K3 + tap) * 64 + lane];
+        for (int c = 0; c < NCB; ++c) a[c] = w_k[pp * C::W_SEG + (c * C::K3 + tap) * 64];
+      };
+      // prefetch distance: 1 step when a step already holds >= 4 independent MFMAs, else 3 steps with the
+      // issue order pinned (a single-accumulator wave otherwise waits for LDS before every MFMA).
+      constexpr int DIST = (ROWS * NCB >= 4) ? 1 : 3;
+      float bfq[DIST + 1][ROWS], afq[DIST + 1][NCB];
+#pragma unroll
+      for (int s = 0; s < DIST && s < NS; ++s) load_frag(s, bfq[s % (DIST + 1)], afq[s % (DIST + 1)]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + DIST < NS) load_frag(s + DIST, bfq[(s + DIST) % (DIST + 1)], afq[(s + DIST) % (DIST + 1)]);
+        if constexpr (DIST > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
+          for (int r = 0; r < ROWS; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s % (DIST + 1)][c], bfq[s % (DIST + 1)][r], acc[c][r], 0, 0, 0);
+        if constexpr (DIST > 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (chunk + 1 < nchunk) {
@@ -294,6 +316,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_mfma_kernel(const float* __rest
       commit(chunk + 1, nxt, nxt + C::IN_ELEMS);
     }
     __syncthreads();
+  }
+
+  if constexpr (KS == 2) {
+    // combine the two K halves through LDS (the staging buffers are free after the final barrier)
+    float* red = lds + ((size_t)wave * NCB * ROWS * 16) * 64 + lane;
+    if (ks == 1) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) red[((c * ROWS + r) * 16 + g) * 64] = acc[c][r][g];
+    }
+    __syncthreads();
+    if (ks == 1) return;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[c][r][g] += red[((c * ROWS + r) * 16 + g) * 64];
   }
 
   // ---- epilogue: y = acc*scale + shift ; relu ; * mul ; coalesced NCDHW stores (or fused 2x2x2 max-pool) ----
@@ -480,20 +523,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
   }
 }
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
 int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, Epilogue ep,
                hipStream_t st) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
   const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;   // as packed (padded to 2 blocks)
   const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
   const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
   if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
   const size_t lds = sizeof(float) * 2 * C::LDS_FLOATS;   // double-buffered
-  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL>;
+  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(256), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
                      tiles_z, ncb_total, ep);
   return m3d::check_launch("conv3d_mfma");
 }
@@ -565,16 +608,51 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       if (width < 24) return M3D_EUNSUPPORTED;
       return launch_cfg<3, 2, 32, 4, 2, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
+    // tuning override (tools/bench_layers.py only): M3D_TUNE_K3=<variant index>
+    if (const char* tv = getenv("M3D_TUNE_K3")) {
+      const int v = atoi(tv);
+#define M3D_V(i, ...) if (v == i) return launch_cfg<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      M3D_V(0, 3, 2, 32, 4, 2, 4, 1)
+      M3D_V(1, 3, 2, 32, 2, 2, 4, 1)
+      M3D_V(2, 3, 4, 32, 1, 2, 4, 1)
+      M3D_V(3, 3, 2, 32, 4, 1, 4, 1)
+      M3D_V(4, 3, 4, 32, 4, 1, 4, 1)
+      M3D_V(5, 3, 4, 32, 2, 2, 4, 1)
+      M3D_V(6, 3, 2, 32, 2, 1, 4, 1)
+      M3D_V(7, 3, 4, 32, 2, 1, 4, 1)
+      M3D_V(8, 3, 2, 32, 4, 2, 2, 2)
+      M3D_V(10, 3, 4, 16, 1, 1, 4, 1)
+      M3D_V(11, 3, 8, 16, 1, 1, 4, 1)
+      M3D_V(12, 3, 4, 16, 2, 1, 4, 1)
+      M3D_V(13, 3, 8, 16, 2, 1, 4, 1)
+      M3D_V(14, 3, 4, 16, 1, 2, 4, 1)
+      M3D_V(15, 3, 8, 16, 1, 2, 4, 1)
+      M3D_V(16, 3, 4, 16, 2, 2, 4, 1)
+      M3D_V(20, 3, 8, 16, 1, 1, 4, 1, false, 2)
+      M3D_V(21, 3, 4, 16, 1, 1, 4, 1, false, 2)
+      M3D_V(22, 3, 16, 16, 1, 1, 4, 1, false, 2)
+      M3D_V(23, 3, 8, 16, 1, 2, 4, 1, false, 2)
+      M3D_V(30, 3, 4, 32, 2, 2, 4, 1, false, 2)
+      M3D_V(31, 3, 8, 32, 2, 2, 4, 1, false, 2)
+      M3D_V(33, 3, 4, 32, 1, 2, 4, 1, false, 2)
+      M3D_V(34, 3, 8, 32, 1, 2, 4, 1, false, 2)
+#undef M3D_V
+    }
     if (xb == 32) {
       const long long wg_big = (vox / 512) * ((ncb_total + 1) / 2);
       if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       const long long wg_mid = (vox / 256) * ((ncb_total + 1) / 2);
+      // 32^3-class maps: one workgroup per CU -> split K over two groups of 4 waves (2 waves/SIMD)
+      if (wg_mid >= 128 && wg_mid < 1024 && cin >= 16)
+        return launch_cfg<3, 8, 32, 2, 2, 4, 1, false, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       if (wg_mid >= 256) return launch_cfg<3, 2, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
     if (xb == 16) {
       const long long wg = (vox / 256) * ((ncb_total + 1) / 2);
       if (wg >= 512) return launch_cfg<3, 4, 16, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      // 16^3-class maps: exactly one 32x32 output block per SIMD -> split K in the workgroup for 2 waves/SIMD
+      if (cin >= 16) return launch_cfg<3, 8, 16, 1, 1, 4, 1, false, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 16, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
     {
