@@ -88,7 +88,7 @@ def bench_prm(args, rank, world, dist):
     import oracle as O
     cfg = O.Cfg.soma()
     P = O.make_params(stride=4, num_anchors=14, mlp_dim=cfg.mlp_dim, seed=0)
-    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), peak_chunk=32)
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
     S, H, W = 64, 160, 160
     vol = torch.from_numpy(synth_volume(rank, 160)[:S]).reshape(1, 1, S, H, W).contiguous().cuda()
     npk = []

@@ -163,7 +163,8 @@ int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_
  *                     d_origin_up) -> this layer's conv-input window d_out [P,C,Wn,Wn,Wn], Wn = (pool?2:1)*U +
  *                     2*border: max-unpool routing by d_argmax (if pool), ReLU mask (d_xnext > 0; pooled values
  *                     if pool), * d_scale[c] (BatchNorm, may be NULL), / (|norm|+1e-10) with norm < 1e-10 -> 0.
- *   m3d_prm_stem_dgrad backward-data of conv1a (5^3, one output channel) with relu(W), times (data - offset),
+ *   m3d_prm_stem_prepare_weights  d_weight [C,1,5,5,5] -> d_wf [C,125] = flipped relu(W) (once per model).
+ *   m3d_prm_stem_dgrad backward-data of conv1a (5^3, one output channel) with d_wf, times (data - offset),
  *                     clamp(min=0); d_out [P,Wn^3]; d_sums [P] = per-peak sum (for prm / prm.sum()).
  *   m3d_prm_scatter   dense [P,D,H,W] = window / sum at each peak's origin (caller zero-fills d_dense).
  * ------------------------------------------------------------------------------------------------------- */
@@ -174,7 +175,8 @@ int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peak
                     int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height,
                     int up_width, const float* d_scale, const float* d_norm, int depth, int height, int width,
                     float* d_out, int32_t* d_origin_out, void* stream);
-int m3d_prm_stem_dgrad(const float* d_gn, const float* d_weight, const float* d_data, const float* d_data_offset,
+int m3d_prm_stem_prepare_weights(const float* d_weight, int channels, float* d_wf, void* stream);
+int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float* d_data, const float* d_data_offset,
                        const int32_t* d_origins, int num_peaks, int channels, int win, int depth, int height,
                        int width, float* d_out, float* d_sums, void* stream);
 int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,

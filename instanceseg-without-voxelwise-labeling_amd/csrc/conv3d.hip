@@ -638,6 +638,11 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       M3D_V(34, 3, 8, 32, 1, 2, 4, 1, false, 2)
 #undef M3D_V
     }
+    if (ncb_total == 1) {   // <= 32 output channels (e.g. the dgrad of conv2a): never pad to a second, empty cout block
+      if (xb == 32) return launch_cfg<3, 2, 32, 4, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      if (xb == 16) return launch_cfg<3, 4, 16, 2, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      return launch_cfg<3, 4, 8, 2, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+    }
     if (xb == 32) {
       const long long wg_big = (vox / 512) * ((ncb_total + 1) / 2);
       if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);

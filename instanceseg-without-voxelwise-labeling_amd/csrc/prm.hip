@@ -91,76 +91,128 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   }
 }
 
-// ---- stem dgrad: conv1a is 1 -> 32 channels, 5^3; its backward-data has ONE output channel, so the MFMA tile
-// would be 1/32 full.  VALU direct form: out[p,v] = (data[v] - off) * sum_{c,t} relu(W)[c][t] * G[p,c][v - t + 2].
-// Each thread produces 8 consecutive x; one (dz,dy) row of 12 inputs feeds 40 FMAs.  Tile 32 x 8 x 8 voxels.
-__global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __restrict__ gn /*[P,32,Wn^3]*/,
-                                                             const float* __restrict__ w /*[32,125] raw conv1a weight*/,
+// ---- stem dgrad: conv1a is 1 -> 32 channels, 5^3; its backward-data has ONE output channel, so an MFMA tile
+// would be 1/32 full.  VALU direct form:  out[p,v] = (data[v] - off) * sum_{c,t} Wf[c][t] * G[p,c][v + t - 2],
+// Wf = flipped relu(W) (prepared once by prm_stem_prep_kernel so that the tap weights are wave-uniform scalar
+// loads, not LDS traffic).  Each thread owns 8 x  by 2 y outputs: one dz-slab of 6 rows x 12 inputs (18 ds_read_b128)
+// feeds 16 * 25 = 400 FMAs.  Tile 32 x 16 x 8 voxels, the next channel's halo tile is fetched into registers
+// while the current one is consumed (double-buffered LDS).
+__global__ void prm_stem_prep_kernel(const float* __restrict__ w /*[C,125]*/, int C, float* __restrict__ wf) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= C * 125) return;
+  const int c = e / 125, t = e % 125;
+  const float v = w[c * 125 + (124 - t)];          // dgrad of a "same" conv: W'[t'] = W[124 - t']
+  wf[e] = v > 0.f ? v : 0.f;                        // relu(W), peak_backprop_3d.py:41
+}
+
+constexpr int SD_TX = 32, SD_TY = 16, SD_TZ = 8, SD_HX = SD_TX + 4, SD_HY = SD_TY + 4, SD_HZ = SD_TZ + 4;
+constexpr int SD_TILE = SD_HZ * SD_HY * SD_HX;            // 8640 floats
+constexpr int SD_NI = (SD_TILE + 255) / 256;              // 34 staging registers
+
+__global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __restrict__ gn /*[P,C,Wn^3]*/,
+                                                             const float* __restrict__ wf /*[C,125] flipped relu(W)*/,
                                                              const float* __restrict__ data /*[D,H,W]*/,
                                                              const float* __restrict__ data_off, const int* __restrict__ origins,
                                                              int Wn, int D, int H, int W, int C, float* __restrict__ out /*[P,Wn^3]*/,
                                                              float* __restrict__ sums /*[P]*/) {
-  constexpr int TX = 32, TY = 8, TZ = 8, HX = TX + 4, HY = TY + 4, HZ = TZ + 4;
-  __shared__ float tile[HZ * HY * HX];
-  __shared__ float wl[125];
+  extern __shared__ float sd_lds[];                       // 2 x SD_TILE
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  const int tiles = (Wn + TX - 1) / TX, tilesy = (Wn + TY - 1) / TY;
+  const int tiles = (Wn + SD_TX - 1) / SD_TX, tilesy = (Wn + SD_TY - 1) / SD_TY;
   int bid = blockIdx.x;
   const int tx = bid % tiles; bid /= tiles;
   const int ty = bid % tilesy; bid /= tilesy;
   const int tz = bid;
   const int p = blockIdx.y;
-  const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
-  const int lx = (tid & 3) * 8, ly = (tid >> 2) & 7, lz = tid >> 5;
-  float acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const int x0 = tx * SD_TX, y0 = ty * SD_TY, z0 = tz * SD_TZ;
+  const int lx = (tid & 3) * 8, ly = ((tid >> 2) & 7) * 2, lz = tid >> 5;
   const size_t w3 = (size_t)Wn * Wn * Wn;
-  for (int c = 0; c < C; ++c) {
-    __syncthreads();
+
+  // staging: element e of the halo tile <-> offset inside one channel window (-1 = zero); recomputed per channel
+  // (cheap VALU) rather than kept in 34 registers
+  auto elem_off = [&](int e) __attribute__((always_inline)) -> int {
+    const int hz = e / (SD_HY * SD_HX), hy = (e / SD_HX) % SD_HY, hx = e % SD_HX;
+    const int z = z0 + hz - 2, y = y0 + hy - 2, x = x0 + hx - 2;
+    const bool ok = (e < SD_TILE) & (z >= 0) & (z < Wn) & (y >= 0) & (y < Wn) & (x >= 0) & (x < Wn);
+    return ok ? (int)(((size_t)z * Wn + y) * Wn + x) : -1;
+  };
+  float rin[SD_NI];
+  auto prefetch = [&](int c) __attribute__((always_inline)) {
     const float* g = gn + ((size_t)p * C + c) * w3;
-    for (int e = tid; e < HZ * HY * HX; e += 256) {
-      const int hz = e / (HY * HX), hy = (e / HX) % HY, hx = e % HX;
-      const int z = z0 + hz - 2, y = y0 + hy - 2, x = x0 + hx - 2;
-      tile[e] = ((z >= 0) & (z < Wn) & (y >= 0) & (y < Wn) & (x >= 0) & (x < Wn)) ? g[((size_t)z * Wn + y) * Wn + x] : 0.f;
+#pragma unroll
+    for (int i = 0; i < SD_NI; ++i) {
+      const int o = elem_off(tid + i * 256);
+      rin[i] = g[o < 0 ? 0 : o];
     }
-    if (tid < 125) { const float v = w[c * 125 + tid]; wl[tid] = v > 0.f ? v : 0.f; }   // relu(W), peak_backprop_3d.py:41
-    __syncthreads();
-    // dgrad of a "same" conv: out[v] += Wf[t'] * G[v + t' - 2] with Wf[t'] = W[124 - t']
+  };
+  auto commit = [&](float* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int dz = 0; dz < 5; ++dz)
+    for (int i = 0; i < SD_NI; ++i) {
+      const int e = tid + i * 256;
+      if (e < SD_TILE) dst[e] = elem_off(e) < 0 ? 0.f : rin[i];
+    }
+  };
+
+  float acc[2][8];
 #pragma unroll
-      for (int dy = 0; dy < 5; ++dy) {
-        const float* row = tile + ((lz + dz) * HY + (ly + dy)) * HX + lx;
-        float r[12];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 12; ++i) r[i] = row[i];
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+
+  prefetch(0);
+  commit(sd_lds);
+  __syncthreads();
+  for (int c = 0; c < C; ++c) {
+    const float* tile = sd_lds + (c & 1) * SD_TILE;
+    if (c + 1 < C) prefetch(c + 1);
+    const float* wc = wf + c * 125;
+#pragma unroll 1
+    for (int dz = 0; dz < 5; ++dz) {
+      float r[6][12];
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-          const float wv = wl[124 - ((dz * 5 + dy) * 5 + dx)];
+      for (int yy = 0; yy < 6; ++yy) {
+        const float4* row = reinterpret_cast<const float4*>(tile + ((lz + dz) * SD_HY + (ly + yy)) * SD_HX + lx);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] = fmaf(wv, r[i + dx], acc[i]);
+        for (int q = 0; q < 3; ++q) {
+          const float4 v = row[q];
+          r[yy][4 * q] = v.x; r[yy][4 * q + 1] = v.y; r[yy][4 * q + 2] = v.z; r[yy][4 * q + 3] = v.w;
         }
       }
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const float wv = wc[(dz * 5 + dy) * 5 + dx];      // wave-uniform -> scalar load
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(wv, r[j + dy][i + dx], acc[j][i]);
+        }
+    }
+    if (c + 1 < C) commit(sd_lds + ((c + 1) & 1) * SD_TILE);
+    __syncthreads();
   }
   // PreHook multiply, clamp(min=0) (peak_response_mapping_3d.py:170), per-peak sum for the normalisation (:171)
-  const int z = z0 + lz, y = y0 + ly;
+  const int z = z0 + lz;
   const int oz = origins[3 * p], oy = origins[3 * p + 1], ox = origins[3 * p + 2];
   float local = 0.f;
   const float off = *data_off;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int x = x0 + lx + i;
-    if (z < Wn && y < Wn && x < Wn) {
-      const int qz = oz + z, qy = oy + y, qx = ox + x;
-      float v = 0.f;
-      if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
-        v = (data[((size_t)qz * H + qy) * W + qx] - off) * acc[i];
-        v = v > 0.f ? v : 0.f;
+  for (int j = 0; j < 2; ++j) {
+    const int y = y0 + ly + j;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int x = x0 + lx + i;
+      if (z < Wn && y < Wn && x < Wn) {
+        const int qz = oz + z, qy = oy + y, qx = ox + x;
+        float v = 0.f;
+        if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
+          v = (data[((size_t)qz * H + qy) * W + qx] - off) * acc[j][i];
+          v = v > 0.f ? v : 0.f;
+        }
+        out[(size_t)p * w3 + ((size_t)z * Wn + y) * Wn + x] = v;
+        local += v;
       }
-      out[(size_t)p * w3 + ((size_t)z * Wn + y) * Wn + x] = v;
-      local += v;
     }
   }
 #pragma unroll
@@ -220,15 +272,24 @@ M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int 
   return m3d::check_launch("prm_prepare");
 }
 
-M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_weight, const float* d_data, const float* d_data_offset,
+M3D_API int m3d_prm_stem_prepare_weights(const float* d_weight, int channels, float* d_wf, void* stream) {
+  if (!d_weight || !d_wf || channels <= 0) return M3D_EINVAL;
+  hipLaunchKernelGGL(prm_stem_prep_kernel, dim3((channels * 125 + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_weight,
+                     channels, d_wf);
+  return m3d::check_launch("prm_stem_prepare_weights");
+}
+
+M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float* d_data, const float* d_data_offset,
                                const int32_t* d_origins, int num_peaks, int channels, int win, int depth, int height, int width,
                                float* d_out, float* d_sums, void* stream) {
   if (num_peaks < 0 || channels <= 0 || win <= 0) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
-  if (!d_gn || !d_weight || !d_data || !d_data_offset || !d_origins || !d_out || !d_sums || num_peaks > 65535) return M3D_EINVAL;
-  const int tx = (win + 31) / 32, ty = (win + 7) / 8, tz = (win + 7) / 8;
+  if (!d_gn || !d_wf || !d_data || !d_data_offset || !d_origins || !d_out || !d_sums || num_peaks > 65535) return M3D_EINVAL;
+  const int tx = (win + SD_TX - 1) / SD_TX, ty = (win + SD_TY - 1) / SD_TY, tz = (win + SD_TZ - 1) / SD_TZ;
+  const size_t lds = sizeof(float) * 2 * SD_TILE;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(prm_stem_dgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipMemsetAsync(d_sums, 0, sizeof(float) * num_peaks, m3d::as_stream(stream));
-  hipLaunchKernelGGL(prm_stem_dgrad_kernel, dim3(tx * ty * tz, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_gn, d_weight,
+  hipLaunchKernelGGL(prm_stem_dgrad_kernel, dim3(tx * ty * tz, num_peaks), dim3(256), lds, m3d::as_stream(stream), d_gn, d_wf,
                      d_data, d_data_offset, d_origins, win, depth, height, width, channels, d_out, d_sums);
   return m3d::check_launch("prm_stem_dgrad");
 }

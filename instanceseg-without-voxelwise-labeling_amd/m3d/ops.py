@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -273,9 +273,21 @@ def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm):
     return out, oo
 
 
+def prm_stem_prepare_weights(weight):
+    """weight [C,1,5,5,5] -> [C,125] flipped relu(W) for prm_stem_dgrad."""
+    _need_gpu(weight)
+    weight = _f32c(weight)
+    Cc = weight.shape[0]
+    wf = torch.empty((Cc, 125), dtype=torch.float32, device=weight.device)
+    check(lib().m3d_prm_stem_prepare_weights(_ptr(weight), Cc, _ptr(wf), _stream()), "prm_stem_prepare_weights")
+    return wf
+
+
 def prm_stem_dgrad(gn, weight, data, data_off, origins):
-    """gn [P,C,Wn,Wn,Wn]; weight [C,1,5,5,5]; data [D,H,W] -> (windows [P,Wn,Wn,Wn] clamped, sums [P])."""
+    """gn [P,C,Wn,Wn,Wn]; weight = prm_stem_prepare_weights(conv1a.weight); data [D,H,W] ->
+    (windows [P,Wn,Wn,Wn] clamped, sums [P])."""
     _need_gpu(gn, weight, data, data_off, origins)
+    assert weight.dim() == 2 and weight.shape[1] == 125
     P, Cc, Wn = gn.shape[0], gn.shape[1], gn.shape[2]
     out = torch.empty((P, Wn, Wn, Wn), dtype=torch.float32, device=gn.device)
     sums = torch.empty((P,), dtype=torch.float32, device=gn.device)

@@ -14,9 +14,10 @@ from .model import DetectorM3D
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=32):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30):
         self.det = det
         self.cfg = det.cfg
+        self.window_budget = window_budget if peak_chunk is None else None
         self.peak_chunk = peak_chunk
         P = det.P
         self.layers = []
@@ -28,6 +29,7 @@ class PRMEngine:
                                     dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU), weight=w))
         w = P["RPN.RPN_conv.weight"]
         self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU))
+        self.stem_wf = ops.prm_stem_prepare_weights(P["Conv_Body.conv1a.weight"])
         self.w_cls = P["RPN.RPN_cls_score.weight"]
         self.cls_norm_conv = ops.PackedConv3d(self.w_cls, ops.W_RELU)
         self.w_cls2d = self.w_cls.reshape(self.w_cls.shape[0], self.w_cls.shape[1]).contiguous()
@@ -68,20 +70,42 @@ class PRMEngine:
     # ---------------------------------------------------------------- backward for a batch of peaks
     def backward_windows(self, peaks_ashw, saved, top, data):
         """peaks_ashw: int32 CUDA [P,4] (anchor, s, h, w).  Returns (windows [P,Wn,Wn,Wn] (un-normalised, clamped),
-        sums [P], origins int32 [P,3])."""
-        outs, sums, origs = [], [], []
-        for c0 in range(0, peaks_ashw.shape[0], self.peak_chunk):
-            pk = peaks_ashw[c0:c0 + self.peak_chunk].contiguous()
-            g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
-            origin = pk[:, 1:4].contiguous()
-            for rec in reversed(saved[1:]):
-                gn, origin = ops.prm_prepare(g, origin, rec["pool"], 1, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
-                g = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
-            rec = saved[0]                       # conv1a: 5^3, one input channel -> VALU stem dgrad
-            gn, origin = ops.prm_prepare(g, origin, rec["pool"], 2, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
-            w, s = ops.prm_stem_dgrad(gn, rec["weight"], data[0, 0], rec["off"], origin)
-            outs.append(w); sums.append(s); origs.append(origin)
-        return torch.cat(outs), torch.cat(sums), torch.cat(origs)
+        sums [P], origins int32 [P,3]).
+
+        All peaks go through a layer in ONE launch while the layer's window batch stays under `window_budget`
+        bytes (the stride-8/4 layers have 3^3..18^3 windows: per-launch latency, not work, dominates there);
+        the big-window tail (38^3..84^3) is processed in peak chunks to bound the working set."""
+        budget = self.window_budget
+
+        def run_layer(rec, g, origin, border):
+            gn, origin = ops.prm_prepare(g, origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
+            if rec["k"] == 5:                    # conv1a: 5^3, one input channel -> VALU stem dgrad
+                w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
+                return (w, s), origin
+            return ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin), origin
+
+        def tail(layers, g, origin):
+            """Run the remaining layers (top -> bottom) on the given peak subset."""
+            if not layers:
+                return g, origin
+            rec = layers[0]
+            border = 2 if rec["k"] == 5 else 1
+            P, Cc, U = g.shape[0], rec["n"].shape[0], g.shape[2]
+            Wn = (2 if rec["pool"] else 1) * U + 2 * border
+            per_peak = 4 * Wn ** 3 * max(Cc, rec["x"].shape[0]) * 2      # prepare output + conv output
+            chunk = self.peak_chunk if self.peak_chunk else max(1, min(P, int(budget // per_peak)))
+            if chunk >= P:
+                g2, o2 = run_layer(rec, g, origin, border)
+                return (g2, o2) if rec["k"] == 5 else tail(layers[1:], g2, o2)
+            outs = [tail(layers, g[c0:c0 + chunk].contiguous(), origin[c0:c0 + chunk].contiguous()) for c0 in range(0, P, chunk)]
+            wins = torch.cat([o[0][0] for o in outs]); sums = torch.cat([o[0][1] for o in outs]); orig = torch.cat([o[1] for o in outs])
+            return (wins, sums), orig
+
+        pk = peaks_ashw.contiguous()
+        g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
+        origin = pk[:, 1:4].contiguous()
+        (win, sums), origins = tail(list(reversed(saved)), g, origin)
+        return win, sums, origins
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193
     def prm_tile(self, data, peak_threshold=0.1, dense=True):
