@@ -51,7 +51,7 @@ class DetectorM3D:
     # ---- lib/modeling/DSN.py:57-68
     def conv_body(self, x):
         for conv, scale, shift, pool in self.body:
-            if pool and conv.supports_pool(x.shape[-1]):
+            if pool and conv.supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
                 x = conv.pooled(x, scale=scale, shift=shift, relu=True)      # conv+BN+ReLU+MaxPool in one kernel
             else:
                 x = conv(x, scale=scale, shift=shift, relu=True)

@@ -150,8 +150,14 @@ class PackedConv3d:
         check(lib().m3d_conv3d_pack_weights(_ptr(weight), self.cin_w, self.cout_w, self.k, mode, _ptr(self.packed), _stream()),
               "conv3d_pack_weights")
 
-    def supports_pool(self, width):
-        return (self.k == 5 and self.cin == 1 and self.cout <= 32) or (self.k == 3 and width >= 24)
+    def supports_pool(self, width, voxels=None):
+        """Fused conv+pool exists for the 5^3 stem and for k=3 on 32-wide x blocks; it uses the big 32x4x4 tile, so
+        it only pays when that tile still yields >= 512 workgroups (same rule as the C dispatcher)."""
+        if self.k == 5 and self.cin == 1 and self.cout <= 32:
+            return True
+        if self.k != 3 or width < 24:
+            return False
+        return voxels is None or (voxels // 512) * ((self.cout + 63) // 64) >= 512
 
     def pooled(self, x, scale=None, shift=None, relu=False, in_offset=None, return_argmax=False):
         """conv + scale/shift + ReLU + MaxPool3d(2,2) in one kernel (m3d_conv3d_forward_pool2)."""

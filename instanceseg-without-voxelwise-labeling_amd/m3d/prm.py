@@ -42,7 +42,7 @@ class PRMEngine:
         for L in self.layers:
             off = ops.reduce_min(x)
             n = L["norm_conv"](x, in_offset=off)
-            if L["pool"] and L["conv"].supports_pool(x.shape[-1]):
+            if L["pool"] and L["conv"].supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
                 xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
                 y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
