@@ -113,23 +113,77 @@ __device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int c
 }
 
 
-// Fused 2x2x2 max-pool epilogue (XB = 32, four rows per wave = the 2x2 (z,y) footprint of one pooling window row).
-// v[r] is the post-activation value of row r = zz*2 + yy at this lane's x; the pooling window index is
-// q = zz*4 + yy*2 + (x&1), scanned in (z,y,x) order with "first maximum wins" like nn.MaxPool3d (DSN.py:21,26).
-__device__ inline void pool4_store(const Epilogue& ep, float* __restrict__ out, const float v[4], int lane_x, int b, int co,
-                                   int cout, int oz, int oy, int ox, int OD, int OH, int OW) {
-  float best = v[0];
-  int q = lane_x & 1;
+// ---- lean epilogues --------------------------------------------------------------------------------------
+// An accumulator register g of a 32x32 block belongs to output channel co0 + KG(g), co0 = block base + 4*(lane>>5).
+__device__ __host__ constexpr int KG(int g) { return (g & 3) + 8 * (g >> 2); }
+
+struct ChanAffine { float sc[16], sh[16]; };
+
+// per-channel scale/shift of this lane's 16 channels, loaded ONCE per 32-channel block (not per row / element)
+__device__ inline void load_affine(const Epilogue& ep, int co0, int cout, ChanAffine& A) {
 #pragma unroll
-  for (int r = 1; r < 4; ++r)
-    if (v[r] > best || (v[r] != v[r] && best == best)) { best = v[r]; q = r * 2 + (lane_x & 1); }
-  const float ov = __shfl_xor(best, 1, 64);
-  const int oq = __shfl_xor(q, 1, 64);
-  if (ov > best || (ov == best && oq < q) || (ov != ov && best == best)) { best = ov; q = oq; }
-  if (((lane_x & 1) == 0) & (oz < OD) & (oy < OH) & (ox < OW)) {
-    const size_t o = ((((size_t)b * cout + co) * OD + oz) * OH + oy) * OW + ox;
-    out[o] = best;
-    if (ep.argmax) ep.argmax[o] = (uint8_t)q;
+  for (int g = 0; g < 16; ++g) {
+    const int co = min(co0 + KG(g), cout - 1);
+    A.sc[g] = ep.scale ? ep.scale[co] : 1.f;
+    A.sh[g] = ep.shift ? ep.shift[co] : 0.f;
+  }
+}
+
+// one accumulator block row -> NCDHW stores: pointer arithmetic is one add per store (KG(g) * DHW)
+__device__ inline void store_block(const Epilogue& ep, float* __restrict__ out, const f32x16& a, const ChanAffine& A, int b,
+                                   int cout, int co0, size_t DHW, int H, int W, int z, int y, int x) {
+  const size_t sp = ((size_t)z * H + y) * W + x;
+  if (ep.mul || ep.full) {            // PRM paths: element-wise multiply tensors (rare, keep the general form)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = co0 + KG(g);
+      if (co < cout) {
+        const size_t o = ((size_t)b * cout + co) * DHW + sp;
+        out[o] = apply_epilogue(ep, a[g], b, co, z, y, x, o);
+      }
+    }
+    return;
+  }
+  float* p = out + ((size_t)b * cout + co0) * DHW + sp;
+  const bool all = co0 + KG(15) < cout;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    if (all || co0 + KG(g) < cout) {
+      float v = a[g] * A.sc[g] + A.sh[g];
+      if (ep.relu) v = fmaxf(v, 0.f);
+      p[(size_t)KG(g) * DHW] = v;
+    }
+  }
+}
+
+// Fused 2x2x2 max-pool epilogue (XB = 32, four rows per wave = the 2x2 (z,y) footprint of one pooling window row).
+// Row r = zz*2 + yy; window index q = zz*4 + yy*2 + (x&1), (z,y,x) scan order, first maximum wins like
+// nn.MaxPool3d (DSN.py:21,26).
+__device__ inline void pool_block(const Epilogue& ep, float* __restrict__ out, const f32x16 (&a)[4], const ChanAffine& A, int b,
+                                  int cout, int co0, int lane_x, int oz, int oy, int ox, int OD, int OH, int OW) {
+  const size_t ODHW = (size_t)OD * OH * OW;
+  const size_t o0 = ((size_t)b * cout + co0) * ODHW + ((size_t)oz * OH + oy) * OW + ox;
+  const bool inb = ((lane_x & 1) == 0) & (oz < OD) & (oy < OH) & (ox < OW);
+  const int xq = lane_x & 1;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float best = a[0][g] * A.sc[g] + A.sh[g];
+    if (ep.relu) best = fmaxf(best, 0.f);
+    int q = xq;
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      float v = a[r][g] * A.sc[g] + A.sh[g];
+      if (ep.relu) v = fmaxf(v, 0.f);
+      if (v > best) { best = v; q = r * 2 + xq; }
+    }
+    const float ov = __shfl_xor(best, 1, 64);
+    const int oq = __shfl_xor(q, 1, 64);
+    if (ov > best || (ov == best && oq < q)) { best = ov; q = oq; }
+    if (inb && co0 + KG(g) < cout) {
+      const size_t o = o0 + (size_t)KG(g) * ODHW;
+      out[o] = best;
+      if (ep.argmax) ep.argmax[o] = (uint8_t)q;
+    }
   }
 }
 
@@ -340,45 +394,20 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
   }
 
   // ---- epilogue: y = acc*scale + shift ; relu ; * mul ; coalesced NCDHW stores (or fused 2x2x2 max-pool) ----
-  if constexpr (POOL) {
-    const int OD = D / 2, OH = H / 2, OW = W / 2;
-    const int oz = (z0 + wz * 2) >> 1, oy = (y0 + wy * 2) >> 1, ox = (x0 + jx) >> 1;
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-        const int coc = co < cout ? co : cout - 1;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = acc[c][r][g];
-          if (ep.scale) t = t * ep.scale[coc];
-          if (ep.shift) t = t + ep.shift[coc];
-          if (ep.relu) t = t > 0.f ? t : 0.f;
-          v[r] = t;
-        }
-        pool4_store(ep, out, v, jx, b, coc, cout, co < cout ? oz : OD, oy, ox, OD, OH, OW);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
+  for (int c = 0; c < NCB; ++c) {
+    const int co0 = (cot * NCB + c) * 32 + 4 * (lane >> 5);
+    ChanAffine A;
+    load_affine(ep, co0, cout, A);
+    if constexpr (POOL) {
+      pool_block(ep, out, acc[c], A, b, cout, co0, jx, (z0 + wz * 2) >> 1, (y0 + wy * 2) >> 1, (x0 + jx) >> 1, D / 2, H / 2, W / 2);
+    } else {
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         const int z = z0 + wz * C::RZ + r / C::RY;
         const int x = x0 + jx;
         const int y = y0 + (wy * C::RY + r % C::RY) * C::YB + jy;
-        if (x < W && y < H && z < D) {
-#pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            const int co = (cot * NCB + c) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-            if (co < cout) {
-              const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-              out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
-            }
-          }
-        }
+        if (x < W && y < H && z < D) store_block(ep, out, acc[c][r], A, b, cout, co0, DHW, H, W, z, y, x);
       }
     }
   }
@@ -480,44 +509,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
       for (int r = 0; r < ROWS; ++r) acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[r], acc[c][r], 0, 0, 0);
   }
   (void)K; (void)K3;
-  if constexpr (POOL) {
-    const int OD = D / 2, OH = H / 2, OW = W / 2;
-    const int oz = (z0 + wz * 2) >> 1, oy = (y0 + wy * 2) >> 1, ox = (x0 + jx) >> 1;
 #pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-        const int coc = co < cout ? co : cout - 1;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float t = acc[c][r][g];
-          if (ep.scale) t = t * ep.scale[coc];
-          if (ep.shift) t = t + ep.shift[coc];
-          if (ep.relu) t = t > 0.f ? t : 0.f;
-          v[r] = t;
-        }
-        pool4_store(ep, out, v, jx, b, coc, cout, co < cout ? oz : OD, oy, ox, OD, OH, OW);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
+  for (int c = 0; c < NCB; ++c) {
+    const int co0 = c * 32 + 4 * (lane >> 5);
+    ChanAffine A;
+    load_affine(ep, co0, cout, A);
+    if constexpr (POOL) {
+      pool_block(ep, out, acc[c], A, b, cout, co0, jx, (z0 + wz * 2) >> 1, (y0 + wy * 2) >> 1, (x0 + jx) >> 1, D / 2, H / 2, W / 2);
+    } else {
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         const int z = z0 + wz * RZ + r / RY;
         const int x = x0 + jx, y = y0 + wy * RY + r % RY;
-        if (x < W && y < H && z < D) {
-#pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            const int co = c * 32 + (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-            if (co < cout) {
-              const size_t o = ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-              out[o] = apply_epilogue(ep, acc[c][r][g], b, co, z, y, x, o);
-            }
-          }
-        }
+        if (x < W && y < H && z < D) store_block(ep, out, acc[c][r], A, b, cout, co0, DHW, H, W, z, y, x);
       }
     }
   }
