@@ -67,3 +67,12 @@ def test_shard_all_gather_gloo_world2():
         p.join(60)
     expect = [(min(i + 1, 4), float(i)) for i in range(5)]      # capped at 4, global item order restored
     assert res[0] == expect and res[1] == expect
+
+
+def test_product_anchors_match_reference(golden):
+    from m3d.config import Cfg, generate_anchors_3d
+    g = golden("anchors")
+    assert np.array_equal(Cfg.nuclei().anchors, g["nuclei"]) and Cfg.nuclei().anchors.dtype == np.float64
+    assert np.array_equal(Cfg.soma().anchors, g["soma"])
+    assert Cfg.nuclei().num_anchors == 35 and Cfg.soma().num_anchors == 14
+    assert generate_anchors_3d().shape == (6, 6)
