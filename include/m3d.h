@@ -183,6 +183,22 @@ int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* 
                     int depth, int height, int width, float* d_dense, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * PRM post-processing feeding the Otsu step.
+ *   m3d_prm_quantize_u8  per map: fm -= min; fm /= max; fm *= 255 -> uint8, float32 arithmetic
+ *                        (tools/infer_simple.py:233-238; what the reference stores in its PRM TIFFs).
+ *   m3d_roi_normalize    per detection: crop the inclusive box (x1,y1,z1,x2,y2,z2: int32 [R,6], tile coords) from
+ *                        the uint16 tile and from the RoI's own uint8 PRM map, normalise both to similar ranges and
+ *                        write them back to back at d_offsets[r] (int64 [R+1], offsets[r+1]-offsets[r] = crop voxels):
+ *                        mode 0 = soma  (tools/binarization_soma.py:81-91), mode 1 = nuclei
+ *                        (tools/binarization_nuclei.py:107-121).  float64 arithmetic, np.round / astype semantics.
+ *                        The outputs are exactly the (image, prm) inputs of m3d_otsu2d_batch.
+ * ------------------------------------------------------------------------------------------------------- */
+int m3d_prm_quantize_u8(const float* d_prm, int num_maps, int64_t voxels_per_map, uint8_t* d_out, void* stream);
+int m3d_roi_normalize(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes,
+                      const int64_t* d_offsets, int num_rois, int depth, int height, int width, int mode,
+                      uint16_t* d_out_image, uint16_t* d_out_prm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Per-RoI 2D-Otsu binarisation.  Replaces otsu.otsu_py_2d_fast (tools/otsu.py:199-284) for uint16 inputs
  * (the callers normalise to uint16: tools/binarization_soma.py:85-91, binarization_nuclei.py:110-121).
  * A batch of `num_rois` independent crops: crop r occupies voxels [offsets[r], offsets[r+1]) of d_image /

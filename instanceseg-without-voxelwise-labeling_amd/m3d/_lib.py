@@ -17,7 +17,7 @@ SYMBOLS = [
     "m3d_prm_seed", "m3d_prm_prepare", "m3d_prm_stem_prepare_weights", "m3d_prm_stem_dgrad", "m3d_prm_scatter",
     "m3d_maxpool3d_2x_forward", "m3d_maxpool3d_2x_backward",
     "m3d_reduce_min_workspace_bytes", "m3d_reduce_min",
-    "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch",
+    "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch", "m3d_prm_quantize_u8", "m3d_roi_normalize",
 ]
 
 

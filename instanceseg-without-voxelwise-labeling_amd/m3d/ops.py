@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -309,3 +309,33 @@ def prm_scatter(windows, sums, origins, shape):
     dense = torch.zeros((P, D, H, W), dtype=torch.float32, device=windows.device)
     check(lib().m3d_prm_scatter(_ptr(windows), _ptr(sums), _ptr(origins), P, Wn, D, H, W, _ptr(dense), _stream()), "prm_scatter")
     return dense
+
+
+# ------------------------------------------------------------------ PRM post-processing -> Otsu
+def prm_quantize_u8(prms):
+    """prms float32 [P, D, H, W] CUDA -> uint8 [P, D, H, W] (infer_simple.py:233-238 per map)."""
+    _need_gpu(prms)
+    prms = _f32c(prms)
+    out = torch.empty(prms.shape, dtype=torch.uint8, device=prms.device)
+    P = prms.shape[0]
+    check(lib().m3d_prm_quantize_u8(_ptr(prms), P, C.c_int64(prms[0].numel() if P else 1), _ptr(out), _stream()), "prm_quantize_u8")
+    return out
+
+
+def roi_normalize(image_u16, prm_u8, boxes, mode):
+    """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
+    Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch."""
+    _need_gpu(image_u16, prm_u8, boxes)
+    assert image_u16.dtype == torch.uint16 and prm_u8.dtype == torch.uint8 and boxes.dtype == torch.int32
+    R = boxes.shape[0]
+    D, H, W = image_u16.shape
+    b = boxes.cpu().numpy().astype(np.int64)
+    sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
+    assert R == 0 or (sizes.min() > 0 and b[:, :3].min() >= 0 and b[:, 3].max() < W and b[:, 4].max() < H and b[:, 5].max() < D)
+    offs = torch.from_numpy(np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)).to(image_u16.device)
+    total = int(offs[-1]) if R else 0
+    oi = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
+    op = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
+    check(lib().m3d_roi_normalize(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
+                                  R, D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _stream()), "roi_normalize")
+    return oi, op, offs

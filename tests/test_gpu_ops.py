@@ -305,3 +305,47 @@ def test_conv3d_fused_pool_equals_conv_then_pool(m3d, cin, cout, k, D, H, W):
     picked = y[torch.arange(B, device="cuda").view(B, 1, 1, 1, 1), torch.arange(Cc, device="cuda").view(1, Cc, 1, 1, 1), zz, yy, xx]
     assert torch.allclose(picked, out, rtol=1e-5, atol=1e-5)
     assert (am == am_ref).float().mean() > 0.999
+
+
+# ------------------------------------------------------------------ PRM post-processing -> Otsu
+@pytest.mark.parametrize("mode", ["soma", "nuclei"])
+def test_quantize_normalize_otsu_chain_bit_exact(m3d, mode):
+    """uint8 PRM quantisation (infer_simple.py:233-238) -> box crop + normalisation (binarization_*.py) ->
+    otsu_py_2d_fast, all on device, against the NumPy restatements in the oracle (integer outputs: bit-exact)."""
+    rs = np.random.RandomState(11)
+    D, H, W = 20, 36, 40
+    zz, yy, xx = np.mgrid[0:D, 0:H, 0:W]
+    img = (rs.randn(D, H, W) * 12 + 110).clip(0, 65535)
+    R = 5
+    prms, boxes = [], []
+    for r in range(R):
+        c = np.array([rs.uniform(5, D - 5), rs.uniform(8, H - 8), rs.uniform(8, W - 8)])
+        rad = rs.uniform(3, 6)
+        d2 = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2
+        img += rs.uniform(300, 900) * np.exp(-d2 / (2 * rad * rad))
+        p = np.exp(-d2 / (2 * (rad * 0.8) ** 2)).astype(np.float32) * (rs.rand(D, H, W).astype(np.float32) * 0.3 + 0.7)
+        p[d2 > (3 * rad) ** 2] = 0
+        prms.append(p / p.sum())
+        h = int(2.2 * rad)
+        lo = np.maximum(np.round(c).astype(int) - h, 0)
+        hi = np.minimum(np.round(c).astype(int) + h, [D - 1, H - 1, W - 1])
+        boxes.append([lo[2], lo[1], lo[0], hi[2], hi[1], hi[0]])
+    img = img.clip(0, 65535).astype(np.uint16)
+    prms = np.stack(prms).astype(np.float32)
+    boxes = np.array(boxes, np.int32)
+    q = m3d.prm_quantize_u8(dev(prms))
+    q_ref = np.stack([O.quantize_prm_u8(p) for p in prms])
+    assert np.array_equal(q.cpu().numpy(), q_ref)
+    oi, op, offs = m3d.roi_normalize(torch.from_numpy(img).cuda(), q, dev(boxes), mode)
+    mask, kb, status = m3d.otsu2d_batch(oi, op, offs, 4096)
+    oi, op, offs, mask, kb = oi.cpu().numpy(), op.cpu().numpy(), offs.cpu().numpy(), mask.cpu().numpy(), kb.cpu().numpy()
+    norm = O.normalize_soma if mode == "soma" else O.normalize_nuclei
+    for r in range(R):
+        x1, y1, z1, x2, y2, z2 = boxes[r]
+        bi = img[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1]
+        bp = q_ref[r][z1:z2 + 1, y1:y2 + 1, x1:x2 + 1]
+        a, b = norm(bi.copy(), bp.copy())
+        assert np.array_equal(oi[offs[r]:offs[r + 1]].reshape(a.shape), a), r
+        assert np.array_equal(op[offs[r]:offs[r + 1]].reshape(b.shape), b), r
+        m, k, bb = O.otsu_py_2d_fast(a, b)
+        assert (k, bb) == tuple(kb[r]) and np.array_equal(mask[offs[r]:offs[r + 1]].reshape(m.shape), m), r
