@@ -212,7 +212,7 @@ def main():
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": dom_ms, "algorithmic_gflop_per_launch": dom_flops / 1e9},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's torch-CPU restatement)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O
