@@ -273,40 +273,36 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
   const size_t w_pair_stride4 = (size_t)ncb_total * C::K3 * 64 / 4;      // one channel pair, all (padded) cout blocks
   const size_t w_tile_off4 = (size_t)cot * NCB * C::K3 * 64 / 4;
 
-  // Loads are unconditional (index clamped to a valid element) and carry NO arithmetic: anything applied to a
-  // loaded value here would make the compiler wait for the load before the MFMA loop.  Zero padding and the
-  // PRM input offset are applied in commit(), after the loop.
-  auto prefetch = [&](int chunk) __attribute__((always_inline)) {
-    const float* src = in_b + (size_t)chunk * CC * DHW;
-    const int cvalid = min(CC, cin - chunk * CC);          // channels present in this chunk
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int g = goff[i];
-      const bool ok = (g >= 0) & (((tid + i * C::NT) / C::CS) < cvalid);
-      rin[i] = src[ok ? g : 0];
-    }
-    const f32x4* ws = wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4;
-#pragma unroll
-    for (int i = 0; i < C::NW4; ++i) {
+  // Staging of chunk c+1 is spread THROUGH the MFMA loop of chunk c (loads in its first third, LDS writes to the
+  // other buffer in its last third): a block of ~100 address/VMEM/LDS instructions in front of the loop would
+  // leave the matrix pipe idle once per chunk (measured: 8-19 % of kernel time).  Loads are unconditional
+  // (index clamped to a valid element) and carry no arithmetic; zero padding and the PRM input offset are
+  // applied at commit time.
+  constexpr int NL = C::NI + C::NW4;                         // staging operations per thread and chunk
+  auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
+    if (idx < C::NI) {
+      const int g = goff[idx];
+      const int cvalid = min(CC, cin - chunk * CC);
+      const bool ok = (g >= 0) & (((tid + idx * C::NT) / C::CS) < cvalid);
+      rin[idx] = (in_b + (size_t)chunk * CC * DHW)[ok ? g : 0];
+    } else {
+      const int i = idx - C::NI;
       int e = tid + i * C::NT;
-      if (e >= C::W_ELEMS / 4) e = C::W_ELEMS / 4 - 1;     // only the last i can overshoot (compile-time for the rest)
+      if (e >= C::W_ELEMS / 4) e = C::W_ELEMS / 4 - 1;       // only the last i can overshoot
       const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
-      rw[i] = ws[(size_t)pr * w_pair_stride4 + o];
+      rw[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
     }
   };
-  auto commit = [&](int chunk, float* dst_in, float* dst_w) __attribute__((always_inline)) {
-    const int cvalid = min(CC, cin - chunk * CC);
-#pragma unroll
-    for (int i = 0; i < C::NI; ++i) {
-      const int g = goff[i];
-      const bool ok = (g >= 0) & (((tid + i * C::NT) / C::CS) < cvalid);
-      if (g != -2) dst_in[tid + i * C::NT] = ok ? rin[i] - in_off : 0.f;
-    }
-    f32x4* lw4 = reinterpret_cast<f32x4*>(dst_w);
-#pragma unroll
-    for (int i = 0; i < C::NW4; ++i) {
+  auto commit1 = [&](int idx, int chunk, float* dst_in, float* dst_w) __attribute__((always_inline)) {
+    if (idx < C::NI) {
+      const int g = goff[idx];
+      const int cvalid = min(CC, cin - chunk * CC);
+      const bool ok = (g >= 0) & (((tid + idx * C::NT) / C::CS) < cvalid);
+      if (g != -2) dst_in[tid + idx * C::NT] = ok ? rin[idx] - in_off : 0.f;
+    } else {
+      const int i = idx - C::NI;
       const int e = tid + i * C::NT;
-      if (e < C::W_ELEMS / 4) lw4[e] = rw[i];
+      if (e < C::W_ELEMS / 4) reinterpret_cast<f32x4*>(dst_w)[e] = rw[i];
     }
   };
 
@@ -322,17 +318,21 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
   const int jx = (lane & 31) % XB, jy = (lane & 31) / XB;
   const int b_base = (lane >> 5) * C::CS + wz * C::RZ * (C::HY * C::HX) + (wy * C::RY * C::YB + jy) * C::HX + jx;
 
-  // double-buffered LDS: chunk c is computed from buffer c&1 while chunk c+1 is committed to the other one;
+  // double-buffered LDS: chunk c is computed from buffer c&1 while chunk c+1 is staged into the other one;
   // one barrier per chunk.
-  prefetch(0);
-  commit(0, lds_in, lds_w);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) issue(i, 0);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) commit1(i, 0, lds_in, lds_w);
   __syncthreads();
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
     const float* cur_w = cur_in + C::IN_ELEMS;
-    if (chunk + 1 < nchunk) prefetch(chunk + 1);
-    // K loop of this chunk, software-pipelined by one step: the fragments of step s+1 are requested from LDS
-    // before the MFMAs of step s issue, so a wave with few accumulators does not sit on the LDS latency.
+    float* nxt_in = lds + ((chunk + 1) & 1) * C::LDS_FLOATS;
+    float* nxt_w = nxt_in + C::IN_ELEMS;
+    const int nchk = min(chunk + 1, nchunk - 1);   // the last chunk re-stages itself (never read): keeps the loop branch-free
+    // K loop of this chunk, software-pipelined: the fragments of step s+DIST are requested from LDS before the
+    // MFMAs of step s issue, so a wave with few accumulators does not sit on the LDS latency.
     {
       const float* in_k = cur_in + b_base + ks * (C::PP * 2 * C::CS);       // K-split group offset (0 when KS == 1)
       const float* w_k = cur_w + ks * (C::PP * C::W_SEG) + lane;
@@ -347,27 +347,30 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
 #pragma unroll
         for (int c = 0; c < NCB; ++c) a[c] = w_k[pp * C::W_SEG + (c * C::K3 + tap) * 64];
       };
-      // prefetch distance: 1 step when a step already holds >= 4 independent MFMAs, else 3 steps with the
-      // issue order pinned (a single-accumulator wave otherwise waits for LDS before every MFMA).
       constexpr int DIST = (ROWS * NCB >= 4) ? 1 : 3;
+      constexpr int THIRD = NS / 3 > 0 ? NS / 3 : 1;
+      constexpr int LPS = (NL + THIRD - 1) / THIRD;                 // staging ops per K step
+      constexpr int CSTART = NS - (NL + LPS - 1) / LPS;             // first step of the commit phase
       float bfq[DIST + 1][ROWS], afq[DIST + 1][NCB];
 #pragma unroll
       for (int s = 0; s < DIST && s < NS; ++s) load_frag(s, bfq[s % (DIST + 1)], afq[s % (DIST + 1)]);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         if (s + DIST < NS) load_frag(s + DIST, bfq[(s + DIST) % (DIST + 1)], afq[(s + DIST) % (DIST + 1)]);
-        if constexpr (DIST > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < LPS; ++q)
+          if (s * LPS + q < NL) issue(s * LPS + q, nchk);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
           for (int r = 0; r < ROWS; ++r)
             acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s % (DIST + 1)][c], bfq[s % (DIST + 1)][r], acc[c][r], 0, 0, 0);
-        if constexpr (DIST > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < LPS; ++q)
+          if (s >= CSTART && (s - CSTART) * LPS + q < NL) commit1((s - CSTART) * LPS + q, nchk, nxt_in, nxt_w);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    if (chunk + 1 < nchunk) {
-      float* nxt = lds + ((chunk + 1) & 1) * C::LDS_FLOATS;
-      commit(chunk + 1, nxt, nxt + C::IN_ELEMS);
     }
     __syncthreads();
   }
