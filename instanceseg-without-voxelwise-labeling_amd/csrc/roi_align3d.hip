@@ -21,7 +21,7 @@ struct AxisSample {  // one (bin, sub-sample) along one axis
   int valid;         // 0 => whole sample contributes 0 (coordinate outside [-1, dim])
 };
 
-constexpr int kMaxTable = 256;  // A * grid per axis (7 bins * adaptive grid <= 36 fits comfortably)
+constexpr int kMaxTable = 64;   // A * grid per axis (7 bins * adaptive grid <= 9); larger adaptive grids leave the output zero
 
 __device__ inline AxisSample make_sample(float start, float bin, int p, int i, int grid, int dim, double lo_limit) {
   // coordinate: roi_start + p*bin + (i + .5f)*bin/grid   (roi_align_kernel_3d.cu:130-138)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void roi_align3d_kernel(const float* __restric
 // (|diff| <~ 1e-6 * max|f|, tests use 1e-5).  One workgroup = one RoI x a range of channels, processed CH
 // channels at a time so that sub-volume + both intermediates fit in LDS.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kSepLdsFloats = 14 * 1024;   // 56 KB of dynamic LDS -> 2 workgroups per CU
+constexpr int kSepLdsFloats = 6 * 1024;    // 24 KB of dynamic LDS -> 6 workgroups (24 waves) per CU
 
 struct AxisTaps { int lo, hi, n; };        // sub-volume range [lo, hi] and number of taps per bin
 
@@ -224,68 +224,156 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
   }
   const int z0 = rng[0], y0 = rng[2], x0 = rng[4];
   const int ez = rng[1] - z0 + 1, ey = rng[3] - y0 + 1, ex = rng[5] - x0 + 1;
-  const int per_ch = ez * ey * ex + ez * ey * AW + ez * AH * AW;
+  const int sub = ez * ey * ex, n1 = ez * ey * AW, n2 = ez * AH * AW;
+  const int per_ch = sub + n1 + n2;
+  const float inv_count = 1.0f / (float)(g.grid_s * g.grid_h * g.grid_w);
+  const int HW = H * W;
   if (per_ch > kSepLdsFloats) {                          // huge RoI: sub-volume does not fit LDS -> reference order
     roi_exact_forward_range(feat, out, g, tz, ty, tx, n, c0, c1, C, S, H, W, AS, AH, AW);
     return;
   }
-  const int CH = min(kSepLdsFloats / per_ch, c1 - c0);
-  float* fsub = dyn;                                     // [CH][ez][ey][ex]
-  float* t1 = fsub + (size_t)CH * ez * ey * ex;          // [CH][ez][ey][AW]
-  float* t2 = t1 + (size_t)CH * ez * ey * AW;            // [CH][ez][AH][AW]
-  const float inv_count = 1.0f / (float)(g.grid_s * g.grid_h * g.grid_w);
-  const int HW = H * W;
-  for (int cb = c0; cb < c1; cb += CH) {
-    const int nc = min(CH, c1 - cb);
-    // stage the sub-volume (rows of ex contiguous floats)
-    const int sub = ez * ey * ex;
-    for (int e = tid; e < nc * sub; e += 256) {
-      const int c = e / sub, r = e % sub;
-      const int z = r / (ey * ex), y = (r / ex) % ey, x = r % ex;
-      fsub[e] = feat[((size_t)g.batch * C + cb + c) * S * HW + (size_t)(z0 + z) * HW + (y0 + y) * W + (x0 + x)];
-    }
-    __syncthreads();
-    // pass X: t1[c][z][y][pw] = sum over the samples of bin pw of  h*f[lo] + l*f[hi]
-    const int n1 = ez * ey * AW;
-    for (int e = tid; e < nc * n1; e += 256) {
-      const int c = e / n1, r = e % n1;
-      const int pw = r % AW, zy = r / AW;
-      const float* row = fsub + (size_t)c * sub + (size_t)zy * ex - x0;
+  // one pass set over elements [first, first+stride, ...) of one channel held in (fsub, t1, t2)
+  auto passes = [&](const float* fsub, float* t1, float* t2, float* oc, int first, int stride, bool block_sync)
+                    __attribute__((always_inline)) {
+    for (int e = first; e < n1; e += stride) {           // pass X: t1[z][y][pw] = sum_samples h*f[lo] + l*f[hi]
+      const int pw = e % AW, zy = e / AW;
+      const float* row = fsub + zy * ex - x0;
       float acc = 0.f;
       for (int i = 0; i < g.grid_w; ++i) {
-        const AxisSample s = tx[pw * g.grid_w + i];
-        if (s.valid) acc += s.h * row[s.lo] + s.l * row[s.hi];
+        const AxisSample sm = tx[pw * g.grid_w + i];
+        if (sm.valid) acc += sm.h * row[sm.lo] + sm.l * row[sm.hi];
       }
       t1[e] = acc;
     }
-    __syncthreads();
-    // pass Y: t2[c][z][ph][pw]
-    const int n2 = ez * AH * AW;
-    for (int e = tid; e < nc * n2; e += 256) {
-      const int c = e / n2, r = e % n2;
-      const int pw = r % AW, ph = (r / AW) % AH, z = r / (AW * AH);
-      const float* col = t1 + (size_t)c * n1 + ((size_t)z * ey - y0) * AW + pw;
+    if (block_sync) __syncthreads();
+    for (int e = first; e < n2; e += stride) {           // pass Y: t2[z][ph][pw]
+      const int pw = e % AW, ph = (e / AW) % AH, z = e / (AW * AH);
+      const float* col = t1 + (z * ey - y0) * AW + pw;
       float acc = 0.f;
       for (int i = 0; i < g.grid_h; ++i) {
-        const AxisSample s = ty[ph * g.grid_h + i];
-        if (s.valid) acc += s.h * col[s.lo * AW] + s.l * col[s.hi * AW];
+        const AxisSample sm = ty[ph * g.grid_h + i];
+        if (sm.valid) acc += sm.h * col[sm.lo * AW] + sm.l * col[sm.hi * AW];
       }
       t2[e] = acc;
     }
-    __syncthreads();
-    // pass Z + average; e runs in the output's memory order (c, ph, pw, ps) -> coalesced stores
-    for (int e = tid; e < nc * bins; e += 256) {
-      const int c = e / bins, b = e % bins;
-      const int ps = b % AS, pw = (b / AS) % AW, ph = b / AS / AW;
-      const float* col = t2 + (size_t)c * n2 - (size_t)z0 * AH * AW + ph * AW + pw;
+    if (block_sync) __syncthreads();
+    for (int e = first; e < bins; e += stride) {         // pass Z + average, output memory order (ph, pw, ps)
+      const int ps = e % AS, pw = (e / AS) % AW, ph = e / AS / AW;
+      const float* col = t2 - z0 * AH * AW + ph * AW + pw;
       float acc = 0.f;
       for (int i = 0; i < g.grid_s; ++i) {
-        const AxisSample s = tz[ps * g.grid_s + i];
-        if (s.valid) acc += s.h * col[s.lo * AH * AW] + s.l * col[s.hi * AH * AW];
+        const AxisSample sm = tz[ps * g.grid_s + i];
+        if (sm.valid) acc += sm.h * col[sm.lo * AH * AW] + sm.l * col[sm.hi * AH * AW];
       }
-      out[((size_t)n * C + cb + c) * bins + b] = acc * inv_count;
+      oc[e] = acc * inv_count;
     }
-    __syncthreads();
+  };
+  if (4 * per_ch > kSepLdsFloats) {
+    // medium RoI: the whole workgroup cooperates on one channel at a time (block barriers between the passes)
+    float* fsub = dyn; float* t1 = fsub + sub; float* t2 = t1 + n1;
+    for (int c = c0; c < c1; ++c) {
+      const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+      __syncthreads();
+      for (int e = tid; e < sub; e += 256) fsub[e] = fc[(size_t)(e / (ey * ex)) * HW + ((e / ex) % ey) * W + e % ex];
+      __syncthreads();
+      passes(fsub, t1, t2, out + ((size_t)n * C + c) * bins, tid, 256, true);
+    }
+    return;
+  }
+  // small RoI (the common case): every WAVE works alone on one channel at a time in its own LDS slice, no workgroup
+  // barriers (the three short dependent passes are latency-bound).  LDS operations of one wave execute in order, so a
+  // pass may read what other lanes of the same wave wrote.  The next channel's sub-volume is fetched into registers
+  // while the current one is processed.
+  const int wave = tid >> 6, lane = tid & 63;
+  float* fsub = dyn + (size_t)wave * per_ch;             // [ez][ey][ex]
+  float* t1 = fsub + sub;                                // [ez][ey][AW]
+  float* t2 = t1 + n1;                                   // [ez][AH][AW]
+  constexpr int kMaxStage = (kSepLdsFloats / 4 + 63) / 64;   // registers per lane that can hold one sub-volume
+  float stage[kMaxStage];
+  int soff[kMaxStage];
+#pragma unroll
+  for (int i = 0; i < kMaxStage; ++i) {
+    const int e = lane + i * 64;
+    soff[i] = -1;
+    if (i * 64 < sub && e < sub) soff[i] = (e / (ey * ex)) * HW + ((e / ex) % ey) * W + e % ex;   // wave-uniform skip
+  }
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+    const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+#pragma unroll
+    for (int i = 0; i < kMaxStage; ++i) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
+  };
+  // register-tap fast path (7x7x7 bins, sampling grid 2 — the shipped configs): every lane keeps a FIXED (ph, pw)
+  // for the whole RoI, so all interpolation taps, weights and LDS offsets are precomputed once per RoI; per channel the
+  // three passes are bare {ds_read x4, fma x4, ds_write} bodies (the generic table-driven passes spend 2/3 of their
+  // LDS traffic and most of their VALU work on re-reading the tap tables and re-deriving addresses per element).
+  const bool reg_taps = (g.grid_s == 2) & (g.grid_h == 2) & (g.grid_w == 2) & (AS == 7) & (AH == 7) & (AW == 7);
+  if (!reg_taps) {
+    if (c0 + wave < c1) fetch(c0 + wave);
+    for (int c = c0 + wave; c < c1; c += 4) {
+#pragma unroll
+      for (int i = 0; i < kMaxStage; ++i)
+        if (soff[i] >= 0) fsub[lane + i * 64] = stage[i];
+      if (c + 4 < c1) fetch(c + 4);
+      passes(fsub, t1, t2, out + ((size_t)n * C + c) * bins, lane, 64, false);
+    }
+    return;
+  }
+  const int my_pw = lane % 7, my_rx = lane / 7, my_ph = (lane / 7) % 7;
+  float xw[4], yw[4], zw[7][4];
+  int xo[4], yo[4], zo[7][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const AxisSample sx = tx[my_pw * 2 + i], sy = ty[my_ph * 2 + i];
+    xw[2 * i] = sx.valid ? sx.h : 0.f; xw[2 * i + 1] = sx.valid ? sx.l : 0.f;
+    xo[2 * i] = sx.valid ? sx.lo - x0 : 0; xo[2 * i + 1] = sx.valid ? sx.hi - x0 : 0;
+    yw[2 * i] = sy.valid ? sy.h : 0.f; yw[2 * i + 1] = sy.valid ? sy.l : 0.f;
+    yo[2 * i] = sy.valid ? (sy.lo - y0) * 7 : 0; yo[2 * i + 1] = sy.valid ? (sy.hi - y0) * 7 : 0;
+  }
+#pragma unroll
+  for (int ps = 0; ps < 7; ++ps)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const AxisSample sz = tz[ps * 2 + i];
+      zw[ps][2 * i] = sz.valid ? sz.h * inv_count : 0.f; zw[ps][2 * i + 1] = sz.valid ? sz.l * inv_count : 0.f;
+      zo[ps][2 * i] = sz.valid ? (sz.lo - z0) * 49 : 0; zo[ps][2 * i + 1] = sz.valid ? (sz.hi - z0) * 49 : 0;
+    }
+  const int nrows = ez * ey;
+  const int nst = (sub + 63) / 64;                         // staging registers actually needed (wave-uniform)
+  if (c0 + wave < c1) {
+    const float* fc = feat + ((size_t)g.batch * C + c0 + wave) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+#pragma unroll
+    for (int i = 0; i < kMaxStage; ++i) if (i < nst) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
+  }
+  for (int c = c0 + wave; c < c1; c += 4) {
+#pragma unroll
+    for (int i = 0; i < kMaxStage; ++i)
+      if (i < nst && soff[i] >= 0) fsub[lane + i * 64] = stage[i];
+    if (c + 4 < c1) {
+      const float* fc = feat + ((size_t)g.batch * C + c + 4) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+#pragma unroll
+      for (int i = 0; i < kMaxStage; ++i) if (i < nst) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
+    }
+    if (my_rx < 9) {                                       // pass X: lanes 0..62 <-> (row mod 9, pw)
+      const float* row = fsub + my_rx * ex;
+      float* dst = t1 + my_rx * 7 + my_pw;
+      for (int zy = my_rx; zy < nrows; zy += 9) {
+        *dst = (xw[0] * row[xo[0]] + xw[1] * row[xo[1]]) + (xw[2] * row[xo[2]] + xw[3] * row[xo[3]]);
+        row += 9 * ex; dst += 63;
+      }
+    }
+    if (lane < 49) {
+      const float* col = t1 + my_pw;                       // pass Y: lane <-> (ph, pw), loop over z
+      float* dst = t2 + lane;
+      for (int z = 0; z < ez; ++z) {
+        *dst = (yw[0] * col[yo[0]] + yw[1] * col[yo[1]]) + (yw[2] * col[yo[2]] + yw[3] * col[yo[3]]);
+        col += ey * 7; dst += 49;
+      }
+      const float* cz = t2 + lane;                         // pass Z (+ 1/count folded into the weights)
+      float* oc = out + ((size_t)n * C + c) * 343 + lane * 7;
+#pragma unroll
+      for (int ps = 0; ps < 7; ++ps)
+        oc[ps] = (zw[ps][0] * cz[zo[ps][0]] + zw[ps][1] * cz[zo[ps][1]]) + (zw[ps][2] * cz[zo[ps][2]] + zw[ps][3] * cz[zo[ps][3]]);
+    }
   }
 }
 
@@ -298,8 +386,10 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
   if (ratio > 0 && (AS * ratio > kMaxTable || AH * ratio > kMaxTable || AW * ratio > kMaxTable)) return M3D_EUNSUPPORTED;
   // enough workgroups to fill 256 CUs several times over; at least 8 channels per workgroup so the LDS
   // tables are amortised.
+  // one workgroup per (RoI, channel chunk): the per-RoI setup (sample tables, tap registers) is amortised over the
+  // chunk, so chunks are as large as possible while the grid still holds >= ~2048 workgroups (8 per CU)
   int chunks = 1;
-  while ((long)R * chunks < 4096 && chunks * 8 < C) chunks *= 2;
+  while ((long)R * chunks < 2048 && chunks * 16 < C) chunks *= 2;
   int cpb = (C + chunks - 1) / chunks;
   chunks = (C + cpb - 1) / cpb;
   dim3 grid(R, chunks), block(256);
