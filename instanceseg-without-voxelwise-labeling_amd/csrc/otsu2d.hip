@@ -17,13 +17,13 @@
 
 namespace {
 
-struct Edges { double lo, hi, step; int G; };
+struct Edges { double lo, hi, step, inv_step; int G; };
 
 __device__ inline double edge_at(const Edges& e, int i) { return i == e.G ? e.hi : (double)i * e.step + e.lo; }
 
 // np.searchsorted(edges, v, 'right') - 1 with v == last edge -> G-1 (numpy histogramdd)
 __device__ inline int bin_of(const Edges& e, double v) {
-  int i = (int)((v - e.lo) / e.step);
+  int i = (int)((v - e.lo) * e.inv_step);      // initial guess only; the two loops below make it exact
   i = i < 0 ? 0 : (i > e.G ? e.G : i);
   while (i < e.G && edge_at(e, i + 1) <= v) ++i;
   while (i > 0 && edge_at(e, i) > v) --i;
@@ -35,6 +35,7 @@ __device__ inline Edges make_edges(int vmin, int vmax, int G) {
   e.lo = (double)vmin; e.hi = (double)vmax; e.G = G;
   if (vmin == vmax) { e.lo -= 0.5; e.hi += 0.5; }       // histogramdd: flat axis widened
   e.step = (e.hi - e.lo) / (double)G;                    // linspace: delta / div
+  e.inv_step = 1.0 / e.step;
   return e;
 }
 
@@ -44,19 +45,23 @@ __device__ inline unsigned long long wave_sum_u64(unsigned long long v) {
   return v;
 }
 
-// one workgroup (256 threads) per RoI.  diag = per-RoI workspace: 3 arrays of (2*Gmax) u64.
-__global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict__ image, const uint16_t* __restrict__ prm,
-                                                     const int64_t* __restrict__ offsets, int max_g,
+// one workgroup (kOtsuThreads threads) per RoI.  diag = per-RoI workspace: 3 arrays of (2*Gmax) u64.
+constexpr int kOtsuThreads = 1024;
+constexpr int kOtsuWaves = kOtsuThreads / 64;
+
+__global__ __launch_bounds__(kOtsuThreads) void otsu2d_kernel(const uint16_t* __restrict__ image, const uint16_t* __restrict__ prm,
+                                                     const int64_t* __restrict__ offsets, int max_g, int lds_g,
                                                      unsigned long long* __restrict__ ws, uint8_t* __restrict__ mask,
                                                      int32_t* __restrict__ kb, int32_t* __restrict__ status) {
   const int roi = blockIdx.x;
   const int64_t beg = offsets[roi], end = offsets[roi + 1];
   const int64_t V = end - beg;
   const int tid = threadIdx.x;
-  __shared__ int s_red[4][4];
+  __shared__ int s_red[kOtsuWaves][4];
   __shared__ int s_mm[4];
-  __shared__ double s_best[4];
-  __shared__ int s_bestb[4];
+  __shared__ double s_best[kOtsuWaves];
+  __shared__ int s_bestb[kOtsuWaves];
+  __shared__ unsigned long long s_part[3][kOtsuThreads];
   __shared__ unsigned long long s_tot[2];
   if (V <= 0) {
     if (tid == 0) { kb[2 * roi] = 0; kb[2 * roi + 1] = 0; status[roi] = 2; }
@@ -68,7 +73,8 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
 
   // ---- pass 1: min / max of both channels (otsu.py:201, histogram2d range=None) ----
   int gmin = 65535, gmax = 0, pmin = 65535, pmax = 0;
-  for (int64_t i = tid; i < V; i += 256) {
+#pragma unroll 4
+  for (int64_t i = tid; i < V; i += kOtsuThreads) {
     const int a = img[i], p = pr[i];
     gmin = min(gmin, a); gmax = max(gmax, a); pmin = min(pmin, p); pmax = max(pmax, p);
   }
@@ -80,10 +86,9 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   if ((tid & 63) == 0) { s_red[tid >> 6][0] = gmin; s_red[tid >> 6][1] = gmax; s_red[tid >> 6][2] = pmin; s_red[tid >> 6][3] = pmax; }
   __syncthreads();
   if (tid == 0) {
-    s_mm[0] = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
-    s_mm[1] = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
-    s_mm[2] = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
-    s_mm[3] = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
+    int a = s_red[0][0], b = s_red[0][1], c = s_red[0][2], d = s_red[0][3];
+    for (int w = 1; w < kOtsuWaves; ++w) { a = min(a, s_red[w][0]); b = max(b, s_red[w][1]); c = min(c, s_red[w][2]); d = max(d, s_red[w][3]); }
+    s_mm[0] = a; s_mm[1] = b; s_mm[2] = c; s_mm[3] = d;
   }
   __syncthreads();
   gmin = s_mm[0]; gmax = s_mm[1]; pmin = s_mm[2]; pmax = s_mm[3];
@@ -94,15 +99,20 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   }
   const Edges e1 = make_edges(gmin, gmax, G), e2 = make_edges(pmin, pmax, G);   // :203
   const int ND = 2 * G;                                                   // diagonals 0 .. 2G-2
-  unsigned long long* dN = ws + (size_t)roi * 3 * (2 * (size_t)max_g);
-  unsigned long long* dM1 = dN + 2 * (size_t)max_g;
-  unsigned long long* dM2 = dM1 + 2 * (size_t)max_g;
-  for (int d = tid; d < ND; d += 256) { dN[d] = 0ull; dM1[d] = 0ull; dM2[d] = 0ull; }
+  // the three diagonal histograms live in LDS when they fit (G <= lds_g: soma-style ~330 levels), else in the
+  // caller's global workspace (nuclei-style ranges of thousands of levels)
+  extern __shared__ unsigned long long lds_hist[];
+  const bool in_lds = G <= lds_g;
+  unsigned long long* dN = in_lds ? lds_hist : ws + (size_t)roi * 3 * (2 * (size_t)max_g);
+  unsigned long long* dM1 = dN + 2 * (size_t)(in_lds ? lds_g : max_g);
+  unsigned long long* dM2 = dM1 + 2 * (size_t)(in_lds ? lds_g : max_g);
+  for (int d = tid; d < ND; d += kOtsuThreads) { dN[d] = 0ull; dM1[d] = 0ull; dM2[d] = 0ull; }
   __syncthreads();
 
   // ---- pass 2: integer diagonal histograms + totals ----
   unsigned long long t1 = 0, t2 = 0;
-  for (int64_t i = tid; i < V; i += 256) {
+#pragma unroll 2
+  for (int64_t i = tid; i < V; i += kOtsuThreads) {
     const int c = bin_of(e1, (double)img[i]);
     const int r = bin_of(e2, (double)pr[i]);
     t1 += (unsigned long long)c; t2 += (unsigned long long)r;
@@ -119,10 +129,24 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   __threadfence_block();
   __syncthreads();
 
-  // ---- pass 3: inclusive prefix over diagonals (single wave-serial scan is enough: ND <= 2*max_g) ----
-  if (tid == 0) {
+  // ---- pass 3: inclusive prefix over diagonals: each thread owns L consecutive entries (local sums, block scan of
+  // the per-thread totals, then the local running sums are written back) ----
+  {
+    const int L = (ND + kOtsuThreads - 1) / kOtsuThreads;
+    const int d0 = tid * L, d1 = min(ND, d0 + L);
     unsigned long long a = 0, b = 0, c = 0;
-    for (int d = 0; d < ND; ++d) { a += dN[d]; b += dM1[d]; c += dM2[d]; dN[d] = a; dM1[d] = b; dM2[d] = c; }
+    for (int d = d0; d < d1; ++d) { a += dN[d]; b += dM1[d]; c += dM2[d]; }
+    s_part[0][tid] = a; s_part[1][tid] = b; s_part[2][tid] = c;
+    __syncthreads();
+    for (int off = 1; off < kOtsuThreads; off <<= 1) {       // Hillis-Steele inclusive scan of the totals
+      unsigned long long va = 0, vb = 0, vc = 0;
+      if (tid >= off) { va = s_part[0][tid - off]; vb = s_part[1][tid - off]; vc = s_part[2][tid - off]; }
+      __syncthreads();
+      s_part[0][tid] += va; s_part[1][tid] += vb; s_part[2][tid] += vc;
+      __syncthreads();
+    }
+    a = s_part[0][tid] - a; b = s_part[1][tid] - b; c = s_part[2][tid] - c;   // exclusive prefix of this thread's range
+    for (int d = d0; d < d1; ++d) { a += dN[d]; b += dM1[d]; c += dM2[d]; dN[d] = a; dM1[d] = b; dM2[d] = c; }
   }
   __threadfence_block();
   __syncthreads();
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   double best = 0.0;                                                      // var_b_max = 0 (:219)
   int best_b = 0x7FFFFFFF;
   const int nb = b_up > b_dw ? (b_up - b_dw) : 1;                          // b_dw itself is always evaluated (:243-250)
-  for (int t = tid; t < nb; t += 256) {
+  for (int t = tid; t < nb; t += kOtsuThreads) {
     const int b = b_dw + t;
     const int d = b - 2 * gmin - 1;                                        // cells with r + c <= d are background
     double p0 = 0, u00 = 0, u01 = 0;
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_bestb[tid >> 6] = best_b; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < kOtsuWaves; ++w)
       if (s_best[w] > s_best[0] || (s_best[w] == s_best[0] && s_bestb[w] < s_bestb[0])) { s_best[0] = s_best[w]; s_bestb[0] = s_bestb[w]; }
   }
   __syncthreads();
@@ -174,7 +198,8 @@ __global__ __launch_bounds__(256) void otsu2d_kernel(const uint16_t* __restrict_
   }
   // ---- pass 5: mask (:276-282) ----
   const int x_hi = found ? min(best_b - gmin, gmax) : gmin;                // x_g_min = (g_min - b_max)/k_max ; :277-278
-  for (int64_t i = tid; i < V; i += 256) {
+#pragma unroll 4
+  for (int64_t i = tid; i < V; i += kOtsuThreads) {
     uint8_t m = 255;
     const int ix = img[i];
     if (found && ix >= gmin && ix < x_hi) {
@@ -200,7 +225,9 @@ M3D_API int m3d_otsu2d_batch(const uint16_t* d_image, const uint16_t* d_prm, con
   if (!d_image || !d_prm || !d_offsets || !d_mask || !d_kb || !d_status || !d_ws) return M3D_EINVAL;
   if (ws_bytes < m3d_otsu2d_workspace_bytes(num_rois, max_gray_range)) return M3D_EWORKSPACE;
   unsigned long long* ws = (unsigned long long*)m3d::align_up((size_t)d_ws, 256);
-  hipLaunchKernelGGL(otsu2d_kernel, dim3(num_rois), dim3(256), 0, m3d::as_stream(stream), d_image, d_prm, d_offsets,
-                     max_gray_range, ws, d_mask, d_kb, d_status);
+  const int lds_g = max_gray_range < 1024 ? max_gray_range : 1024;          // 3 * 2 * 1024 * 8 B = 48 KB
+  const size_t lds = sizeof(unsigned long long) * 3 * 2 * (size_t)lds_g;
+  hipLaunchKernelGGL(otsu2d_kernel, dim3(num_rois), dim3(kOtsuThreads), lds, m3d::as_stream(stream), d_image, d_prm, d_offsets,
+                     max_gray_range, lds_g, ws, d_mask, d_kb, d_status);
   return m3d::check_launch("otsu2d_batch");
 }
