@@ -68,10 +68,11 @@ def bench_prm(args, rank, world, dist):
     from m3d.config import Cfg
     from m3d.synth import make_params, synth_volume
     from m3d import tiling
-    cfg = Cfg.soma()
-    P = make_params(stride=4, num_anchors=14, mlp_dim=cfg.mlp_dim, seed=0)
+    nuclei = args.workload == "prm-nuclei"
+    cfg = Cfg.nuclei(score_thresh=0.0) if nuclei else Cfg.soma()
+    P = make_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
-    S, H, W = 64, 160, 160
+    S, H, W = cfg.in_size
     vol = torch.from_numpy(tiling.norm1(synth_volume(rank, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
     npk = []
 
@@ -95,8 +96,9 @@ def bench_prm(args, rank, world, dist):
                           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "PRM tile 1x64x160x160 soma net (stride 4, 14 anchors): PRM forward + box head + "
-                                                 "batched peak back-propagation [configs[3]]", "peaks_per_tile": npk[-1],
+                          "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation%s" %
+                                                 (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
+                                                  "" if nuclei else " [configs[3]]")), "peaks_per_tile": npk[-1],
                                      "prm_forward_ms": fwd_ms}}))
 
 
@@ -105,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect", "prm"])
+    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect", "prm", "prm-nuclei"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
     from m3d.synth import make_params, synth_volume
     from m3d import tiling
 
-    if args.workload == "prm":
+    if args.workload in ("prm", "prm-nuclei"):
         return bench_prm(args, rank, world, dist)
     cfg = Cfg.nuclei()
     P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=(args.workload == "detect"))

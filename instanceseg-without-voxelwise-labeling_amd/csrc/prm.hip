@@ -52,42 +52,68 @@ struct PrepParams {
   int UD, UH, UW;          // X_{L+1} resolution
 };
 
+// One thread per output voxel (no pooling between this layer and the upper one).  grid = (ceil(Wn^3/256), C, P):
+// no 64-bit div/mod chains, channel and peak come from the block index.
 __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
-  const long long w3 = (long long)q.Wn * q.Wn * q.Wn;
-  const long long total = (long long)q.P * q.C * w3;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(e % q.Wn);
-    long long t = e / q.Wn;
-    const int y = (int)(t % q.Wn); t /= q.Wn;
-    const int z = (int)(t % q.Wn); t /= q.Wn;
-    const int c = (int)(t % q.C);
-    const int p = (int)(t / q.C);
-    const int m = q.pool ? 2 : 1;
-    const int oz = q.origin_up[3 * p] * m - q.border, oy = q.origin_up[3 * p + 1] * m - q.border,
-              ox = q.origin_up[3 * p + 2] * m - q.border;
-    if (c == 0 && z == 0 && y == 0 && x == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
-    const int iz = z - q.border, iy = y - q.border, ix = x - q.border;     // inner (un-padded) window coords
-    const int inner = q.Wn - 2 * q.border;
-    float g = 0.f;
-    const int qz = oz + z, qy = oy + y, qx = ox + x;                       // position in this layer's tensor
-    if ((iz >= 0) & (iz < inner) & (iy >= 0) & (iy < inner) & (ix >= 0) & (ix < inner) & (qz >= 0) & (qz < q.D) & (qy >= 0) &
-        (qy < q.H) & (qx >= 0) & (qx < q.W)) {
-      const int uz = q.pool ? (iz >> 1) : iz, uy = q.pool ? (iy >> 1) : iy, ux = q.pool ? (ix >> 1) : ix;
-      const int az = q.origin_up[3 * p] + uz, ay = q.origin_up[3 * p + 1] + uy, ax = q.origin_up[3 * p + 2] + ux;
-      if ((az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) & (ax >= 0) & (ax < q.UW)) {
-        const size_t upos = (((size_t)c * q.UD + az) * q.UH + ay) * q.UW + ax;
-        g = q.gup[(((size_t)p * q.C + c) * q.U + uz) * q.U * q.U + (size_t)uy * q.U + ux];
-        if (q.pool) {
-          const int child = ((qz & 1) << 2) | ((qy & 1) << 1) | (qx & 1);
-          if (q.argmax[upos] != child) g = 0.f;                             // max-unpool routing
-        }
-        if (!(q.xnext[upos] > 0.f)) g = 0.f;                                // ReLU backward (output > 0)
-        if (q.scale) g = g * q.scale[c];                                    // eval-mode BatchNorm backward
-        const float n = q.norm[(((size_t)c * q.D + qz) * q.H + qy) * q.W + qx];
-        g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                       // PostHook, peak_backprop_3d.py:30-33
-      }
+  const int w3 = q.Wn * q.Wn * q.Wn;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, p = blockIdx.z;
+  const int oz = q.origin_up[3 * p] - q.border, oy = q.origin_up[3 * p + 1] - q.border, ox = q.origin_up[3 * p + 2] - q.border;
+  if (e == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+  if (e >= w3) return;
+  const int x = e % q.Wn, y = (e / q.Wn) % q.Wn, z = e / (q.Wn * q.Wn);
+  const int iz = z - q.border, iy = y - q.border, ix = x - q.border;       // inner (un-padded) window coords == upper coords
+  const int qz = oz + z, qy = oy + y, qx = ox + x;                         // position in this layer's tensor (== X_{L+1})
+  float g = 0.f;
+  if ((iz >= 0) & (iz < q.U) & (iy >= 0) & (iy < q.U) & (ix >= 0) & (ix < q.U) & (qz >= 0) & (qz < q.D) & (qy >= 0) & (qy < q.H) &
+      (qx >= 0) & (qx < q.W)) {
+    const size_t pos = (((size_t)c * q.D + qz) * q.H + qy) * q.W + qx;
+    g = q.gup[(((size_t)p * q.C + c) * q.U + iz) * q.U * q.U + (size_t)iy * q.U + ix];
+    if (!(q.xnext[pos] > 0.f)) g = 0.f;                                    // ReLU backward (output > 0)
+    if (q.scale) g = g * q.scale[c];                                       // eval-mode BatchNorm backward
+    const float n = q.norm[pos];
+    g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                          // PostHook, peak_backprop_3d.py:30-33
+  }
+  q.out[((size_t)p * q.C + c) * w3 + e] = g;
+}
+
+// MaxPool3d(2,2) between this layer and the upper one: one thread per 2x2x2 output block, i.e. per UPPER voxel (plus a
+// one-block shell for the zero border).  Exactly one child of an inner block receives the routed gradient, so the
+// upper-resolution tensors (gradient, argmax, pooled value) are read once per block, the norm conv once per block,
+// and the eight outputs are written as four 8-byte stores.  grid = (ceil((U+2)^3/256), C, P).
+__global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
+  const int UB = q.U + 2;                                                  // blocks per axis incl. the shell
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y, p = blockIdx.z;
+  const int uz0 = q.origin_up[3 * p], uy0 = q.origin_up[3 * p + 1], ux0 = q.origin_up[3 * p + 2];
+  const int oz = 2 * uz0 - q.border, oy = 2 * uy0 - q.border, ox = 2 * ux0 - q.border;
+  if (e == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+  if (e >= UB * UB * UB) return;
+  // block b covers inner coordinates 2*(b-1) .. 2*(b-1)+1 shifted so that every window voxel belongs to one block:
+  // window coordinate w = inner + border; blocks are aligned to the INNER grid (pooling windows).
+  const int bx = e % UB - 1, by = (e / UB) % UB - 1, bz = e / (UB * UB) - 1;      // upper-window voxel index, -1 .. U
+  float vals[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vals[k] = 0.f;
+  const int az = uz0 + bz, ay = uy0 + by, ax = ux0 + bx;                          // upper tensor position
+  if ((bz >= 0) & (bz < q.U) & (by >= 0) & (by < q.U) & (bx >= 0) & (bx < q.U) & (az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) &
+      (ax >= 0) & (ax < q.UW)) {
+    const size_t upos = (((size_t)c * q.UD + az) * q.UH + ay) * q.UW + ax;
+    float g = q.gup[(((size_t)p * q.C + c) * q.U + bz) * q.U * q.U + (size_t)by * q.U + bx];
+    if (!(q.xnext[upos] > 0.f)) g = 0.f;                                           // ReLU backward on the pooled value
+    if (q.scale) g = g * q.scale[c];
+    const int child = q.argmax[upos];                                              // max-unpool routing
+    const int qz = 2 * az + (child >> 2), qy = 2 * ay + ((child >> 1) & 1), qx = 2 * ax + (child & 1);
+    if ((qz < q.D) & (qy < q.H) & (qx < q.W)) {
+      const float n = q.norm[(((size_t)c * q.D + qz) * q.H + qy) * q.W + qx];
+      vals[child] = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);
     }
-    q.out[e] = g;
+  }
+  float* o = q.out + ((size_t)p * q.C + c) * q.Wn * q.Wn * q.Wn;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int wz = 2 * bz + (k >> 2) + q.border, wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
+    if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) o[((size_t)wz * q.Wn + wy) * q.Wn + wx] = vals[k];
   }
 }
 
@@ -265,10 +291,16 @@ M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int 
   q.norm = d_norm; q.out = d_out; q.origin_out = d_origin_out; q.P = num_peaks; q.C = channels; q.U = up_size;
   q.Wn = (pool ? 2 : 1) * up_size + 2 * border; q.border = border; q.pool = pool ? 1 : 0;
   q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
-  const long long total = (long long)num_peaks * channels * q.Wn * q.Wn * q.Wn;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(prm_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream), q);
+  if (channels > 65535 || num_peaks > 65535) return M3D_EUNSUPPORTED;
+  if (pool) {
+    if (border > 2) return M3D_EUNSUPPORTED;      // the one-block shell covers borders of 1 or 2 voxels
+    const int ub = up_size + 2;
+    hipLaunchKernelGGL(prm_prepare_pool_kernel, dim3((ub * ub * ub + 255) / 256, channels, num_peaks), dim3(256), 0,
+                       m3d::as_stream(stream), q);
+  } else {
+    hipLaunchKernelGGL(prm_prepare_kernel, dim3((q.Wn * q.Wn * q.Wn + 255) / 256, channels, num_peaks), dim3(256), 0,
+                       m3d::as_stream(stream), q);
+  }
   return m3d::check_launch("prm_prepare");
 }
 
