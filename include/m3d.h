@@ -209,6 +209,30 @@ int m3d_otsu2d_batch(const uint16_t* d_image, const uint16_t* d_prm, const int64
                      int max_gray_range, uint8_t* d_mask, int32_t* d_kb, int32_t* d_status, void* d_ws,
                      size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Connected-component post-processing of the Otsu masks, batched per RoI (the step after Otsu: SURVEY 8f-2).
+ * Crops are concatenated; crop r = voxels [d_offsets[r], d_offsets[r+1]) with dims d_dims[3r..3r+2] = (ez,ey,ex).
+ *   m3d_cc_largest_batch   keep the largest 26-connected component (skimage.measure.label / cc3d default
+ *                          connectivity; tools/binarization_soma.py:96-98, binarization_nuclei.py:125-130).
+ *                          tie_last = 1: among equal sizes the highest label id (argsort(...)[-1], soma),
+ *                          0: the lowest (np.argmax, nuclei).  invert = 1 runs on the complement and writes
+ *                          255 everywhere except its largest component = hole filling (nuclei :132-137).
+ *                          d_status[r] = 1 when there is no component at all.
+ *   m3d_binary_closing6_batch  scipy.ndimage.binary_closing defaults: 6-neighbourhood, 1 iteration, border 0
+ *                          (binarization_nuclei.py:139).
+ *   m3d_paint_instances    write d_ids[r] into the uint32 label volume wherever crop r (box int32 [R,6] inclusive)
+ *                          is set and no SMALLER id covers the voxel == "paint only where still 0" in ascending
+ *                          id order (binarization_soma.py:99-102).  The volume must be pre-filled with 0xFFFFFFFF.
+ * ------------------------------------------------------------------------------------------------------- */
+size_t m3d_cc_workspace_bytes(int64_t total_voxels);
+int m3d_cc_largest_batch(const uint8_t* d_mask, const int64_t* d_offsets, const int32_t* d_dims, int num_rois,
+                         int64_t total_voxels, int invert, int tie_last, uint8_t* d_out, int32_t* d_status,
+                         void* d_ws, size_t ws_bytes, void* stream);
+int m3d_binary_closing6_batch(const uint8_t* d_mask, const int64_t* d_offsets, const int32_t* d_dims, int num_rois,
+                              int64_t total_voxels, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
+int m3d_paint_instances(const uint8_t* d_mask, const int64_t* d_offsets, const int32_t* d_boxes, const int32_t* d_ids,
+                        int num_rois, int depth, int height, int width, uint32_t* d_volume, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,9 @@
 """Per-detection binarisation on device: uint8 PRM quantisation -> box crop + normalisation -> 2D-Otsu.
 
 Counterpart of the per-detection loop of tools/binarization_soma.py:66-94 and tools/binarization_nuclei.py:92-124
-up to (and including) `otsu_py_2d_fast`.  Connected components / hole filling / closing / label painting
-(binarization_soma.py:96-102, binarization_nuclei.py:125-145) are the next row."""
+up to (and including) `otsu_py_2d_fast` (`binarize_tile`), and the whole loop body including largest connected
+component, hole filling, closing and label painting (binarization_soma.py:96-105, binarization_nuclei.py:125-150)
+without a host round trip (`segment_tile`)."""
 import numpy as np
 import torch
 
@@ -46,3 +47,41 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
         m = mask[offs[j]:offs[j + 1]].reshape(z2 - z1 + 1, y2 - y1 + 1, x2 - x1 + 1)
         out[i] = (boxes[i], m, int(kb[j, 0]), int(kb[j, 1]))
     return out
+
+
+def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_id=1):
+    """The reference's per-detection loop body for one tile, entirely on device.
+    image_u16 [S,H,W] uint16/int32 CUDA, prms float32 [P,S,H,W] CUDA, dets [P,7] in tile coordinates, ALREADY in the
+    order the reference loops over them (soma: NMS-kept, score-descending, binarization_soma.py:56-61; nuclei: NMS
+    order filtered by score > 0.4, binarization_nuclei.py:80-86).  Detection d gets mask id first_id + d whether or not
+    it ends up painted (mask_id is incremented before the `continue`, binarization_soma.py:66).
+    Returns (labels int32 [S,H,W] CUDA, painted bool [P] CUDA): labels holds, per voxel, the id of the first
+    detection whose final mask covers it; painted[d] says whether id d occurs at all (`mask_id in np.unique(seg)`)."""
+    S, H, W = image_u16.shape
+    P = int(prms.shape[0])
+    dev = image_u16.device
+    if P == 0:
+        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), torch.zeros((0,), dtype=torch.bool, device=dev)
+    boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
+    ok = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
+         (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
+    idx = np.nonzero(ok)[0]
+    painted = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if len(idx) == 0:
+        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
+    q = ops.prm_quantize_u8(prms)
+    idx_t = torch.from_numpy(idx).to(dev)
+    bsel = torch.from_numpy(boxes[idx]).to(dev)
+    oi, op, offs = ops.roi_normalize(image_u16, q[idx_t].contiguous(), bsel, mode)
+    mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
+    dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
+    cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))
+    if mode == "nuclei":
+        cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
+        cc = ops.binary_closing6_batch(cc, offs, dims)
+    ids = (idx_t + first_id).to(torch.int32)
+    nonempty = q[idx_t].reshape(len(idx), -1).amax(1) > 0                                 # binarization_soma.py:74-76
+    ids = torch.where((st_otsu == 0) & (st_cc == 0) & nonempty, ids, torch.full_like(ids, -1))   # skipped: never paints
+    labels = ops.paint_instances(cc, offs, bsel, ids, (S, H, W))
+    present = torch.bincount(labels.reshape(-1), minlength=first_id + P)[first_id:first_id + P] > 0
+    return labels, present

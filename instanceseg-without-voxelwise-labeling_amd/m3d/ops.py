@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -339,3 +339,44 @@ def roi_normalize(image_u16, prm_u8, boxes, mode):
     check(lib().m3d_roi_normalize(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
                                   R, D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _stream()), "roi_normalize")
     return oi, op, offs
+
+
+# ------------------------------------------------------------------ connected components / closing / painting
+def cc_largest_batch(mask, offsets, dims, invert=False, tie_last=True):
+    """mask uint8 flat (crops concatenated), offsets int64 [R+1], dims int32 [R,3] (ez,ey,ex).
+    Returns (out uint8 flat {0,255}, status int32 [R])."""
+    _need_gpu(mask, offsets, dims)
+    assert mask.dtype == torch.uint8 and offsets.dtype == torch.int64 and dims.dtype == torch.int32
+    R = dims.shape[0]
+    total = int(mask.numel())
+    out = torch.empty_like(mask)
+    status = torch.zeros((R,), dtype=torch.int32, device=mask.device)
+    wsb = lib().m3d_cc_workspace_bytes(C.c_int64(total))
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=mask.device)
+    check(lib().m3d_cc_largest_batch(_ptr(mask), _ptr(offsets), _ptr(dims.contiguous()), R, C.c_int64(total), int(bool(invert)),
+                                     int(bool(tie_last)), _ptr(out), _ptr(status), _ptr(ws), C.c_size_t(wsb), _stream()),
+          "cc_largest_batch")
+    return out, status
+
+
+def binary_closing6_batch(mask, offsets, dims):
+    _need_gpu(mask, offsets, dims)
+    R = dims.shape[0]
+    total = int(mask.numel())
+    out = torch.empty_like(mask)
+    ws = torch.empty((total + 512,), dtype=torch.uint8, device=mask.device)
+    check(lib().m3d_binary_closing6_batch(_ptr(mask), _ptr(offsets), _ptr(dims.contiguous()), R, C.c_int64(total), _ptr(out),
+                                          _ptr(ws), C.c_size_t(total + 512), _stream()), "binary_closing6_batch")
+    return out
+
+
+def paint_instances(mask, offsets, boxes, ids, shape):
+    """Returns the int32 label volume [D,H,W]: id of the first (lowest-id) instance covering each voxel, 0 elsewhere.
+    ids < 0 (0xFFFFFFFF as unsigned) never win, i.e. mark a skipped detection."""
+    _need_gpu(mask, offsets, boxes, ids)
+    D, H, W = shape
+    vol = torch.full((D, H, W), -1, dtype=torch.int32, device=mask.device)      # 0xFFFFFFFF sentinel
+    R = boxes.shape[0]
+    check(lib().m3d_paint_instances(_ptr(mask), _ptr(offsets), _ptr(boxes.contiguous()), _ptr(ids.contiguous()), R, D, H, W,
+                                    _ptr(vol), _stream()), "paint_instances")
+    return torch.where(vol == -1, torch.zeros_like(vol), vol)

@@ -1,0 +1,154 @@
+"""GPU parity: largest 26-connected component / hole filling / 6-connected closing / instance painting
+(csrc/cc3d.hip) against the oracle's scipy restatement of tools/binarization_soma.py:96-105 and
+tools/binarization_nuclei.py:125-150.  Byte / index work: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def m3d():
+    import m3d as _m
+    assert torch.cuda.is_available()
+    return _m
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def pack(masks):
+    offs = np.concatenate(([0], np.cumsum([m.size for m in masks]))).astype(np.int64)
+    dims = np.array([m.shape for m in masks], np.int32)
+    flat = np.concatenate([m.ravel() for m in masks]).astype(np.uint8)
+    return dev(flat), dev(offs), dev(dims), offs
+
+
+def snake(shape):
+    """One long serpentine component + a few specks: worst case for label propagation."""
+    m = np.zeros(shape, np.uint8)
+    D, H, W = shape
+    for z in range(0, D, 2):
+        for y in range(0, H, 2):
+            m[z, y, :] = 255
+            if y + 1 < H:
+                m[z, y + 1, (W - 1) if (y // 2) % 2 == 0 else 0] = 255
+        if z + 1 < D:
+            last_y = (H - 1) // 2 * 2
+            m[z + 1, last_y if (z // 2) % 2 == 0 else 0, 0] = 255
+    return m
+
+
+def random_masks(rs, n):
+    out = []
+    for i in range(n):
+        shape = tuple(int(v) for v in rs.randint(1, 40, 3))
+        p = rs.choice([0.05, 0.15, 0.3, 0.6, 0.9])
+        out.append(((rs.rand(*shape) < p) * 255).astype(np.uint8))
+    return out
+
+
+def test_largest_cc_both_tie_rules(m3d):
+    rs = np.random.RandomState(0)
+    masks = random_masks(rs, 40)
+    # explicit size ties: two / three equal blobs, first and last in raster order
+    t = np.zeros((5, 9, 9), np.uint8); t[0, 0, 0:2] = 255; t[2, 4, 4:6] = 255; t[4, 8, 7:9] = 255
+    masks += [t, snake((9, 13, 17)), snake((24, 30, 31)), np.full((3, 4, 5), 255, np.uint8), np.zeros((4, 4, 4), np.uint8),
+              np.array([[[255]]], np.uint8)]
+    flat, offs, dims, ho = pack(masks)
+    for tie_last, ref in ((True, O.largest_cc_soma), (False, O.largest_cc_nuclei)):
+        out, status = m3d.cc_largest_batch(flat, offs, dims, invert=False, tie_last=tie_last)
+        out, status = out.cpu().numpy(), status.cpu().numpy()
+        for r, m in enumerate(masks):
+            got = out[ho[r]:ho[r + 1]].reshape(m.shape)
+            if not m.any():
+                assert status[r] == 1 and not got.any()
+                continue
+            assert status[r] == 0
+            assert np.array_equal(got, ref(m).astype(np.uint8) * 255), (r, tie_last, m.shape)
+
+
+def test_fill_holes_and_closing(m3d):
+    rs = np.random.RandomState(1)
+    masks = []
+    for i in range(30):
+        shape = tuple(int(v) for v in rs.randint(3, 36, 3))
+        zz, yy, xx = np.mgrid[0:shape[0], 0:shape[1], 0:shape[2]]
+        c = [s / 2 for s in shape]
+        d = ((zz - c[0]) / (shape[0] / 2.5)) ** 2 + ((yy - c[1]) / (shape[1] / 2.5)) ** 2 + ((xx - c[2]) / (shape[2] / 2.5)) ** 2
+        m = (d < 1) & (rs.rand(*shape) < 0.85)                   # a blob with holes; touches borders sometimes
+        if not m.any():
+            m[0, 0, 0] = True
+        masks.append(m.astype(np.uint8) * 255)
+    flat, offs, dims, ho = pack(masks)
+    cc, st = m3d.cc_largest_batch(flat, offs, dims, invert=False, tie_last=False)
+    filled, _ = m3d.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)
+    closed = m3d.binary_closing6_batch(filled, offs, dims)
+    closed = closed.cpu().numpy()
+    for r, m in enumerate(masks):
+        ref = O.fill_and_close_nuclei(O.largest_cc_nuclei(m))
+        assert np.array_equal(closed[ho[r]:ho[r + 1]].reshape(m.shape), ref.astype(np.uint8) * 255), r
+
+
+def test_paint_first_writer_wins(m3d):
+    rs = np.random.RandomState(2)
+    D, H, W = 12, 30, 33
+    R = 25
+    boxes, masks = [], []
+    for r in range(R):
+        lo = np.array([rs.randint(0, W - 6), rs.randint(0, H - 6), rs.randint(0, D - 3)])
+        hi = np.minimum(lo + rs.randint(1, 14, 3), [W - 1, H - 1, D - 1])
+        boxes.append([lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]])
+        masks.append(((rs.rand(hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1) < 0.6) * 255).astype(np.uint8))
+    flat, offs, dims, ho = pack(masks)
+    ids = np.arange(1, R + 1, dtype=np.int32)
+    ids[7] = -1                                                    # a skipped detection
+    vol = m3d.paint_instances(flat, offs, dev(np.array(boxes, np.int32)), dev(ids), (D, H, W)).cpu().numpy()
+    ref = np.zeros((D, H, W), np.int32)
+    for r, (x1, y1, z1, x2, y2, z2) in enumerate(boxes):
+        if ids[r] < 0:
+            continue
+        v = ref[z1:z2 + 1, y1:y2 + 1, x1:x2 + 1]
+        z = v == 0
+        v[z] = (masks[r] > 0).astype(np.int32)[z] * ids[r]
+    assert np.array_equal(vol, ref)
+
+
+@pytest.mark.parametrize("mode", ["soma", "nuclei"])
+def test_segment_tile_bit_exact(m3d, mode):
+    """quantise -> crop/normalise -> Otsu -> largest CC (-> fill -> close) -> paint, device vs oracle loop."""
+    from m3d.binarize import segment_tile, det_boxes_int
+    rs = np.random.RandomState(5)
+    D, H, W = 24, 64, 64
+    zz, yy, xx = np.mgrid[0:D, 0:H, 0:W]
+    img = (rs.randn(D, H, W) * 12 + 110).clip(0, 65535)
+    R = 14
+    prms, dets = [], []
+    for r in range(R):
+        c = np.array([rs.uniform(4, D - 4), rs.uniform(8, H - 8), rs.uniform(8, W - 8)])
+        rad = rs.uniform(3, 6)
+        d2 = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2
+        img += rs.uniform(300, 900) * np.exp(-d2 / (2 * rad * rad))
+        p = np.exp(-d2 / (2 * (rad * 0.8) ** 2)).astype(np.float32) * (rs.rand(D, H, W).astype(np.float32) * 0.3 + 0.7)
+        p[d2 > (3 * rad) ** 2] = 0
+        if r == 3:
+            p[:] = 0                                                # an empty PRM: skipped, but keeps its mask id
+        prms.append(p / max(p.sum(), 1e-9))
+        h = 2.2 * rad
+        dets.append([c[2] - h, c[1] - h, c[0] - h, c[2] + h, c[1] + h, c[0] + h, rs.uniform(0.5, 1)])
+    img = img.clip(0, 65535).astype(np.uint16)
+    prms = np.stack(prms).astype(np.float32)
+    dets = np.array(dets, np.float32)
+    if mode == "soma":                                              # soma boxes are not clamped by the reference
+        dets[:, :3] = np.maximum(dets[:, :3], 0); dets[:, 3] = np.minimum(dets[:, 3], W - 1)
+        dets[:, 4] = np.minimum(dets[:, 4], H - 1); dets[:, 5] = np.minimum(dets[:, 5], D - 1)
+    labels, painted = segment_tile(torch.from_numpy(img).cuda(), dev(prms), dets, mode, max_gray_range=4096)
+    q_ref = np.stack([O.quantize_prm_u8(p) if p.max() > 0 else np.zeros(p.shape, np.uint8) for p in prms])
+    seg, painted_ref = O.segment_tile(img, q_ref, det_boxes_int(dets, (D, H, W), mode), mode)
+    assert np.array_equal(labels.cpu().numpy().astype(np.uint16), seg)
+    assert np.array_equal(painted.cpu().numpy(), painted_ref)
+    assert painted_ref.sum() >= R - 3 and not painted_ref[3]
