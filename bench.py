@@ -102,6 +102,27 @@ def bench_prm(args, rank, world, dist):
                                      "prm_forward_ms": fwd_ms}}))
 
 
+def pmc_traffic(symbol):
+    """HBM-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/pmc_probe.py -> tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json; counters cannot be read from inside
+    this process).  Returned as roofline.traffic with the algorithmic bytes beside it."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+        k = [e for e in d["kernels"] if e["kernel"] == symbol]
+        if not k:
+            return {}
+        alg = (64 * 64 ** 3 + 64 * 32 ** 3 + 64 * 64 * 27) * 4        # conv2b+pool: input + pooled output + weights, once each
+        return {"traffic": k[0]["traffic"], "traffic_unit": "bytes/launch (FETCH_SIZE x%.2f gfx950 correction + WRITE_SIZE)" %
+                d["calibration"]["fetch_factor_dword_loads"], "algorithmic_bytes_per_launch": alg,
+                "traffic_source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +235,7 @@ def main():
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": dom_ms, "algorithmic_gflop_per_launch": dom_flops / 1e9},
         }
+        res["roofline"].update(pmc_traffic("conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"))
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's torch-CPU restatement)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -95,6 +95,7 @@ struct Epilogue {
   const int* origins;   // [batch, 3] (z, y, x)
   int FD, FH, FW;
   uint8_t* argmax;      // fused 2x2x2 max-pool variants only: [batch, cout, D/2, H/2, W/2] or null
+  int xcd_map;          // 1: XCD-contiguous tile order, cout tile slowest (set by the launcher, see xcd_contiguous)
 };
 
 __device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int co, int z, int y, int x, size_t o) {
@@ -193,6 +194,15 @@ __device__ inline void pool_block(const Epilogue& ep, float* __restrict__ out, c
 //   ROWS : voxel blocks per wave (stacked along y);  NCB : 32-channel output blocks per workgroup
 //   WZ, WY: wave grid inside the workgroup (WZ * WY == 4); tile = XB x (WY*ROWS*YB) x WZ voxels
 // ------------------------------------------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2.  Map the ids one XCD receives
+// onto a CONTIGUOUS range of tiles, so that the halo planes neighbouring tiles share are re-read from that XCD's L2
+// instead of being fetched over the fabric once per XCD (measured with FETCH_SIZE: profiles/r01_pmc_traffic.json).
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+  const int per = n >> 3, rem = n & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
 template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
 struct Cfg {
   static constexpr int NT = 256 * KS;                    // threads per workgroup (KS = in-workgroup split of K)
@@ -236,7 +246,14 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
   // block -> (cout tile, x tile, y tile, z tile), batch = blockIdx.y
   int bid = blockIdx.x;
   const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
-  const int cot = bid % co_tiles; bid /= co_tiles;
+  int cot;
+  if (ep.xcd_map) {   // each XCD: one contiguous run of spatial tiles of (mostly) one cout tile -> its L2 holds that slab + those weights
+    bid = xcd_contiguous(bid, gridDim.x);
+    const int sp = tiles_x * tiles_y * tiles_z;
+    cot = bid / sp; bid -= cot * sp;
+  } else {
+    cot = bid % co_tiles; bid /= co_tiles;
+  }
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; bid /= tiles_y;
   const int tz = bid;
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
   float* lds_w = lds + IN_PAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wz = wave / WY, wy = wave % WY;
-  int bid = blockIdx.x;
+  int bid = ep.xcd_map ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; bid /= tiles_y;
   const int tz = bid;
@@ -530,6 +547,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
   }
 }
 
+inline int xcd_map_enabled() {   // M3D_XCD_MAP=0 restores the plain round-robin order (A/B measurements)
+  const char* e = getenv("M3D_XCD_MAP");
+  return !(e && e[0] == '0');
+}
+
 template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
 int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, Epilogue ep,
                hipStream_t st) {
@@ -539,6 +561,7 @@ int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int
   const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
   const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
   if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
+  ep.xcd_map = xcd_map_enabled();
   const size_t lds = sizeof(float) * 2 * C::LDS_FLOATS;   // double-buffered
   auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
   if (lds > 64 * 1024)
@@ -581,6 +604,7 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
   const size_t DHW = (size_t)depth * height * width;
   if (DHW * 32 >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // int offsets inside a channel chunk
   if (k == 5) {
+    ep.xcd_map = xcd_map_enabled();
     if (cin != 1 || cout > 64) return M3D_EUNSUPPORTED;
     const int tiles_x = (width + 31) / 32;
     if (batch > 65535) return M3D_EUNSUPPORTED;

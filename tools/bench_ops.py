@@ -61,7 +61,7 @@ x = torch.randn(1, 64, 64, 64, 64, device="cuda")
 t = timeit(lambda: m3d.maxpool3d_2x(x))
 print("maxpool3d_2x 64x64^3: %8.1f us  %.2f TB/s of 8 (reads+writes %.0f MB)" % (t * 1e6, x.numel() * 4.5 / t / 1e12, x.numel() * 4.5 / 1e6))
 # ---- Otsu: 300 RoIs of ~30^3
-imgs, prms = [], []
+imgs, prms, shapes = [], [], []
 for i in range(300):
     shp = tuple(rs.randint(20, 40, 3))
     zz, yy, xx = np.mgrid[0:shp[0], 0:shp[1], 0:shp[2]]
@@ -69,7 +69,7 @@ for i in range(300):
     img = (600 * np.exp(-(r / 8) ** 2) + 100 + rs.randn(*shp) * 15).clip(0, 65535).astype(np.uint16)
     prm = (255 * np.exp(-(r / 7) ** 2)).astype(np.uint8)
     a_, b_ = O.normalize_soma(img, prm)
-    imgs.append(a_.ravel()); prms.append(b_.ravel())
+    imgs.append(a_.ravel()); prms.append(b_.ravel()); shapes.append(shp)
 offs = torch.from_numpy(np.concatenate(([0], np.cumsum([a_.size for a_ in imgs]))).astype(np.int64)).cuda()
 I = torch.from_numpy(np.concatenate(imgs)).cuda(); Pm = torch.from_numpy(np.concatenate(prms)).cuda()
 t = timeit(lambda: m3d.otsu2d_batch(I, Pm, offs, 1024), reps=10)
@@ -77,3 +77,14 @@ V = I.numel()
 t0 = time.perf_counter(); O.otsu_py_2d_fast(imgs[0].reshape(-1, 1, 1), prms[0].reshape(-1, 1, 1)); tc = time.perf_counter() - t0
 print("otsu2d_batch 300 RoIs (%.1f Mvoxel): %8.1f us  %.0f RoIs/s  %.2f TB/s algorithmic (2x2B read x2 + 1B written)  [oracle C: %.0f us per RoI]" %
       (V / 1e6, t * 1e6, 300 / t, V * 9 / t / 1e12, tc * 1e6))
+# ---- largest CC / hole fill / closing on the Otsu masks of those 300 RoIs
+mask, _, _ = m3d.otsu2d_batch(I, Pm, offs, 1024)
+dims = torch.from_numpy(np.array(shapes, np.int32)).cuda()
+t1 = timeit(lambda: m3d.cc_largest_batch(mask, offs, dims, invert=False, tie_last=True), reps=10)
+cc, _ = m3d.cc_largest_batch(mask, offs, dims, invert=False, tie_last=False)
+t2 = timeit(lambda: m3d.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False), reps=10)
+t3 = timeit(lambda: m3d.binary_closing6_batch(cc, offs, dims), reps=10)
+m0 = mask[:int(offs[1])].cpu().numpy().reshape(shapes[0])
+t0 = time.perf_counter(); O.largest_cc_soma(m0); tc = time.perf_counter() - t0
+print("cc_largest_batch 300 RoIs (%.1f Mvoxel): foreground %8.1f us, complement (hole fill) %8.1f us, closing6 %8.1f us  "
+      "[scipy label per RoI: %.0f us]" % (V / 1e6, t1 * 1e6, t2 * 1e6, t3 * 1e6, tc * 1e6))

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes over tools/pmc_probe.py (FETCH_SIZE, WRITE_SIZE counter_collection.csv) into
+per-kernel HBM traffic, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+  * both counters are reported in KiB;
+  * gfx950's FETCH_SIZE under-counts coalesced reads (the guide measures exactly 1/2 for 16 B/lane); the factor for
+    each access width is calibrated here from launches of known byte count in the same pass
+    (min_partial_kernel: 4 B/lane dword loads, the conv kernels' width; torch copy: 16 B/lane);
+  * WRITE_SIZE is taken as exact (checked against the copy's known byte count).
+usage: pmc_traffic.py FETCH.csv WRITE.csv CAL_BYTES out.json"""
+import csv, json, sys, collections
+
+
+def load(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]) * 1024.0)
+    return d
+
+
+def main():
+    fetch, write, cal_bytes, out = load(sys.argv[1]), load(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
+    def find(d, frag):
+        ks = [k for k in d if frag in k[0]]
+        return max(ks, key=lambda k: sum(d[k]) / len(d[k])) if ks else None
+    k_min = find(fetch, "min_partial_kernel")
+    others = [k for k in fetch if "min_partial" not in k[0] and "conv3d" not in k[0]]
+    k_cpy = max(others, key=lambda k: sum(fetch[k]) / len(fetch[k])) if others else None      # the 1.25 GiB torch copy
+    f_dword = cal_bytes / (sum(fetch[k_min]) / len(fetch[k_min]))
+    f_vec = cal_bytes / (sum(fetch[k_cpy]) / len(fetch[k_cpy])) if k_cpy else None
+    w_chk = (sum(write[k_cpy]) / len(write[k_cpy])) / cal_bytes if k_cpy and k_cpy in write else None
+    res = {"units": "bytes per launch", "calibration": {"known_bytes": cal_bytes, "fetch_factor_dword_loads": f_dword,
+           "fetch_factor_16B_loads": f_vec, "write_size_over_known": w_chk,
+           "kernels": {"dword": k_min[0][:80], "vec": k_cpy[0][:80] if k_cpy else None}}, "kernels": []}
+    for k in sorted(fetch, key=lambda k: -sum(fetch[k]) / len(fetch[k])):
+        if "conv3d" not in k[0]:
+            continue
+        fr = sum(fetch[k]) / len(fetch[k])
+        wr = sum(write[k]) / len(write[k]) if k in write else None
+        res["kernels"].append({"kernel": k[0].split("(float")[0].replace("void (anonymous namespace)::", ""), "grid": k[1],
+                               "launches": len(fetch[k]), "fetch_raw": fr, "fetch_corrected": fr * f_dword, "write": wr,
+                               "traffic": fr * f_dword + (wr or 0)})
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
