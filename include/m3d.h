@@ -121,6 +121,17 @@ int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, i
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
 
+/* Backward-weights and bias gradient of the same stride-1 "same" convolution (what autograd computes for the
+ * F.conv3d calls of lib/prm/peak_backprop_3d.py:40-42 and every nn.Conv3d of lib/modeling/DSN.py:19-36 in training):
+ *   dW[co,ci,dz,dy,dx] = sum_{b,z,y,x} gy[b,co,z,y,x] * x[b,ci,z+dz-k/2,...]     db[co] = sum gy[b,co,...]
+ * fp32 MFMA implicit GEMM with the voxel index as the reduction dimension; split-K partials go to the workspace and
+ * are summed in a fixed order (deterministic).  k = 1, 3 any cin; k = 5 with cin = 1.  d_grad_weight is [cout,cin,k,k,k]. */
+size_t m3d_conv3d_wgrad_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width, int k);
+int m3d_conv3d_wgrad(const float* d_in, const float* d_grad_out, float* d_grad_weight, int batch, int cin, int cout,
+                     int depth, int height, int width, int k, void* d_ws, size_t ws_bytes, void* stream);
+int m3d_conv3d_bias_grad(const float* d_grad_out, float* d_grad_bias, int batch, int cout, int depth, int height,
+                         int width, void* stream);
+
 /* Conv + scale/shift + ReLU + MaxPool3d(2,2) fused (DSN.py:58,60-61: pool1/pool2 directly follow a conv):
  * writes only the pooled tensor [batch,cout,D/2,H/2,W/2] (8x fewer output bytes, no separate pool pass) and,
  * if d_argmax != NULL, the window index (z*4+y*2+x, first maximum) for the PRM un-pooling.  Supported for the

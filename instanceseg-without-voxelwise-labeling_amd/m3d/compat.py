@@ -161,17 +161,18 @@ def _packed(weight, mode):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(weight)
+        ctx.save_for_backward(weight, x if weight.requires_grad else None)
         ctx.has_bias = bias is not None
         return _packed(weight, ops.W_PLAIN)(x, shift=bias.detach().contiguous() if bias is not None else None)
 
     @staticmethod
     def backward(ctx, gy):
-        weight, = ctx.saved_tensors
-        gx = _packed(weight, ops.W_DGRAD)(gy.contiguous()) if ctx.needs_input_grad[0] else None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            raise NotImplementedError("conv3d weight/bias gradients (training) are outside the inference hot path")
-        return gx, None, None
+        weight, x = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = _packed(weight, ops.W_DGRAD)(gy) if ctx.needs_input_grad[0] else None
+        gw = ops.conv3d_wgrad(x, gy, weight.shape[2]) if ctx.needs_input_grad[1] else None
+        gb = ops.conv3d_bias_grad(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
 
 
 def _qualifies(x, weight, stride, padding, dilation, groups):

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -339,6 +339,31 @@ def roi_normalize(image_u16, prm_u8, boxes, mode):
     check(lib().m3d_roi_normalize(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
                                   R, D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _stream()), "roi_normalize")
     return oi, op, offs
+
+
+# ------------------------------------------------------------------ conv backward-weights / bias gradient
+def conv3d_wgrad(x, grad_out, k):
+    """dW [cout,cin,k,k,k] of a stride-1 pad-k/2 conv: x [B,cin,D,H,W], grad_out [B,cout,D,H,W] (fp32 CUDA)."""
+    _need_gpu(x, grad_out)
+    x, grad_out = _f32c(x), _f32c(grad_out)
+    B, cin, D, H, W = x.shape
+    cout = grad_out.shape[1]
+    assert grad_out.shape == (B, cout, D, H, W)
+    dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
+    wsb = lib().m3d_conv3d_wgrad_workspace_bytes(B, cin, cout, D, H, W, k)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+    check(lib().m3d_conv3d_wgrad(_ptr(x), _ptr(grad_out), _ptr(dw), B, cin, cout, D, H, W, k, _ptr(ws), C.c_size_t(wsb), _stream()),
+          "conv3d_wgrad")
+    return dw
+
+
+def conv3d_bias_grad(grad_out):
+    _need_gpu(grad_out)
+    grad_out = _f32c(grad_out)
+    B, cout, D, H, W = grad_out.shape
+    db = torch.empty((cout,), dtype=torch.float32, device=grad_out.device)
+    check(lib().m3d_conv3d_bias_grad(_ptr(grad_out), _ptr(db), B, cout, D, H, W, _stream()), "conv3d_bias_grad")
+    return db
 
 
 # ------------------------------------------------------------------ connected components / closing / painting

@@ -69,6 +69,18 @@ def test_conv3d_interception_runs_unmodified_module_code(compat):
     n.backward(g)
     ref_gx = torch.nn.grad.conv3d_input(x.shape, wpos.double(), g.double(), 1, 1)
     assert (x.grad.double() - ref_gx).abs().max().item() / ref_gx.abs().max().item() < 5e-6
+    # training-style backward: weight and bias gradients come from the wgrad / bias-grad kernels
+    conv.zero_grad()
+    x2 = torch.randn(2, 8, 6, 10, 34, device="cuda", requires_grad=True)
+    y2 = conv(x2)
+    g2 = torch.randn_like(y2)
+    y2.backward(g2)
+    xr = x2.detach().double().cpu().requires_grad_()
+    wr = conv.weight.detach().double().cpu().requires_grad_()
+    br = conv.bias.detach().double().cpu().requires_grad_()
+    compat._orig_conv3d(xr, wr, br, 1, 1).backward(g2.double().cpu())
+    for got, ref in ((x2.grad, xr.grad), (conv.weight.grad, wr.grad), (conv.bias.grad, br.grad)):
+        assert (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
     # a non-qualifying call (stride 2) falls through to torch's own conv
     z = F.conv3d(x.detach(), conv.weight.detach(), None, 2, 1)
     assert z.shape[-1] == 17

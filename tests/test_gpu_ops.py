@@ -192,6 +192,26 @@ def test_conv3d_dgrad_pack(m3d):
     assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("B,cin,cout,D,H,W,k", [
+    (2, 5, 7, 5, 6, 19, 3), (1, 40, 70, 8, 9, 17, 3), (1, 64, 64, 16, 16, 32, 3), (1, 64, 33, 6, 8, 16, 1),
+    (1, 256, 245, 4, 8, 8, 1), (2, 1, 32, 9, 10, 21, 5), (1, 1, 20, 6, 7, 40, 5), (1, 128, 128, 4, 4, 16, 3)])
+def test_conv3d_wgrad_and_bias_grad_vs_fp64(m3d, B, cin, cout, D, H, W, k):
+    """dW / db of the stride-1 same conv (MFMA split-K wgrad, deterministic reduction) against torch's fp64 autograd."""
+    g = torch.Generator().manual_seed(B + cin + cout + k)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    gy = torch.randn(B, cout, D, H, W, generator=g)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (cout, cin, k, k, k), gy.double(), 1, k // 2)
+    dw = m3d.conv3d_wgrad(x.cuda(), gy.cuda(), k)
+    dw2 = m3d.conv3d_wgrad(x.cuda(), gy.cuda(), k)
+    assert torch.equal(dw, dw2)                              # fixed-order split-K reduction
+    err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-4, err
+    assert err < 1e-5, err
+    db = m3d.conv3d_bias_grad(gy.cuda()).cpu().double()
+    rb = gy.double().sum((0, 2, 3, 4))
+    assert (db - rb).abs().max().item() / rb.abs().max().item() < 1e-5
+
+
 def test_conv3d_linearity_full_size(m3d):
     """Size-independent property at the BASELINE config[1] size (conv2b on 64^3): conv(a*x + y) = a*conv(x) + conv(y)."""
     g = torch.Generator().manual_seed(7)
