@@ -667,10 +667,13 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       M3D_V(31, 3, 8, 32, 2, 2, 4, 1, false, 2)
       M3D_V(33, 3, 4, 32, 1, 2, 4, 1, false, 2)
       M3D_V(34, 3, 8, 32, 1, 2, 4, 1, false, 2)
+      M3D_V(35, 3, 8, 32, 2, 1, 4, 1, false, 2)
+      M3D_V(36, 3, 8, 32, 1, 1, 4, 1, false, 2)
+      M3D_V(24, 3, 8, 16, 2, 1, 4, 1, false, 2)
 #undef M3D_V
     }
     if (ncb_total == 1) {   // <= 32 output channels (e.g. the dgrad of conv2a): never pad to a second, empty cout block
-      if (xb == 32) return launch_cfg<3, 2, 32, 4, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      if (xb == 32) return launch_cfg<3, 4, 32, 4, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       if (xb == 16) return launch_cfg<3, 4, 16, 2, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 8, 2, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
@@ -679,8 +682,11 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       if (wg_big >= 512) return launch_cfg<3, 2, 32, 4, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       const long long wg_mid = (vox / 256) * ((ncb_total + 1) / 2);
       // 32^3-class maps: one workgroup per CU -> split K over two groups of 4 waves (2 waves/SIMD)
-      if (wg_mid >= 128 && wg_mid < 1024 && cin >= 16)
+      if (wg_mid >= 256 && wg_mid < 1024 && cin >= 16)
         return launch_cfg<3, 8, 32, 2, 2, 4, 1, false, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      // fewer than one such workgroup per CU (e.g. 128 -> 64 channels on 32^3, the dgrad of conv3a): halve the voxel tile
+      if (wg_mid >= 64 && wg_mid < 256 && cin >= 16)
+        return launch_cfg<3, 8, 32, 1, 2, 4, 1, false, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       if (wg_mid >= 256) return launch_cfg<3, 2, 32, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 32, 1, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }

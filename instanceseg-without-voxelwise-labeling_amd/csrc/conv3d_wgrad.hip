@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
   int tapoff[C::NTW];
 #pragma unroll
   for (int n = 0; n < C::NTW; ++n) {
-    const int t = tw + C::TW * n;
+    int t = tw + C::TW * n;
+    if (t >= C::TAPS) t = C::TAPS - 1;                  // surplus slot of the last wave: computed, never stored
     const int dz = t / (K * K), dy = (t / K) % K, dx = t % K;
     tapoff[n] = (dz * C::HY + dy) * C::HX + dx;
   }
@@ -72,42 +73,65 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     const int b = q / tiles_z;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     __syncthreads();                                   // the previous tile's MFMAs have read the LDS
-    // ---- stage gy[cb*32 + c][tile]  (x fastest: 16-float runs)
-    for (int e = tid; e < 32 * TV; e += 256) {
-      const int c = e / TV, v = e % TV;
-      const int xx = x0 + (v & 15), yy = y0 + ((v >> 4) & 3), zz = z0 + (v >> 6);
-      const int co = cb * 32 + c;
-      float val = 0.f;
-      if (co < cout && xx < W && yy < H && zz < D) val = gy[((size_t)b * cout + co) * DHW + ((size_t)zz * H + yy) * W + xx];
-      lds_g[c * GS + v] = val;
+    // ---- stage gy[cb*32 + c][tile] and x[ib*32 + c][halo tile] (zero padded); x fastest -> 16/18-float runs.
+    // Loads are issued in batches of U before the first LDS write so their latencies overlap.
+    constexpr int U = 8;
+#pragma unroll 1
+    for (int e0 = 0; e0 < 32 * TV; e0 += 256 * U) {
+      float val[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256 + tid;
+        const int c = e / TV, v = e % TV;
+        const int xx = x0 + (v & 15), yy = y0 + ((v >> 4) & 3), zz = z0 + (v >> 6);
+        const int co = cb * 32 + c;
+        const bool ok = (e < 32 * TV) & (co < cout) & (xx < W) & (yy < H) & (zz < D);
+        const size_t g = ok ? ((size_t)b * cout + co) * DHW + ((size_t)zz * H + yy) * W + xx : 0;
+        const float r = gy[g];
+        val[u] = ok ? r : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < 32 * TV) lds_g[(e / TV) * GS + e % TV] = val[u];
+      }
     }
-    // ---- stage x[ib*32 + c][halo tile], zero padded
-    for (int e = tid; e < 32 * C::HV; e += 256) {
-      const int c = e / C::HV, r = e % C::HV;
-      const int hx = r % C::HX, hy = (r / C::HX) % C::HY, hz = r / (C::HX * C::HY);
-      const int xx = x0 + hx - C::P, yy = y0 + hy - C::P, zz = z0 + hz - C::P;
-      const int ci = ib * 32 + c;
-      float val = 0.f;
-      if (ci < cin && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D)
-        val = x[((size_t)b * cin + ci) * DHW + ((size_t)zz * H + yy) * W + xx];
-      lds_x[c * C::XS + r] = val;
+#pragma unroll 1
+    for (int e0 = 0; e0 < 32 * C::HV; e0 += 256 * U) {
+      float val[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256 + tid;
+        const int c = e / C::HV, r = e % C::HV;
+        const int hx = r % C::HX, hy = (r / C::HX) % C::HY, hz = r / (C::HX * C::HY);
+        const int xx = x0 + hx - C::P, yy = y0 + hy - C::P, zz = z0 + hz - C::P;
+        const int ci = ib * 32 + c;
+        const bool ok = (e < 32 * C::HV) & (ci < cin) & ((unsigned)xx < (unsigned)W) & ((unsigned)yy < (unsigned)H) &
+                        ((unsigned)zz < (unsigned)D);
+        const size_t g = ok ? ((size_t)b * cin + ci) * DHW + ((size_t)zz * H + yy) * W + xx : 0;
+        const float rv = x[g];
+        val[u] = ok ? rv : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < 32 * C::HV) lds_x[(e / C::HV) * C::XS + e % C::HV] = val[u];
+      }
     }
     __syncthreads();
     // ---- MFMA: k-step = voxel pair (v, v+1); A = gy[co = lane%32][v + lane/32], B = x[ci = lane%32][v + lane/32 + tap]
     const float* ga = lds_g + cl * GS + kh;
     const float* xa = lds_x + cl * C::XS + kh;
-
-    for (int vp = vg; vp < TV / 2; vp += C::VG) {
-      const int v = vp * 2;
+#pragma unroll 4
+    for (int i = 0; i < TV / 2 / C::VG; ++i) {
+      const int v = (vg + i * C::VG) * 2;
       const float a = ga[v];
       const int hb = (((v >> 6)) * C::HY + ((v >> 4) & 3)) * C::HX + (v & 15);
+      float bv[C::NTW];
 #pragma unroll
-      for (int n = 0; n < C::NTW; ++n) {
-        if (tw + C::TW * n < C::TAPS) {                // wave-uniform
-          const float bv = xa[hb + tapoff[n]];
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[n], 0, 0, 0);
-        }
-      }
+      for (int n = 0; n < C::NTW; ++n) bv[n] = xa[hb + tapoff[n]];
+#pragma unroll
+      for (int n = 0; n < C::NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[n], acc[n], 0, 0, 0);
     }
   }
   // ---- write this workgroup's partial: acc[i = co][j = ci]; col j = lane&31, row i = (r&3) + 8*(r>>2) + 4*(lane>>5)

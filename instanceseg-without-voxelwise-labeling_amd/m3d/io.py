@@ -1,0 +1,168 @@
+"""On-disk formats of the reference's drivers, host side only.
+
+* multi-page grayscale TIFF, LZW strips - what libtiff's `write_image(page, compression='lzw')` produces for 2-D pages
+  (tools/infer_simple.py:241-245; binarization_soma.py:106-109; binarization_nuclei.py:151-154) and what
+  skimage.io.imread reads back (binarization_soma.py:68, binarization_nuclei.py:95);
+* `dets.npy` beside the per-peak PRM stacks (infer_simple.py:247), the `{name}.npy` score / box tables of the
+  binarisation scripts (binarization_soma.py:105, binarization_nuclei.py:150);
+* the detection pickle `dict(all_boxes=cls_boxes)` (infer_simple.py:258-265, utils/my_io.py:40-44).
+The LZW strip codec is C (csrc/tiff_lzw.c -> libm3dio.so, include/m3d_io.h); the IFD framing is here."""
+import ctypes as C
+import os
+import pickle
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_io = None
+
+
+def _lib():
+    global _io
+    if _io is None:
+        path = os.environ.get("M3D_IO_LIB_PATH", os.path.join(os.path.dirname(_HERE), "csrc", "libm3dio.so"))
+        if not os.path.exists(path):
+            raise RuntimeError("libm3dio.so not built (make -C csrc); the TIFF codec has no Python fallback: %s" % path)
+        lib = C.CDLL(path)
+        lib.m3d_tiff_lzw_bound.restype = C.c_size_t
+        lib.m3d_tiff_lzw_bound.argtypes = [C.c_size_t]
+        for f in (lib.m3d_tiff_lzw_encode, lib.m3d_tiff_lzw_decode):
+            f.restype = C.c_size_t
+            f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _io = lib
+    return _io
+
+
+def lzw_encode(raw):
+    raw = bytes(raw)
+    cap = _lib().m3d_tiff_lzw_bound(len(raw))
+    dst = C.create_string_buffer(cap)
+    n = _lib().m3d_tiff_lzw_encode(raw, len(raw), dst, cap)
+    if n == 0:
+        raise RuntimeError("tiff_lzw_encode failed")
+    return dst.raw[:n]
+
+
+def lzw_decode(comp, nbytes):
+    comp = bytes(comp)
+    dst = C.create_string_buffer(max(nbytes, 1))
+    n = _lib().m3d_tiff_lzw_decode(comp, len(comp), dst, nbytes)
+    if n != nbytes:
+        raise ValueError("tiff_lzw_decode: stream ended after %d of %d bytes" % (n, nbytes))
+    return dst.raw[:nbytes]
+
+
+# TIFF tags used
+_W, _H, _BPS, _COMP, _PHOTO, _STRIPOFF, _SPP, _RPS, _STRIPCNT, _PLANAR, _PREDICTOR, _SFMT = \
+    256, 257, 258, 259, 262, 273, 277, 278, 279, 284, 317, 339
+
+
+def write_tiff_stack(path, vol, compression="lzw"):
+    """vol: uint8 / uint16 array [pages, H, W] (a 2-D array is one page).  Little-endian classic TIFF, one strip per
+    page, BlackIsZero, no predictor (libtiff's default for write_image)."""
+    vol = np.asarray(vol)
+    if vol.ndim == 2:
+        vol = vol[None]
+    if vol.ndim != 3 or vol.dtype not in (np.uint8, np.uint16):
+        raise ValueError("write_tiff_stack: need a uint8/uint16 [pages,H,W] array, got %s %s" % (vol.dtype, vol.shape))
+    bps = vol.dtype.itemsize * 8
+    P, H, W = vol.shape
+    comp = {"lzw": 5, None: 1, "none": 1}[compression]
+    out = bytearray(b"II*\x00\x00\x00\x00\x00")          # header; first-IFD offset patched below
+    prev_next_field = 4
+    for p in range(P):
+        raw = np.ascontiguousarray(vol[p]).astype("<u%d" % (bps // 8), copy=False).tobytes()
+        data = lzw_encode(raw) if comp == 5 else raw
+        if len(out) & 1:
+            out += b"\x00"
+        data_off = len(out)
+        out += data
+        if len(out) & 1:
+            out += b"\x00"
+        ifd_off = len(out)
+        struct.pack_into("<I", out, prev_next_field, ifd_off)
+        tags = [(_W, 4, W), (_H, 4, H), (_BPS, 3, bps), (_COMP, 3, comp), (_PHOTO, 3, 1), (_STRIPOFF, 4, data_off), (_SPP, 3, 1),
+                (_RPS, 4, H), (_STRIPCNT, 4, len(data)), (_PLANAR, 3, 1), (_SFMT, 3, 1)]
+        out += struct.pack("<H", len(tags))
+        for tag, typ, val in tags:
+            out += struct.pack("<HHI", tag, typ, 1) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+        prev_next_field = len(out)
+        out += b"\x00\x00\x00\x00"
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def read_tiff_stack(path):
+    """Reads what the reference's tools produce or consume: classic TIFF, 8/16-bit single-sample pages, strips,
+    uncompressed or LZW, optional horizontal predictor, either byte order.  Returns [pages, H, W]."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    bo = {b"II": "<", b"MM": ">"}.get(buf[:2])
+    if bo is None or struct.unpack(bo + "H", buf[2:4])[0] != 42:
+        raise ValueError("%s: not a classic TIFF" % path)
+    tsize = {1: 1, 2: 1, 3: 2, 4: 4, 5: 8, 16: 8}
+    tfmt = {1: "B", 3: "H", 4: "I", 16: "Q"}
+    pages = []
+    off = struct.unpack(bo + "I", buf[4:8])[0]
+    while off:
+        n = struct.unpack(bo + "H", buf[off:off + 2])[0]
+        tags = {}
+        for i in range(n):
+            e = off + 2 + 12 * i
+            tag, typ, cnt = struct.unpack(bo + "HHI", buf[e:e + 8])
+            if typ not in tfmt:
+                continue
+            size = tsize[typ] * cnt
+            src = e + 8 if size <= 4 else struct.unpack(bo + "I", buf[e + 8:e + 12])[0]
+            tags[tag] = struct.unpack(bo + "%d%s" % (cnt, tfmt[typ]), buf[src:src + size])
+        off = struct.unpack(bo + "I", buf[off + 2 + 12 * n:off + 6 + 12 * n])[0]
+        W, H = tags[_W][0], tags[_H][0]
+        bps = tags.get(_BPS, (1,))[0]
+        comp = tags.get(_COMP, (1,))[0]
+        if tags.get(_SPP, (1,))[0] != 1 or bps not in (8, 16) or comp not in (1, 5):
+            raise ValueError("%s: unsupported page (samples %s, bits %s, compression %s)" % (path, tags.get(_SPP), bps, comp))
+        rps = min(tags.get(_RPS, (H,))[0], H)
+        offs, cnts = tags[_STRIPOFF], tags[_STRIPCNT]
+        bpp = bps // 8
+        raw = bytearray()
+        for s, (so, sc) in enumerate(zip(offs, cnts)):
+            rows = min(rps, H - s * rps)
+            chunk = buf[so:so + sc]
+            raw += lzw_decode(chunk, rows * W * bpp) if comp == 5 else chunk[:rows * W * bpp]
+        page = np.frombuffer(bytes(raw), dtype=np.dtype("u%d" % bpp).newbyteorder(bo)).reshape(H, W)
+        page = page.astype("u%d" % bpp)
+        if tags.get(_PREDICTOR, (1,))[0] == 2:
+            page = np.cumsum(page, axis=1, dtype=page.dtype)
+        pages.append(page)
+    return np.stack(pages) if pages else np.zeros((0, 0, 0), np.uint8)
+
+
+def save_prm_instances(save_path, prms_u8, dets):
+    """tools/infer_simple.py:233-247: one `{ch}.tif` per peak response map (already quantised to uint8 and un-padded)
+    and `dets.npy` (float64 [P,7])."""
+    os.makedirs(save_path, exist_ok=True)
+    for ch, fm in enumerate(prms_u8):
+        write_tiff_stack(os.path.join(save_path, "%d.tif" % ch), np.asarray(fm, dtype=np.uint8))
+    np.save(os.path.join(save_path, "dets.npy"), np.asarray(dets))
+
+
+def load_prm_instances(instance_path):
+    """What tools/binarization_*.py read per tile: dets.npy and the n `{i}.tif` stacks (binarization_nuclei.py:60-69,95)."""
+    dets = np.load(os.path.join(instance_path, "dets.npy"))
+    prms = [read_tiff_stack(os.path.join(instance_path, "%d.tif" % i)) for i in range(dets.shape[0])]
+    return dets, prms
+
+
+def save_segmentation(save_path, name, seg_u16, table):
+    """binarization_soma.py:104-109 / binarization_nuclei.py:149-154: `{name}.npy` (score / id-box table) and the uint16
+    label stack `{name}.tif`."""
+    os.makedirs(save_path, exist_ok=True)
+    np.save(os.path.join(save_path, "%s.npy" % name), np.asarray(table))
+    write_tiff_stack(os.path.join(save_path, "%s.tif" % name), np.asarray(seg_u16, dtype=np.uint16))
+
+
+def save_detections(det_file, cls_boxes):
+    """infer_simple.py:258-265 + utils/my_io.py:40-44: pickle of dict(all_boxes=cls_boxes), highest protocol."""
+    with open(os.path.abspath(det_file), "wb") as f:
+        pickle.dump(dict(all_boxes=cls_boxes), f, pickle.HIGHEST_PROTOCOL)

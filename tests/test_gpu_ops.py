@@ -160,7 +160,8 @@ def _conv_case(m3d, B, cin, cout, D, H, W, k, seed, **kw):
 @pytest.mark.parametrize("B,cin,cout,D,H,W,k", [
     (1, 1, 32, 8, 16, 40, 5), (1, 32, 64, 8, 12, 32, 3), (1, 64, 64, 9, 13, 33, 3), (2, 64, 128, 8, 8, 32, 3),
     (1, 128, 128, 6, 16, 16, 3), (1, 128, 256, 4, 8, 16, 3), (1, 256, 256, 5, 6, 7, 3), (1, 256, 245, 4, 16, 16, 1),
-    (1, 128, 98, 3, 10, 40, 1), (1, 3, 5, 4, 5, 6, 3), (1, 1, 20, 6, 7, 9, 5), (1, 256, 256, 2, 25, 25, 3)])
+    (1, 128, 98, 3, 10, 40, 1), (1, 3, 5, 4, 5, 6, 3), (1, 1, 20, 6, 7, 9, 5), (1, 256, 256, 2, 25, 25, 3),
+    (1, 128, 64, 16, 32, 32, 3), (1, 64, 32, 8, 32, 64, 3)])
 def test_conv3d_forward_vs_fp64(m3d, B, cin, cout, D, H, W, k):
     y, ref = _conv_case(m3d, B, cin, cout, D, H, W, k, seed=cin * 7 + k)
     err = (y.double() - ref).abs().max().item() / ref.abs().max().item()

@@ -1,0 +1,75 @@
+"""On-disk formats: the LZW TIFF writer/reader against an independent implementation (Pillow's libtiff),
+plus the npy / pickle side files.  Host-only; runs without a GPU."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
+from m3d import io as mio  # noqa: E402
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def volumes():
+    rs = np.random.RandomState(0)
+    zz, yy, xx = np.mgrid[0:7, 0:33, 0:41]
+    blob = (255 * np.exp(-((zz - 3) ** 2 / 4.0 + (yy - 16) ** 2 / 40.0 + (xx - 20) ** 2 / 60.0))).astype(np.uint8)
+    lab = np.zeros((5, 64, 48), np.uint16); lab[1:4, 10:30, 5:25] = 7; lab[2:5, 28:60, 20:44] = 300
+    return [blob, rs.randint(0, 256, (3, 17, 19)).astype(np.uint8), np.zeros((2, 8, 8), np.uint8), lab,
+            rs.randint(0, 65536, (2, 31, 29)).astype(np.uint16), np.full((1, 200, 300), 255, np.uint8),
+            np.tile(np.arange(256, dtype=np.uint8), (4, 64, 16)).reshape(4, 64, 4096)[:, :, :700].copy()]
+
+
+def test_lzw_round_trip_including_table_resets():
+    rs = np.random.RandomState(1)
+    for raw in (b"", b"a", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaa", bytes(rs.randint(0, 256, 100000).astype(np.uint8)),
+                bytes(rs.randint(0, 4, 300000).astype(np.uint8)), bytes(np.zeros(70000, np.uint8))):
+        comp = mio.lzw_encode(raw)
+        assert mio.lzw_decode(comp, len(raw)) == raw
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_tiff_written_here_is_read_by_libtiff(tmp_path, i):
+    vol = volumes()[i]
+    p = str(tmp_path / "v.tif")
+    mio.write_tiff_stack(p, vol)
+    im = PIL.open(p)
+    assert im.n_frames == vol.shape[0]
+    for k in range(vol.shape[0]):
+        im.seek(k)
+        assert im.info.get("compression") == "tiff_lzw"
+        assert np.array_equal(np.array(im), vol[k]), k
+    assert np.array_equal(mio.read_tiff_stack(p), vol)
+
+
+@pytest.mark.parametrize("i", range(7))
+@pytest.mark.parametrize("compression", ["tiff_lzw", "raw"])
+def test_tiff_written_by_libtiff_is_read_here(tmp_path, i, compression):
+    vol = volumes()[i]
+    p = str(tmp_path / "v.tif")
+    frames = [PIL.fromarray(vol[k]) for k in range(vol.shape[0])]
+    frames[0].save(p, save_all=True, append_images=frames[1:], compression=compression)
+    got = mio.read_tiff_stack(p)
+    assert got.dtype == vol.dtype and np.array_equal(got, vol)
+
+
+def test_instance_tree_and_side_files(tmp_path):
+    rs = np.random.RandomState(2)
+    prms = [rs.randint(0, 256, (6, 20, 20)).astype(np.uint8) for _ in range(3)]
+    dets = rs.rand(3, 7)
+    sp = str(tmp_path / "instances" / "4")
+    mio.save_prm_instances(sp, prms, dets)
+    assert sorted(os.listdir(sp)) == ["0.tif", "1.tif", "2.tif", "dets.npy"]
+    d2, p2 = mio.load_prm_instances(sp)
+    assert d2.dtype == np.float64 and np.array_equal(d2, dets) and all(np.array_equal(a, b) for a, b in zip(prms, p2))
+    seg = np.zeros((4, 16, 16), np.uint16); seg[1:3, 2:9, 2:9] = 2
+    mio.save_segmentation(str(tmp_path / "seg"), "img1", seg, np.array([[2, 0.9]], np.float32))
+    assert np.array_equal(mio.read_tiff_stack(str(tmp_path / "seg" / "img1.tif")), seg)
+    boxes = [[], np.arange(14, dtype=np.float32).reshape(2, 7)]
+    mio.save_detections(str(tmp_path / "img1.pkl"), boxes)
+    back = pickle.load(open(str(tmp_path / "img1.pkl"), "rb"))
+    assert list(back) == ["all_boxes"] and np.array_equal(back["all_boxes"][1], boxes[1])
