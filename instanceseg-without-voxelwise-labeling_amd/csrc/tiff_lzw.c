@@ -51,8 +51,8 @@ M3D_EXPORT size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst
       if (found >= 0) { prefix = found; continue; }
       put(&w, prefix, width);
       hkey[h] = key; hval[h] = (uint16_t)next; next++;
-      if (next == 511 || next == 1023 || next == 2047) width++;            /* early change */
-      if (next == MAXCODE) {
+      if (next == 512 || next == 1024 || next == 2048) width++;            /* the decoder's table lags one entry behind, */
+      if (next == MAXCODE) {                                               /* so it switches at 511 / 1023 / 2047         */
         put(&w, CLEAR, width);
         for (int j = 0; j < HSIZE; ++j) hkey[j] = EMPTY;
         width = 9; next = FIRST;
@@ -61,7 +61,8 @@ M3D_EXPORT size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst
     }
     put(&w, prefix, width);
     next++;                                                     /* the decoder adds an entry for this code too */
-    if (next == 511 || next == 1023 || next == 2047) width++;
+    if (next == MAXCODE) { put(&w, CLEAR, width); width = 9; }
+    else if (next == 512 || next == 1024 || next == 2048) width++;
   }
   put(&w, EOI, width);
   if (w.nbits > 0) put(&w, 0, 8 - w.nbits);

@@ -49,9 +49,35 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     return out
 
 
+def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range):
+    """Device pipeline for the detections of one tile: crop + normalise -> 2D-Otsu -> largest 26-connected component
+    (-> hole fill -> 6-closing for nuclei).  image_u16 [S,H,W] CUDA, q uint8 [P,S,H,W] CUDA (quantised PRMs),
+    boxes int32 ndarray [P,6] inclusive tile coordinates.  Returns (masks uint8 flat, offsets, boxes CUDA int32 [n,6],
+    idx LongTensor [n] (rows of `boxes` that were processed), ok bool [n] (False: the reference skips / fails))."""
+    S, H, W = image_u16.shape
+    dev = image_u16.device
+    okb = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
+          (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
+    idx = np.nonzero(okb)[0]
+    if len(idx) == 0:
+        return None
+    idx_t = torch.from_numpy(idx).to(dev)
+    bsel = torch.from_numpy(boxes[idx]).to(dev)
+    qs = q[idx_t].contiguous()
+    oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode)
+    mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
+    dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
+    cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))
+    if mode == "nuclei":
+        cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
+        cc = ops.binary_closing6_batch(cc, offs, dims)
+    nonempty = qs.reshape(len(idx), -1).amax(1) > 0                                       # binarization_soma.py:74-76
+    return cc, offs, bsel, idx_t, (st_otsu == 0) & (st_cc == 0) & nonempty
+
+
 def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_id=1):
     """The reference's per-detection loop body for one tile, entirely on device.
-    image_u16 [S,H,W] uint16/int32 CUDA, prms float32 [P,S,H,W] CUDA, dets [P,7] in tile coordinates, ALREADY in the
+    image_u16 [S,H,W] uint16 CUDA, prms float32 [P,S,H,W] CUDA, dets [P,7] in tile coordinates, ALREADY in the
     order the reference loops over them (soma: NMS-kept, score-descending, binarization_soma.py:56-61; nuclei: NMS
     order filtered by score > 0.4, binarization_nuclei.py:80-86).  Detection d gets mask id first_id + d whether or not
     it ends up painted (mask_id is incremented before the `continue`, binarization_soma.py:66).
@@ -60,28 +86,105 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     S, H, W = image_u16.shape
     P = int(prms.shape[0])
     dev = image_u16.device
-    if P == 0:
-        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), torch.zeros((0,), dtype=torch.bool, device=dev)
-    boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
-    ok = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
-         (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
-    idx = np.nonzero(ok)[0]
     painted = torch.zeros((P,), dtype=torch.bool, device=dev)
-    if len(idx) == 0:
+    if P == 0:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
-    q = ops.prm_quantize_u8(prms)
-    idx_t = torch.from_numpy(idx).to(dev)
-    bsel = torch.from_numpy(boxes[idx]).to(dev)
-    oi, op, offs = ops.roi_normalize(image_u16, q[idx_t].contiguous(), bsel, mode)
-    mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
-    dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
-    cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))
-    if mode == "nuclei":
-        cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
-        cc = ops.binary_closing6_batch(cc, offs, dims)
+    boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
+    r = _tile_instance_masks(image_u16, ops.prm_quantize_u8(prms), boxes, mode, max_gray_range)
+    if r is None:
+        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
+    cc, offs, bsel, idx_t, ok = r
     ids = (idx_t + first_id).to(torch.int32)
-    nonempty = q[idx_t].reshape(len(idx), -1).amax(1) > 0                                 # binarization_soma.py:74-76
-    ids = torch.where((st_otsu == 0) & (st_cc == 0) & nonempty, ids, torch.full_like(ids, -1))   # skipped: never paints
+    ids = torch.where(ok, ids, torch.full_like(ids, -1))                                   # skipped: never paints
     labels = ops.paint_instances(cc, offs, bsel, ids, (S, H, W))
     present = torch.bincount(labels.reshape(-1), minlength=first_id + P)[first_id:first_id + P] > 0
     return labels, present
+
+
+# ----------------------------------------------------------------------------- whole-volume drivers
+def soma_tiles():
+    """binarization_soma.py:42-52: (num, ss, hs, ws) of the fixed 3 x 2 x 2 tile grid (64 x 160 x 160 tiles)."""
+    return [(s * 4 + h * 2 + w, s * 32, h * 96, w * 96) for s in range(3) for h in range(2) for w in range(2)]
+
+
+def nuclei_tiles(height, width, patch_size=200, overlap=100):
+    """binarization_nuclei.py:50-56."""
+    widx = list(range(0, width - patch_size, patch_size - overlap)) + [width - patch_size]
+    hidx = list(range(0, height - patch_size, patch_size - overlap)) + [height - patch_size]
+    return [(ih * len(widx) + iw, 0, h, w) for ih, h in enumerate(hidx) for iw, w in enumerate(widx)]
+
+
+def binarize_volume(img, tiles, dataset, nms_thresh=None, max_gray_range=8192):
+    """Whole-volume counterpart of tools/binarization_soma.py:34-109 / tools/binarization_nuclei.py:36-154.
+    img: the raw uint16 volume [S,H,W] (ndarray); tiles: {num: (dets float64 [n,7] tile coordinates, prm_u8 uint8
+    [n,s,h,w])} as written by infer_simple's PRM branch (m3d.io.load_prm_instances / m3d.infer.infer_prm).
+    Returns (seg uint16 ndarray [S,H,W], table float64): soma rows [mask_id, score] (:103-104); nuclei rows
+    [mask_id, x1, y1, z1, x2, y2, z2, score] (:147-148)."""
+    img = np.asarray(img)
+    S, H, W = img.shape
+    if dataset == "nuclei":
+        from scipy import ndimage                                             # the reference's own calls (:44-45)
+        img = ndimage.median_filter(ndimage.gaussian_filter(img, sigma=1), size=3)
+        grid, tshape = nuclei_tiles(H, W), (S, 200, 200)
+        nms_thresh = 0.15 if nms_thresh is None else nms_thresh
+    else:
+        grid, tshape = soma_tiles(), (64, 160, 160)
+        nms_thresh = 0.23 if nms_thresh is None else nms_thresh
+    dets = np.empty((0, 7), np.float32 if dataset == "soma" else np.float64)
+    inst = []                                                                 # (num, i, ws, hs, ss)
+    for num, ss, hs, ws in grid:
+        if num not in tiles or len(tiles[num][0]) == 0:
+            continue
+        off = np.array([ws, hs, ss, ws, hs, ss, 0], np.float32 if dataset == "soma" else np.int64)
+        d = np.asarray(tiles[num][0]) + off
+        dets = np.concatenate((dets, d), 0)
+        if dataset == "soma":
+            dets = dets.astype(np.float32)                                    # :52
+        inst += [(num, i, ws, hs, ss) for i in range(len(d))]
+    inst = np.array(inst, dtype=np.int64).reshape(-1, 5)
+    if dataset == "nuclei":                                                   # :71-77 (condition2 really tests `width`)
+        c1 = (dets[:, 0] > 10) & (dets[:, 3] < W - 10) & ((dets[:, 3] - dets[:, 0] + 1) < 32)
+        c2 = (dets[:, 1] > 10) & (dets[:, 4] < W - 10) & ((dets[:, 4] - dets[:, 1] + 1) < 32)
+        keep = ~(c1 | c2)
+        dets, inst = dets[keep].astype(np.float32), inst[keep]
+    empty_tab = np.zeros((0, 2 if dataset == "soma" else 8), np.float64)
+    if len(dets) == 0:
+        return np.zeros(img.shape, np.uint16), empty_tab
+    keep = ops.nms3d(torch.from_numpy(np.ascontiguousarray(dets)).cuda(), nms_thresh, by_volume=(dataset == "nuclei")).cpu().numpy()
+    dets, inst = dets[keep].copy(), inst[keep].copy()
+    if dataset == "soma":
+        order = np.argsort(dets[:, -1], kind="stable")[::-1]                  # :59 (tie rule: descending index)
+    else:
+        order = np.nonzero(dets[:, -1] > 0.4)[0]                              # :83-85
+    dets, inst = dets[order], inst[order]
+    n = len(dets)
+    mask_ids = np.arange(1, n + 1)
+    img_d = torch.from_numpy(np.ascontiguousarray(img.astype(np.uint16))).cuda()
+    vol = torch.full((S, H, W), -1, dtype=torch.int32, device="cuda")
+    boxes_glob = np.zeros((n, 6), np.int64)
+    for num in np.unique(inst[:, 0]):
+        sel = np.nonzero(inst[:, 0] == num)[0]
+        _, _, ws, hs, ss = inst[sel[0]]
+        off6 = np.array([ws, hs, ss, ws, hs, ss])
+        ts, th, tw = tshape
+        tile_img = img_d[ss:ss + ts, hs:hs + th, ws:ws + tw].contiguous()
+        local = dets[sel, :6].astype(np.float64) - off6                       # soma :78, nuclei :97-98
+        boxes = det_boxes_int(np.hstack((local, dets[sel, 6:7])), tuple(tile_img.shape), dataset)
+        boxes_glob[sel] = boxes + off6
+        q = torch.from_numpy(np.ascontiguousarray(np.asarray(tiles[num][1])[inst[sel, 1]])).cuda()
+        r = _tile_instance_masks(tile_img, q, boxes, dataset, max_gray_range)
+        if r is None:
+            continue
+        cc, offs, bsel, idx_t, ok = r
+        ids = torch.from_numpy(mask_ids[sel]).to(idx_t.device)[idx_t].to(torch.int32)
+        ids = torch.where(ok, ids, torch.full_like(ids, -1))
+        gb = (bsel + torch.tensor([ws, hs, ss, ws, hs, ss], dtype=torch.int32, device=bsel.device)).contiguous()
+        ops.paint_instances_into(vol, cc, offs, gb, ids)
+    labels = torch.where(vol == -1, torch.zeros_like(vol), vol)
+    present = (torch.bincount(labels.reshape(-1), minlength=n + 1)[1:n + 1] > 0).cpu().numpy()
+    seg = labels.cpu().numpy().astype(np.uint16)
+    if dataset == "soma":
+        table = np.array([[mask_ids[d], dets[d, -1]] for d in range(n) if present[d]], np.float64).reshape(-1, 2)
+    else:
+        table = np.array([[mask_ids[d], *boxes_glob[d], dets[d, -1]] for d in range(n) if present[d]], np.float64).reshape(-1, 8)
+    return seg, table

@@ -1,14 +1,15 @@
 """Counterparts of the reference's inference drivers on the HIP path.
 
   im_detect_all   lib/core/test.py:54-177  (detection mode: pad, tile, per-tile detect, offset, cross-tile NMS)
-  infer_prm       tools/infer_simple.py:176-247 (PRM mode: per tile dets.npy + uint8 PRMs; TIFF container is a
-                  'next' row)
+  infer_prm       tools/infer_simple.py:176-247 (PRM mode: per tile `instances/{num}/{ch}.tif` (LZW) + dets.npy, the tree
+                  tools/binarization_*.py read; whole-volume binarisation: m3d.binarize.binarize_volume)
 """
 import os
 
 import numpy as np
 import torch
 
+from . import io as mio
 from . import ops, tiling
 
 
@@ -70,8 +71,5 @@ def infer_prm(engine, im, dataset="nuclei", patch=None, overlap=100, out_dir=Non
         rec = dict(num=num, start=(s, h, w), dets=dets, prm_u8=u8, peaks=out["peaks"].cpu().numpy())
         results.append(rec)
         if out_dir is not None:                                               # :213-216,246-247
-            sp = os.path.join(out_dir, "instances", str(num))
-            os.makedirs(sp, exist_ok=True)
-            np.save(os.path.join(sp, "dets.npy"), dets)
-            np.savez_compressed(os.path.join(sp, "prms_u8.npz"), *u8)
+            mio.save_prm_instances(os.path.join(out_dir, "instances", str(num)), u8, dets)   # {ch}.tif (LZW) + dets.npy
     return results

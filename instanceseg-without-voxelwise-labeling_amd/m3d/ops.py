@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -395,13 +395,20 @@ def binary_closing6_batch(mask, offsets, dims):
     return out
 
 
+def paint_instances_into(vol, mask, offsets, boxes, ids):
+    """Accumulating form: vol is an int32 [D,H,W] volume pre-filled with -1 (0xFFFFFFFF); several calls (one per tile)
+    may paint into it; finish with `torch.where(vol == -1, 0, vol)`."""
+    _need_gpu(vol, mask, offsets, boxes, ids)
+    assert vol.dtype == torch.int32 and vol.is_contiguous() and boxes.dtype == torch.int32 and ids.dtype == torch.int32
+    D, H, W = vol.shape
+    check(lib().m3d_paint_instances(_ptr(mask), _ptr(offsets), _ptr(boxes.contiguous()), _ptr(ids.contiguous()), boxes.shape[0],
+                                    D, H, W, _ptr(vol), _stream()), "paint_instances")
+    return vol
+
+
 def paint_instances(mask, offsets, boxes, ids, shape):
     """Returns the int32 label volume [D,H,W]: id of the first (lowest-id) instance covering each voxel, 0 elsewhere.
     ids < 0 (0xFFFFFFFF as unsigned) never win, i.e. mark a skipped detection."""
-    _need_gpu(mask, offsets, boxes, ids)
-    D, H, W = shape
-    vol = torch.full((D, H, W), -1, dtype=torch.int32, device=mask.device)      # 0xFFFFFFFF sentinel
-    R = boxes.shape[0]
-    check(lib().m3d_paint_instances(_ptr(mask), _ptr(offsets), _ptr(boxes.contiguous()), _ptr(ids.contiguous()), R, D, H, W,
-                                    _ptr(vol), _stream()), "paint_instances")
+    vol = torch.full(tuple(shape), -1, dtype=torch.int32, device=mask.device)      # 0xFFFFFFFF sentinel
+    paint_instances_into(vol, mask, offsets, boxes, ids)
     return torch.where(vol == -1, torch.zeros_like(vol), vol)

@@ -152,3 +152,75 @@ def test_segment_tile_bit_exact(m3d, mode):
     assert np.array_equal(labels.cpu().numpy().astype(np.uint16), seg)
     assert np.array_equal(painted.cpu().numpy(), painted_ref)
     assert painted_ref.sum() >= R - 3 and not painted_ref[3]
+
+
+def _synth_volume_with_tiles(dataset, rs):
+    """A volume with Gaussian blobs, and per-tile (dets, uint8 PRM) records for every tile that contains a blob -
+    the same blob shows up in all overlapping tiles, so cross-tile NMS and first-writer painting both matter."""
+    from m3d.binarize import soma_tiles, nuclei_tiles
+    if dataset == "soma":
+        S, H, W = 128, 256, 256
+        grid, tshape, nblob = soma_tiles(), (64, 160, 160), 14
+    else:
+        S, H, W = 64, 300, 300          # boxes must be >= 32 wide or touch the border to survive binarization_nuclei.py:71-77
+        grid, tshape, nblob = nuclei_tiles(H, W), (S, 200, 200), 10
+    img = (rs.randn(S, H, W) * 12 + 110)
+    blobs = []
+    for i in range(nblob):
+        if dataset == "soma":
+            c = np.array([rs.uniform(6, S - 6), rs.uniform(12, H - 12), rs.uniform(12, W - 12)])
+            rad = rs.uniform(3, 6)
+        else:
+            c = np.array([rs.uniform(24, 40), rs.uniform(22, H - 22), rs.uniform(22, W - 22)])
+            rad = rs.uniform(7.5, 9) if i % 4 else rs.uniform(4, 6)
+        lo = np.maximum(np.floor(c - 4 * rad).astype(int), 0); hi = np.minimum(np.ceil(c + 4 * rad).astype(int) + 1, [S, H, W])
+        zz, yy, xx = np.mgrid[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        d2 = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2
+        img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] += rs.uniform(400, 900) * np.exp(-d2 / (2 * rad * rad))
+        blobs.append((c, rad))
+    img = img.clip(0, 65535).astype(np.uint16)
+    tiles = {}
+    for num, ss, hs, ws in grid:
+        dets, prms = [], []
+        for c, rad in blobs:
+            lc = c - np.array([ss, hs, ws])
+            h = 2.2 * rad
+            if np.any(lc - h < 1) or np.any(lc + h > np.array(tshape) - 2):
+                continue
+            zz, yy, xx = np.mgrid[0:tshape[0], 0:tshape[1], 0:tshape[2]]
+            d2 = (zz - lc[0]) ** 2 + (yy - lc[1]) ** 2 + (xx - lc[2]) ** 2
+            p = np.exp(-d2 / (2 * (rad * 0.8) ** 2)) * (rs.rand(*tshape) * 0.3 + 0.7)
+            p[d2 > (3 * rad) ** 2] = 0
+            prms.append((p / p.max() * 255).astype(np.uint8))
+            jit = rs.uniform(-0.4, 0.4, 6)
+            dets.append([lc[2] - h + jit[0], lc[1] - h + jit[1], lc[0] - h + jit[2], lc[2] + h + jit[3], lc[1] + h + jit[4],
+                         lc[0] + h + jit[5], rs.uniform(0.45, 1.0)])
+        if dets:
+            tiles[num] = (np.array(dets, np.float64), np.stack(prms))
+    return img, tiles
+
+
+@pytest.mark.parametrize("dataset", ["soma", "nuclei"])
+def test_binarize_volume_through_the_file_tree(m3d, dataset, tmp_path):
+    """PRM instance tree on disk (LZW TIFF + dets.npy, as infer_simple writes it) -> cross-tile NMS -> per-detection
+    Otsu / components -> uint16 label stack + table, against the oracle's restatement of the two scripts."""
+    from m3d.binarize import binarize_volume
+    from m3d import io as mio
+    rs = np.random.RandomState(21)
+    img, tiles = _synth_volume_with_tiles(dataset, rs)
+    assert len(tiles) >= 4
+    root = str(tmp_path / "prm" / "img1")
+    for num, (dets, prms) in tiles.items():
+        mio.save_prm_instances(root + "/instances/%d" % num, prms, dets)
+    loaded = {}
+    for num in tiles:
+        d, p = mio.load_prm_instances(root + "/instances/%d" % num)
+        loaded[num] = (d, np.stack(p))
+        assert np.array_equal(loaded[num][1], tiles[num][1])
+    seg, table = binarize_volume(img, loaded, dataset, max_gray_range=4096)
+    seg_ref, table_ref = O.binarize_volume(img, tiles, dataset)
+    assert seg_ref.max() >= 5 and len(table_ref) >= 5
+    assert np.array_equal(seg, seg_ref)
+    assert table.shape == table_ref.shape and np.array_equal(table, table_ref.astype(np.float64))
+    mio.save_segmentation(str(tmp_path / "out"), "img1", seg, table)
+    assert np.array_equal(mio.read_tiff_stack(str(tmp_path / "out" / "img1.tif")), seg_ref)
