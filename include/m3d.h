@@ -228,7 +228,8 @@ int m3d_otsu2d_batch(const uint16_t* d_image, const uint16_t* d_prm, const int64
  *                          tie_last = 1: among equal sizes the highest label id (argsort(...)[-1], soma),
  *                          0: the lowest (np.argmax, nuclei).  invert = 1 runs on the complement and writes
  *                          255 everywhere except its largest component = hole filling (nuclei :132-137).
- *                          d_status[r] = 1 when there is no component at all.
+ *                          d_status[r] = 1 when there is no component at all, 2 for inconsistent dims / offsets,
+ *                          3 if the label propagation did not converge within its sweep bound (output zeroed).
  *   m3d_binary_closing6_batch  scipy.ndimage.binary_closing defaults: 6-neighbourhood, 1 iteration, border 0
  *                          (binarization_nuclei.py:139).
  *   m3d_paint_instances    write d_ids[r] into the uint32 label volume wherever crop r (box int32 [R,6] inclusive)

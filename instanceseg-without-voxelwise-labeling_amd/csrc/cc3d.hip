@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kT) void cc_largest_kernel(const uint8_t* __restric
     cnt[v] = 0;
   }
   __syncthreads();
-  for (int iter = 0; iter < 4096; ++iter) {            // bounded: every iteration strictly lowers some label
+  bool converged = false;
+  for (int iter = 0; iter < 8192; ++iter) {            // bounded: every iteration strictly lowers some label
     int changed = 0;
     for (int v = tid; v < V; v += kT) {
       int l = lab[v];
@@ -74,7 +75,12 @@ __global__ __launch_bounds__(kT) void cc_largest_kernel(const uint8_t* __restric
       for (int k = 0; k < 4; ++k) { const int up = lab[best - 1]; if (up && up < best) best = up; else break; }
       if (best < l) { lab[v] = best; changed = 1; }
     }
-    if (!block_or(changed, &s_flag)) break;
+    if (!block_or(changed, &s_flag)) { converged = true; break; }
+  }
+  if (!converged) {                                    // never seen (a 50^3 serpentine needs < 100 sweeps); fail loudly
+    if (tid == 0 && status) status[r] = 3;
+    for (int v = tid; v < V; v += kT) o[v] = 0;
+    return;
   }
   // component sizes (root = label; a converged component has the label of its first voxel)
   for (int v = tid; v < V; v += kT) {
