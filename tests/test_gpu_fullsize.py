@@ -62,3 +62,45 @@ def test_full_tile_detect_and_prm(name):
         assert torch.allclose(tot, sums, rtol=1e-3)
         pk = res["peaks"][:, 2:].to(torch.int32) * s                      # the peak's own voxel lies inside its window
         assert ((pk >= org) & (pk < org + w.shape[1])).all()
+
+
+def test_wgrad_dgrad_adjoint_identity_full_size():
+    """Size-independent property at the BASELINE config[1] size (conv2b, 64 -> 64 channels on 64^3):
+    <conv(x, W), g> = <x, dgrad(g, W)> = <W, wgrad(x, g)> - the three kernels are adjoints of one bilinear form."""
+    import m3d
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 64, 64, 64, generator=g).cuda()
+    gy = torch.randn(1, 64, 64, 64, 64, generator=g).cuda()
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).cuda()
+    y = m3d.PackedConv3d(w)(x)
+    gx = m3d.PackedConv3d(w, mode=m3d.W_DGRAD)(gy)
+    gw = m3d.conv3d_wgrad(x, gy, 3)
+    a = (y.double() * gy.double()).sum().item()
+    b = (x.double() * gx.double()).sum().item()
+    c = (w.double() * gw.double()).sum().item()
+    scale = (y.double().norm() * gy.double().norm()).item()
+    assert abs(a - b) / scale < 1e-6 and abs(a - c) / scale < 1e-6, (a, b, c)
+
+
+def test_largest_component_is_idempotent_and_a_subset_full_size():
+    """300 Otsu-sized crops (up to 50^3): cc(cc(m)) == cc(m), cc(m) is a subset of m, and the hole-filled mask contains it."""
+    import m3d
+    rs = np.random.RandomState(4)
+    shapes = [tuple(int(v) for v in rs.randint(10, 51, 3)) for _ in range(300)]
+    masks = []
+    for shp in shapes:
+        zz, yy, xx = np.mgrid[0:shp[0], 0:shp[1], 0:shp[2]]
+        r2 = ((zz - shp[0] / 2) / (shp[0] / 2.2)) ** 2 + ((yy - shp[1] / 2) / (shp[1] / 2.2)) ** 2 + ((xx - shp[2] / 2) / (shp[2] / 2.2)) ** 2
+        masks.append((((r2 < 1) & (rs.rand(*shp) < 0.8)) | (rs.rand(*shp) < 0.02)).astype(np.uint8).ravel() * 255)
+    offs = torch.from_numpy(np.concatenate(([0], np.cumsum([m.size for m in masks]))).astype(np.int64)).cuda()
+    dims = torch.from_numpy(np.array(shapes, np.int32)).cuda()
+    m = torch.from_numpy(np.concatenate(masks)).cuda()
+    cc, st = m3d.cc_largest_batch(m, offs, dims, invert=False, tie_last=False)
+    assert (st == 0).all()
+    cc2, _ = m3d.cc_largest_batch(cc, offs, dims, invert=False, tie_last=False)
+    assert torch.equal(cc, cc2)
+    assert ((cc > 0) & (m == 0)).sum().item() == 0 and (cc > 0).sum().item() > 0.5 * (m > 0).sum().item()
+    filled, _ = m3d.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)
+    assert ((cc > 0) & (filled == 0)).sum().item() == 0
+    filled2, _ = m3d.cc_largest_batch(filled, offs, dims, invert=True, tie_last=False)
+    assert torch.equal(filled, filled2)
