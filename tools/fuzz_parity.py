@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP ops against the CPU oracle (test infrastructure; not part of the product path):
+random shapes / parameters / degenerate inputs per op, bit-exact where the contract says so.
+  python tools/fuzz_parity.py [seconds per op] [seed]"""
+import os, sys, time, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch, m3d
+import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rand_boxes(rs, n, span=100, smax=40, grid=None):
+    c = rs.uniform(0, span, (n, 3)); s = rs.uniform(0.5, smax, (n, 3))
+    b = np.hstack((c - s / 2, c + s / 2))
+    if grid:                                     # coarse grid -> many exact coordinate / IoU ties
+        b = np.round(b / grid) * grid
+    return b
+
+
+def f_nms(rs):
+    n = int(rs.choice([1, 2, 3, 63, 64, 65, 127, 300, 1000, 2500]))
+    b = rand_boxes(rs, n, span=rs.choice([30, 100, 300]), grid=rs.choice([None, None, 1.0, 4.0]))
+    mode = rs.randint(4)
+    sc = rs.uniform(0, 1, n) if mode == 0 else np.round(rs.uniform(0, 1, n), 1) if mode == 1 else \
+        np.ones(n) if mode == 2 else rs.permutation(n) / n
+    if rs.rand() < 0.2:
+        b[rs.randint(n)] = b[rs.randint(n)]      # exact duplicate box
+    if rs.rand() < 0.2:
+        b[rs.randint(n), 3:] = b[rs.randint(n), :3] - 5   # inverted box (negative extents)
+    dets = np.hstack((b, sc[:, None])).astype(np.float32)
+    thr = float(rs.choice([0.0, 0.15, 0.23, 0.5, 0.99, 1.0]))
+    byv = bool(rs.randint(2))
+    got = m3d.nms3d(dev(dets), thr, by_volume=byv).cpu().numpy()
+    ref = O.nms_3d(dets, thr, by_volume=byv)
+    assert np.array_equal(got, ref), ("nms", n, thr, byv, mode)
+
+
+def f_overlaps(rs):
+    n, k = int(rs.randint(1, 700)), int(rs.randint(1, 90))
+    a = rand_boxes(rs, n, grid=rs.choice([None, 2.0])).astype(np.float32)
+    q = rand_boxes(rs, k, grid=rs.choice([None, 2.0])).astype(np.float32)
+    if rs.rand() < 0.3:
+        q[0] = a[0]
+    assert np.array_equal(m3d.bbox_overlaps3d(dev(a), dev(q)).cpu().numpy(), O.bbox_overlaps_3d(a, q)), ("overlaps", n, k)
+
+
+def f_transform(rs):
+    n, k = int(rs.randint(1, 1200)), int(rs.choice([1, 2]))
+    b = rand_boxes(rs, n).astype(np.float32)
+    d = (rs.randn(n, 6 * k) * rs.choice([0.1, 1.0, 5.0])).astype(np.float32)
+    w = (1., 1., 1., 1., 1., 1.) if rs.rand() < 0.5 else (10., 10., 10., 5., 5., 5.)
+    got = m3d.bbox_transform3d(dev(b), dev(d), w).cpu().numpy()
+    ref = O.bbox_transform_3d(b, d, w)
+    assert np.allclose(got, ref, rtol=3e-7, atol=1e-4) and (got == ref).mean() > 0.95, ("transform", n, k)
+    shp = (int(rs.randint(8, 200)), int(rs.randint(8, 300)), int(rs.randint(8, 300)))
+    got = m3d.bbox_transform3d(dev(b), dev(d), w, clip_to=shp).cpu().numpy()
+    ref = O.clip_tiled_boxes_3d(ref, shp)
+    assert np.allclose(got, ref, rtol=3e-7, atol=1e-4), ("clip", n, k)
+
+
+def f_proposals(rs):
+    cfg = O.Cfg() if rs.rand() < 0.5 else O.Cfg.soma()
+    A = cfg.anchors.shape[0]
+    S, H, W = int(rs.randint(1, 9)), int(rs.randint(1, 20)), int(rs.randint(1, 20))
+    sc = rs.uniform(0, 1, (A, S, H, W)).astype(np.float32)
+    mode = rs.randint(3)
+    if mode == 1:
+        sc[rs.uniform(0, 1, sc.shape) > 0.98] = 1.0
+    elif mode == 2:
+        sc = np.round(sc, 2)
+    dl = (rs.randn(6 * A, S, H, W) * rs.choice([0.05, 0.3, 2.0])).astype(np.float32)
+    st = cfg.stride
+    info = np.array([S * st, H * st, W * st, 1.0])
+    pre, post = int(rs.choice([1, 50, 1000, 6000])), int(rs.choice([1, 30, 1000]))
+    thr = float(rs.choice([0.15, 0.23, 0.7]))
+    r0, p0, k0 = O.generate_proposals_3d(sc, dl, info, cfg.anchors, st, pre, post, thr, 0)
+    r1, p1, k1 = m3d.generate_proposals3d(dev(sc), dev(dl), cfg.anchors, float(st), info, pre, post, thr)
+    assert np.array_equal(k1.cpu().numpy(), k0), ("proposals idx", A, S, H, W, pre, post, thr, mode)
+    assert np.array_equal(p1.cpu().numpy(), p0)
+    assert np.allclose(r1.cpu().numpy(), r0, rtol=3e-7, atol=1e-4)
+
+
+def f_roialign(rs):
+    B, Cc = int(rs.randint(1, 3)), int(rs.choice([1, 3, 16, 64]))
+    S, H, W = int(rs.randint(1, 18)), int(rs.randint(1, 28)), int(rs.randint(1, 28))
+    f = rs.randn(B, Cc, S, H, W).astype(np.float32)
+    R = int(rs.randint(1, 60))
+    scale = float(rs.choice([0.125, 0.25]))
+    ext = max(S, H, W) / scale
+    c = rs.uniform(-0.2 * ext, 1.2 * ext, (R, 3)); s = rs.uniform(0.5, 0.8 * ext, (R, 3))
+    rois = np.hstack((rs.randint(0, B, (R, 1)), c - s / 2, c + s / 2)).astype(np.float32)
+    res = int(rs.choice([1, 3, 7]))
+    ratio = int(rs.choice([0, 1, 2, 3]))
+    got = m3d.roi_align3d_forward(dev(f), dev(rois), res, res, res, scale, ratio, exact=True).cpu().numpy()
+    ref = O.roi_align_3d_forward(f, rois, res, res, res, scale, ratio)
+    assert np.array_equal(got, ref), ("roialign exact", f.shape, R, res, ratio)
+    fast = m3d.roi_align3d_forward(dev(f), dev(rois), res, res, res, scale, ratio).cpu().numpy()
+    assert np.abs(fast - ref).max() <= 2e-5 * max(1.0, np.abs(f).max()), ("roialign sep", f.shape, R, res, ratio, np.abs(fast - ref).max())
+
+
+def f_otsu(rs):
+    n = int(rs.randint(1, 12))
+    imgs, prms = [], []
+    for _ in range(n):
+        shp = tuple(int(v) for v in rs.randint(1, 40, 3))
+        kind = rs.randint(4)
+        zz, yy, xx = np.mgrid[0:shp[0], 0:shp[1], 0:shp[2]]
+        r = np.sqrt((zz - shp[0] / 2) ** 2 + (yy - shp[1] / 2) ** 2 + (xx - shp[2] / 2) ** 2)
+        img = (rs.uniform(100, 3000) * np.exp(-(r / rs.uniform(2, 12)) ** 2) + rs.uniform(0, 200) + rs.randn(*shp) * rs.uniform(0, 30)).clip(0, 65535)
+        prm = (255 * np.exp(-(r / rs.uniform(2, 10)) ** 2) * (rs.rand(*shp) if kind == 1 else 1)).astype(np.uint8)
+        if kind == 2:
+            prm[:] = rs.randint(0, 3)
+        if kind == 3:
+            img = np.round(img / 50) * 50
+        img = img.astype(np.uint16)
+        if prm.max() == 0:
+            prm.flat[0] = 1
+        a, b = (O.normalize_soma if rs.rand() < 0.5 else O.normalize_nuclei)(img, prm)
+        imgs.append(a); prms.append(b)
+    offs = np.concatenate(([0], np.cumsum([a.size for a in imgs]))).astype(np.int64)
+    G = 8192
+    mask, kb, st = m3d.otsu2d_batch(dev(np.concatenate([a.ravel() for a in imgs])), dev(np.concatenate([b.ravel() for b in prms])), dev(offs), G)
+    mask, kb, st = mask.cpu().numpy(), kb.cpu().numpy(), st.cpu().numpy()
+    for i in range(n):
+        try:
+            m, k, b = O.otsu_py_2d_fast(imgs[i], prms[i])
+        except ValueError:
+            assert st[i] != 0, ("otsu status", i)
+            continue
+        assert st[i] == 0 and (k, b) == tuple(kb[i]) and np.array_equal(mask[offs[i]:offs[i + 1]].reshape(m.shape), m), ("otsu", imgs[i].shape, k, b, kb[i])
+
+
+def f_cc(rs):
+    n = int(rs.randint(1, 10))
+    masks = []
+    for _ in range(n):
+        shp = tuple(int(v) for v in rs.randint(1, 34, 3))
+        p = rs.choice([0.03, 0.1, 0.2, 0.35, 0.6, 0.95])
+        m = (rs.rand(*shp) < p)
+        if rs.rand() < 0.3:
+            m = np.kron(m[::2, ::2, ::2], np.ones((2, 2, 2), bool))[:shp[0], :shp[1], :shp[2]] if min(shp) > 1 else m
+        masks.append(np.ascontiguousarray(m).astype(np.uint8) * 255)
+    offs = np.concatenate(([0], np.cumsum([m.size for m in masks]))).astype(np.int64)
+    dims = np.array([m.shape for m in masks], np.int32)
+    flat = dev(np.concatenate([m.ravel() for m in masks]))
+    for tie_last, ref in ((True, O.largest_cc_soma), (False, O.largest_cc_nuclei)):
+        out, st = m3d.cc_largest_batch(flat, dev(offs), dev(dims), invert=False, tie_last=tie_last)
+        out, st = out.cpu().numpy(), st.cpu().numpy()
+        for i, m in enumerate(masks):
+            if not m.any():
+                assert st[i] == 1; continue
+            assert np.array_equal(out[offs[i]:offs[i + 1]].reshape(m.shape), ref(m).astype(np.uint8) * 255), ("cc", m.shape, tie_last)
+    cc, st = m3d.cc_largest_batch(flat, dev(offs), dev(dims), invert=False, tie_last=False)
+    fl, st2 = m3d.cc_largest_batch(cc, dev(offs), dev(dims), invert=True, tie_last=False)
+    cl = m3d.binary_closing6_batch(fl, dev(offs), dev(dims)).cpu().numpy()
+    st, st2 = st.cpu().numpy(), st2.cpu().numpy()
+    for i, m in enumerate(masks):
+        if st[i] != 0 or st2[i] != 0:
+            continue
+        ref = O.fill_and_close_nuclei(O.largest_cc_nuclei(m))
+        assert np.array_equal(cl[offs[i]:offs[i + 1]].reshape(m.shape), ref.astype(np.uint8) * 255), ("fill+close", m.shape)
+
+
+def f_conv(rs):
+    k = int(rs.choice([1, 3, 3, 3, 5]))
+    cin = 1 if k == 5 else int(rs.choice([1, 3, 16, 32, 33, 64, 100, 128]))
+    cout = int(rs.choice([1, 5, 32, 33, 64, 96, 128])) if k != 5 else int(rs.choice([8, 32, 48]))
+    B = int(rs.choice([1, 1, 2]))
+    D, H, W = int(rs.randint(1, 12)), int(rs.randint(1, 24)), int(rs.randint(1, 70))
+    x = torch.from_numpy(rs.randn(B, cin, D, H, W).astype(np.float32))
+    w = torch.from_numpy((rs.randn(cout, cin, k, k, k) * (2.0 / (cin * k ** 3)) ** 0.5).astype(np.float32))
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, k // 2)
+    y = m3d.PackedConv3d(w.cuda())(x.cuda()).cpu().double()
+    den = max(ref.abs().max().item(), 1e-3)
+    assert (y - ref).abs().max().item() / den < 1e-5, ("conv fwd", B, cin, cout, D, H, W, k)
+    if k != 5:
+        gy = torch.from_numpy(rs.randn(B, cout, D, H, W).astype(np.float32))
+        refx = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), 1, k // 2)
+        gx = m3d.PackedConv3d(w.cuda(), mode=m3d.W_DGRAD)(gy.cuda()).cpu().double()
+        assert (gx - refx).abs().max().item() / max(refx.abs().max().item(), 1e-3) < 1e-5, ("conv dgrad", B, cin, cout, D, H, W, k)
+    gy = torch.from_numpy(rs.randn(B, cout, D, H, W).astype(np.float32))
+    refw = torch.nn.grad.conv3d_weight(x.double(), w.shape, gy.double(), 1, k // 2)
+    gw = m3d.conv3d_wgrad(x.cuda(), gy.cuda(), k).cpu().double()
+    assert (gw - refw).abs().max().item() / max(refw.abs().max().item(), 1e-3) < 2e-5, ("conv wgrad", B, cin, cout, D, H, W, k)
+
+
+ops = [("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
+       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad", f_conv)]
+bad = 0
+for name, fn in ops:
+    t0, n, fails = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        rs = np.random.RandomState(seed0 * 1000003 + n)
+        try:
+            fn(rs)
+        except AssertionError as e:
+            fails += 1
+            if fails <= 3:
+                print("  MISMATCH %s case %d: %s" % (name, n, e)); traceback.print_exc(limit=1)
+        n += 1
+    print("%-28s %5d cases, %d mismatches" % (name, n, fails), flush=True)
+    bad += fails
+sys.exit(1 if bad else 0)
