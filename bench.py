@@ -166,20 +166,15 @@ def main():
 
     def step(timed):
         x = vol
-        for li, (conv, scale, shift, pool) in enumerate(det.body):
-            fused = pool and conv.supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4])
-            run = (lambda t: conv.pooled(t, scale=scale, shift=shift, relu=True)) if fused else \
-                  (lambda t: conv(t, scale=scale, shift=shift, relu=True))
+        for li in range(len(det.body)):
             if timed and li in dom_layers:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                x = run(x)
+                x = det.body_layer(li, x)
                 e1.record()
                 dom_ev.append((e0, e1))
             else:
-                x = run(x)
-            if pool and not fused:
-                x = m3d.maxpool3d_2x(x)
+                x = det.body_layer(li, x)
         if args.workload == "backbone":
             return x
         prob, deltas = det.rpn(x)

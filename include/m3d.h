@@ -121,6 +121,22 @@ int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, i
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
 
+/* 3x3x3 forward convolution with the Winograd F(2,3) transform along x (csrc/conv3d_wino.hip): the same operation as
+ * m3d_conv3d_forward for k = 3, plain weights, no input offset / PRM multiply, at 2/3 of the MFMA work.  Results
+ * agree with the direct kernel to a few fp32 ulp (tolerance of this path: 1e-4 relative, north_star), not bit for
+ * bit, so the PRM norm / backward convolutions never use it.  Own packed-weight layout (36 slots per cout x cin).
+ * Returns M3D_EUNSUPPORTED for maps narrower than 24 voxels (callers then use m3d_conv3d_forward). */
+size_t m3d_conv3d_wino_packed_weight_bytes(int cin, int cout);
+int m3d_conv3d_wino_pack_weights(const float* d_weight /*[cout,cin,3,3,3]*/, int cin, int cout, float* d_packed,
+                                 void* stream);
+int m3d_conv3d_wino_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                            int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                            void* stream);
+/* the same fused with MaxPool3d(2,2) (DSN.py:60-61): writes [batch,cout,D/2,H/2,W/2]; width >= 48 */
+int m3d_conv3d_wino_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                  int depth, int height, int width, const float* d_scale, const float* d_shift,
+                                  int relu, void* stream);
+
 /* Backward-weights and bias gradient of the same stride-1 "same" convolution (what autograd computes for the
  * F.conv3d calls of lib/prm/peak_backprop_3d.py:40-42 and every nn.Conv3d of lib/modeling/DSN.py:19-36 in training):
  *   dW[co,ci,dz,dy,dx] = sum_{b,z,y,x} gy[b,co,z,y,x] * x[b,ci,z+dz-k/2,...]     db[co] = sum gy[b,co,...]

@@ -9,6 +9,8 @@ The state-dict key layout is the reference's: Conv_Body.conv1a.weight
 
 Linear layers go to rocBLAS through torch (plain library GEMMs); every other op is a libm3d.so kernel.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -39,7 +41,14 @@ class DetectorM3D:
             scale = (params[b + ".weight"] / torch.sqrt(params[b + ".running_var"] + BN_EPS)).contiguous()
             shift = ((params[c + ".bias"] - params[b + ".running_mean"]) * scale + params[b + ".bias"]).contiguous()
             self.body.append((conv, scale, shift, pool))
+        # plain-forward 3x3x3 layers also get Winograd-x weights (2/3 of the MFMA work; maps >= 24 voxels wide).
+        # The PRM engine keeps using the direct kernels in self.body (its masks test exact zeros).
+        self.use_wino = os.environ.get("M3D_WINO", "1") != "0"
+        self.body_wino = [ops.WinoConv3d(params["Conv_Body." + cname + ".weight"])
+                          if (self.use_wino and params["Conv_Body." + cname + ".weight"].shape[-1] == 3) else None
+                          for cname, _, _ in dsn_layers(cfg.stride)]
         self.rpn_conv = ops.PackedConv3d(params["RPN.RPN_conv.weight"])
+        self.rpn_conv_wino = ops.WinoConv3d(params["RPN.RPN_conv.weight"]) if self.use_wino else None
         self.rpn_conv_bias = params["RPN.RPN_conv.bias"].contiguous()
         self.A = params["RPN.RPN_cls_score.weight"].shape[0]
         # the two 1x1x1 heads share their input: one conv with A + 6A output channels (rpn_heads.py:96-98)
@@ -49,19 +58,31 @@ class DetectorM3D:
         self.has_head = "Box_Head.fc1.weight" in params
 
     # ---- lib/modeling/DSN.py:57-68
+    def body_layer(self, li, x):
+        """conv + eval-BN + ReLU (+ MaxPool) of body layer li: Winograd-x kernel where it has a tile configuration,
+        otherwise the direct MFMA kernel; the pool is fused into the conv launch when the map is large enough."""
+        conv, scale, shift, pool = self.body[li]
+        wino = self.body_wino[li]
+        width = x.shape[-1]
+        if wino is not None and wino.supports(width):
+            if pool and wino.supports_pool(width):
+                return wino.pooled(x, scale=scale, shift=shift, relu=True)
+            x = wino(x, scale=scale, shift=shift, relu=True)
+            return ops.maxpool3d_2x(x) if pool else x
+        if pool and conv.supports_pool(width, x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
+            return conv.pooled(x, scale=scale, shift=shift, relu=True)          # conv+BN+ReLU+MaxPool in one kernel
+        x = conv(x, scale=scale, shift=shift, relu=True)
+        return ops.maxpool3d_2x(x) if pool else x
+
     def conv_body(self, x):
-        for conv, scale, shift, pool in self.body:
-            if pool and conv.supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
-                x = conv.pooled(x, scale=scale, shift=shift, relu=True)      # conv+BN+ReLU+MaxPool in one kernel
-            else:
-                x = conv(x, scale=scale, shift=shift, relu=True)
-                if pool:
-                    x = ops.maxpool3d_2x(x)
+        for li in range(len(self.body)):
+            x = self.body_layer(li, x)
         return x
 
     # ---- lib/modeling/rpn_heads.py:94-116
     def rpn(self, feat):
-        h = self.rpn_conv(feat, shift=self.rpn_conv_bias, relu=True)
+        rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1])) else self.rpn_conv
+        h = rc(feat, shift=self.rpn_conv_bias, relu=True)
         o = self.rpn_heads(h, shift=self.rpn_heads_bias)
         logits, deltas = o[:, :self.A], o[:, self.A:]
         return torch.sigmoid(logits), deltas.contiguous()

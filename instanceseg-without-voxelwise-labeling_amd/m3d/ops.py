@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -339,6 +339,54 @@ def roi_normalize(image_u16, prm_u8, boxes, mode):
     check(lib().m3d_roi_normalize(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
                                   R, D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _stream()), "roi_normalize")
     return oi, op, offs
+
+
+# ------------------------------------------------------------------ Winograd-x 3x3x3 forward
+class WinoConv3d(object):
+    """3x3x3 forward conv (stride 1, pad 1) through the Winograd-F(2,3)-along-x MFMA kernel; weights packed once.
+    `supports(width)` says whether the kernel has a tile configuration for the map (else use PackedConv3d)."""
+
+    def __init__(self, weight):
+        _need_gpu(weight)
+        w = _f32c(weight)
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        nbytes = lib().m3d_conv3d_wino_packed_weight_bytes(self.cin, self.cout)
+        self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
+        check(lib().m3d_conv3d_wino_pack_weights(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
+
+    @staticmethod
+    def supports(width):
+        return width >= 24
+
+    def __call__(self, x, scale=None, shift=None, relu=False, out=None):
+        _need_gpu(x)
+        x = _f32c(x)
+        B, cin, D, H, W = x.shape
+        assert cin == self.cin
+        if out is None:
+            out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_wino_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                                            _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
+                                            int(bool(relu)), _stream()), "conv3d_wino_forward")
+        return out
+
+    @staticmethod
+    def supports_pool(width):
+        return width >= 48
+
+    def pooled(self, x, scale=None, shift=None, relu=False):
+        """conv + scale/shift + ReLU + MaxPool3d(2,2) in one launch; returns [B,cout,D//2,H//2,W//2]."""
+        _need_gpu(x)
+        x = _f32c(x)
+        B, cin, D, H, W = x.shape
+        assert cin == self.cin
+        out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_wino_forward_pool2(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                                                  _ptr(scale) if scale is not None else None,
+                                                  _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),
+              "conv3d_wino_forward_pool2")
+        return out
 
 
 # ------------------------------------------------------------------ conv backward-weights / bias gradient

@@ -213,6 +213,40 @@ def test_conv3d_wgrad_and_bias_grad_vs_fp64(m3d, B, cin, cout, D, H, W, k):
     assert (db - rb).abs().max().item() / rb.abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("B,cin,cout,D,H,W", [
+    (1, 32, 64, 6, 9, 64), (1, 64, 64, 5, 8, 70), (2, 5, 7, 4, 5, 48), (1, 64, 128, 6, 11, 32), (1, 128, 128, 4, 6, 37),
+    (1, 33, 40, 3, 4, 24), (1, 16, 96, 7, 13, 129), (1, 256, 256, 3, 25, 25), (1, 2, 200, 2, 3, 100)])
+def test_conv3d_winograd_x_vs_fp64(m3d, B, cin, cout, D, H, W):
+    """The F(2,3)-along-x kernel computes the same conv + scale/shift + ReLU as the direct kernel (every tile
+    configuration, ragged sizes, odd widths -> unpaired stores)."""
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+    conv = m3d.WinoConv3d(w.cuda())
+    y = conv(x.cuda()).cpu().double()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-4, err                                   # north_star tolerance
+    assert err < 5e-6, err                                   # what the fp32 transform actually delivers
+    ref2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+    y2 = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+    assert (y2 - ref2).abs().max().item() / ref2.abs().max().item() < 5e-6
+    if W >= 48 and D >= 2 and H >= 2:
+        yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+        refp = torch.nn.functional.max_pool3d(ref2, 2, 2)
+        assert yp.shape == refp.shape
+        assert (yp - refp).abs().max().item() / refp.abs().max().item() < 5e-6
+
+
+def test_conv3d_winograd_rejects_narrow_maps(m3d):
+    conv = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda())
+    assert not conv.supports(16) and conv.supports(24) and not conv.supports_pool(32)
+    with pytest.raises(m3d.M3DError):
+        conv(torch.randn(1, 4, 4, 16, 16).cuda())
+
+
 def test_conv3d_linearity_full_size(m3d):
     """Size-independent property at the BASELINE config[1] size (conv2b on 64^3): conv(a*x + y) = a*conv(x) + conv(y)."""
     g = torch.Generator().manual_seed(7)
