@@ -75,12 +75,15 @@ struct WCfg {
   static constexpr int PP = CC / 2 / KS;
   static constexpr int YB = 32 / XT;
   static constexpr int TX = 2 * XT, TY = WY * ROWS * YB, TZ = WZ;
-  static constexpr int HXP = 2 * XT + 2, HY = TY + 2, HZ = TZ + 2;
+  static constexpr int EP = XT + 2;                           // entries per (even | odd) plane of one row: E[0..XT+1], O[0..XT+1]
+  static constexpr int HXP = 2 * EP, HY = TY + 2, HZ = TZ + 2;
+  static constexpr int QR = EP / 2;                           // 16-byte quads per row: x0-1+4q .. x0+2+4q -> O[2q],E[2q],O[2q+1],E[2q+1]
   static constexpr int CS = HXP * HY * HZ;
   static constexpr int IN_ELEMS = CC * CS;
+  static constexpr int NQUAD = CC * HZ * HY * QR;
   static constexpr int W_SEG = NCB * WT * 64;
   static constexpr int W_ELEMS = (CC / 2) * W_SEG;
-  static constexpr int NI = (IN_ELEMS + NT - 1) / NT;
+  static constexpr int NI = (NQUAD + NT - 1) / NT;           // input staging quads per thread
   static constexpr int NW4 = (W_ELEMS / 4 + NT - 1) / NT;
   static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS;
   static_assert(CC % (2 * KS) == 0, "whole channel pairs per K group");
@@ -118,25 +121,35 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
   const size_t DHW = (size_t)D * H * W;
   const float* in_b = in + (size_t)b * cin * DHW;
 
-  // LDS position e = (ci, hz, hy, pos): pos <= XT: E plane, x = x0 + 2 pos;  pos > XT: O plane, u = pos - XT - 1, x = x0 + 2u - 1
-  int goff[C::NI];
+  // Input staging works on 16-byte quads of four consecutive x (one buffer_load_dwordx4 + two ds_write_b64 instead of
+  // four dword loads / writes): quad e = (ci, hz, hy, q) covers x = x0-1+4q .. x0+2+4q = O[2q], E[2q], O[2q+1], E[2q+1]
+  // of its row.  Buffer loads return 0 for every dword at or beyond num_records (channels past cin in the last chunk, the
+  // tail of the last row); zero padding inside the tensor (x / y / z outside the volume) is a 4-bit mask applied at commit time.
+  int gq[C::NI], mq[C::NI], lq[C::NI];
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
     const int e = tid + i * C::NT;
-    int g = -2;
-    if (e < C::IN_ELEMS) {
-      const int ci = e / C::CS;
-      const int r = e % C::CS;
-      const int hz = r / (C::HY * C::HXP), hy = (r / C::HXP) % C::HY, pos = r % C::HXP;
-      const int x = pos <= XT ? x0 + 2 * pos : x0 + 2 * (pos - XT - 1) - 1;
-      const int z = z0 + hz - 1, y = y0 + hy - 1;
-      const bool ok = (z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
-      g = ok ? (int)(ci * DHW + ((size_t)z * H + y) * W + x) : -1;
+    gq[i] = 0; mq[i] = -1; lq[i] = 0;
+    if (e < C::NQUAD) {
+      const int q = e % C::QR;
+      const int row = e / C::QR;                      // (ci * HZ + hz) * HY + hy
+      const int hy = row % C::HY, hz = (row / C::HY) % C::HZ, ci = row / (C::HY * C::HZ);
+      const int z = z0 + hz - 1, y = y0 + hy - 1, xf = x0 - 1 + 4 * q;
+      const bool rok = (z >= 0) & (z < D) & (y >= 0) & (y < H);
+      int m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
+      long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
+      if (rok && lin < 0) { lin = 0; m |= 16; }      // a negative buffer offset drops the whole quad (measured): load x = 0..3
+      mq[i] = m;                                     // and shift by one element at commit time (bit 4)
+      gq[i] = rok ? (int)(lin * 4) : 0;              // byte offset inside the chunk (host guarantees it fits 31 bits)
+      lq[i] = row * C::HXP + 2 * q;
     }
-    goff[i] = g;
   }
 
-  float rin[C::NI];
+  f32x4 rin[C::NI];
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
   f32x4 rw[C::NW4];
   const int nchunk = (cin + CC - 1) / CC;
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
@@ -145,10 +158,8 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
   constexpr int NL = C::NI + C::NW4;
   auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
     if (idx < C::NI) {
-      const int g = goff[idx];
-      const int cvalid = min(CC, cin - chunk * CC);
-      const bool ok = (g >= 0) & (((tid + idx * C::NT) / C::CS) < cvalid);
-      rin[idx] = (in_b + (size_t)chunk * CC * DHW)[ok ? g : 0];
+      const int voff = gq[idx] + chunk * (int)(CC * DHW * sizeof(float));
+      rin[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
     } else {
       const int i = idx - C::NI;
       int e = tid + i * C::NT;
@@ -159,10 +170,15 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
   };
   auto commit1 = [&](int idx, int chunk, float* dst_in, float* dst_w) __attribute__((always_inline)) {
     if (idx < C::NI) {
-      const int g = goff[idx];
-      const int cvalid = min(CC, cin - chunk * CC);
-      const bool ok = (g >= 0) & (((tid + idx * C::NT) / C::CS) < cvalid);
-      if (g != -2) dst_in[tid + idx * C::NT] = ok ? rin[idx] : 0.f;
+      const int m = mq[idx];
+      if (m >= 0) {
+        f32x4 v = rin[idx];
+        if (m & 16) v = f32x4{0.f, v[0], v[1], v[2]};
+        const f32x2 ev = {(m & 2) ? v[1] : 0.f, (m & 8) ? v[3] : 0.f};
+        const f32x2 ov = {(m & 1) ? v[0] : 0.f, (m & 4) ? v[2] : 0.f};
+        *reinterpret_cast<f32x2*>(dst_in + lq[idx]) = ev;
+        *reinterpret_cast<f32x2*>(dst_in + lq[idx] + C::EP) = ov;
+      }
     } else {
       const int i = idx - C::NI;
       const int e = tid + i * C::NT;
@@ -198,15 +214,27 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
     const float* in_k = cur_in + b_base + ks * (C::PP * 2 * C::CS);
     const float* w_k = cur_w + ks * (C::PP * C::W_SEG) + lane;
     constexpr int NS = 9 * C::PP;
-    auto load_frag = [&](int s, float (&bf)[ROWS][4], float (&af)[NCB][4]) __attribute__((always_inline)) {
+    // B fragments: raw LDS reads run TWO steps ahead, the +-transform one step ahead, so the VALU ops never wait on
+    // the LDS latency in front of a step's MFMAs (a transform fed by a read issued in the same step stalls the wave
+    // once per step).  A fragments (plain LDS reads) run one step ahead.
+    auto read_raw = [&](int s, float (&rw4)[ROWS][4]) __attribute__((always_inline)) {
       const int tap9 = s / C::PP, pp = s % C::PP;
       const int dz = tap9 / 3, dy = tap9 % 3;
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP) + (dy + r * C::YB) * C::HXP;
-        const float e0 = p[0], e1 = p[1], o0 = p[XT + 1], o1 = p[XT + 2];
+        rw4[r][0] = p[0]; rw4[r][1] = p[1]; rw4[r][2] = p[C::EP]; rw4[r][3] = p[C::EP + 1];   // E[t], E[t+1], O[t], O[t+1]
+      }
+    };
+    auto transform = [&](const float (&rw4)[ROWS][4], float (&bf)[ROWS][4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const float e0 = rw4[r][0], e1 = rw4[r][1], o0 = rw4[r][2], o1 = rw4[r][3];
         bf[r][0] = o0 - o1; bf[r][1] = e0 + o1; bf[r][2] = o1 - e0; bf[r][3] = e0 - e1;
       }
+    };
+    auto load_a = [&](int s, float (&af)[NCB][4]) __attribute__((always_inline)) {
+      const int tap9 = s / C::PP, pp = s % C::PP;
 #pragma unroll
       for (int c = 0; c < NCB; ++c)
 #pragma unroll
@@ -215,11 +243,16 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
     constexpr int THIRD = NS / 3 > 0 ? NS / 3 : 1;
     constexpr int LPS = (NL + THIRD - 1) / THIRD;
     constexpr int CSTART = NS - (NL + LPS - 1) / LPS;
-    float bfq[2][ROWS][4], afq[2][NCB][4];
-    load_frag(0, bfq[0], afq[0]);
+    float rawq[2][ROWS][4], bfq[2][ROWS][4], afq[2][NCB][4];
+    read_raw(0, rawq[0]);
+    if (NS > 1) read_raw(1, rawq[1]);
+    load_a(0, afq[0]);
+    transform(rawq[0], bfq[0]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) load_frag(s + 1, bfq[(s + 1) & 1], afq[(s + 1) & 1]);
+      if (s + 1 < NS) transform(rawq[(s + 1) & 1], bfq[(s + 1) & 1]);     // raw(s+1) was requested a full step ago
+      if (s + 2 < NS) read_raw(s + 2, rawq[s & 1]);
+      if (s + 1 < NS) load_a(s + 1, afq[(s + 1) & 1]);
 #pragma unroll
       for (int q = 0; q < LPS; ++q)
         if (s * LPS + q < NL) issue(s * LPS + q, nchk);
@@ -389,7 +422,7 @@ M3D_API int m3d_conv3d_wino_forward(const float* d_in, const float* d_packed, fl
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
     return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
-  if (DHW * 32 >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // 32-bit buffer offsets per batch item
   WEpi ep{d_scale, d_shift, relu, 0};
   hipStream_t st = m3d::as_stream(stream);
   int variant = -1;
@@ -402,7 +435,9 @@ M3D_API int m3d_conv3d_wino_forward(const float* d_in, const float* d_packed, fl
   M3D_W(6, 4, 16, 1, 2, 2, 4, 1)
 #undef M3D_W
   if (variant >= 0) return M3D_EUNSUPPORTED;
-  if (width >= 48) return launch_wino<4, 32, 1, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  if (width >= 48) return launch_wino<4, 32, 1, 2, 4, 2, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  // 24..47: 32 x 4 x 4 voxels x 32 channels per workgroup, 8 waves, 8 channels per barrier (4 % faster than the split-K tile)
+  if (width >= 24 && cout >= 64) return launch_wino<8, 16, 1, 1, 4, 2, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   if (width >= 24) return launch_wino<4, 16, 1, 2, 2, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   return M3D_EUNSUPPORTED;
 }
@@ -414,7 +449,7 @@ M3D_API int m3d_conv3d_wino_forward_pool2(const float* d_in, const float* d_pack
                                           void* stream) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
-  if (DHW * 32 >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
   WEpi ep{d_scale, d_shift, relu, 0};
   return launch_wino<4, 32, 1, 2, 2, 4, 1, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
 }
