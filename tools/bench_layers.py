@@ -10,7 +10,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 L = [("conv1a", 1, 32, 5, size), ("conv2a", 32, 64, 3, size // 2), ("conv2b", 64, 64, 3, size // 2),
      ("conv3a", 64, 128, 3, size // 4), ("conv3b", 128, 128, 3, size // 4), ("conv4a", 128, 256, 3, size // 8),
      ("conv4b", 256, 256, 3, size // 8), ("rpn_conv", 256, 256, 3, size // 8), ("rpn_heads", 256, 245, 1, size // 8)]
-tot_t, tot_f = 0.0, 0.0
+tot_t, tot_f, tot_w = 0.0, 0.0, 0.0
 only = os.environ.get('LAYERS')
 for name, cin, cout, k, s in L:
     if only and name not in only.split(','):
@@ -35,6 +35,22 @@ for name, cin, cout, k, s in L:
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * cin * cout * k ** 3 * s ** 3
     tot_t += ms; tot_f += fl
-    print("%-12s cin %3d cout %3d k%d %3d^3  %8.3f ms  %7.2f GFLOP  %6.2f TFLOP/s (%.1f%% of 157.3)" %
-          (name, cin, cout, k, s, ms, fl / 1e9, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100))
-print("TOTAL %.3f ms  %.2f GFLOP  %.2f TFLOP/s" % (tot_t, tot_f / 1e9, tot_f / tot_t / 1e9))
+    line = "%-12s cin %3d cout %3d k%d %3d^3  direct %8.3f ms %6.2f TFLOP/s (%.1f%%)" % (name, cin, cout, k, s, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100)
+    msw = ms
+    if k == 3 and m3d.WinoConv3d.supports(s) and os.environ.get("M3D_WINO", "1") != "0":      # what the pipeline runs by default
+        wino = m3d.WinoConv3d(w)
+        runw = (lambda: wino.pooled(x, scale=sc, shift=sh, relu=True)) if (fused and wino.supports_pool(s)) else \
+               (lambda: wino(x, scale=sc, shift=sh, relu=True, out=out))
+        for _ in range(3):
+            runw()
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps):
+            runw()
+        e1.record(); torch.cuda.synchronize()
+        msw = e0.elapsed_time(e1) / reps
+        line += "   winograd-x %8.3f ms %6.2f TFLOP/s algorithmic (%.1f%%; %.1f%% executed)" % (
+            msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 2 / 3)
+    tot_w += msw
+    print(line)
+print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (winograd-x where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
+      (tot_t, tot_f / tot_t / 1e9, tot_w, tot_f / tot_w / 1e9, tot_f / 1e9))
