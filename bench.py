@@ -154,8 +154,12 @@ def main():
     cfg = Cfg.nuclei()
     P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=(args.workload == "detect"))
     det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
-    vol_np = tiling.norm1(synth_volume(rank, (VOL, VOL, VOL)), np.float32).astype(np.float32)   # blob.py:179-184
-    vol = torch.from_numpy(vol_np).view(1, 1, VOL, VOL, VOL).cuda()
+    # configs[1]: one volume per step; configs[2] (--workload detect): a batch of 4 volumes per step, one after the other
+    # (the reference's tiler handles one tile at a time, core/test.py:91-145)
+    nvol = 4 if args.workload == "detect" else 1
+    vols = [torch.from_numpy(tiling.norm1(synth_volume(rank * nvol + v, (VOL, VOL, VOL)), np.float32).astype(np.float32))   # blob.py:179-184
+            .view(1, 1, VOL, VOL, VOL).cuda() for v in range(nvol)]
+    vol = vols[0]
 
     # dominant kernel = conv2b (64->64, 3^3, 64^3 voxels) with the fused BN+ReLU+MaxPool epilogue: 57.98 GFLOP
     # ALGORITHMIC per launch, 34 % of the backbone FLOPs and the single largest kernel; launched
@@ -167,7 +171,12 @@ def main():
     dom_ev = []
 
     def step(timed):
-        x = vol
+        out = None
+        for v in vols:
+            out = step_volume(timed, v)
+        return out
+
+    def step_volume(timed, x):
         for li in range(len(det.body)):
             if timed and li in dom_layers:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -216,7 +225,7 @@ def main():
     if rank == 0:
         dom_ms = float(np.mean([a.elapsed_time(b) for a, b in dom_ev]))
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        voxels = world * args.steps * VOL ** 3
+        voxels = world * args.steps * nvol * VOL ** 3
         res = {
             "metric": "voxels/sec end-to-end infer_simple (128^3 vol); 3D-conv TFLOPS vs roofline",
             "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -224,8 +233,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool), 1x1x128x128x128 per rank [configs[1]]"
                                     if args.workload == "backbone" else
-                                    "detection-mode infer tile: backbone+RPN+proposals+RoIAlign3D+2mlp head+NMS, 1x1x128^3 per rank"),
-                       "volumes_per_step": world, "net": "nuclei stride-8 dsn_body, 35 anchors",
+                                    "detection-mode infer: backbone+RPN+proposals+RoIAlign3D+2mlp head+NMS, batch of 4 x (1x128^3) per rank [configs[2]]"),
+                       "volumes_per_step": world * nvol, "net": "nuclei stride-8 dsn_body, 35 anchors",
                        "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9,
                        "backbone_tflops_whole_step": (backbone_flops(VOL) / (dt / args.steps) / 1e12) if args.workload == "backbone" else None},
             "roofline": {"bound": "mfma",
