@@ -17,8 +17,8 @@ class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30):
         self.det = det
         self.cfg = det.cfg
-        self.window_budget = window_budget if peak_chunk is None else None
-        self.peak_chunk = peak_chunk
+        self.peak_chunk = peak_chunk or None          # 0 / None: size the batches from window_budget
+        self.window_budget = window_budget
         P = det.P
         self.layers = []
         names = [c for c, _, _ in __import__("m3d.model", fromlist=["dsn_layers"]).dsn_layers(det.cfg.stride)]
