@@ -102,6 +102,9 @@ def bench_prm(args, rank, world, dist):
                                      "prm_forward_ms": fwd_ms}}))
 
 
+WINO_WORK = {0: 1.0, 1: 2.0 / 3.0, 2: 4.0 / 9.0}   # fraction of the algorithmic multiply-adds issued as MFMA work
+
+
 def pmc_traffic(symbol):
     """HBM-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (tools/pmc_probe.py -> tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json; counters cannot be read from inside
@@ -238,17 +241,21 @@ def main():
                        "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9,
                        "backbone_tflops_whole_step": (backbone_flops(VOL) / (dt / args.steps) / 1e12) if args.workload == "backbone" else None},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b 64->64 3^3 @64^3, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)"
-                                    if det.use_wino else
+                         "kernel": ("conv3d_wino2_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x) + fused BN/ReLU/MaxPool)"
+                                    if det.wino_mode == 2 else
+                                    "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b 64->64 3^3 @64^3, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)"
+                                    if det.wino_mode == 1 else
                                     "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b 64->64 3^3 @64^3 + fused BN/ReLU/MaxPool)"),
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": dom_ms, "algorithmic_gflop_per_launch": dom_flops / 1e9,
-                         "mfma_executed_tflops": achieved * (2.0 / 3.0 if det.use_wino else 1.0),
-                         "mfma_executed_frac": achieved * (2.0 / 3.0 if det.use_wino else 1.0) / FP32_MFMA_PEAK_TFLOPS,
-                         "note": ("achieved counts the ALGORITHMIC 2*Cin*Cout*27 FLOP per output voxel; the Winograd-x kernel issues 2/3 of "
-                                  "them as MFMA work (mfma_executed_*), which is why frac can exceed 1") if det.use_wino else None},
+                         "mfma_executed_tflops": achieved * WINO_WORK[det.wino_mode],
+                         "mfma_executed_frac": achieved * WINO_WORK[det.wino_mode] / FP32_MFMA_PEAK_TFLOPS,
+                         "note": ("achieved counts the ALGORITHMIC 2*Cin*Cout*27 FLOP per output voxel; the Winograd kernel issues %s of "
+                                  "them as MFMA work (mfma_executed_*), which is why frac can exceed 1" % ("4/9" if det.wino_mode == 2 else "2/3"))
+                                 if det.use_wino else None},
         }
-        res["roofline"].update(pmc_traffic("conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>" if det.use_wino else
+        res["roofline"].update(pmc_traffic("conv3d_wino2_kernel<4, 32, 2, 2, true>" if det.wino_mode == 2 else
+                                           "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>" if det.wino_mode == 1 else
                                            "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"))
         if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
             # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's torch-CPU restatement)

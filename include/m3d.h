@@ -137,6 +137,18 @@ int m3d_conv3d_wino_forward_pool2(const float* d_in, const float* d_packed, floa
                                   int depth, int height, int width, const float* d_scale, const float* d_shift,
                                   int relu, void* stream);
 
+/* The same with Winograd F(2x2,3x3) on the (y,x) plane (csrc/conv3d_wino2.hip): 4/9 of the MFMA work; own packed layout
+ * (48 slots per cout x cin); maps >= 24 wide, fused pool >= 48 wide; same few-ulp agreement with the direct kernel. */
+size_t m3d_conv3d_wino2_packed_weight_bytes(int cin, int cout);
+int m3d_conv3d_wino2_pack_weights(const float* d_weight /*[cout,cin,3,3,3]*/, int cin, int cout, float* d_packed,
+                                  void* stream);
+int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                             int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                             void* stream);
+int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                   int depth, int height, int width, const float* d_scale, const float* d_shift,
+                                   int relu, void* stream);
+
 /* Backward-weights and bias gradient of the same stride-1 "same" convolution (what autograd computes for the
  * F.conv3d calls of lib/prm/peak_backprop_3d.py:40-42 and every nn.Conv3d of lib/modeling/DSN.py:19-36 in training):
  *   dW[co,ci,dz,dy,dx] = sum_{b,z,y,x} gy[b,co,z,y,x] * x[b,ci,z+dz-k/2,...]     db[co] = sum gy[b,co,...]

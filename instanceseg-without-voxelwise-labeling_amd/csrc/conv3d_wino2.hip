@@ -1,0 +1,439 @@
+// 3x3x3 forward convolution with Winograd F(2x2, 3x3) on the (y, x) plane, fp32 MFMA implicit GEMM for gfx950.
+// Same operation as conv3d.hip's direct kernel and conv3d_wino.hip's F(2,3)-along-x kernel (stride 1, pad 1, fused
+// per-channel scale/shift + ReLU, optional fused MaxPool3d(2,2): the conv + eval-BN + ReLU [+ pool] groups of
+// lib/modeling/DSN.py:58-67), with 16/36 = 4/9 of the matrix-core work:
+//
+//   per 2x2 output patch and per (ci, dz):  M[eta][xi] = (By^T d Bx)[eta][xi] * (G g G^T)[eta][xi],   Y = A^T M A
+//   with the 1-D F(2,3) matrices  B^T d = (d0-d2, d1+d2, d2-d1, d1-d3),  G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2),
+//   A^T m = (m0+m1+m2, m1-m2-m3)  applied along y (eta) and x (xi); the z taps stay a direct 3-term sum.
+//
+// GEMM view per (eta, xi): i = 32 output channels (A = transformed weights, packed offline: 48 slots per cout x cin),
+// j = 32 patches (XT x-pairs x YT y-pairs), k = 2 input channels.  16 accumulator blocks per wave (256 AGPRs), so the
+// kernel runs ONE wave per SIMD (4-wave workgroups, one per CU) and relies on the long MFMA runs between fragment loads
+// (16 MFMAs = 1024 cycles per K step) instead of a second wave to hide LDS latency.
+// * the input halo tile sits in LDS with x de-interleaved per row (E[u] = in[x0+2u], O[u] = in[x0+2u-1]) exactly as in
+//   conv3d_wino.hip; a lane reads its 4 rows x 4 x-values (16 ds_read_b32, conflict-free: the row pitch is padded so
+//   that two y-pairs land 16 banks apart), combines rows (y transform) and columns (x transform) with 32 VALU ops;
+// * the inverse transform is 12 adds per channel on accumulators of the same lane and leaves each lane with a 2x2
+//   output patch: 8-byte stores, and the fused pool needs no cross-lane step in (y, x), only one LDS exchange in z;
+// * coefficients are +-1, 1/2, 1/4: errors stay at the fp32 few-ulp level (tests: < 1e-5 relative against fp64).
+#include <stdlib.h>
+
+#include "m3d_common.h"
+
+// timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU
+#ifndef M3D_EXP
+#define M3D_EXP 0
+#endif
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WT2 = 48;   // weight slots per (cout, cin): 3 dz x 4 eta x 4 xi
+
+// Wp[cin_pair][cout_block32][dz*16 + eta*4 + xi][lane64] = (G g_dz G^T)[eta][xi], co = cb*32 + (lane&31), ci = 2*pair + (lane>>5)
+__global__ __launch_bounds__(256) void wino2_pack_kernel(const float* __restrict__ w, int cin, int cout, float* __restrict__ wp,
+                                                         int ncb, int npair) {
+  const long long total = (long long)npair * ncb * WT2 * 64;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(e & 63);
+    long long t = e >> 6;
+    const int slot = (int)(t % WT2); t /= WT2;
+    const int cb = (int)(t % ncb); t /= ncb;
+    const int cpair = (int)t;
+    const int co = cb * 32 + (lane & 31), ci = 2 * cpair + (lane >> 5);
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      const int dz = slot >> 4, eta = (slot >> 2) & 3, xi = slot & 3;
+      const float* g = w + ((size_t)co * cin + ci) * 27 + dz * 9;      // g[dy*3 + dx]
+      float col[3];                                                      // (G g)[eta][dx]
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float a = g[dx], b = g[3 + dx], c = g[6 + dx];
+        col[dx] = eta == 0 ? a : eta == 1 ? 0.5f * (a + b + c) : eta == 2 ? 0.5f * (a - b + c) : c;
+      }
+      v = xi == 0 ? col[0] : xi == 1 ? 0.5f * (col[0] + col[1] + col[2]) : xi == 2 ? 0.5f * (col[0] - col[1] + col[2]) : col[2];
+    }
+    wp[e] = v;
+  }
+}
+
+struct W2Epi {
+  const float* scale;
+  const float* shift;
+  int relu;
+  int xcd_map;
+};
+
+__device__ __forceinline__ int xcd_contiguous2(int bid, int n) {
+  const int per = n >> 3, rem = n & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
+// CC input channels per chunk; XT x-pairs and YT = 32/XT y-pairs per wave block; WZ x WY waves (4 per workgroup).
+template <int CC, int XT, int WZ, int WY, bool POOL>
+struct W2Cfg {
+  static constexpr int NT = 256;
+  static constexpr int PP = CC / 2;
+  static constexpr int YT = 32 / XT;
+  static constexpr int TX = 2 * XT, TY = 2 * YT * WY, TZ = WZ;
+  static constexpr int EP = XT + 2;
+  static constexpr int QR = EP / 2;                            // 16-byte quads per row
+  // row pitch: the YT y-pairs of a block sit 2*HXP floats apart; 2*HXP = XT (mod 32) puts them on disjoint banks
+  static constexpr int HXP = (YT == 1) ? 2 * EP : ((2 * EP - XT / 2 + 15) / 16 * 16 + XT / 2);
+  static constexpr int HY = TY + 2, HZ = TZ + 2;
+  static constexpr int CS = HXP * HY * HZ;
+  static constexpr int IN_ELEMS = CC * CS;
+  static constexpr int NQUAD = CC * HZ * HY * QR;
+  static constexpr int W_SEG = WT2 * 64;                       // one cout block
+  static constexpr int W_ELEMS = PP * W_SEG;
+  static constexpr int NI = (NQUAD + NT - 1) / NT;
+  static constexpr int NW4 = (W_ELEMS / 4 + NT - 1) / NT;
+  static constexpr int DUMP = IN_ELEMS + W_ELEMS;              // 2 x 8-byte dump slots behind each buffer (branch-free staging)
+  static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS + ((EP + 2 + 3) / 4) * 4;
+  static constexpr int RED_FLOATS = POOL ? 4 * 16 * 64 : 0;
+  static constexpr int SMEM_FLOATS = 2 * LDS_FLOATS > RED_FLOATS ? 2 * LDS_FLOATS : RED_FLOATS;
+  static_assert(WZ * WY == 4, "4 waves per workgroup, one per SIMD");
+  static_assert(!POOL || WZ == 2, "fused pool: the z pair lives in waves wz = 0, 1");
+  static_assert(HXP % 2 == 0, "8-byte LDS stores");
+  static_assert((W_ELEMS / 4) % NT == 0, "weight staging is branch-free: whole float4 rounds");
+};
+
+template <int CC, int XT, int WZ, int WY, bool POOL>
+__global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                              float* __restrict__ out, int cin, int cout, int D, int H, int W,
+                                                              int tiles_x, int tiles_y, int tiles_z, int ncb_total, W2Epi ep) {
+  using C = W2Cfg<CC, XT, WZ, WY, POOL>;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wz = wave / WY, wy = wave % WY;
+
+  int bid = blockIdx.x;
+  const int co_tiles = (cout + 31) / 32;
+  int cot;
+  if (ep.xcd_map) {
+    bid = xcd_contiguous2(bid, gridDim.x);
+    const int sp = tiles_x * tiles_y * tiles_z;
+    cot = bid / sp; bid -= cot * sp;
+  } else {
+    cot = bid % co_tiles; bid /= co_tiles;
+  }
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int tz = bid;
+  const int b = blockIdx.y;
+  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const size_t DHW = (size_t)D * H * W;
+  const float* in_b = in + (size_t)b * cin * DHW;
+
+  // ---- input staging descriptors: 16-byte quads, see conv3d_wino.hip
+  int gq[C::NI], mq[C::NI], lq[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int e = tid + i * C::NT;
+    gq[i] = 0; mq[i] = 0; lq[i] = C::DUMP;          // quads beyond the tile: masked to zero, written to a dump slot
+    if (e < C::NQUAD) {
+      const int q = e % C::QR;
+      const int row = e / C::QR;
+      const int hy = row % C::HY, hz = (row / C::HY) % C::HZ, ci = row / (C::HY * C::HZ);
+      const int z = z0 + hz - 1, y = y0 + hy - 1, xf = x0 - 1 + 4 * q;
+      const bool rok = (z >= 0) & (z < D) & (y >= 0) & (y < H);
+      int m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
+      long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
+      if (rok && lin < 0) { lin = 0; m |= 16; }
+      mq[i] = m;
+      gq[i] = rok ? (int)(lin * 4) : 0;
+      lq[i] = row * C::HXP + 2 * q;
+    }
+  }
+  f32x4 rin[C::NI];
+  f32x4 rw[C::NW4];
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
+  const int nchunk = (cin + CC - 1) / CC;
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const size_t w_pair_stride4 = (size_t)ncb_total * WT2 * 64 / 4;
+  const size_t w_tile_off4 = (size_t)cot * WT2 * 64 / 4;
+  constexpr int NL = C::NI + C::NW4;
+  auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
+    if (idx < C::NI) {
+      const int voff = gq[idx] + chunk * (int)(CC * DHW * sizeof(float));
+      rin[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
+    } else {
+      const int i = idx - C::NI;
+      const int e = tid + i * C::NT;
+      const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
+      rw[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
+    }
+  };
+  auto commit1 = [&](int idx, float* dst_in, float* dst_w) __attribute__((always_inline)) {
+    if (idx < C::NI) {                                 // branch-free: the K loop must stay one scheduling region
+      const int m = mq[idx];
+      const f32x4 v = rin[idx];
+      const bool sh = (m & 16) != 0;
+      const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
+      const f32x2 ev = {(m & 2) ? v1 : 0.f, (m & 8) ? v3 : 0.f};
+      const f32x2 ov = {(m & 1) ? v0 : 0.f, (m & 4) ? v2 : 0.f};
+      *reinterpret_cast<f32x2*>(dst_in + lq[idx]) = ev;
+      *reinterpret_cast<f32x2*>(dst_in + lq[idx] + C::EP) = ov;
+    } else {
+      const int i = idx - C::NI;
+      reinterpret_cast<f32x4*>(dst_w)[tid + i * C::NT] = rw[i];
+    }
+  };
+
+  f32x16 acc[4][4];   // [eta][xi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[a][x][g] = 0.f;
+
+  const int jt = (lane & 31) % XT, ju = (lane & 31) / XT;
+  // B base: channel half, the wave's z plane, halo row 2*(wy*YT + ju) (= output row pair's y-1), E[jt]
+  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HXP) + 2 * (wy * C::YT + ju) * C::HXP + jt;
+
+#pragma unroll
+  for (int i = 0; i < NL; ++i) issue(i, 0);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) commit1(i, lds, lds + C::IN_ELEMS);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
+    const float* cur_w = cur_in + C::IN_ELEMS;
+    float* nxt_in = lds + ((chunk + 1) & 1) * C::LDS_FLOATS;
+    float* nxt_w = nxt_in + C::IN_ELEMS;
+    const int nchk = min(chunk + 1, nchunk - 1);
+    const float* in_k = cur_in + b_base;
+    const float* w_k = cur_w + lane;
+    constexpr int NS = 3 * C::PP;                      // K steps per chunk: dz x channel pair
+    auto read_raw = [&](int s, float (&r)[4][4]) __attribute__((always_inline)) {
+      const int dz = s / C::PP, pp = s % C::PP;
+      const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {                    // 4 halo rows x (E[t], E[t+1], O[t], O[t+1])
+        r[a][0] = p[a * C::HXP]; r[a][1] = p[a * C::HXP + 1]; r[a][2] = p[a * C::HXP + C::EP]; r[a][3] = p[a * C::HXP + C::EP + 1];
+      }
+    };
+    auto transform = [&](const float (&r)[4][4], float (&bf)[4][4]) __attribute__((always_inline)) {
+#if (M3D_EXP & 4)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bf[a][v] = r[a][v];
+      return;
+#endif
+      float c[4][4];                                   // rows combined (y transform), still raw in x
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        c[0][v] = r[0][v] - r[2][v]; c[1][v] = r[1][v] + r[2][v]; c[2][v] = r[2][v] - r[1][v]; c[3][v] = r[1][v] - r[3][v];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {                    // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
+        bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
+      }
+    };
+    auto load_a = [&](int s, float (&af)[16]) __attribute__((always_inline)) {
+      const int dz = s / C::PP, pp = s % C::PP;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
+    };
+    constexpr int HALF = (NS + 1) / 2;
+    constexpr int LPH = (NL + HALF - 1) / HALF;
+    float raw[2][4][4], bfq[2][4][4], afq[2][16];
+    read_raw(0, raw[0]);
+    if (NS > 1) read_raw(1, raw[1]);
+    load_a(0, afq[0]);
+    transform(raw[0], bfq[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
+      if (s + 2 < NS) read_raw(s + 2, raw[s & 1]);
+      if (s + 1 < NS) load_a(s + 1, afq[(s + 1) & 1]);
+#if !(M3D_EXP & 1)
+#pragma unroll
+      for (int q = 0; q < LPH; ++q)
+        if (s < HALF && s * LPH + q < NL) issue(s * LPH + q, nchk);
+#endif
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          acc[a][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][a * 4 + x], bfq[s & 1][a][x], acc[a][x], 0, 0, 0);
+#if !(M3D_EXP & 1)
+#pragma unroll
+      for (int q = 0; q < LPH; ++q)
+        if (s >= NS - HALF && (s - (NS - HALF)) * LPH + q < NL) commit1((s - (NS - HALF)) * LPH + q, nxt_in, nxt_w);
+#endif
+      // One wave per SIMD: nothing else fills the matrix pipe while this wave issues LDS / VALU / VMEM work, so that work
+      // (all of it for LATER steps, independent of this step's MFMAs) is spread between the 16 MFMAs instead of sitting
+      // in front of them: per MFMA slot 2 LDS reads and 3 VALU ops; VMEM and LDS writes go wherever the scheduler likes.
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if !(M3D_EXP & 2)
+    __syncthreads();
+#endif
+  }
+
+  // ---- inverse transform: over xi, then over eta -> y[row][col] for the lane's 2x2 patch
+  f32x16 yv[2][2];
+  {
+    f32x16 p0[4], p1[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      p0[a] = acc[a][0] + acc[a][1] + acc[a][2];
+      p1[a] = acc[a][1] - acc[a][2] - acc[a][3];
+    }
+    yv[0][0] = p0[0] + p0[1] + p0[2]; yv[1][0] = p0[1] - p0[2] - p0[3];
+    yv[0][1] = p1[0] + p1[1] + p1[2]; yv[1][1] = p1[1] - p1[2] - p1[3];
+  }
+  const int co0 = cot * 32 + 4 * (lane >> 5);
+  const int z = z0 + wz;
+  const int x = x0 + 2 * jt;
+  const int y = y0 + 2 * (wy * C::YT + ju);
+
+  if constexpr (POOL) {
+    // conv + scale/shift + ReLU + MaxPool3d(2,2): the (y, x) 2x2 footprint is in the lane; the z pair is wave wz = 0 / 1
+    float pooled[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = min(co0 + (g & 3) + 8 * (g >> 2), cout - 1);
+      const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v = yv[r][c][g] * sc + sh;
+          if (ep.relu) v = fmaxf(v, 0.f);
+          m = fmaxf(m, v);
+        }
+      pooled[g] = m;
+    }
+    float* red = lds + (size_t)wy * 16 * 64 + lane;     // final barrier of the chunk loop has passed: staging area is free
+    if (wz == 1) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) red[g * 64] = pooled[g];
+    }
+    __syncthreads();
+    if (wz == 1) return;
+    const int PD = D / 2, PH = H / 2, PW = W / 2;
+    const int zp = z0 >> 1, yp = y >> 1, xp = x >> 1;
+    if (zp >= PD || yp >= PH || xp >= PW) return;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = co0 + (g & 3) + 8 * (g >> 2);
+      if (co < cout)
+        out[((size_t)b * cout + co) * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = fmaxf(pooled[g], red[g * 64]);
+    }
+    return;
+  }
+
+  if (!(z < D && y < H && x < W)) return;
+  const bool pair_ok = ((W & 1) == 0);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int co = co0 + (g & 3) + 8 * (g >> 2);
+    if (co >= cout) continue;
+    const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (y + r >= H) continue;
+      float v0 = yv[r][0][g] * sc + sh, v1 = yv[r][1][g] * sc + sh;
+      if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      float* o = out + ((size_t)b * cout + co) * DHW + ((size_t)z * H + y + r) * W + x;
+      if (pair_ok) {
+        *reinterpret_cast<f32x2*>(o) = f32x2{v0, v1};
+      } else {
+        o[0] = v0;
+        if (x + 1 < W) o[1] = v1;
+      }
+    }
+  }
+}
+
+inline int xcd_map_enabled2() {
+  const char* e = getenv("M3D_XCD_MAP");
+  return !(e && e[0] == '0');
+}
+
+template <int CC, int XT, int WZ, int WY, bool POOL = false>
+int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st) {
+  using C = W2Cfg<CC, XT, WZ, WY, POOL>;
+  const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
+  const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;
+  const int co_tiles = (cout + 31) / 32;
+  const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
+  if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
+  ep.xcd_map = xcd_map_enabled2();
+  const size_t lds = sizeof(float) * C::SMEM_FLOATS;
+  if (lds > 160 * 1024) return M3D_EUNSUPPORTED;
+  auto kern = conv3d_wino2_kernel<CC, XT, WZ, WY, POOL>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y, tiles_z,
+                     ncb_total, ep);
+  return m3d::check_launch("conv3d_wino2");
+}
+
+}  // namespace
+
+M3D_API size_t m3d_conv3d_wino2_packed_weight_bytes(int cin, int cout) {
+  if (cin <= 0 || cout <= 0) return 0;
+  const size_t npair = ((cin + 1) / 2 + 15) / 16 * 16, ncb = ((cout + 31) / 32 + 1) / 2 * 2;
+  return sizeof(float) * npair * ncb * (size_t)WT2 * 64;
+}
+
+M3D_API int m3d_conv3d_wino2_pack_weights(const float* d_weight, int cin, int cout, float* d_packed, void* stream) {
+  if (!d_weight || !d_packed || cin <= 0 || cout <= 0) return M3D_EINVAL;
+  const int npair = ((cin + 1) / 2 + 15) / 16 * 16, ncb = ((cout + 31) / 32 + 1) / 2 * 2;
+  hipLaunchKernelGGL(wino2_pack_kernel, dim3(1024), dim3(256), 0, m3d::as_stream(stream), d_weight, cin, cout, d_packed, ncb, npair);
+  return m3d::check_launch("wino2_pack");
+}
+
+M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                                     int height, int width, const float* d_scale, const float* d_shift, int relu, void* stream) {
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
+    return M3D_EINVAL;
+  const size_t DHW = (size_t)depth * height * width;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
+  W2Epi ep{d_scale, d_shift, relu, 0};
+  hipStream_t st = m3d::as_stream(stream);
+  int variant = -1;
+  if (const char* tv = getenv("M3D_TUNE_WINO2")) variant = atoi(tv);
+#define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
+  M3D_W2(1, 4, 32, 4, 1)
+  M3D_W2(2, 4, 32, 1, 4)
+  M3D_W2(3, 4, 16, 2, 2)      // 32 x 8 y x 2 z
+  M3D_W2(4, 4, 16, 4, 1)
+  M3D_W2(5, 4, 16, 1, 4)
+#undef M3D_W2
+  if (variant >= 0) return M3D_EUNSUPPORTED;
+  if (width >= 48) return launch_wino2<4, 32, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  if (width >= 24) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  return M3D_EUNSUPPORTED;
+}
+
+M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                           int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                           void* stream) {
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
+  const size_t DHW = (size_t)depth * height * width;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
+  W2Epi ep{d_scale, d_shift, relu, 0};
+  return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
+}

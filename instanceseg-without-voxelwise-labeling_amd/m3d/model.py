@@ -41,14 +41,16 @@ class DetectorM3D:
             scale = (params[b + ".weight"] / torch.sqrt(params[b + ".running_var"] + BN_EPS)).contiguous()
             shift = ((params[c + ".bias"] - params[b + ".running_mean"]) * scale + params[b + ".bias"]).contiguous()
             self.body.append((conv, scale, shift, pool))
-        # plain-forward 3x3x3 layers also get Winograd-x weights (2/3 of the MFMA work; maps >= 24 voxels wide).
+        # plain-forward 3x3x3 layers also get Winograd weights: F(2x2,3x3) on (y,x) (4/9 of the MFMA work; M3D_WINO=2,
+        # default) or F(2,3) along x (2/3; M3D_WINO=1); maps >= 24 voxels wide.  M3D_WINO=0: direct kernels only.
         # The PRM engine keeps using the direct kernels in self.body (its masks test exact zeros).
-        self.use_wino = os.environ.get("M3D_WINO", "1") != "0"
-        self.body_wino = [ops.WinoConv3d(params["Conv_Body." + cname + ".weight"])
+        self.wino_mode = int(os.environ.get("M3D_WINO", "2"))
+        self.use_wino = self.wino_mode != 0
+        self.body_wino = [ops.WinoConv3d(params["Conv_Body." + cname + ".weight"], two_d=(self.wino_mode == 2))
                           if (self.use_wino and params["Conv_Body." + cname + ".weight"].shape[-1] == 3) else None
                           for cname, _, _ in dsn_layers(cfg.stride)]
         self.rpn_conv = ops.PackedConv3d(params["RPN.RPN_conv.weight"])
-        self.rpn_conv_wino = ops.WinoConv3d(params["RPN.RPN_conv.weight"]) if self.use_wino else None
+        self.rpn_conv_wino = ops.WinoConv3d(params["RPN.RPN_conv.weight"], two_d=(self.wino_mode == 2)) if self.use_wino else None
         self.rpn_conv_bias = params["RPN.RPN_conv.bias"].contiguous()
         self.A = params["RPN.RPN_cls_score.weight"].shape[0]
         # the two 1x1x1 heads share their input: one conv with A + 6A output channels (rpn_heads.py:96-98)

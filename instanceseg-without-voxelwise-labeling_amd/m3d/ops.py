@@ -343,17 +343,25 @@ def roi_normalize(image_u16, prm_u8, boxes, mode):
 
 # ------------------------------------------------------------------ Winograd-x 3x3x3 forward
 class WinoConv3d(object):
-    """3x3x3 forward conv (stride 1, pad 1) through the Winograd-F(2,3)-along-x MFMA kernel; weights packed once.
+    """3x3x3 forward conv (stride 1, pad 1) through a Winograd MFMA kernel; weights transformed and packed once.
+    two_d=False: F(2,3) along x (2/3 of the MFMA work); two_d=True: F(2x2,3x3) on the (y,x) plane (4/9).
     `supports(width)` says whether the kernel has a tile configuration for the map (else use PackedConv3d)."""
 
-    def __init__(self, weight):
+    def __init__(self, weight, two_d=False):
         _need_gpu(weight)
         w = _f32c(weight)
         assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
-        nbytes = lib().m3d_conv3d_wino_packed_weight_bytes(self.cin, self.cout)
+        self.two_d = bool(two_d)
+        L = lib()
+        self._bytes, self._pack, self._fwd, self._pool = \
+            (L.m3d_conv3d_wino2_packed_weight_bytes, L.m3d_conv3d_wino2_pack_weights, L.m3d_conv3d_wino2_forward,
+             L.m3d_conv3d_wino2_forward_pool2) if self.two_d else \
+            (L.m3d_conv3d_wino_packed_weight_bytes, L.m3d_conv3d_wino_pack_weights, L.m3d_conv3d_wino_forward,
+             L.m3d_conv3d_wino_forward_pool2)
+        nbytes = self._bytes(self.cin, self.cout)
         self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
-        check(lib().m3d_conv3d_wino_pack_weights(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
+        check(self._pack(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
 
     @staticmethod
     def supports(width):
@@ -366,9 +374,9 @@ class WinoConv3d(object):
         assert cin == self.cin
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
-        check(lib().m3d_conv3d_wino_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
-                                            _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
-                                            int(bool(relu)), _stream()), "conv3d_wino_forward")
+        check(self._fwd(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                        _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
+                        int(bool(relu)), _stream()), "conv3d_wino_forward")
         return out
 
     @staticmethod
@@ -382,9 +390,9 @@ class WinoConv3d(object):
         B, cin, D, H, W = x.shape
         assert cin == self.cin
         out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
-        check(lib().m3d_conv3d_wino_forward_pool2(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
-                                                  _ptr(scale) if scale is not None else None,
-                                                  _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),
+        check(self._pool(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                         _ptr(scale) if scale is not None else None,
+                         _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),
               "conv3d_wino_forward_pool2")
         return out
 

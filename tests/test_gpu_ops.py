@@ -216,16 +216,17 @@ def test_conv3d_wgrad_and_bias_grad_vs_fp64(m3d, B, cin, cout, D, H, W, k):
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [
     (1, 32, 64, 6, 9, 64), (1, 64, 64, 5, 8, 70), (2, 5, 7, 4, 5, 48), (1, 64, 128, 6, 11, 32), (1, 128, 128, 4, 6, 37),
     (1, 33, 40, 3, 4, 24), (1, 16, 96, 7, 13, 129), (1, 256, 256, 3, 25, 25), (1, 2, 200, 2, 3, 100)])
-def test_conv3d_winograd_x_vs_fp64(m3d, B, cin, cout, D, H, W):
-    """The F(2,3)-along-x kernel computes the same conv + scale/shift + ReLU as the direct kernel (every tile
-    configuration, ragged sizes, odd widths -> unpaired stores)."""
+@pytest.mark.parametrize("two_d", [False, True])
+def test_conv3d_winograd_vs_fp64(m3d, B, cin, cout, D, H, W, two_d):
+    """The F(2,3)-along-x and F(2x2,3x3)-on-(y,x) kernels compute the same conv + scale/shift + ReLU (+ fused pool) as
+    the direct kernel (every tile configuration, ragged sizes, odd widths / heights -> unpaired stores)."""
     g = torch.Generator().manual_seed(B * 1000 + cin + cout + W)
     x = torch.randn(B, cin, D, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
     sc = torch.rand(cout, generator=g) + 0.5
     sh = torch.randn(cout, generator=g)
     ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
-    conv = m3d.WinoConv3d(w.cuda())
+    conv = m3d.WinoConv3d(w.cuda(), two_d=two_d)
     y = conv(x.cuda()).cpu().double()
     err = (y - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-4, err                                   # north_star tolerance

@@ -35,6 +35,25 @@ for name, cin, cout, s, variants in L:
     ref = torch.relu(torch.nn.functional.conv3d(x[:, :, :10].double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))[:, :, :8]
     ms_d = timeit(lambda: direct(x, scale=sc, shift=sh, relu=True, out=out))
     print("%-7s direct            %.3f ms %6.1f TF  err %.2e" % (name, ms_d, fl / ms_d / 1e9, (yd[:, :, :8].double() - ref).abs().max().item() / ref.abs().max().item()))
+    w2 = m3d.WinoConv3d(w, two_d=True)
+    for v2 in [None] + ([0, 1, 2] if s >= 48 else [3, 4, 5]):
+        if v2 is None:
+            os.environ.pop("M3D_TUNE_WINO2", None)
+        else:
+            os.environ["M3D_TUNE_WINO2"] = str(v2)
+        try:
+            yw = w2(x, scale=sc, shift=sh, relu=True)
+            err = (yw[:, :, :8].double() - ref).abs().max().item() / ref.abs().max().item()
+            ms = timeit(lambda: w2(x, scale=sc, shift=sh, relu=True, out=out))
+            print("%-7s wino2D variant %-4s %.3f ms %6.1f TF (algorithmic)  err vs fp64 %.2e" % (name, v2, ms, fl / ms / 1e9, err))
+        except Exception as e:
+            print("%-7s wino2D variant %-4s failed: %s" % (name, v2, e))
+    os.environ.pop("M3D_TUNE_WINO2", None)
+    if s >= 48:
+        yp = w2.pooled(x, scale=sc, shift=sh, relu=True)
+        errp = (yp - torch.nn.functional.max_pool3d(yd, 2, 2)).abs().max().item() / yd.abs().max().item()
+        ms = timeit(lambda: w2.pooled(x, scale=sc, shift=sh, relu=True))
+        print("%-7s wino2D +pool       %.3f ms %6.1f TF (algorithmic)  err vs direct+pool %.2e" % (name, ms, fl / ms / 1e9, errp))
     for v in [None] + variants:
         if v is None:
             os.environ.pop("M3D_TUNE_WINO", None)
