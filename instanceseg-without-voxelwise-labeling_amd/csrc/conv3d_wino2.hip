@@ -152,30 +152,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
       lq[i] = row * C::HXP + 2 * q;
     }
   }
-  f32x4 rin[C::NI];
-  f32x4 rw[C::NW4];
+  // weights and input quads are staged one after the other through the SAME registers (weights: loads in step 0,
+  // LDS writes in step 2; input: loads in step 2, writes in step NS-2)
+  constexpr int NSTG = C::NI > C::NW4 ? C::NI : C::NW4;
+  f32x4 stg[NSTG];
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
   const int nchunk = (cin + CC - 1) / CC;
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
   const size_t w_pair_stride4 = (size_t)ncb_total * WT2 * 64 / 4;
   const size_t w_tile_off4 = (size_t)cot * WT2 * 64 / 4;
-  constexpr int NL = C::NI + C::NW4;
   auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
     if (idx < C::NI) {
       const int voff = gq[idx] + chunk * (int)(CC * DHW * sizeof(float));
-      rin[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
+      stg[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
     } else {
       const int i = idx - C::NI;
       const int e = tid + i * C::NT;
       const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
-      rw[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
+      stg[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
     }
   };
   auto commit1 = [&](int idx, float* dst_in, float* dst_w) __attribute__((always_inline)) {
     if (idx < C::NI) {                                 // branch-free: the K loop must stay one scheduling region
       const int m = mq[idx];
-      const f32x4 v = rin[idx];
+      const f32x4 v = stg[idx];
       const bool sh = (m & 16) != 0;
       const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
       const f32x2 ev = {(m & 2) ? v1 : 0.f, (m & 8) ? v3 : 0.f};
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
       *reinterpret_cast<f32x2*>(dst_in + lq[idx] + C::EP) = ov;
     } else {
       const int i = idx - C::NI;
-      reinterpret_cast<f32x4*>(dst_w)[tid + i * C::NT] = rw[i];
+      reinterpret_cast<f32x4*>(dst_w)[tid + i * C::NT] = stg[i];
     }
   };
 
@@ -200,11 +201,61 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   // B base: channel half, the wave's z plane, halo row 2*(wy*YT + ju) (= output row pair's y-1), E[jt]
   const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HXP) + 2 * (wy * C::YT + ju) * C::HXP + jt;
 
+  constexpr int NS = 3 * C::PP;                        // K steps per chunk: dz x channel pair
+  static_assert(NS % 2 == 0 && NS >= 4, "the fragment rings are indexed statically across the chunk loop");
+  auto read_raw = [&](const float* in_k, int s, float (&r)[4][4]) __attribute__((always_inline)) {
+    const int dz = s / C::PP, pp = s % C::PP;
+    const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP);
 #pragma unroll
-  for (int i = 0; i < NL; ++i) issue(i, 0);
+    for (int a = 0; a < 4; ++a) {                      // 4 halo rows x (E[t], E[t+1], O[t], O[t+1])
+      r[a][0] = p[a * C::HXP]; r[a][1] = p[a * C::HXP + 1]; r[a][2] = p[a * C::HXP + C::EP]; r[a][3] = p[a * C::HXP + C::EP + 1];
+    }
+  };
+  auto transform = [&](const float (&r)[4][4], float (&bf)[4][4]) __attribute__((always_inline)) {
+#if (M3D_EXP & 4)
 #pragma unroll
-  for (int i = 0; i < NL; ++i) commit1(i, lds, lds + C::IN_ELEMS);
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bf[a][v] = r[a][v];
+    return;
+#endif
+    float c[4][4];                                     // rows combined (y transform), still raw in x
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      c[0][v] = r[0][v] - r[2][v]; c[1][v] = r[1][v] + r[2][v]; c[2][v] = r[2][v] - r[1][v]; c[3][v] = r[1][v] - r[3][v];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                      // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
+      bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
+    }
+  };
+  auto load_a = [&](const float* w_k, int s, float (&af)[16]) __attribute__((always_inline)) {
+    const int dz = s / C::PP, pp = s % C::PP;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
+  };
+
+  // ---- prologue: chunk 0 -> buffer 0, first fragments
+#pragma unroll
+  for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, 0);
+#pragma unroll
+  for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, lds, lds + C::IN_ELEMS);
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) issue(i, 0);
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) commit1(i, lds, lds + C::IN_ELEMS);
   __syncthreads();
+  float raw[2][4][4], bfq[2][4][4], afq[2][16];
+  read_raw(lds + b_base, 0, raw[0]);
+  read_raw(lds + b_base, 1, raw[1]);
+  load_a(lds + C::IN_ELEMS + lane, 0, afq[0]);
+  transform(raw[0], bfq[0]);
+
+  // ---- K loop, software-pipelined ACROSS chunks.  With one wave per SIMD nothing hides a refill of the fragment
+  // pipeline after the chunk barrier, so the barrier sits at the end of step NS-2 (all staging writes of the next chunk
+  // are done by then and every LDS read of the current chunk has been issued and waited for) and the last step's 16
+  // MFMAs cover the first fragment reads of the next chunk.
+  constexpr int SW = 0, SX = (NS - 2) / 2;             // weights: loads in step SW, writes in step SX; input: loads SX, writes NS-2
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
     const float* cur_w = cur_in + C::IN_ELEMS;
@@ -213,54 +264,28 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
     const int nchk = min(chunk + 1, nchunk - 1);
     const float* in_k = cur_in + b_base;
     const float* w_k = cur_w + lane;
-    constexpr int NS = 3 * C::PP;                      // K steps per chunk: dz x channel pair
-    auto read_raw = [&](int s, float (&r)[4][4]) __attribute__((always_inline)) {
-      const int dz = s / C::PP, pp = s % C::PP;
-      const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {                    // 4 halo rows x (E[t], E[t+1], O[t], O[t+1])
-        r[a][0] = p[a * C::HXP]; r[a][1] = p[a * C::HXP + 1]; r[a][2] = p[a * C::HXP + C::EP]; r[a][3] = p[a * C::HXP + C::EP + 1];
-      }
-    };
-    auto transform = [&](const float (&r)[4][4], float (&bf)[4][4]) __attribute__((always_inline)) {
-#if (M3D_EXP & 4)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) bf[a][v] = r[a][v];
-      return;
-#endif
-      float c[4][4];                                   // rows combined (y transform), still raw in x
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        c[0][v] = r[0][v] - r[2][v]; c[1][v] = r[1][v] + r[2][v]; c[2][v] = r[2][v] - r[1][v]; c[3][v] = r[1][v] - r[3][v];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {                    // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
-        bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
-      }
-    };
-    auto load_a = [&](int s, float (&af)[16]) __attribute__((always_inline)) {
-      const int dz = s / C::PP, pp = s % C::PP;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
-    };
-    constexpr int HALF = (NS + 1) / 2;
-    constexpr int LPH = (NL + HALF - 1) / HALF;
-    float raw[2][4][4], bfq[2][4][4], afq[2][16];
-    read_raw(0, raw[0]);
-    if (NS > 1) read_raw(1, raw[1]);
-    load_a(0, afq[0]);
-    transform(raw[0], bfq[0]);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
-      if (s + 2 < NS) read_raw(s + 2, raw[s & 1]);
-      if (s + 1 < NS) load_a(s + 1, afq[(s + 1) & 1]);
+      if (s + 2 < NS) read_raw(in_k, s + 2, raw[s & 1]);
+      if (s + 1 < NS) load_a(w_k, s + 1, afq[(s + 1) & 1]);
+      if (s == NS - 1) {                               // next chunk's first fragments (its buffer is complete: barrier below)
+        read_raw(nxt_in + b_base, 0, raw[0]);
+        read_raw(nxt_in + b_base, 1, raw[1]);
+        load_a(nxt_w + lane, 0, afq[0]);
+        transform(raw[0], bfq[0]);
+      }
 #if !(M3D_EXP & 1)
+      if (s == SW) {
 #pragma unroll
-      for (int q = 0; q < LPH; ++q)
-        if (s < HALF && s * LPH + q < NL) issue(s * LPH + q, nchk);
+        for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, nchk);
+      }
+      if (s == SX) {
+#pragma unroll
+        for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, nxt_in, nxt_w);
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) issue(i, nchk);
+      }
 #endif
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -268,9 +293,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
         for (int x = 0; x < 4; ++x)
           acc[a][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][a * 4 + x], bfq[s & 1][a][x], acc[a][x], 0, 0, 0);
 #if !(M3D_EXP & 1)
+      if (s == NS - 2) {
 #pragma unroll
-      for (int q = 0; q < LPH; ++q)
-        if (s >= NS - HALF && (s - (NS - HALF)) * LPH + q < NL) commit1((s - (NS - HALF)) * LPH + q, nxt_in, nxt_w);
+        for (int i = 0; i < C::NI; ++i) commit1(i, nxt_in, nxt_w);
+      }
 #endif
       // One wave per SIMD: nothing else fills the matrix pipe while this wave issues LDS / VALU / VMEM work, so that work
       // (all of it for LATER steps, independent of this step's MFMAs) is spread between the 16 MFMAs instead of sitting
@@ -282,11 +308,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
 #if !(M3D_EXP & 2)
-    __syncthreads();
+      if (s == NS - 2) __syncthreads();
 #endif
+    }
   }
+  __syncthreads();                                     // the pool exchange below reuses the staging area
 
   // ---- inverse transform: over xi, then over eta -> y[row][col] for the lane's 2x2 patch
   f32x16 yv[2][2];
