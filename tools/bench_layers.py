@@ -37,20 +37,23 @@ for name, cin, cout, k, s in L:
     tot_t += ms; tot_f += fl
     line = "%-12s cin %3d cout %3d k%d %3d^3  direct %8.3f ms %6.2f TFLOP/s (%.1f%%)" % (name, cin, cout, k, s, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100)
     msw = ms
-    if k == 3 and m3d.WinoConv3d.supports(s) and os.environ.get("M3D_WINO", "1") != "0":      # what the pipeline runs by default
-        wino = m3d.WinoConv3d(w)
-        runw = (lambda: wino.pooled(x, scale=sc, shift=sh, relu=True)) if (fused and wino.supports_pool(s)) else \
-               (lambda: wino(x, scale=sc, shift=sh, relu=True, out=out))
-        for _ in range(3):
-            runw()
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(reps):
-            runw()
-        e1.record(); torch.cuda.synchronize()
-        msw = e0.elapsed_time(e1) / reps
-        line += "   winograd-x %8.3f ms %6.2f TFLOP/s algorithmic (%.1f%%; %.1f%% executed)" % (
-            msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 2 / 3)
+    mode = int(os.environ.get("M3D_WINO", "2"))
+    if k == 3 and m3d.WinoConv3d.supports(s) and mode != 0:                  # what the pipeline runs by default
+        for two_d in ((False, True) if mode == 2 else (False,)):
+            wino = m3d.WinoConv3d(w, two_d=two_d)
+            runw = (lambda: wino.pooled(x, scale=sc, shift=sh, relu=True)) if (fused and wino.supports_pool(s)) else \
+                   (lambda: wino(x, scale=sc, shift=sh, relu=True, out=out))
+            for _ in range(3):
+                runw()
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(reps):
+                runw()
+            e1.record(); torch.cuda.synchronize()
+            msw = e0.elapsed_time(e1) / reps
+            frac = 4.0 / 9.0 if two_d else 2.0 / 3.0
+            line += "   %s %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% executed)" % (
+                "F(2x2,3x3)" if two_d else "F(2,3)x", msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * frac)
     tot_w += msw
     print(line)
-print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (winograd-x where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
+print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (Winograd where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
       (tot_t, tot_f / tot_t / 1e9, tot_w, tot_f / tot_w / 1e9, tot_f / 1e9))
