@@ -145,6 +145,13 @@ int m3d_conv3d_wino2_pack_weights(const float* d_weight /*[cout,cin,3,3,3]*/, in
 int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                              int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                              void* stream);
+/* small maps (12..23 voxels wide, e.g. the 16^3 stage-4 layers): 16x16x2 output tiles with split-K over workgroups;
+ * partial results go to the caller's workspace and are summed in a fixed order by a second kernel (deterministic).
+ * m3d_conv3d_wino2_forward_ws dispatches to m3d_conv3d_wino2_forward for maps >= 24 wide (workspace unused). */
+size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
+int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                void* d_ws, size_t ws_bytes, void* stream);
 int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                    int depth, int height, int width, const float* d_scale, const float* d_shift,
                                    int relu, void* stream);

@@ -66,6 +66,10 @@ struct W2Epi {
   const float* shift;
   int relu;
   int xcd_map;
+  // split-K over workgroups (small maps: too few output blocks to fill the chip): blockIdx.z = slice; slice s handles
+  // channel chunks [s*cps, (s+1)*cps) and writes its un-scaled partial result to out + s*slice_stride
+  int ksplit, cps;
+  size_t slice_stride;
 };
 
 __device__ __forceinline__ int xcd_contiguous2(int bid, int n) {
@@ -156,7 +160,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   f32x4 stg[NSTG];
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
-  const int nchunk = (cin + CC - 1) / CC;
+  const int nchunk_all = (cin + CC - 1) / CC;
+  const int c_begin = ep.ksplit > 1 ? (int)blockIdx.z * ep.cps : 0;
+  const int nchunk = ep.ksplit > 1 ? min(nchunk_all, c_begin + ep.cps) : nchunk_all;     // one past this slice's last chunk
+  if (ep.ksplit > 1) out += (size_t)blockIdx.z * ep.slice_stride;
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
   const size_t w_pair_stride4 = (size_t)ncb_total * WT2 * 64 / 4;
   const size_t w_tile_off4 = (size_t)cot * WT2 * 64 / 4;
@@ -235,11 +242,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
 
   // ---- prologue: chunk 0 -> buffer 0, first fragments
 #pragma unroll
-  for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, 0);
+  for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, c_begin);
 #pragma unroll
   for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, lds, lds + C::IN_ELEMS);
 #pragma unroll
-  for (int i = 0; i < C::NI; ++i) issue(i, 0);
+  for (int i = 0; i < C::NI; ++i) issue(i, c_begin);
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) commit1(i, lds, lds + C::IN_ELEMS);
   __syncthreads();
@@ -254,10 +261,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   // are done by then and every LDS read of the current chunk has been issued and waited for) and the last step's 16
   // MFMAs cover the first fragment reads of the next chunk.
   constexpr int SW = 0, SX = (NS - 2) / 2;             // weights: loads in step SW, writes in step SX; input: loads SX, writes NS-2
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const float* cur_in = lds + (chunk & 1) * C::LDS_FLOATS;
+  for (int chunk = c_begin; chunk < nchunk; ++chunk) {
+    const float* cur_in = lds + ((chunk - c_begin) & 1) * C::LDS_FLOATS;
     const float* cur_w = cur_in + C::IN_ELEMS;
-    float* nxt_in = lds + ((chunk + 1) & 1) * C::LDS_FLOATS;
+    float* nxt_in = lds + ((chunk - c_begin + 1) & 1) * C::LDS_FLOATS;
     float* nxt_w = nxt_in + C::IN_ELEMS;
     const int nchk = min(chunk + 1, nchunk - 1);
     const float* in_k = cur_in + b_base;
@@ -399,13 +406,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   }
 }
 
+// split-K epilogue: out = act(scale * sum_s partial[s] + shift), fixed summation order
+__global__ __launch_bounds__(256) void wino2_reduce_kernel(const float* __restrict__ ws, int ksplit, size_t slice_stride,
+                                                           float* __restrict__ out, int cout, size_t DHW, size_t total,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += ws[s * slice_stride + i];
+    const int co = (int)((i / DHW) % cout);
+    v = v * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+    out[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
 inline int xcd_map_enabled2() {
   const char* e = getenv("M3D_XCD_MAP");
   return !(e && e[0] == '0');
 }
 
 template <int CC, int XT, int WZ, int WY, bool POOL = false>
-int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st) {
+int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
+                 int ksplit = 1) {
   using C = W2Cfg<CC, XT, WZ, WY, POOL>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
   const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;
@@ -418,8 +439,8 @@ int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, i
   auto kern = conv3d_wino2_kernel<CC, XT, WZ, WY, POOL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y, tiles_z,
-                     ncb_total, ep);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B, ksplit), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
+                     tiles_z, ncb_total, ep);
   return m3d::check_launch("conv3d_wino2");
 }
 
@@ -444,7 +465,7 @@ M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, f
     return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
-  W2Epi ep{d_scale, d_shift, relu, 0};
+  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
   hipStream_t st = m3d::as_stream(stream);
   int variant = -1;
   if (const char* tv = getenv("M3D_TUNE_WINO2")) variant = atoi(tv);
@@ -468,6 +489,56 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
-  W2Epi ep{d_scale, d_shift, relu, 0};
+  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
   return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
+}
+
+// ---- small maps (12..23 voxels wide, e.g. the 16^3 stage-4 layers): 16x16x2 output tiles and split-K over workgroups
+namespace {
+struct SplitPlan { int ksplit, cps; size_t slice; };
+SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int width) {
+  const long long tiles = (long long)((width + 15) / 16) * ((height + 15) / 16) * ((depth + 1) / 2) * ((cout + 31) / 32) * batch;
+  const int nchunk = (cin + 3) / 4;
+  int ks = (int)(256 / (tiles > 0 ? tiles : 1));             // one workgroup per CU (256 CUs), never a ragged second round
+  if (ks > 8) ks = 8;
+  if (ks > nchunk) ks = nchunk;
+  if (ks < 1) ks = 1;
+  const int cps = (nchunk + ks - 1) / ks;
+  ks = (nchunk + cps - 1) / cps;                             // no empty slice
+  return SplitPlan{ks, cps, (size_t)batch * cout * depth * height * width};
+}
+}  // namespace
+
+M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0 || width >= 24 || width < 12) return 0;
+  const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
+  return p.ksplit > 1 ? p.ksplit * p.slice * sizeof(float) : 0;
+}
+
+M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                        int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                        void* d_ws, size_t ws_bytes, void* stream) {
+  if (width >= 24)
+    return m3d_conv3d_wino2_forward(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, d_scale, d_shift, relu, stream);
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
+    return M3D_EINVAL;
+  if (width < 12) return M3D_EUNSUPPORTED;
+  const size_t DHW = (size_t)depth * height * width;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
+  hipStream_t st = m3d::as_stream(stream);
+  const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
+  if (p.ksplit <= 1) {
+    W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
+    return launch_wino2<4, 8, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  }
+  if (!d_ws || ws_bytes < p.ksplit * p.slice * sizeof(float)) return M3D_EWORKSPACE;
+  W2Epi ep{nullptr, nullptr, 0, 0, p.ksplit, p.cps, p.slice};
+  const int rc = launch_wino2<4, 8, 2, 2>(d_in, d_packed, (float*)d_ws, batch, cin, cout, depth, height, width, ep, st, p.ksplit);
+  if (rc != M3D_OK) return rc;
+  const size_t total = p.slice;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, p.ksplit, p.slice, d_out, cout,
+                     DHW, total, d_scale, d_shift, relu);
+  return m3d::check_launch("wino2_reduce");
 }

@@ -363,9 +363,11 @@ class WinoConv3d(object):
         self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
         check(self._pack(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
 
-    @staticmethod
-    def supports(width):
-        return width >= 24
+    def supports(self_or_width, width=None):
+        """supports(width): maps >= 24 voxels wide; the 2-D kernel also has a split-K path for 12..23."""
+        if width is None:                       # called on the class: WinoConv3d.supports(w)
+            return self_or_width >= 24
+        return width >= (12 if self_or_width.two_d else 24)
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None):
         _need_gpu(x)
@@ -374,6 +376,15 @@ class WinoConv3d(object):
         assert cin == self.cin
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
+        if self.two_d and W < 24:
+            wsb = lib().m3d_conv3d_wino2_workspace_bytes(B, cin, self.cout, D, H, W)
+            if getattr(self, "_ws", None) is None or self._ws.numel() < wsb or self._ws.device != x.device:
+                self._ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
+            check(lib().m3d_conv3d_wino2_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                                                    _ptr(scale) if scale is not None else None,
+                                                    _ptr(shift) if shift is not None else None, int(bool(relu)),
+                                                    _ptr(self._ws), C.c_size_t(wsb), _stream()), "conv3d_wino2_forward_ws")
+            return out
         check(self._fwd(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                         _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
                         int(bool(relu)), _stream()), "conv3d_wino_forward")

@@ -241,11 +241,33 @@ def test_conv3d_winograd_vs_fp64(m3d, B, cin, cout, D, H, W, two_d):
         assert (yp - refp).abs().max().item() / refp.abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 128, 256, 16, 16, 16), (1, 256, 256, 8, 25, 23), (2, 20, 40, 3, 13, 12),
+                                                (1, 256, 70, 5, 9, 17), (1, 6, 33, 2, 30, 21)])
+def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
+    """Maps 12..23 wide (the 16^3 stage-4 layers): 16x16x2 tiles, K split over workgroups, fixed-order reduction."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = torch.randn(B, cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1)
+                     + sh.double().view(1, -1, 1, 1, 1))
+    conv = m3d.WinoConv3d(w.cuda(), two_d=True)
+    assert conv.supports(W)
+    y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    assert torch.equal(y, conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True))      # deterministic
+    assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+
+
 def test_conv3d_winograd_rejects_narrow_maps(m3d):
     conv = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda())
     assert not conv.supports(16) and conv.supports(24) and not conv.supports_pool(32)
     with pytest.raises(m3d.M3DError):
         conv(torch.randn(1, 4, 4, 16, 16).cuda())
+    conv2 = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda(), two_d=True)
+    assert conv2.supports(16) and not conv2.supports(11)
+    with pytest.raises(m3d.M3DError):
+        conv2(torch.randn(1, 4, 4, 8, 8).cuda())
 
 
 def test_conv3d_linearity_full_size(m3d):

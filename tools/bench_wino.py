@@ -7,7 +7,8 @@ import torch, m3d
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 L = [("conv2a", 32, 64, size // 2, [0, 1]), ("conv2b", 64, 64, size // 2, [0, 1]),
-     ("conv3a", 64, 128, size // 4, [4, 5, 6]), ("conv3b", 128, 128, size // 4, [4, 5, 6])]
+     ("conv3a", 64, 128, size // 4, [4, 5, 6]), ("conv3b", 128, 128, size // 4, [4, 5, 6]),
+     ("conv4a", 128, 256, size // 8, []), ("conv4b", 256, 256, size // 8, [])]
 
 
 def timeit(fn, reps=20):
@@ -36,7 +37,7 @@ for name, cin, cout, s, variants in L:
     ms_d = timeit(lambda: direct(x, scale=sc, shift=sh, relu=True, out=out))
     print("%-7s direct            %.3f ms %6.1f TF  err %.2e" % (name, ms_d, fl / ms_d / 1e9, (yd[:, :, :8].double() - ref).abs().max().item() / ref.abs().max().item()))
     w2 = m3d.WinoConv3d(w, two_d=True)
-    for v2 in [None] + ([0, 1, 2] if s >= 48 else [3, 4, 5]):
+    for v2 in [None] + ([0, 1, 2] if s >= 48 else [3, 4, 5] if s >= 24 else []):
         if v2 is None:
             os.environ.pop("M3D_TUNE_WINO2", None)
         else:
@@ -54,7 +55,7 @@ for name, cin, cout, s, variants in L:
         errp = (yp - torch.nn.functional.max_pool3d(yd, 2, 2)).abs().max().item() / yd.abs().max().item()
         ms = timeit(lambda: w2.pooled(x, scale=sc, shift=sh, relu=True))
         print("%-7s wino2D +pool       %.3f ms %6.1f TF (algorithmic)  err vs direct+pool %.2e" % (name, ms, fl / ms / 1e9, errp))
-    for v in [None] + variants:
+    for v in ([None] + variants) if s >= 24 else []:
         if v is None:
             os.environ.pop("M3D_TUNE_WINO", None)
         else:
