@@ -186,9 +186,10 @@ def f_conv(rs):
         refx = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), 1, k // 2)
         gx = m3d.PackedConv3d(w.cuda(), mode=m3d.W_DGRAD)(gy.cuda()).cpu().double()
         assert (gx - refx).abs().max().item() / max(refx.abs().max().item(), 1e-3) < 1e-5, ("conv dgrad", B, cin, cout, D, H, W, k)
-    if k == 3 and W >= 24:                         # Winograd-x forward (+ fused pool when it applies)
+    two_d = bool(rs.randint(2))
+    if k == 3 and W >= (12 if two_d else 24):      # Winograd forward (split-K path below 24 wide; fused pool when it applies)
         sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)); sh = torch.from_numpy(rs.randn(cout).astype(np.float32))
-        wc = m3d.WinoConv3d(w.cuda(), two_d=bool(rs.randint(2)))
+        wc = m3d.WinoConv3d(w.cuda(), two_d=two_d)
         r2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
         yw = wc(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
         assert (yw - r2).abs().max().item() / max(r2.abs().max().item(), 1e-3) < 1e-5, ("conv wino", B, cin, cout, D, H, W)
