@@ -156,6 +156,15 @@ int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, flo
                                    int depth, int height, int width, const float* d_scale, const float* d_shift,
                                    int relu, void* stream);
 
+/* conv1a (5x5x5, one input channel; DSN.py:19,58) with Winograd F(2,5) along x (csrc/conv3d_stem_wino.hip): 0.62x the MFMA
+ * work of the direct stem kernel; own packed layout; pool != 0 fuses MaxPool3d(2,2) and writes [batch,cout,D/2,H/2,W/2].
+ * Maps >= 32 voxels wide; agreement with the direct kernel ~1e-6 relative to the tensor maximum. */
+size_t m3d_conv3d_stem_wino_packed_weight_bytes(int cout);
+int m3d_conv3d_stem_wino_pack_weights(const float* d_weight /*[cout,1,5,5,5]*/, int cout, float* d_packed, void* stream);
+int m3d_conv3d_stem_wino_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
+                                 int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
+                                 void* stream);
+
 /* Backward-weights and bias gradient of the same stride-1 "same" convolution (what autograd computes for the
  * F.conv3d calls of lib/prm/peak_backprop_3d.py:40-42 and every nn.Conv3d of lib/modeling/DSN.py:19-36 in training):
  *   dW[co,ci,dz,dy,dx] = sum_{b,z,y,x} gy[b,co,z,y,x] * x[b,ci,z+dz-k/2,...]     db[co] = sum gy[b,co,...]

@@ -49,6 +49,10 @@ class DetectorM3D:
         self.body_wino = [ops.WinoConv3d(params["Conv_Body." + cname + ".weight"], two_d=(self.wino_mode == 2))
                           if (self.use_wino and params["Conv_Body." + cname + ".weight"].shape[-1] == 3) else None
                           for cname, _, _ in dsn_layers(cfg.stride)]
+        self.stem_wino = None                                      # conv1a: F(2,5) along x
+        w1 = params["Conv_Body.conv1a.weight"]
+        if self.use_wino and tuple(w1.shape[1:]) == (1, 5, 5, 5):
+            self.stem_wino = ops.StemWinoConv3d(w1)
         self.rpn_conv = ops.PackedConv3d(params["RPN.RPN_conv.weight"])
         self.rpn_conv_wino = ops.WinoConv3d(params["RPN.RPN_conv.weight"], two_d=(self.wino_mode == 2)) if self.use_wino else None
         self.rpn_conv_bias = params["RPN.RPN_conv.bias"].contiguous()
@@ -66,6 +70,9 @@ class DetectorM3D:
         conv, scale, shift, pool = self.body[li]
         wino = self.body_wino[li]
         width = x.shape[-1]
+        if li == 0 and self.stem_wino is not None and self.stem_wino.supports(width):
+            return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True) if pool else \
+                self.stem_wino(x, scale=scale, shift=shift, relu=True)
         if wino is not None and wino.supports(width):
             if pool and wino.supports_pool(width):
                 return wino.pooled(x, scale=scale, shift=shift, relu=True)

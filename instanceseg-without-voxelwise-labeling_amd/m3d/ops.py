@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -406,6 +406,44 @@ class WinoConv3d(object):
                          _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),
               "conv3d_wino_forward_pool2")
         return out
+
+
+class StemWinoConv3d(object):
+    """conv1a (5x5x5, Cin = 1, stride 1, pad 2) through the Winograd F(2,5)-along-x MFMA kernel, optionally fused with
+    MaxPool3d(2,2); maps >= 32 voxels wide (else use PackedConv3d)."""
+
+    def __init__(self, weight):
+        _need_gpu(weight)
+        w = _f32c(weight)
+        assert w.dim() == 5 and tuple(w.shape[1:]) == (1, 5, 5, 5)
+        self.cout, self.cin = int(w.shape[0]), 1
+        nbytes = lib().m3d_conv3d_stem_wino_packed_weight_bytes(self.cout)
+        self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
+        check(lib().m3d_conv3d_stem_wino_pack_weights(_ptr(w), self.cout, _ptr(self.packed), _stream()), "stem_wino_pack")
+
+    @staticmethod
+    def supports(width):
+        return width >= 32
+
+    def _run(self, x, scale, shift, relu, pool, out):
+        _need_gpu(x)
+        x = _f32c(x)
+        B, cin, D, H, W = x.shape
+        assert cin == 1
+        if out is None:
+            shp = (B, self.cout, D // 2, H // 2, W // 2) if pool else (B, self.cout, D, H, W)
+            out = torch.empty(shp, dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_stem_wino_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, self.cout, D, H, W,
+                                                 _ptr(scale) if scale is not None else None,
+                                                 _ptr(shift) if shift is not None else None, int(bool(relu)), int(bool(pool)),
+                                                 _stream()), "conv3d_stem_wino_forward")
+        return out
+
+    def __call__(self, x, scale=None, shift=None, relu=False, out=None):
+        return self._run(x, scale, shift, relu, False, out)
+
+    def pooled(self, x, scale=None, shift=None, relu=False):
+        return self._run(x, scale, shift, relu, True, None)
 
 
 # ------------------------------------------------------------------ conv backward-weights / bias gradient

@@ -259,6 +259,30 @@ def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
     assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("B,cout,D,H,W", [(1, 32, 6, 8, 64), (2, 32, 5, 7, 70), (1, 20, 4, 6, 33), (1, 48, 3, 5, 128), (1, 32, 9, 3, 37)])
+def test_conv3d_stem_winograd_vs_fp64(m3d, B, cout, D, H, W):
+    """conv1a through the F(2,5)-along-x kernel (+ fused pool): same result as the direct stem kernel to fp32 rounding;
+    ragged sizes, the head / tail quads of the tensor, more than one 32-channel block."""
+    g = torch.Generator().manual_seed(cout + W)
+    x = torch.randn(B, 1, D, H, W, generator=g)
+    w = torch.randn(cout, 1, 5, 5, 5, generator=g) * (2.0 / 125) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 2)
+    conv = m3d.StemWinoConv3d(w.cuda())
+    y = conv(x.cuda()).cpu().double()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-4, err
+    assert err < 1e-5, err
+    ref2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+    y2 = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+    assert (y2 - ref2).abs().max().item() / ref2.abs().max().item() < 1e-5
+    if D >= 2 and H >= 2:
+        yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+        refp = torch.nn.functional.max_pool3d(ref2, 2, 2)
+        assert yp.shape == refp.shape and (yp - refp).abs().max().item() / refp.abs().max().item() < 1e-5
+
+
 def test_conv3d_winograd_rejects_narrow_maps(m3d):
     conv = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda())
     assert not conv.supports(16) and conv.supports(24) and not conv.supports_pool(32)

@@ -55,6 +55,17 @@ for name, cin, cout, k, s in L:
             frac = 4.0 / 9.0 if two_d else 2.0 / 3.0
             line += "   %s %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% executed)" % (
                 "F(2x2,3x3)" if two_d else "F(2,3)x", msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * frac)
+    if k == 5 and mode != 0 and m3d.StemWinoConv3d.supports(s):
+        sw = m3d.StemWinoConv3d(w)
+        runw = (lambda: sw.pooled(x, scale=sc, shift=sh, relu=True)) if fused else (lambda: sw(x, scale=sc, shift=sh, relu=True, out=out))
+        for _ in range(3):
+            runw()
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps):
+            runw()
+        e1.record(); torch.cuda.synchronize()
+        msw = e0.elapsed_time(e1) / reps
+        line += "   F(2,5)x %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% executed)" % (msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 0.624)
     tot_w += msw
     print(line)
 print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (Winograd where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
