@@ -174,7 +174,7 @@ def f_conv(rs):
     cin = 1 if k == 5 else int(rs.choice([1, 3, 16, 32, 33, 64, 100, 128]))
     cout = int(rs.choice([1, 5, 32, 33, 64, 96, 128])) if k != 5 else int(rs.choice([8, 32, 48]))
     B = int(rs.choice([1, 1, 2]))
-    D, H, W = int(rs.randint(1, 12)), int(rs.randint(1, 24)), int(rs.randint(1, 140 if k == 3 else 70))
+    D, H, W = int(rs.randint(1, 12)), int(rs.randint(1, 24)), int(rs.randint(1, 140 if k in (3, 5) else 70))
     x = torch.from_numpy(rs.randn(B, cin, D, H, W).astype(np.float32))
     w = torch.from_numpy((rs.randn(cout, cin, k, k, k) * (2.0 / (cin * k ** 3)) ** 0.5).astype(np.float32))
     ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, k // 2)
@@ -186,6 +186,16 @@ def f_conv(rs):
         refx = torch.nn.grad.conv3d_input(x.shape, w.double(), gy.double(), 1, k // 2)
         gx = m3d.PackedConv3d(w.cuda(), mode=m3d.W_DGRAD)(gy.cuda()).cpu().double()
         assert (gx - refx).abs().max().item() / max(refx.abs().max().item(), 1e-3) < 1e-5, ("conv dgrad", B, cin, cout, D, H, W, k)
+    if k == 5 and W >= 32:                         # Winograd F(2,5) stem (+ fused pool)
+        sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)); sh = torch.from_numpy(rs.randn(cout).astype(np.float32))
+        sw = m3d.StemWinoConv3d(w.cuda())
+        r2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+        ys = sw(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+        assert (ys - r2).abs().max().item() / max(r2.abs().max().item(), 1e-3) < 2e-5, ("stem wino", B, cout, D, H, W)
+        if D >= 2 and H >= 2:
+            yp = sw.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+            rp = torch.nn.functional.max_pool3d(r2, 2, 2)
+            assert (yp - rp).abs().max().item() / max(rp.abs().max().item(), 1e-3) < 2e-5, ("stem wino pool", B, cout, D, H, W)
     two_d = bool(rs.randint(2))
     if k == 3 and W >= (12 if two_d else 24):      # Winograd forward (split-K path below 24 wide; fused pool when it applies)
         sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)); sh = torch.from_numpy(rs.randn(cout).astype(np.float32))
