@@ -363,11 +363,9 @@ class WinoConv3d(object):
         self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
         check(self._pack(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
 
-    def supports(self_or_width, width=None):
-        """supports(width): maps >= 24 voxels wide; the 2-D kernel also has a split-K path for 12..23."""
-        if width is None:                       # called on the class: WinoConv3d.supports(w)
-            return self_or_width >= 24
-        return width >= (12 if self_or_width.two_d else 24)
+    def supports(self, width):
+        """maps >= 24 voxels wide; the 2-D kernel also has a split-K path for 12..23"""
+        return width >= (12 if self.two_d else 24)
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None):
         _need_gpu(x)

@@ -104,3 +104,36 @@ def test_largest_component_is_idempotent_and_a_subset_full_size():
     assert ((cc > 0) & (filled == 0)).sum().item() == 0
     filled2, _ = m3d.cc_largest_batch(filled, offs, dims, invert=True, tie_last=False)
     assert torch.equal(filled, filled2)
+
+
+@pytest.mark.parametrize("name", ["soma", "nuclei"])
+def test_full_tile_detections_equal_the_oracle(name):
+    """Full-size tile through the PRM-mode forward + proposals + box head + NMS on the GPU vs the oracle (torch-CPU convs +
+    oracle C ops): same kept detections / peaks, boxes to fp32 rounding (the back-propagation itself is checked at
+    small sizes and by properties above - the oracle needs seconds per peak at this size)."""
+    import oracle as O
+    cfg, det, eng, data = _run(name)
+    S, H, W = cfg.in_size
+    out = eng.prm_tile(data, dense=False)
+    ocfg = O.Cfg(mlp_dim=128) if name == "nuclei" else O.Cfg.soma(mlp_dim=128)
+    P = {k: v.cpu() for k, v in det.P.items()}
+    with torch.no_grad():
+        im_info = np.array([S, H, W, 1.0])
+        feat, prob, deltas, _ = O.prm_forward(P, ocfg, data.cpu())
+        rois, probs, keep_idx = O.generate_proposals_3d(prob[0].numpy(), deltas[0].numpy(), im_info, ocfg.anchors, ocfg.stride,
+                                                        ocfg.pre_nms_topN, ocfg.post_nms_topN, ocfg.rpn_nms_thresh, ocfg.rpn_min_size)
+        cls, bbox = O.box_head_forward(P, feat, rois, ocfg.roi_res, 1.0 / ocfg.stride, ocfg.sampling_ratio)
+        pred = O.clip_tiled_boxes_3d(O.bbox_transform_3d(rois[:, 1:7], bbox.numpy().reshape(-1, bbox.shape[-1]), ocfg.bbox_reg_weights),
+                                     im_info[:3])
+        sc, bx, _, cls_keep = O.box_results_with_nms_and_limit(cls.numpy().reshape(-1, cls.shape[-1]), pred, keep_idx, ocfg.num_classes,
+                                                               ocfg.score_thresh, ocfg.nms, ocfg.detections_per_im)
+    keep = sc > 0.1
+    if out is None or out.get("dets") is None:
+        assert keep.sum() == 0
+        return
+    g = out["dets"].cpu().numpy()
+    assert len(g) == int(keep.sum())
+    assert np.allclose(g, np.hstack((bx, sc[:, None]))[keep], rtol=1e-4, atol=2e-3)
+    A = prob.shape[1]
+    ref_peaks = np.stack([np.array(np.unravel_index(i, prob.shape[-3:] + (A,)))[[3, 0, 1, 2]] for i in cls_keep[1][keep]])
+    assert np.array_equal(out["peaks"].cpu().numpy()[:, 1:], ref_peaks)
