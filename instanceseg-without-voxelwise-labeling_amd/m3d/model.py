@@ -83,10 +83,26 @@ class DetectorM3D:
         x = conv(x, scale=scale, shift=shift, relu=True)
         return ops.maxpool3d_2x(x) if pool else x
 
-    def conv_body(self, x):
-        for li in range(len(self.body)):
+    def conv_body(self, x, first=0, last=None):
+        for li in range(first, len(self.body) if last is None else last):
             x = self.body_layer(li, x)
         return x
+
+    def capture_body(self, x, first=0, last=None):
+        """HIP graph of body layers [first, last) on the STATIC input tensor x: returns (replay, out).  `replay()` re-runs
+        the captured launches (one graph launch instead of one per kernel); `out` is the static output tensor.
+        The caller keeps x alive and refills it in place."""
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm up on a side stream (lazy module loads, attribute calls)
+            for _ in range(2):
+                self.conv_body(x, first, last)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self.conv_body(x, first, last)
+        return g.replay, out
 
     # ---- lib/modeling/rpn_heads.py:94-116
     def rpn(self, feat):

@@ -392,13 +392,14 @@ class WinoConv3d(object):
     def supports_pool(width):
         return width >= 48
 
-    def pooled(self, x, scale=None, shift=None, relu=False):
+    def pooled(self, x, scale=None, shift=None, relu=False, out=None):
         """conv + scale/shift + ReLU + MaxPool3d(2,2) in one launch; returns [B,cout,D//2,H//2,W//2]."""
         _need_gpu(x)
         x = _f32c(x)
         B, cin, D, H, W = x.shape
         assert cin == self.cin
-        out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
         check(self._pool(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                          _ptr(scale) if scale is not None else None,
                          _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),

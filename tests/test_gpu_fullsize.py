@@ -137,3 +137,18 @@ def test_full_tile_detections_equal_the_oracle(name):
     A = prob.shape[1]
     ref_peaks = np.stack([np.array(np.unravel_index(i, prob.shape[-3:] + (A,)))[[3, 0, 1, 2]] for i in cls_keep[1][keep]])
     assert np.array_equal(out["peaks"].cpu().numpy()[:, 1:], ref_peaks)
+
+
+def test_body_hip_graph_replays_the_eager_result():
+    """DetectorM3D.capture_body: the captured HIP graph reproduces the eager backbone bit for bit, also after the static
+    input has been refilled in place."""
+    cfg, det, eng, data = _run("nuclei")
+    x = data[:, :, :32, :64, :64].contiguous()
+    ref = det.conv_body(x).clone()
+    replay, out = det.capture_body(x)
+    replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    x.copy_(torch.randn_like(x))
+    ref2 = det.conv_body(x).clone()
+    replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref2) and not torch.equal(ref, ref2)
