@@ -125,8 +125,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   if (ep.xcd_map) bid = xcd_contiguous2(bid, gridDim.x);
   cot = bid % co_tiles; bid /= co_tiles;
   const int tx = bid % tiles_x; bid /= tiles_x;
-  const int ty = bid % tiles_y; bid /= tiles_y;
-  const int tz = bid;
+  // z tiles in groups of 4 inside the y sweep: the tiles an XCD works on at the same time form a compact (y, z) block whose
+  // halo planes stay in its 4 MB L2 (a full-y, single-z slab order re-fetches every z halo plane for the next slab)
+  constexpr int ZG = 4;
+  int ty, tz;
+  {
+    const int n_full = tiles_z / ZG, full = n_full * ZG * tiles_y;
+    if (bid < full) {
+      const int zl = bid % ZG; bid /= ZG;
+      ty = bid % tiles_y; tz = (bid / tiles_y) * ZG + zl;
+    } else {
+      const int zr = tiles_z - n_full * ZG, rem = bid - full;
+      ty = rem / zr; tz = n_full * ZG + rem % zr;
+    }
+  }
   const int b = blockIdx.y;
   const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
   const size_t DHW = (size_t)D * H * W;
