@@ -243,7 +243,12 @@ def f_prm(rs):
     assert np.array_equal(out["peaks"].cpu().numpy(), np.asarray(peaks)), ("prm peaks", S, H, W, soma)
     assert np.allclose(out["dets"].cpu().numpy(), np.asarray(dets), rtol=1e-4, atol=1e-3)
     pr = np.asarray(prms)
-    assert np.allclose(out["prms"].cpu().numpy(), pr, rtol=5e-3, atol=5e-6 * pr.max()), ("prm maps", S, H, W, soma)
+    got = out["prms"].cpu().numpy()
+    # a peak whose gradient dies on the way down has an all-zero map; prm / prm.sum() is then NaN in the reference too
+    # (peak_response_mapping_3d.py:171): the NaN pattern must be identical
+    assert np.array_equal(np.isnan(got), np.isnan(pr)), ("prm NaN pattern", S, H, W, soma)
+    scale = np.nanmax(pr) if np.isfinite(pr).any() else 1.0
+    assert np.allclose(got, pr, rtol=5e-3, atol=5e-6 * scale, equal_nan=True), ("prm maps", S, H, W, soma)
 
 
 ops = [("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
