@@ -264,6 +264,16 @@ int m3d_otsu2d_batch(const uint16_t* d_image, const uint16_t* d_prm, const int64
                      int max_gray_range, uint8_t* d_mask, int32_t* d_kb, int32_t* d_status, void* d_ws,
                      size_t ws_bytes, void* stream);
 
+/* Volume pre-filters of tools/binarization_nuclei.py:44-45, bit-exact with SciPy 1.15 (uint16 volumes):
+ *   m3d_gaussian_filter_u16  ndimage.gaussian_filter(img, sigma): separable correlate1d along z, y, x with 'reflect'
+ *                            borders, fp64 accumulation in SciPy's order, truncation to uint16 after every pass.
+ *                            d_weights: radius+1 doubles (centre first) computed by the host exactly as SciPy does;
+ *                            d_tmp: scratch volume of the same size.
+ *   m3d_median_filter3_u16   ndimage.median_filter(img, size=3): rank 13 of the 27 reflect-padded neighbours. */
+int m3d_gaussian_filter_u16(const uint16_t* d_in, uint16_t* d_out, uint16_t* d_tmp, int depth, int height, int width,
+                            const double* d_weights, int radius, void* stream);
+int m3d_median_filter3_u16(const uint16_t* d_in, uint16_t* d_out, int depth, int height, int width, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Connected-component post-processing of the Otsu masks, batched per RoI (the step after Otsu: SURVEY 8f-2).
  * Crops are concatenated; crop r = voxels [d_offsets[r], d_offsets[r+1]) with dims d_dims[3r..3r+2] = (ez,ey,ex).

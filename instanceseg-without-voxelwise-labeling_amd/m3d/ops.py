@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -468,6 +468,34 @@ def conv3d_bias_grad(grad_out):
     db = torch.empty((cout,), dtype=torch.float32, device=grad_out.device)
     check(lib().m3d_conv3d_bias_grad(_ptr(grad_out), _ptr(db), B, cout, D, H, W, _stream()), "conv3d_bias_grad")
     return db
+
+
+# ------------------------------------------------------------------ volume pre-filters (binarization_nuclei.py:44-45)
+def gaussian_filter_u16(vol, sigma=1.0, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(vol, sigma) for a uint16 CUDA volume [D,H,W], bit-exact (uint16 after every pass)."""
+    _need_gpu(vol)
+    assert vol.dtype == torch.uint16 and vol.dim() == 3
+    vol = vol.contiguous()
+    radius = int(truncate * float(sigma) + 0.5)                      # scipy/ndimage/_filters.py gaussian_filter1d
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)      # _gaussian_kernel1d, order 0
+    phi = phi / phi.sum()
+    w = torch.from_numpy(np.ascontiguousarray(phi[radius:])).to(vol.device)      # centre first
+    out, tmp = torch.empty_like(vol), torch.empty_like(vol)
+    D, H, W = vol.shape
+    check(lib().m3d_gaussian_filter_u16(_ptr(vol), _ptr(out), _ptr(tmp), D, H, W, _ptr(w), radius, _stream()), "gaussian_filter_u16")
+    return out
+
+
+def median_filter3_u16(vol):
+    """scipy.ndimage.median_filter(vol, size=3) for a uint16 CUDA volume [D,H,W]."""
+    _need_gpu(vol)
+    assert vol.dtype == torch.uint16 and vol.dim() == 3
+    vol = vol.contiguous()
+    out = torch.empty_like(vol)
+    D, H, W = vol.shape
+    check(lib().m3d_median_filter3_u16(_ptr(vol), _ptr(out), D, H, W, _stream()), "median_filter3_u16")
+    return out
 
 
 # ------------------------------------------------------------------ connected components / closing / painting

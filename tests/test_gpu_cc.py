@@ -224,3 +224,19 @@ def test_binarize_volume_through_the_file_tree(m3d, dataset, tmp_path):
     assert table.shape == table_ref.shape and np.array_equal(table, table_ref.astype(np.float64))
     mio.save_segmentation(str(tmp_path / "out"), "img1", seg, table)
     assert np.array_equal(mio.read_tiff_stack(str(tmp_path / "out" / "img1.tif")), seg_ref)
+
+
+@pytest.mark.parametrize("shape", [(7, 9, 11), (1, 5, 3), (3, 2, 70), (20, 33, 47), (64, 128, 96)])
+def test_prefilters_bit_exact_with_scipy(m3d, shape):
+    """ndimage.gaussian_filter(uint16, sigma=1) (uint16 after every axis pass, reflect borders also for axes shorter than
+    the kernel radius) and ndimage.median_filter(size=3): the reference's own SciPy calls (binarization_nuclei.py:44-45)."""
+    from scipy import ndimage
+    rs = np.random.RandomState(sum(shape))
+    a = rs.randint(0, 65536 if shape[0] % 2 else 4000, shape).astype(np.uint16)
+    g = m3d.gaussian_filter_u16(dev(a), 1.0)
+    ref_g = ndimage.gaussian_filter(a, sigma=1)
+    assert np.array_equal(g.cpu().numpy(), ref_g)
+    m = m3d.median_filter3_u16(g)
+    assert np.array_equal(m.cpu().numpy(), ndimage.median_filter(ref_g, size=3))
+    g2 = m3d.gaussian_filter_u16(dev(a), 2.0)                      # another sigma: radius 8
+    assert np.array_equal(g2.cpu().numpy(), ndimage.gaussian_filter(a, sigma=2))

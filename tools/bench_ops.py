@@ -88,3 +88,13 @@ m0 = mask[:int(offs[1])].cpu().numpy().reshape(shapes[0])
 t0 = time.perf_counter(); O.largest_cc_soma(m0); tc = time.perf_counter() - t0
 print("cc_largest_batch 300 RoIs (%.1f Mvoxel): foreground %8.1f us, complement (hole fill) %8.1f us, closing6 %8.1f us  "
       "[scipy label per RoI: %.0f us]" % (V / 1e6, t1 * 1e6, t2 * 1e6, t3 * 1e6, tc * 1e6))
+# ---- volume pre-filters of binarization_nuclei.py:44-45 (uint16, 64 x 1024 x 1024)
+from scipy import ndimage
+vol16 = torch.from_numpy(rs.randint(0, 4000, (64, 1024, 1024)).astype(np.uint16)).cuda()
+tg = timeit(lambda: m3d.gaussian_filter_u16(vol16, 1.0), reps=5)
+gv = m3d.gaussian_filter_u16(vol16, 1.0)
+tm = timeit(lambda: m3d.median_filter3_u16(gv), reps=5)
+small = vol16[:16, :256, :256].cpu().numpy()
+t0 = time.perf_counter(); ndimage.median_filter(ndimage.gaussian_filter(small, sigma=1), size=3); tc = (time.perf_counter() - t0) * 64
+print("prefilters 64x1024x1024 uint16: gaussian(sigma 1) %8.1f us  median 3^3 %8.1f us   [SciPy on one host core, extrapolated from 1/64 of the volume: %.1f s]" %
+      (tg * 1e6, tm * 1e6, tc))
