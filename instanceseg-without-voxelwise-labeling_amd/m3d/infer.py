@@ -61,13 +61,8 @@ def infer_prm(engine, im, dataset="nuclei", patch=None, overlap=100, out_dir=Non
         if out is None or out.get("dets") is None:
             continue                                                          # :225-226
         dets = out["dets"].cpu().numpy()
-        prm = out["prms"].cpu().numpy()
-        u8 = []
-        for ch in range(prm.shape[0]):                                        # :233-240
-            fm = tiling.quantize_u8(prm[ch])
-            if pad_s:
-                fm = fm[pad_s:pad_s + orig_slices]
-            u8.append(fm)
+        q = ops.prm_quantize_u8(out["prms"]).cpu().numpy()                   # :233-238 on device, then 1 byte per voxel D2H
+        u8 = [q[ch][pad_s:pad_s + orig_slices] if pad_s else q[ch] for ch in range(q.shape[0])]   # :239-240
         rec = dict(num=num, start=(s, h, w), dets=dets, prm_u8=u8, peaks=out["peaks"].cpu().numpy())
         results.append(rec)
         if out_dir is not None:                                               # :213-216,246-247

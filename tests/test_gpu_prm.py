@@ -60,3 +60,32 @@ def test_prm_vs_oracle_border_peaks():
     for i, p in enumerate(peaks):
         ref = O.prm_backward(P, osaved, p, p2.shape)[0]
         assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
+
+
+def test_infer_prm_tiles_quantised_maps_and_tree(tmp_path):
+    """m3d.infer.infer_prm (tools/infer_simple.py:176-247): norm1, slice padding, tiling, per-tile PRM, uint8 quantisation on
+    device, instance tree on disk - every tile against the oracle run on the same crop."""
+    from m3d.infer import infer_prm
+    from m3d import io as mio, tiling
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=2)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0)
+    eng = _engine(P, cfg)
+    rs = np.random.RandomState(3)
+    im = (rs.rand(12, 40, 40) * 900 + 50).astype(np.uint16)          # 12 slices -> padded to the 16-slice patch (pad_s = 2)
+    patch, overlap = (16, 24, 24), 8
+    res = infer_prm(eng, im, dataset="nuclei", patch=patch, overlap=overlap, out_dir=str(tmp_path / "img"))
+    vol = tiling.norm1(im, np.float64)
+    vol, pad_s = tiling.pad_slices(vol, patch[0])
+    assert pad_s == 2 and len(res) >= 1
+    for r in res:
+        s, h, w = r["start"]
+        crop = torch.from_numpy(vol[s:s + 16, h:h + 24, w:w + 24].astype(np.float32))[None, None]
+        ref = O.prm_tile(P, cfg, crop)
+        assert ref[1] is not None and np.array_equal(r["peaks"], np.asarray(ref[1]))
+        assert np.allclose(r["dets"], np.asarray(ref[3]), rtol=1e-4, atol=1e-3)
+        for ch, fm in enumerate(np.asarray(ref[2])):
+            q = O.quantize_prm_u8(fm.copy())[pad_s:pad_s + 12]
+            d = np.abs(r["prm_u8"][ch].astype(int) - q.astype(int))
+            assert r["prm_u8"][ch].shape == (12, 24, 24) and d.max() <= 1 and (d > 0).mean() < 5e-3     # fp32 map +-1e-3 -> +-1 level, rarely
+        dets, prms = mio.load_prm_instances(str(tmp_path / "img" / "instances" / str(r["num"])))
+        assert np.array_equal(dets, r["dets"]) and all(np.array_equal(a, b) for a, b in zip(prms, r["prm_u8"]))
