@@ -376,12 +376,15 @@ class WinoConv3d(object):
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
         if self.two_d and W < 24:
             wsb = lib().m3d_conv3d_wino2_workspace_bytes(B, cin, self.cout, D, H, W)
-            if getattr(self, "_ws", None) is None or self._ws.numel() < wsb or self._ws.device != x.device:
-                self._ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
+            key = (torch.cuda.current_stream().cuda_stream, x.device)           # one scratch buffer per stream: tiles on
+            cache = self.__dict__.setdefault("_ws", {})                           # different streams run concurrently
+            ws = cache.get(key)
+            if ws is None or ws.numel() < wsb:
+                ws = cache[key] = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
             check(lib().m3d_conv3d_wino2_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                                                     _ptr(scale) if scale is not None else None,
                                                     _ptr(shift) if shift is not None else None, int(bool(relu)),
-                                                    _ptr(self._ws), C.c_size_t(wsb), _stream()), "conv3d_wino2_forward_ws")
+                                                    _ptr(ws), C.c_size_t(wsb), _stream()), "conv3d_wino2_forward_ws")
             return out
         check(self._fwd(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                         _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
