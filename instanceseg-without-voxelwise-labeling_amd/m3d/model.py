@@ -70,7 +70,10 @@ class DetectorM3D:
         conv, scale, shift, pool = self.body[li]
         wino = self.body_wino[li]
         width = x.shape[-1]
-        if li == 0 and self.stem_wino is not None and self.stem_wino.supports(width):
+        small = x[0].numel() * 4 < 0x7FFFFFFF          # the Winograd kernels address one batch item with 32-bit buffer offsets
+        if not small:
+            wino = None
+        if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(width):
             return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True) if pool else \
                 self.stem_wino(x, scale=scale, shift=shift, relu=True)
         if wino is not None and wino.supports(width):
@@ -106,7 +109,8 @@ class DetectorM3D:
 
     # ---- lib/modeling/rpn_heads.py:94-116
     def rpn(self, feat):
-        rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1])) else self.rpn_conv
+        rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1])
+                                    and feat[0].numel() * 4 < 0x7FFFFFFF) else self.rpn_conv
         h = rc(feat, shift=self.rpn_conv_bias, relu=True)
         o = self.rpn_heads(h, shift=self.rpn_heads_bias)
         logits, deltas = o[:, :self.A], o[:, self.A:]
