@@ -490,7 +490,7 @@ M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, f
   M3D_W2(5, 4, 16, 1, 4)
 #undef M3D_W2
   if (variant >= 0) return M3D_EUNSUPPORTED;
-  if (width >= 48) return launch_wino2<4, 32, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  if (width >= 48) return launch_wino2<4, 32, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);   // 64 x 2 y x 4 z: 4 % faster than 2 x 2
   if (width >= 24) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   return M3D_EUNSUPPORTED;
 }
