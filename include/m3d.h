@@ -149,6 +149,9 @@ int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_
  * partial results go to the caller's workspace and are summed in a fixed order by a second kernel (deterministic).
  * m3d_conv3d_wino2_forward_ws dispatches to m3d_conv3d_wino2_forward for maps >= 24 wide (workspace unused). */
 size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
+/* useful-work x chip-fill score (0..1) of the tile the library would pick (64x2x4, 32x8x2 or 16x16x2 with split-K);
+ * below ~0.5 the direct kernel is the better choice */
+double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width);
 int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                 int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                 void* d_ws, size_t ws_bytes, void* stream);

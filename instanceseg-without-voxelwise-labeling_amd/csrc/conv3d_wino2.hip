@@ -471,41 +471,9 @@ M3D_API int m3d_conv3d_wino2_pack_weights(const float* d_weight, int cin, int co
   return m3d::check_launch("wino2_pack");
 }
 
-M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
-                                     int height, int width, const float* d_scale, const float* d_shift, int relu, void* stream) {
-  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
-    return M3D_EINVAL;
-  const size_t DHW = (size_t)depth * height * width;
-  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
-  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  hipStream_t st = m3d::as_stream(stream);
-  int variant = -1;
-  if (const char* tv = getenv("M3D_TUNE_WINO2")) variant = atoi(tv);
-#define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
-  M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
-  M3D_W2(1, 4, 32, 4, 1)
-  M3D_W2(2, 4, 32, 1, 4)
-  M3D_W2(3, 4, 16, 2, 2)      // 32 x 8 y x 2 z
-  M3D_W2(4, 4, 16, 4, 1)
-  M3D_W2(5, 4, 16, 1, 4)
-#undef M3D_W2
-  if (variant >= 0) return M3D_EUNSUPPORTED;
-  if (width >= 48) return launch_wino2<4, 32, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);   // 64 x 2 y x 4 z: 4 % faster than 2 x 2
-  if (width >= 24) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
-  return M3D_EUNSUPPORTED;
-}
-
-M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
-                                           int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
-                                           void* stream) {
-  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
-  const size_t DHW = (size_t)depth * height * width;
-  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
-  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
-}
-
-// ---- small maps (12..23 voxels wide, e.g. the 16^3 stage-4 layers): 16x16x2 output tiles and split-K over workgroups
+// ---- tile choice.  Three output tiles: 64 x 2 x 4 (XT = 32), 32 x 8 x 2 (XT = 16), 16 x 16 x 2 (XT = 8, with split-K over
+// workgroups when the map has too few tiles to give every CU one).  Score = useful fraction of the computed tile volume
+// x how much of the chip the grid fills; ties go to the wider tile (fewer halo columns per output).
 namespace {
 struct SplitPlan { int ksplit, cps; size_t slice; };
 SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int width) {
@@ -519,10 +487,43 @@ SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int w
   ks = (nchunk + cps - 1) / cps;                             // no empty slice
   return SplitPlan{ks, cps, (size_t)batch * cout * depth * height * width};
 }
+
+int choose_xt(int batch, int cin, int cout, int D, int H, int W, double* best_score = nullptr) {
+  if (best_score) *best_score = 0.0;
+  if (const char* tv = getenv("M3D_TUNE_WINO2_XT")) { if (best_score) *best_score = 1.0; return atoi(tv); }
+  if (W < 12) return 0;
+  auto up = [](int v, int t) { return (double)((v + t - 1) / t) * t; };
+  const double vol = (double)D * H * W, cot = (cout + 31) / 32;
+  double best = -1.0; int xt = 0;
+  const int tx[3] = {64, 32, 16}, ty[3] = {2, 8, 16}, tz[3] = {4, 2, 2}, id[3] = {32, 16, 8};
+  for (int i = 0; i < 3; ++i) {
+    if (id[i] == 32 && W < 48) continue;
+    if (id[i] == 16 && W < 24) continue;
+    const double eff = vol / (up(W, tx[i]) * up(H, ty[i]) * up(D, tz[i]));
+    double wgs = up(W, tx[i]) / tx[i] * up(H, ty[i]) / ty[i] * up(D, tz[i]) / tz[i] * cot * batch;
+    if (id[i] == 8) wgs *= plan_splitk(batch, cin, cout, D, H, W).ksplit;
+    // one workgroup per CU: the grid runs in ceil(wgs / 256) rounds and a ragged last round costs a full one
+    const double rounds = (double)((long long)((wgs + 255.0) / 256.0));
+    const double score = eff * wgs / (256.0 * rounds);
+    if (score > best * 1.02) { best = score; xt = id[i]; }
+  }
+  if (best_score) *best_score = best;
+  return xt;
+}
 }  // namespace
 
+/* useful-work x chip-fill score (0..1) of the best tile for this shape; callers use the direct kernel below ~0.5
+ * (measured: 128 -> 128 channels on 16 x 40 x 40: score 0.39, 0.247 ms vs 0.224 ms direct) */
+M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0.0;
+  double sc = 0.0;
+  (void)choose_xt(batch, cin, cout, depth, height, width, &sc);
+  return sc;
+}
+
 M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
-  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0 || width >= 24 || width < 12) return 0;
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0;
+  if (choose_xt(batch, cin, cout, depth, height, width) != 8) return 0;
   const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
   return p.ksplit > 1 ? p.ksplit * p.slice * sizeof(float) : 0;
 }
@@ -530,22 +531,32 @@ M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, in
 M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                         int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                         void* d_ws, size_t ws_bytes, void* stream) {
-  if (width >= 24)
-    return m3d_conv3d_wino2_forward(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, d_scale, d_shift, relu, stream);
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
     return M3D_EINVAL;
-  if (width < 12) return M3D_EUNSUPPORTED;
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
+  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
+  int variant = -1;
+  if (const char* tv = getenv("M3D_TUNE_WINO2")) variant = atoi(tv);
+#define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
+  M3D_W2(1, 4, 32, 4, 1)
+  M3D_W2(2, 4, 32, 1, 4)
+  M3D_W2(3, 4, 16, 2, 2)      // 32 x 8 y x 2 z
+  M3D_W2(4, 4, 16, 4, 1)
+  M3D_W2(5, 4, 16, 1, 4)
+#undef M3D_W2
+  if (variant >= 0) return M3D_EUNSUPPORTED;
+  const int xt = choose_xt(batch, cin, cout, depth, height, width);
+  if (xt == 32) return launch_wino2<4, 32, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  if (xt == 16) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  if (xt != 8) return M3D_EUNSUPPORTED;
   const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
-  if (p.ksplit <= 1) {
-    W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-    return launch_wino2<4, 8, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
-  }
+  if (p.ksplit <= 1) return launch_wino2<4, 8, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   if (!d_ws || ws_bytes < p.ksplit * p.slice * sizeof(float)) return M3D_EWORKSPACE;
-  W2Epi ep{nullptr, nullptr, 0, 0, p.ksplit, p.cps, p.slice};
-  const int rc = launch_wino2<4, 8, 2, 2>(d_in, d_packed, (float*)d_ws, batch, cin, cout, depth, height, width, ep, st, p.ksplit);
+  W2Epi eps{nullptr, nullptr, 0, 0, p.ksplit, p.cps, p.slice};
+  const int rc = launch_wino2<4, 8, 2, 2>(d_in, d_packed, (float*)d_ws, batch, cin, cout, depth, height, width, eps, st, p.ksplit);
   if (rc != M3D_OK) return rc;
   const size_t total = p.slice;
   size_t blocks = (total + 255) / 256;
@@ -553,4 +564,21 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
   hipLaunchKernelGGL(wino2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, p.ksplit, p.slice, d_out, cout,
                      DHW, total, d_scale, d_shift, relu);
   return m3d::check_launch("wino2_reduce");
+}
+
+/* without a workspace: fails with M3D_EWORKSPACE where the split-K tile would be chosen */
+M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                                     int height, int width, const float* d_scale, const float* d_shift, int relu, void* stream) {
+  return m3d_conv3d_wino2_forward_ws(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, d_scale, d_shift, relu, nullptr, 0,
+                                     stream);
+}
+
+M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                           int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                           void* stream) {
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
+  const size_t DHW = (size_t)depth * height * width;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
+  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
+  return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
 }

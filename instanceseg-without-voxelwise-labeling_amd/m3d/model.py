@@ -76,7 +76,7 @@ class DetectorM3D:
         if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(width):
             return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True) if pool else \
                 self.stem_wino(x, scale=scale, shift=shift, relu=True)
-        if wino is not None and wino.supports(width):
+        if wino is not None and wino.supports(width, (x.shape[0],) + tuple(x.shape[2:])):
             if pool and wino.supports_pool(width):
                 return wino.pooled(x, scale=scale, shift=shift, relu=True)
             x = wino(x, scale=scale, shift=shift, relu=True)
@@ -109,7 +109,7 @@ class DetectorM3D:
 
     # ---- lib/modeling/rpn_heads.py:94-116
     def rpn(self, feat):
-        rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1])
+        rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1], (feat.shape[0],) + tuple(feat.shape[2:]))
                                     and feat[0].numel() * 4 < 0x7FFFFFFF) else self.rpn_conv
         h = rc(feat, shift=self.rpn_conv_bias, relu=True)
         o = self.rpn_heads(h, shift=self.rpn_heads_bias)

@@ -363,9 +363,15 @@ class WinoConv3d(object):
         self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
         check(self._pack(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "wino_pack")
 
-    def supports(self, width):
-        """maps >= 24 voxels wide; the 2-D kernel also has a split-K path for 12..23"""
-        return width >= (12 if self.two_d else 24)
+    def supports(self, width, shape=None):
+        """maps >= 24 voxels wide; the 2-D kernel also has a 16-wide tile with split-K from 12.  With shape = (B, D, H, W)
+        the 2-D kernel additionally asks the library whether its tiles fit the map well enough to beat the direct kernel."""
+        if width < (12 if self.two_d else 24):
+            return False
+        if self.two_d and shape is not None:
+            B, D, H, W = (int(v) for v in shape)
+            return lib().m3d_conv3d_wino2_score(B, self.cin, self.cout, D, H, W) >= 0.5
+        return True
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None):
         _need_gpu(x)
@@ -374,7 +380,7 @@ class WinoConv3d(object):
         assert cin == self.cin
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
-        if self.two_d and W < 24:
+        if self.two_d:                                     # the library picks the tile; small / ragged maps may split K
             wsb = lib().m3d_conv3d_wino2_workspace_bytes(B, cin, self.cout, D, H, W)
             key = (torch.cuda.current_stream().cuda_stream, x.device)           # one scratch buffer per stream: tiles on
             cache = self.__dict__.setdefault("_ws", {})                           # different streams run concurrently
