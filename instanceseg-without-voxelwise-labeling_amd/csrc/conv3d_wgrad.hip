@@ -16,6 +16,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TZ = 2, TY = 4, TX = 16, TV = TZ * TY * TX;   // voxel tile (128 voxels = 64 MFMA k-steps)
 constexpr int GS = TV + 1;                                   // odd channel stride of the gy tile in LDS
@@ -73,49 +74,70 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(const float* __restri
     const int b = q / tiles_z;
     const int x0 = tx * TX, y0 = ty * TY, z0 = tz * TZ;
     __syncthreads();                                   // the previous tile's MFMAs have read the LDS
-    // ---- stage gy[cb*32 + c][tile] and x[ib*32 + c][halo tile] (zero padded); x fastest -> 16/18-float runs.
-    // Loads are issued in batches of U before the first LDS write so their latencies overlap.
-    constexpr int U = 8;
-#pragma unroll 1
-    for (int e0 = 0; e0 < 32 * TV; e0 += 256 * U) {
-      float val[U];
+    // ---- stage gy[cb*32 + c][tile] and x[ib*32 + c][halo tile] (zero padded) as 16-byte quads of four consecutive x:
+    // one buffer_load_dwordx4 each (hardware range check returns 0 for channels past cout / cin; rows and columns outside
+    // the volume are masked), all loads of a batch issued before the first LDS write.
+    {
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(gy + (size_t)b * cout * DHW), 0, (unsigned)((size_t)cout * DHW * sizeof(float)), 0x00020000);
+      constexpr int NQG = 32 * (TZ * TY) * (TX / 4);                   // 1024 quads
+      constexpr int NG = NQG / 256;
+      f32x4 v[NG];
+      int mk[NG], ld[NG];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * 256 + tid;
-        const int c = e / TV, v = e % TV;
-        const int xx = x0 + (v & 15), yy = y0 + ((v >> 4) & 3), zz = z0 + (v >> 6);
-        const int co = cb * 32 + c;
-        const bool ok = (e < 32 * TV) & (co < cout) & (xx < W) & (yy < H) & (zz < D);
-        const size_t g = ok ? ((size_t)b * cout + co) * DHW + ((size_t)zz * H + yy) * W + xx : 0;
-        const float r = gy[g];
-        val[u] = ok ? r : 0.f;
+      for (int u = 0; u < NG; ++u) {
+        const int e = tid + u * 256;
+        const int q = e & 3, row = (e >> 2) & 7, c = e >> 5;
+        const int zz = z0 + (row >> 2), yy = y0 + (row & 3), xf = x0 + 4 * q;
+        const bool rok = (zz < D) & (yy < H);
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m |= (rok && xf + j < W) ? (1 << j) : 0;
+        const long long lin = (long long)(cb * 32 + c) * (long long)DHW + ((long long)zz * H + yy) * W + xf;
+        mk[u] = m; ld[u] = c * GS + row * TX + 4 * q;
+        v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, rok ? (int)(lin * 4) : 0, 0, 0));
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * 256 + tid;
-        if (e < 32 * TV) lds_g[(e / TV) * GS + e % TV] = val[u];
-      }
+      for (int u = 0; u < NG; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_g[ld[u] + j] = ((mk[u] >> j) & 1) ? v[u][j] : 0.f;
     }
+    {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(x + (size_t)b * cin * DHW), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
+      constexpr int QX = (C::HX + 3) / 4;                              // quads per halo row (x0-P .. x0-P+4*QX-1)
+      constexpr int NQX = 32 * C::HZ * C::HY * QX;
+      constexpr int UB = 5;                                            // quads per batch
 #pragma unroll 1
-    for (int e0 = 0; e0 < 32 * C::HV; e0 += 256 * U) {
-      float val[U];
+      for (int e0 = 0; e0 < NQX; e0 += 256 * UB) {
+        f32x4 v[UB];
+        int mk[UB], ld[UB];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * 256 + tid;
-        const int c = e / C::HV, r = e % C::HV;
-        const int hx = r % C::HX, hy = (r / C::HX) % C::HY, hz = r / (C::HX * C::HY);
-        const int xx = x0 + hx - C::P, yy = y0 + hy - C::P, zz = z0 + hz - C::P;
-        const int ci = ib * 32 + c;
-        const bool ok = (e < 32 * C::HV) & (ci < cin) & ((unsigned)xx < (unsigned)W) & ((unsigned)yy < (unsigned)H) &
-                        ((unsigned)zz < (unsigned)D);
-        const size_t g = ok ? ((size_t)b * cin + ci) * DHW + ((size_t)zz * H + yy) * W + xx : 0;
-        const float rv = x[g];
-        val[u] = ok ? rv : 0.f;
-      }
+        for (int u = 0; u < UB; ++u) {
+          const int e = e0 + u * 256 + tid;
+          const int q = e % QX, row = (e / QX) % (C::HZ * C::HY), c = e / (QX * C::HZ * C::HY);
+          const int hz = row / C::HY, hy = row % C::HY;
+          const int zz = z0 + hz - C::P, yy = y0 + hy - C::P, xf = x0 - C::P + 4 * q;
+          const bool rok = (e < NQX) & ((unsigned)zz < (unsigned)D) & ((unsigned)yy < (unsigned)H);
+          int m = 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * 256 + tid;
-        if (e < 32 * C::HV) lds_x[(e / C::HV) * C::XS + e % C::HV] = val[u];
+          for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W && 4 * q + j < C::HX) ? (1 << j) : 0;
+          long long lin = (long long)(ib * 32 + c) * (long long)DHW + ((long long)zz * H + yy) * W + xf;
+          if (rok && lin < 0) { m |= (int)(-lin) << 4; lin = 0; }      // a negative offset drops the whole quad: shift instead
+          mk[u] = m; ld[u] = c * C::XS + row * C::HX + 4 * q;
+          v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, rok ? (int)(lin * 4) : 0, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int sh = mk[u] >> 4;
+          f32x4 w4 = v[u];
+          if (sh == 1) w4 = f32x4{0.f, w4[0], w4[1], w4[2]};
+          else if (sh == 2) w4 = f32x4{0.f, 0.f, w4[0], w4[1]};
+          else if (sh == 3) w4 = f32x4{0.f, 0.f, 0.f, w4[0]};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((e0 + u * 256 + tid) < NQX && 4 * ((e0 + u * 256 + tid) % QX) + j < C::HX) lds_x[ld[u] + j] = ((mk[u] >> j) & 1) ? w4[j] : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -276,6 +298,11 @@ M3D_API int m3d_conv3d_wgrad(const float* d_in, const float* d_grad_out, float* 
       width <= 0)
     return M3D_EINVAL;
   if (!(k == 1 || k == 3 || (k == 5 && cin == 1))) return M3D_EUNSUPPORTED;
+  {   // the k = 1 / 3 kernels address one batch item of x and gy with 32-bit buffer offsets
+    const size_t dhw = (size_t)depth * height * width;
+    if (k != 5 && ((size_t)cin * dhw * sizeof(float) >= 0x7FFFFFFFull || (size_t)cout * dhw * sizeof(float) >= 0x7FFFFFFFull))
+      return M3D_EUNSUPPORTED;
+  }
   if (ws_bytes < m3d_conv3d_wgrad_workspace_bytes(batch, cin, cout, depth, height, width, k)) return M3D_EWORKSPACE;
   const Plan p = make_plan(batch, cin, cout, depth, height, width, k);
   float* partial = (float*)m3d::align_up((size_t)d_ws, 256);
