@@ -1,39 +1,72 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the 3D detection hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload backbone|detect]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload detect|backbone|prm|prm-nuclei]
 
-A "step" is one pass of the hot path over one batch of synthetic 1x128x128x128 volumes already resident in
-HBM.  Workloads (BASELINE.json configs):
-  backbone  configs[1]: dsn_body forward (7 convs + BN + ReLU + 3 max-pools) on one 128^3 volume per rank
-  detect    configs[2]-style: full detection-mode tile (backbone, RPN, on-device proposals, RoIAlign3D,
-            box head, decode, NMS) on one 128^3 volume per rank
-Rank 0 prints ONE JSON line: metric voxels/s (whole job), plus `roofline` for the dominant kernel (the
-conv2b MFMA implicit-GEMM launch, timed live with HIP events on the launch stream) and `cpu_baseline`
-(the oracle's torch-CPU restatement of the same workload on the host cores, rank 0, bounded sample).
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); volumes are independent, so ranks share
-nothing on the data path ("weak" scaling); detect mode ends with the single all_gather of padded detections
-(SURVEY 8e).
+Default workload = BASELINE.json configs[2]: the full detection-mode pipeline of tools/infer_simple.py:249-265 /
+lib/core/test.py:54-177 on a batch of synthetic 1x128x128x128 volumes per rank (4 at N = 1; 8 per rank at N > 1 =
+configs[4]: 64 volumes over 8 GPUs).  One "step" = every volume of the batch through
+    raw uint16 volume -> norm1 (blob.py:179-184, on device) -> dsn_body -> RPN -> proposals (on device) -> RoIAlign3D ->
+    2-MLP head -> decode/clip -> per-class NMS + cap -> cross-tile NMS (core/test.py:159)
+followed by the path's ONE exchange: a single all_gather of the padded detections [vols, 301, 7] (m3d.shard; a no-op at N = 1).
+`value` (voxels/s, whole job) is measured with the raw volumes resident in HBM, as the contract asks; the same line also
+carries `e2e_host_to_host`: the same steps with the raw volumes coming from pinned host memory (H2D on a copy stream,
+double-buffered) and the gathered detections copied back to the host (SURVEY 8d's end-to-end definition).
+`roofline` is for the dominant hand-written kernel of the step, timed live with HIP events on its launch stream;
+`cpu_baseline` is the oracle's restatement of the same per-volume pipeline (torch-CPU convs + oracle C ops) on a bounded sample.
+
+N > 1: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
+their environment, created before this process touches the GPU) unless a launcher (torch.distributed.run) already did.
+`--dry --backend gloo` runs the same launcher + exchange with a stub step on CPU (tests/test_host_logic.py).
+Other workloads: backbone (configs[1]: dsn_body forward only), prm (configs[3]: soma PRM tile), prm-nuclei.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 VOL = 128
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz, no xf32 on gfx950
+HBM_PEAK_GBS = 8000.0
+WINO_WORK = {0: 1.0, 1: 2.0 / 3.0, 2: 4.0 / 9.0}   # fraction of the algorithmic multiply-adds issued as MFMA work
+METRIC = "voxels/sec end-to-end infer_simple (128^3 vol); 3D-conv TFLOPS vs roofline"
 
 
+# ------------------------------------------------------------------------------------------------ launcher (N > 1)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """Start args.gpus child ranks of this script.  The parent never initialises the GPU (importing torch does not) and
+    never exec()s; it waits for the children and returns the worst exit code.  Rank 0's JSON line goes to our stdout."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers
 def host_cores():
-    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box shows 256 logical
-    CPUs but grants a 16-core share per GPU), else the affinity mask."""
+    """Cores this process may really use: the cgroup CPU quota when there is one (the GPU box shows 256 logical CPUs but
+    grants a 16-core share per GPU), else the affinity mask."""
     if "M3D_CPU_THREADS" in os.environ:
         return int(os.environ["M3D_CPU_THREADS"])
     try:
@@ -60,9 +93,85 @@ def backbone_flops(size):
     return sum(conv_flops(*l) for l in L)
 
 
+def pmc_traffic(symbol_prefix):
+    """HBM-side bytes per launch of a kernel from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (tools/pmc_probe.py -> tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json; the counters cannot be collected from inside
+    this process, so this is the committed measurement of the same command, newest round first)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            k = [e for e in d["kernels"] if e["kernel"].replace(" ", "").startswith(symbol_prefix.replace(" ", ""))]
+            if k:
+                return {"traffic": k[0]["traffic"], "traffic_unit": "bytes/launch (FETCH_SIZE x%.2f gfx950 correction + WRITE_SIZE)" %
+                        d["calibration"]["fetch_factor_dword_loads"], "traffic_source": os.path.relpath(f, ROOT)}
+        except Exception:
+            continue
+    return {"traffic": None}
+
+
+def sync_max_time(dt, dist, device):
+    import torch
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_loop(step, steps, warmup, dist, sync):
+    """The contract's timing: W untimed steps, then exactly K steps between barrier + device synchronize on both sides."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------ dry run (CPU, gloo)
+def run_dry(args, rank, world, dist):
+    """Launcher + exchange rehearsal without a GPU: every rank fabricates its volumes' detections, the ONE all_gather
+    of m3d.shard moves them, every rank checks the global list."""
+    import torch
+    from m3d import shard
+    nvol = args.vols_per_rank or (4 if world == 1 else 8)
+    n_items = world * nvol
+    cap = 300
+
+    def fake(i):                                   # item i: (i % 7) + 1 detections whose columns all hold i
+        return torch.full(((i % 7) + 1, 7), float(i))
+    mine = shard.partition(n_items, rank, world)
+    assert len(mine) == nvol
+
+    def step():
+        got = shard.all_gather_detections([fake(i) for i in mine], cap, n_items, dist)
+        assert len(got) == n_items
+        for i, t in enumerate(got):
+            assert t.shape == ((i % 7) + 1, 7) and float(t[0, 0]) == float(i), (i, t.shape)
+    dt = timed_loop(step, args.steps, args.warmup, dist, lambda: None)
+    dt = sync_max_time(dt, dist, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry": True,
+                          "config": {"workload": "DRY RUN (no GPU): launcher + one all_gather of [%d,%d,7] per rank, stub detect step"
+                                     % (nvol, cap + 1), "volumes_per_step": n_items, "backend": args.backend}}))
+
+
+# ------------------------------------------------------------------------------------------------ PRM workloads
 def bench_prm(args, rank, world, dist):
     """configs[3]: PRM_ON soma tile 1x64x160x160: forward (2 convs per layer) + batched peak back-propagation."""
-    import m3d
+    import numpy as np
+    import torch
     from m3d.model import DetectorM3D
     from m3d.prm import PRMEngine
     from m3d.config import Cfg
@@ -79,20 +188,13 @@ def bench_prm(args, rank, world, dist):
     def step():
         out = eng.prm_tile(vol, dense=False)
         npk.append(0 if out is None else int(out["peaks"].shape[0]))
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # forward-only and backward-only split
+    dt = timed_loop(step, args.steps, args.warmup, dist, torch.cuda.synchronize)
+    dt = sync_max_time(dt, dist, "cuda")
     e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     e[0].record(); eng.forward(vol); e[1].record(); torch.cuda.synchronize()
     fwd_ms = e[0].elapsed_time(e[1])
     if rank == 0:
-        print(json.dumps({"metric": "voxels/sec end-to-end infer_simple (PRM_ON soma tile)", "value": world * args.steps * S * H * W / dt,
+        print(json.dumps({"metric": "voxels/sec end-to-end infer_simple (PRM_ON tile)", "value": world * args.steps * S * H * W / dt,
                           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic",
@@ -102,226 +204,208 @@ def bench_prm(args, rank, world, dist):
                                      "prm_forward_ms": fwd_ms}}))
 
 
-WINO_WORK = {0: 1.0, 1: 2.0 / 3.0, 2: 4.0 / 9.0}   # fraction of the algorithmic multiply-adds issued as MFMA work
+# ------------------------------------------------------------------------------------------------ detect / backbone
+def bench_detect(args, rank, world, dist):
+    import numpy as np
+    import torch
+    import m3d
+    from m3d import shard
+    from m3d.model import DetectorM3D, Probe
+    from m3d.config import Cfg
+    from m3d.synth import make_params, synth_volume
 
+    backbone_only = args.workload == "backbone"
+    cfg = Cfg.nuclei(in_size=(VOL, VOL, VOL))
+    P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=not backbone_only)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    nvol = args.vols_per_rank or (1 if backbone_only else (4 if world == 1 else 8))
+    n_items = world * nvol
+    mine = shard.partition(n_items, rank, world)
+    raw_np = np.stack([synth_volume(i, (VOL, VOL, VOL)) for i in mine])              # uint16 [nvol,128,128,128], what io.imread gives
+    raw_host = torch.from_numpy(raw_np).pin_memory()
+    raw_dev = raw_host.cuda()
+    im_info = np.array([VOL, VOL, VOL, 1.0], np.float64)
+    cap = cfg.detections_per_im
+    stats = {"rois": [], "dets": []}
 
-def pmc_traffic(symbol):
-    """HBM-side bytes per launch of the dominant kernel, from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (tools/pmc_probe.py -> tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json; counters cannot be read from inside
-    this process).  Returned as roofline.traffic with the algorithmic bytes beside it."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return {}
-    try:
-        d = json.load(open(files[-1]))
-        k = [e for e in d["kernels"] if e["kernel"] == symbol]
-        if not k:
-            return {}
-        alg = (64 * 64 ** 3 + 64 * 32 ** 3 + 64 * 64 * 27) * 4        # conv2b+pool: input + pooled output + weights, once each
-        return {"traffic": k[0]["traffic"], "traffic_unit": "bytes/launch (FETCH_SIZE x%.2f gfx950 correction + WRITE_SIZE)" %
-                d["calibration"]["fetch_factor_dword_loads"], "algorithmic_bytes_per_launch": alg,
-                "traffic_source": os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return {}
+    def volume(raw_u16):
+        """One volume: norm1 -> detect -> cross-tile NMS.  Returns [n,7] detections (x1,y1,z1,x2,y2,z2,score)."""
+        x = m3d.norm1(raw_u16, f32_arith=True).view(1, 1, VOL, VOL, VOL)              # blob.py:179-184
+        if backbone_only:
+            return det.conv_body(x)
+        out = det.detect_tile(x, im_info)                                              # core/test.py:106-114
+        d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
+        keep = m3d.nms3d(d.contiguous(), cfg.nms)                                      # core/test.py:159 (one tile per volume)
+        stats["rois"].append(int(out["rois"].shape[0])); stats["dets"].append(int(keep.numel()))
+        return d[keep]
+
+    def step_resident():
+        res = [volume(raw_dev[v]) for v in range(nvol)]
+        if backbone_only:
+            return res[-1]
+        return shard.all_gather_packed(shard.pack_detections(res, cap, device="cuda"), n_items, dist)   # THE exchange
+
+    # ---- (1) value: raw volumes resident in HBM
+    for _ in range(args.warmup):
+        step_resident()
+    det.probe = Probe()
+    dt = timed_loop(step_resident, args.steps, 0, dist, torch.cuda.synchronize)
+    dt = sync_max_time(dt, dist, "cuda")
+    torch.cuda.synchronize()
+    kern_ms = det.probe.mean_ms()
+    det.probe = None
+
+    # ---- (2) end to end, host to host: pinned raw volumes -> H2D on a copy stream (double-buffered) -> step -> D2H
+    e2e = None
+    if not backbone_only:
+        copy_stream = torch.cuda.Stream()
+        bufs = [torch.empty_like(raw_dev) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        host_out = torch.empty((world, nvol, cap + 1, 7), dtype=torch.float32).pin_memory()
+        state = {"i": 0}
+
+        def upload(b):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(freed[b])
+                bufs[b].copy_(raw_host, non_blocking=True)
+                ready[b].record(copy_stream)
+
+        for b in range(2):
+            freed[b].record()
+        upload(0)
+
+        def step_host():
+            b = state["i"] & 1
+            state["i"] += 1
+            upload(b ^ 1)                                        # next step's volumes cross PCIe while this step computes
+            torch.cuda.current_stream().wait_event(ready[b])
+            res = [volume(bufs[b][v]) for v in range(nvol)]
+            freed[b].record()
+            g = shard.all_gather_packed(shard.pack_detections(res, cap, device="cuda"), n_items, dist)
+            if rank == 0:
+                host_out.copy_(g, non_blocking=True)
+                torch.cuda.current_stream().synchronize()        # detections are on the host when the step ends
+            return g
+        dt2 = timed_loop(step_host, args.steps, max(1, args.warmup // 2), dist, torch.cuda.synchronize)
+        dt2 = sync_max_time(dt2, dist, "cuda")
+        e2e = {"value": n_items * args.steps * VOL ** 3 / dt2, "unit": "voxels/s", "ms_per_step": dt2 / args.steps * 1e3,
+               "includes": "H2D of the raw uint16 volumes (pinned, copy stream, double-buffered) + D2H of the gathered [%d,%d,7] detections"
+                           % (n_items, cap + 1)}
+
+    if rank != 0:
+        return
+    voxels = n_items * args.steps * VOL ** 3
+    # ---- roofline of the dominant hand-written kernel, from the live HIP-event spans of the timed region
+    wino = det.wino_mode
+    conv2b_alg = conv_flops(64, 64, 3, (VOL // 2) ** 3)                     # 57.98 GFLOP algorithmic per launch (BASELINE.md 2)
+    kern = {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}
+    roof = None
+    if "conv2b" in kern_ms:
+        ms = kern_ms["conv2b"]
+        issued = conv2b_alg * WINO_WORK[wino]
+        roof = {"bound": "mfma",
+                "kernel": {2: "conv3d_wino2_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x) + fused BN/ReLU/MaxPool)",
+                           1: "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)",
+                           0: "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b direct + fused BN/ReLU/MaxPool)"}[wino],
+                "achieved": issued / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": issued / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
+                "issued_gflop_per_launch": issued / 1e9, "algorithmic_gflop_per_launch": conv2b_alg / 1e9,
+                "algorithmic_equivalent_tflops": conv2b_alg / (ms * 1e-3) / 1e12,
+                "note": "achieved/frac count the MFMA FLOPs the kernel ISSUES (Winograd: %s of the algorithmic 2*Cin*Cout*27 per voxel); "
+                        "algorithmic_equivalent_tflops is the direct-convolution FLOP count over the same time" %
+                        {2: "4/9", 1: "2/3", 0: "1"}[wino]}
+        roof.update(pmc_traffic({2: "conv3d_wino2_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
+                                 0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
+    body_ms = sum(v for k, v in kern_ms.items() if k.startswith("conv"))
+    res = {"metric": METRIC, "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": ("dsn_body forward (norm1 + 7 conv3d + BN + ReLU + 3 maxpool), 1x1x128x128x128 per rank [configs[1]]"
+                                   if backbone_only else
+                                   "detection-mode infer_simple: raw u16 volume -> norm1 -> dsn_body -> RPN -> proposals -> RoIAlign3D -> 2-MLP head "
+                                   "-> decode -> NMS -> cross-tile NMS, batch of %d x (1x128^3) per rank, one all_gather of detections per step [%s]"
+                                   % (nvol, "configs[2]" if world == 1 else "configs[4] shape: %d volumes over %d GPUs" % (n_items, world))),
+                      "volumes_per_step": n_items, "volumes_per_rank": nvol, "net": "nuclei stride-8 dsn_body, 35 anchors, MLP 1024",
+                      "inputs": "raw uint16 volumes resident in HBM at the start of the timed region",
+                      "rois_per_volume": (float(np.mean(stats["rois"])) if stats["rois"] else None),
+                      "dets_per_volume": (float(np.mean(stats["dets"])) if stats["dets"] else None),
+                      "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9, "backbone_ms_per_volume": body_ms,
+                      "backbone_algorithmic_tflops": backbone_flops(VOL) / (body_ms * 1e-3) / 1e12 if body_ms else None,
+                      "kernel_ms_per_launch": kern},
+           "roofline": roof}
+    if e2e is not None:
+        res["e2e_host_to_host"] = e2e
+    if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
+        # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's restatement of the same per-volume pipeline)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        ncpu = host_cores()
+        torch.set_num_threads(ncpu)
+        ocfg = O.Cfg()
+
+        def cpu_volume(raw):
+            x = torch.from_numpy(O.norm1(raw, np.float32).astype(np.float32)).view(1, 1, VOL, VOL, VOL)
+            with torch.no_grad():
+                if backbone_only:
+                    return O.dsn_body_forward(P, x, 8)
+                r = O.detect_tile(P, ocfg, x)
+            d = r["cls_boxes"][1]
+            return d[O.nms_3d(np.ascontiguousarray(d, dtype=np.float32), ocfg.nms)] if len(d) else d
+        cpu_volume(raw_np[0])                        # warm-up (thread pool, page-in)
+        nrep, tcpu = 0, 0.0
+        while tcpu < 12.0 and nrep < 8:
+            c0 = time.perf_counter()
+            cpu_volume(raw_np[nrep % nvol])
+            tcpu += time.perf_counter() - c0
+            nrep += 1
+        res["cpu_baseline"] = {"value": nrep * VOL ** 3 / tcpu, "unit": "voxels/s", "cores": ncpu, "kind": "port",
+                               "sample": "%d of the same 1x128^3 volumes through the oracle's restatement of the same pipeline (NumPy norm1, "
+                                         "torch-CPU fp32 convs/linears with %d threads, oracle C proposals/RoIAlign/NMS on 1 thread), %.1f s"
+                                         % (nrep, ncpu, tcpu)}
+        res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+    print(json.dumps(res))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="backbone", choices=["backbone", "detect", "prm", "prm-nuclei"])
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="detect", choices=["detect", "backbone", "prm", "prm-nuclei"])
+    ap.add_argument("--vols-per-rank", type=int, default=0, help="volumes per rank per step (default: 4 at N=1, 8 at N>1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))          # children are created before anything here touches a GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    import torch
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import m3d
-    from m3d.model import DetectorM3D
-    from m3d.config import Cfg
-    from m3d.synth import make_params, synth_volume
-    from m3d import tiling
-
-    if args.workload in ("prm", "prm-nuclei"):
-        return bench_prm(args, rank, world, dist)
-    cfg = Cfg.nuclei()
-    P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=(args.workload == "detect"))
-    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
-    # configs[1]: one volume per step; configs[2] (--workload detect): a batch of 4 volumes per step, one after the other
-    # (the reference's tiler handles one tile at a time, core/test.py:91-145)
-    nvol = 4 if args.workload == "detect" else 1
-    vols = [torch.from_numpy(tiling.norm1(synth_volume(rank * nvol + v, (VOL, VOL, VOL)), np.float32).astype(np.float32))   # blob.py:179-184
-            .view(1, 1, VOL, VOL, VOL).cuda() for v in range(nvol)]
-    vol = vols[0]
-
-    # dominant kernel = conv2b (64->64, 3^3, 64^3 voxels) with the fused BN+ReLU+MaxPool epilogue: 57.98 GFLOP
-    # ALGORITHMIC per launch (BASELINE.md section 2), 34 % of the backbone FLOPs and the single largest kernel; launched
-    # once per step, so rocprofv3 --stats' per-symbol average is this launch.  Symbol: conv3d_wino_kernel<4,32,1,2,2,4,1,true>
-    # (Winograd F(2,3) along x: executes 2/3 of the algorithmic multiply-adds on the matrix cores, so achieved/peak can
-    # exceed 1) or, with M3D_WINO=0, the direct kernel conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1>.
-    dom_layers = (2,)
-    dom_flops = conv_flops(64, 64, 3, (VOL // 2) ** 3)
-    dom_ev = []
-
-    # backbone workload: the layers before and after the dominant one are replayed as two HIP graphs (fewer launch gaps);
-    # the dominant layer stays an eager launch between two events so its duration is measured live in the timed region.
-    # Opt-in (M3D_GRAPH=1): measured 0.9247 vs 0.9251 ms per step - the eager loop is already GPU-bound (the host runs
-    # ahead of nine ~100 us kernels), so the default stays the plain launches.
-    graphs = None
-    if args.workload == "backbone" and os.environ.get("M3D_GRAPH", "0") == "1" and det.wino_mode == 2:
-        try:
-            dl = dom_layers[0]
-            pre, mid_in = det.capture_body(vol, 0, dl)
-            mid_out = det.body_layer(dl, mid_in).clone()
-            post, final = det.capture_body(mid_out, dl + 1, None)
-            graphs = (pre, mid_in, mid_out, post, final, dl)
-        except Exception as e:                            # noqa: BLE001
-            print("bench: graph capture unavailable (%s); eager loop" % e, file=sys.stderr)
-            graphs = None
-
-    def step_graph(timed):
-        pre, mid_in, mid_out, post, final, dl = graphs
-        pre()
-        conv, scale, shift, pool = det.body[dl]
-        e0 = e1 = None
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        det.body_wino[dl].pooled(mid_in, scale=scale, shift=shift, relu=True, out=mid_out)
-        if timed:
-            e1.record()
-            dom_ev.append((e0, e1))
-        post()
-        return final
-
-    def step(timed):
-        if graphs is not None:
-            return step_graph(timed)
-        out = None
-        for v in vols:
-            out = step_volume(timed, v)
-        return out
-
-    def step_volume(timed, x):
-        for li in range(len(det.body)):
-            if timed and li in dom_layers:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                x = det.body_layer(li, x)
-                e1.record()
-                dom_ev.append((e0, e1))
+    if args.dry:
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        run_dry(args, rank, world, dist)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback); --dry rehearses the launcher on CPU")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             else:
-                x = det.body_layer(li, x)
-        if args.workload == "backbone":
-            return x
-        prob, deltas = det.rpn(x)
-        im_info = np.array([VOL, VOL, VOL, 1.0])
-        rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
-        cls, bbox = det.box_head(x, rois)
-        pred = m3d.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, cfg.bbox_reg_weights, clip_to=im_info[:3])
-        sc, bx, _, _ = det.box_results_with_nms_and_limit(cls, pred, keep_idx)
-        out = torch.zeros((cfg.detections_per_im, 7), device="cuda")
-        n = min(sc.numel(), cfg.detections_per_im)
-        out[:n, :6] = bx[:n]
-        out[:n, 6] = sc[:n]
-        if dist is not None:   # the path's one exchange step: all_gather of padded detections (SURVEY 8e)
-            gathered = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(gathered, out)
-        return out
-
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        dom_ms = float(np.mean([a.elapsed_time(b) for a, b in dom_ev]))
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
-        voxels = world * args.steps * nvol * VOL ** 3
-        res = {
-            "metric": "voxels/sec end-to-end infer_simple (128^3 vol); 3D-conv TFLOPS vs roofline",
-            "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool), 1x1x128x128x128 per rank [configs[1]]"
-                                    if args.workload == "backbone" else
-                                    "detection-mode infer: backbone+RPN+proposals+RoIAlign3D+2mlp head+NMS, batch of 4 x (1x128^3) per rank [configs[2]]"),
-                       "volumes_per_step": world * nvol, "net": "nuclei stride-8 dsn_body, 35 anchors",
-                       "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9,
-                       "backbone_tflops_whole_step": (backbone_flops(VOL) / (dt / args.steps) / 1e12) if args.workload == "backbone" else None,
-                       "launch": "2 HIP graphs + 1 eager launch per step" if graphs is not None else "eager launches"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("conv3d_wino2_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x) + fused BN/ReLU/MaxPool)"
-                                    if det.wino_mode == 2 else
-                                    "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b 64->64 3^3 @64^3, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)"
-                                    if det.wino_mode == 1 else
-                                    "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b 64->64 3^3 @64^3 + fused BN/ReLU/MaxPool)"),
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": dom_ms, "algorithmic_gflop_per_launch": dom_flops / 1e9,
-                         "mfma_executed_tflops": achieved * WINO_WORK[det.wino_mode],
-                         "mfma_executed_frac": achieved * WINO_WORK[det.wino_mode] / FP32_MFMA_PEAK_TFLOPS,
-                         "note": ("achieved counts the ALGORITHMIC 2*Cin*Cout*27 FLOP per output voxel; the Winograd kernel issues %s of "
-                                  "them as MFMA work (mfma_executed_*), which is why frac can exceed 1" % ("4/9" if det.wino_mode == 2 else "2/3"))
-                                 if det.use_wino else None},
-        }
-        res["roofline"].update(pmc_traffic("conv3d_wino2_kernel<4, 32, 2, 2, true>" if det.wino_mode == 2 else
-                                           "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>" if det.wino_mode == 1 else
-                                           "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"))
-        if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
-            # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's torch-CPU restatement)
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle as O
-            ncpu = host_cores()
-            torch.set_num_threads(ncpu)
-            Pc = P
-            xv = vol.cpu()
-            with torch.no_grad():
-                f = O.dsn_body_forward if args.workload == "backbone" else None
-                if f is not None:
-                    f(Pc, xv, 8)     # warm-up
-                    nrep, tcpu = 0, 0.0
-                    while tcpu < 10.0 and nrep < 20:
-                        c0 = time.perf_counter()
-                        f(Pc, xv, 8)
-                        tcpu += time.perf_counter() - c0
-                        nrep += 1
-                else:
-                    ocfg = O.Cfg()
-                    O.detect_tile(Pc, ocfg, xv)
-                    nrep, tcpu = 0, 0.0
-                    while tcpu < 10.0 and nrep < 10:
-                        c0 = time.perf_counter()
-                        O.detect_tile(Pc, ocfg, xv)
-                        tcpu += time.perf_counter() - c0
-                        nrep += 1
-            res["cpu_baseline"] = {"value": nrep * VOL ** 3 / tcpu, "unit": "voxels/s", "cores": ncpu, "kind": "port",
-                                   "sample": "%d x the same 1x128^3 workload (oracle: torch-CPU fp32 convs + oracle C ops), "
-                                             "torch.set_num_threads(%d), %.1f s" % (nrep, ncpu, tcpu)}
-        print(json.dumps(res))
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.workload in ("prm", "prm-nuclei"):
+            bench_prm(args, rank, world, dist)
+        else:
+            bench_detect(args, rank, world, dist)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -7,8 +7,9 @@
  *     and never synchronises the device, so calls may be captured into a hipGraph;
  *   - return value: M3D_OK (0) or a negative M3D_E* code; nothing ever calls exit()
  *     (the reference's launchers print and exit(-1): roi_align_kernel_3d.cu:165-169);
- *   - re-entrant, no global mutable state; scratch memory comes from the caller (`d_ws`, sized by the
- *     matching *_workspace_bytes()).
+ *   - re-entrant; scratch memory comes from the caller (`d_ws`, sized by the matching *_workspace_bytes());
+ *     the library never reads the environment: the only process-wide state is the set of explicit tuning
+ *     options below (m3d_set_option), which the CALLER owns and which default to "library decides".
  * Paths in comments are relative to the reference repository.
  */
 #ifndef M3D_H_
@@ -30,6 +31,11 @@ int m3d_version(void);
 const char* m3d_error_string(int code);
 /* Last HIP runtime error text seen by this thread (for M3D_ELAUNCH). */
 const char* m3d_last_hip_error(void);
+/* Tuning options (benchmark / A-B tooling; production callers never set them).  Names: "xcd_map" (1: XCD-aware
+ * workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt"
+ * (tile-variant overrides of the conv dispatchers, -1 = library chooses).  Unknown name -> M3D_EINVAL. */
+int m3d_set_option(const char* name, int value);
+int m3d_get_option(const char* name, int* value);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RoIAlign 3D.  Replaces roi_align_forward_cuda_3d / roi_align_backward_cuda_3d
@@ -209,6 +215,15 @@ int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, 
 size_t m3d_reduce_min_workspace_bytes(void);
 int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
+/* norm1 pre-processing of a raw volume on the device: mask = im > 0; out = (im - mean(im[mask])) / std(im[mask])
+ * (np.std: population).  Replaces the host NumPy code of lib/utils/blob.py:179-184 (float32; f32_arith = 1) and
+ * tools/infer_simple.py:180-183 (float64, crops cast to float32 at :217; f32_arith = 0), so the raw uint16 volume is what
+ * crosses PCIe.  in_dtype: 0 = uint16, 1 = float32.  Statistics are two-pass fp64 sums in a fixed order (deterministic);
+ * d_stats (optional, 3 doubles) receives mean, std, count. */
+size_t m3d_norm1_workspace_bytes(void);
+int m3d_norm1(const void* d_in, int in_dtype, int64_t n, int f32_arith, float* d_out, double* d_stats, void* d_ws,
+              size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Peak-response back-propagation on cropped windows (all kept peaks of a tile as one batch).  Replaces the
  * per-detection `class_response_maps.backward(...)` loop of lib/prm/peak_response_mapping_3d.py:157-172 and
@@ -239,6 +254,14 @@ int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float* d_data
                        int width, float* d_out, float* d_sums, void* stream);
 int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
                     int depth, int height, int width, float* d_dense, void* stream);
+/* Backward-data of the 5^3 / Cin = 1 stem conv for autograd (what cuDNN dgrad computes for conv1a when the input requires
+ * grad: the reference's PRM mode, lib/prm/peak_response_mapping_3d.py:88 + lib/prm/peak_backprop_3d.py:37-44, lib/modeling/DSN.py:19).
+ *   m3d_conv3d_stem5_prepare_dgrad_weights  d_weight [C,1,5,5,5] -> d_wf [C,125], taps flipped (no ReLU: the caller passes
+ *                                           whatever weight the conv ran with)
+ *   m3d_conv3d_stem5_dgrad                  d_grad_out [batch,C,D,H,W] -> d_grad_in [batch,1,D,H,W] */
+int m3d_conv3d_stem5_prepare_dgrad_weights(const float* d_weight, int channels, float* d_wf, void* stream);
+int m3d_conv3d_stem5_dgrad(const float* d_grad_out, const float* d_wf, float* d_grad_in, int batch, int channels, int depth,
+                           int height, int width, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * PRM post-processing feeding the Otsu step.

@@ -548,8 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem5_kernel(const float* __res
 }
 
 inline int xcd_map_enabled() {   // M3D_XCD_MAP=0 restores the plain round-robin order (A/B measurements)
-  const char* e = getenv("M3D_XCD_MAP");
-  return !(e && e[0] == '0');
+  return m3d::opt(m3d::OPT_XCD_MAP) != 0;
 }
 
 template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
@@ -639,9 +638,8 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
       if (width < 24) return M3D_EUNSUPPORTED;
       return launch_cfg<3, 2, 32, 4, 2, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     }
-    // tuning override (tools/bench_layers.py only): M3D_TUNE_K3=<variant index>
-    if (const char* tv = getenv("M3D_TUNE_K3")) {
-      const int v = atoi(tv);
+    // tuning override (tools/bench_layers.py only): m3d_set_option("tune_k3", <variant index>)
+    if (const int v = m3d::opt(m3d::OPT_TUNE_K3); v >= 0) {
 #define M3D_V(i, ...) if (v == i) return launch_cfg<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       M3D_V(0, 3, 2, 32, 4, 2, 4, 1)
       M3D_V(1, 3, 2, 32, 2, 2, 4, 1)

@@ -379,8 +379,7 @@ __global__ __launch_bounds__(64 * WZ * WY * KS, 2) void conv3d_wino_kernel(const
 }
 
 inline int xcd_map_enabled() {
-  const char* e = getenv("M3D_XCD_MAP");
-  return !(e && e[0] == '0');
+  return m3d::opt(m3d::OPT_XCD_MAP) != 0;
 }
 
 template <int CC, int XT, int ROWS, int NCB, int WZ, int WY, int KS, bool POOL = false>
@@ -425,8 +424,7 @@ M3D_API int m3d_conv3d_wino_forward(const float* d_in, const float* d_packed, fl
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;   // 32-bit buffer offsets per batch item
   WEpi ep{d_scale, d_shift, relu, 0};
   hipStream_t st = m3d::as_stream(stream);
-  int variant = -1;
-  if (const char* tv = getenv("M3D_TUNE_WINO")) variant = atoi(tv);
+  const int variant = m3d::opt(m3d::OPT_TUNE_WINO);
 #define M3D_W(i, ...) if (variant == i) return launch_wino<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   M3D_W(0, 4, 32, 1, 2, 2, 4, 1)      // 64 x (4 y) x (2 z) voxels x 64 channels, 8 waves
   M3D_W(1, 4, 32, 1, 2, 4, 2, 1)

@@ -432,8 +432,7 @@ __global__ __launch_bounds__(256) void wino2_reduce_kernel(const float* __restri
 }
 
 inline int xcd_map_enabled2() {
-  const char* e = getenv("M3D_XCD_MAP");
-  return !(e && e[0] == '0');
+  return m3d::opt(m3d::OPT_XCD_MAP) != 0;
 }
 
 template <int CC, int XT, int WZ, int WY, bool POOL = false>
@@ -490,7 +489,7 @@ SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int w
 
 int choose_xt(int batch, int cin, int cout, int D, int H, int W, double* best_score = nullptr) {
   if (best_score) *best_score = 0.0;
-  if (const char* tv = getenv("M3D_TUNE_WINO2_XT")) { if (best_score) *best_score = 1.0; return atoi(tv); }
+  if (const int tv = m3d::opt(m3d::OPT_TUNE_WINO2_XT); tv >= 0) { if (best_score) *best_score = 1.0; return tv; }
   if (W < 12) return 0;
   auto up = [](int v, int t) { return (double)((v + t - 1) / t) * t; };
   const double vol = (double)D * H * W, cot = (cout + 31) / 32;
@@ -537,8 +536,7 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  int variant = -1;
-  if (const char* tv = getenv("M3D_TUNE_WINO2")) variant = atoi(tv);
+  const int variant = m3d::opt(m3d::OPT_TUNE_WINO2);
 #define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
   M3D_W2(1, 4, 32, 4, 1)

@@ -5,7 +5,28 @@ namespace m3d {
 thread_local char g_last_hip_error[256] = "";
 }
 
-M3D_API int m3d_version(void) { return 100; }
+#include <atomic>
+namespace m3d {
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {-1}, {-1}, {-1}, {-1}};
+static const char* const kOptNames[OPT_COUNT] = {"xcd_map", "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt"};
+int opt(Opt o) { return g_opt[o].load(std::memory_order_relaxed); }
+}  // namespace m3d
+
+M3D_API int m3d_version(void) { return 200; }
+
+M3D_API int m3d_set_option(const char* name, int value) {
+  if (!name) return M3D_EINVAL;
+  for (int i = 0; i < m3d::OPT_COUNT; ++i)
+    if (!strcmp(name, m3d::kOptNames[i])) { m3d::g_opt[i].store(value, std::memory_order_relaxed); return M3D_OK; }
+  return M3D_EINVAL;
+}
+
+M3D_API int m3d_get_option(const char* name, int* value) {
+  if (!name || !value) return M3D_EINVAL;
+  for (int i = 0; i < m3d::OPT_COUNT; ++i)
+    if (!strcmp(name, m3d::kOptNames[i])) { *value = m3d::opt((m3d::Opt)i); return M3D_OK; }
+  return M3D_EINVAL;
+}
 
 M3D_API const char* m3d_error_string(int code) {
   switch (code) {

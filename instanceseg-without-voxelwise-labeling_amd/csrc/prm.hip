@@ -123,12 +123,12 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
 // loads, not LDS traffic).  Each thread owns 8 x  by 2 y outputs: one dz-slab of 6 rows x 12 inputs (18 ds_read_b128)
 // feeds 16 * 25 = 400 FMAs.  Tile 32 x 16 x 8 voxels, the next channel's halo tile is fetched into registers
 // while the current one is consumed (double-buffered LDS).
-__global__ void prm_stem_prep_kernel(const float* __restrict__ w /*[C,125]*/, int C, float* __restrict__ wf) {
+__global__ void prm_stem_prep_kernel(const float* __restrict__ w /*[C,125]*/, int C, float* __restrict__ wf, int relu) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= C * 125) return;
   const int c = e / 125, t = e % 125;
   const float v = w[c * 125 + (124 - t)];          // dgrad of a "same" conv: W'[t'] = W[124 - t']
-  wf[e] = v > 0.f ? v : 0.f;                        // relu(W), peak_backprop_3d.py:41
+  wf[e] = (relu && !(v > 0.f)) ? 0.f : v;           // relu(W), peak_backprop_3d.py:41 (plain flip for the autograd dgrad)
 }
 
 // Thread layout NXT (x) x NYT (y) x 8 (z), 8 x 2 outputs per thread: tile 8*NXT x 2*NYT x 8.  <4,8>: 32 x 16 x 8 (the
@@ -142,19 +142,21 @@ struct SDG {
   static_assert(NXT * NYT * 8 <= 256 && HX % 4 == 0, "thread layout / float4 rows");
 };
 
-template <int NXT, int NYT>
-__global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __restrict__ gn /*[P,C,Wn^3]*/,
-                                                             const float* __restrict__ wf /*[C,125] flipped relu(W)*/,
+// PLAIN = true: the bare backward-data of the stem conv for autograd (m3d_conv3d_stem5_dgrad): windows are whole
+// [Wz,Wy,Wx] maps, no PreHook multiply / clamp / sum.
+template <int NXT, int NYT, bool PLAIN>
+__global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __restrict__ gn /*[P,C,Wz,Wy,Wx]*/,
+                                                             const float* __restrict__ wf /*[C,125] flipped (relu) W*/,
                                                              const float* __restrict__ data /*[D,H,W]*/,
                                                              const float* __restrict__ data_off, const int* __restrict__ origins,
-                                                             int Wn, int D, int H, int W, int C, float* __restrict__ out /*[P,Wn^3]*/,
-                                                             float* __restrict__ sums /*[P]*/) {
+                                                             int Wz, int Wy, int Wx, int D, int H, int W, int C,
+                                                             float* __restrict__ out /*[P,Wz,Wy,Wx]*/, float* __restrict__ sums /*[P]*/) {
   using G = SDG<NXT, NYT>;
   constexpr int SD_TX = G::TX, SD_TY = G::TY, SD_TZ = G::TZ, SD_HX = G::HX, SD_HY = G::HY, SD_TILE = G::TILE, SD_NI = G::NI;
   extern __shared__ float sd_lds[];                       // 2 x SD_TILE
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  const int tiles = (Wn + SD_TX - 1) / SD_TX, tilesy = (Wn + SD_TY - 1) / SD_TY;
+  const int tiles = (Wx + SD_TX - 1) / SD_TX, tilesy = (Wy + SD_TY - 1) / SD_TY;
   int bid = blockIdx.x;
   const int tx = bid % tiles; bid /= tiles;
   const int ty = bid % tilesy; bid /= tilesy;
@@ -164,15 +166,15 @@ __global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __rest
   const bool active = tid < NXT * NYT * 8;                // the other threads only help staging
   const int ct = active ? tid : 0;
   const int lx = (ct % NXT) * 8, ly = ((ct / NXT) % NYT) * 2, lz = ct / (NXT * NYT);
-  const size_t w3 = (size_t)Wn * Wn * Wn;
+  const size_t w3 = (size_t)Wz * Wy * Wx;
 
   // staging: element e of the halo tile <-> offset inside one channel window (-1 = zero); recomputed per channel
   // (cheap VALU) rather than kept in 34 registers
   auto elem_off = [&](int e) __attribute__((always_inline)) -> int {
     const int hz = e / (SD_HY * SD_HX), hy = (e / SD_HX) % SD_HY, hx = e % SD_HX;
     const int z = z0 + hz - 2, y = y0 + hy - 2, x = x0 + hx - 2;
-    const bool ok = (e < SD_TILE) & (z >= 0) & (z < Wn) & (y >= 0) & (y < Wn) & (x >= 0) & (x < Wn);
-    return ok ? (int)(((size_t)z * Wn + y) * Wn + x) : -1;
+    const bool ok = (e < SD_TILE) & (z >= 0) & (z < Wz) & (y >= 0) & (y < Wy) & (x >= 0) & (x < Wx);
+    return ok ? (int)(((size_t)z * Wy + y) * Wx + x) : -1;
   };
   float rin[SD_NI];
   auto prefetch = [&](int c) __attribute__((always_inline)) {
@@ -232,6 +234,18 @@ __global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __rest
   }
   // PreHook multiply, clamp(min=0) (peak_response_mapping_3d.py:170), per-peak sum for the normalisation (:171)
   const int z = z0 + lz;
+  if constexpr (PLAIN) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int y = y0 + ly + j;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int x = x0 + lx + i;
+        if (active && z < Wz && y < Wy && x < Wx) out[(size_t)p * w3 + ((size_t)z * Wy + y) * Wx + x] = acc[j][i];
+      }
+    }
+    return;
+  }
   const int oz = origins[3 * p], oy = origins[3 * p + 1], ox = origins[3 * p + 2];
   float local = 0.f;
   const float off = *data_off;
@@ -241,14 +255,14 @@ __global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int x = x0 + lx + i;
-      if (active && z < Wn && y < Wn && x < Wn) {
+      if (active && z < Wz && y < Wy && x < Wx) {
         const int qz = oz + z, qy = oy + y, qx = ox + x;
         float v = 0.f;
         if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
           v = (data[((size_t)qz * H + qy) * W + qx] - off) * acc[j][i];
           v = v > 0.f ? v : 0.f;
         }
-        out[(size_t)p * w3 + ((size_t)z * Wn + y) * Wn + x] = v;
+        out[(size_t)p * w3 + ((size_t)z * Wy + y) * Wx + x] = v;
         local += v;
       }
     }
@@ -319,8 +333,34 @@ M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int 
 M3D_API int m3d_prm_stem_prepare_weights(const float* d_weight, int channels, float* d_wf, void* stream) {
   if (!d_weight || !d_wf || channels <= 0) return M3D_EINVAL;
   hipLaunchKernelGGL(prm_stem_prep_kernel, dim3((channels * 125 + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_weight,
-                     channels, d_wf);
+                     channels, d_wf, 1);
   return m3d::check_launch("prm_stem_prepare_weights");
+}
+
+// Backward-data of the 5^3 / Cin = 1 stem conv for autograd (the F.conv3d interception when the input requires grad - exactly
+// the reference's PRM mode, peak_response_mapping_3d.py:88 + peak_backprop_3d.py:37-44): gx[b,0,v] = sum_{c,t} W[c][124-t] gy[b,c][v+t-2].
+M3D_API int m3d_conv3d_stem5_prepare_dgrad_weights(const float* d_weight, int channels, float* d_wf, void* stream) {
+  if (!d_weight || !d_wf || channels <= 0) return M3D_EINVAL;
+  hipLaunchKernelGGL(prm_stem_prep_kernel, dim3((channels * 125 + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_weight,
+                     channels, d_wf, 0);
+  return m3d::check_launch("conv3d_stem5_prepare_dgrad_weights");
+}
+
+M3D_API int m3d_conv3d_stem5_dgrad(const float* d_grad_out, const float* d_wf, float* d_grad_in, int batch, int channels, int depth,
+                                   int height, int width, void* stream) {
+  if (batch < 0 || channels <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (batch == 0) return M3D_OK;
+  if (!d_grad_out || !d_wf || !d_grad_in || batch > 65535) return M3D_EINVAL;
+  if ((size_t)depth * height * width >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;      // 32-bit offsets inside one channel map
+  using K = SDG<4, 8>;
+  auto kern = prm_stem_dgrad_kernel<4, 8, true>;
+  const int tx = (width + K::TX - 1) / K::TX, ty = (height + K::TY - 1) / K::TY, tz = (depth + 7) / 8;
+  const size_t lds = sizeof(float) * 2 * K::TILE;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(tx * ty * tz, batch), dim3(256), lds, m3d::as_stream(stream), d_grad_out, d_wf,
+                     (const float*)nullptr, (const float*)nullptr, (const int*)nullptr, depth, height, width, depth, height, width,
+                     channels, d_grad_in, (float*)nullptr);
+  return m3d::check_launch("conv3d_stem5_dgrad");
 }
 
 M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float* d_data, const float* d_data_offset,
@@ -335,7 +375,7 @@ M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float
     const size_t lds = sizeof(float) * 2 * TILE;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(tx * ty * tz, num_peaks), dim3(256), lds, m3d::as_stream(stream), d_gn, d_wf, d_data,
-                       d_data_offset, d_origins, win, depth, height, width, channels, d_out, d_sums);
+                       d_data_offset, d_origins, win, win, win, depth, height, width, channels, d_out, d_sums);
   };
   // useful fraction of the computed tile volume decides the layout (84^3: 32x16x8 -> 73 %, 40x12x8 -> 70 %; 40^3: 52 % vs 78 %)
   auto eff = [&](int TX, int TY, double threads) {
@@ -343,9 +383,9 @@ M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float
     return (double)win * win * win / (cx * cy * cz) * threads;
   };
   if (eff(40, 12, 240.0 / 256.0) > eff(32, 16, 1.0))
-    launch(prm_stem_dgrad_kernel<5, 6>, 40, 12, SDG<5, 6>::TILE);
+    launch(prm_stem_dgrad_kernel<5, 6, false>, 40, 12, SDG<5, 6>::TILE);
   else
-    launch(prm_stem_dgrad_kernel<4, 8>, 32, 16, SDG<4, 8>::TILE);
+    launch(prm_stem_dgrad_kernel<4, 8, false>, 32, 16, SDG<4, 8>::TILE);
   return m3d::check_launch("prm_stem_dgrad");
 }
 

@@ -21,7 +21,7 @@ struct AxisSample {  // one (bin, sub-sample) along one axis
   int valid;         // 0 => whole sample contributes 0 (coordinate outside [-1, dim])
 };
 
-constexpr int kMaxTable = 64;   // A * grid per axis (7 bins * adaptive grid <= 9); larger adaptive grids leave the output zero
+constexpr int kMaxTable = 64;   // A * grid per axis (7 bins * adaptive grid <= 9); larger adaptive grids take roi_untabled_range
 
 __device__ inline AxisSample make_sample(float start, float bin, int p, int i, int grid, int dim, double lo_limit) {
   // coordinate: roi_start + p*bin + (i + .5f)*bin/grid   (roi_align_kernel_3d.cu:130-138)
@@ -108,6 +108,63 @@ __device__ inline void roi_exact_forward_range(const float* __restrict__ feat, f
   }
 }
 
+// Adaptive sampling grids (sampling_ratio <= 0, roi_align_kernel_3d.cu:116-123) grow with the RoI: grid = ceil(roi / A) per axis,
+// so a 100-voxel RoI has 15 samples per bin and no longer fits the LDS tables.  Such RoIs take this untabled path: the same
+// make_sample arithmetic evaluated per sample (same values, same summation order as the tabled path and the oracle), just slower.
+template <bool kBackward>
+__device__ inline void roi_untabled_range(const float* __restrict__ feat_or_top, float* __restrict__ out_or_grad, const RoiGeom& g,
+                                          int n, int c0, int c1, int C, int S, int H, int W, int AS, int AH, int AW) {
+  const int bins = AS * AH * AW;
+  const float count = (float)(g.grid_s * g.grid_h * g.grid_w);
+  const int HW = H * W;
+  const int total = (c1 - c0) * bins;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int c = c0 + e / bins;
+    const int b = e % bins;
+    const int ps = b % AS, pw = (b / AS) % AW, ph = b / AS / AW;
+    const size_t plane = ((size_t)g.batch * C + c) * S * HW;
+    float acc = 0.f;
+    const float t = kBackward ? feat_or_top[((size_t)n * C + c) * bins + ps * AH * AW + ph * AW + pw] : 0.f;   // :272-275
+    for (int iz = 0; iz < g.grid_s; ++iz) {
+      const AxisSample z = make_sample(g.start_s, g.bin_s, ps, iz, g.grid_s, S, kBackward ? -0.1 : -1.0);
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const AxisSample y = make_sample(g.start_h, g.bin_h, ph, iy, g.grid_h, H, -1.0);
+        const float hzhy = z.h * y.h, hzly = z.h * y.l, lzhy = z.l * y.h, lzly = z.l * y.l;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const AxisSample x = make_sample(g.start_w, g.bin_w, pw, ix, g.grid_w, W, -1.0);
+          const bool ok = z.valid & y.valid & x.valid;
+          const float w[8] = {hzhy * x.h, hzhy * x.l, hzly * x.h, hzly * x.l, lzhy * x.h, lzhy * x.l, lzly * x.h, lzly * x.l};
+          const int idx[8] = {z.lo * HW + y.lo * W + x.lo, z.lo * HW + y.lo * W + x.hi, z.lo * HW + y.hi * W + x.lo,
+                              z.lo * HW + y.hi * W + x.hi, z.hi * HW + y.lo * W + x.lo, z.hi * HW + y.lo * W + x.hi,
+                              z.hi * HW + y.hi * W + x.lo, z.hi * HW + y.hi * W + x.hi};
+          if (kBackward) {
+            if (!ok) continue;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              float gq = t * w[q];
+              gq = gq / count;
+              atomicAdd(out_or_grad + plane + idx[q], gq);
+            }
+          } else {
+            float val = 0.f;
+            if (ok) {
+              const float* data = feat_or_top + plane;
+              val = w[0] * data[idx[0]];
+#pragma unroll
+              for (int q = 1; q < 8; ++q) val = val + w[q] * data[idx[q]];
+            }
+            acc += val;
+          }
+        }
+      }
+    }
+    if (!kBackward) {
+      acc /= count;
+      out_or_grad[((size_t)n * C + c) * bins + b] = acc;
+    }
+  }
+}
+
 // grid = (num_rois, channel_chunks); block = 256
 template <bool kBackward>
 __global__ __launch_bounds__(256) void roi_align3d_kernel(const float* __restrict__ feat_or_top, const float* __restrict__ rois,
@@ -120,8 +177,10 @@ __global__ __launch_bounds__(256) void roi_align3d_kernel(const float* __restric
   if (threadIdx.x == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio);
   __syncthreads();
   const RoiGeom g = sg;
-  if (AS * g.grid_s > kMaxTable || AH * g.grid_h > kMaxTable || AW * g.grid_w > kMaxTable) {
-    return;   // adaptive grid larger than the table: output left as allocated (zero-filled by the caller)
+  if (AS * g.grid_s > kMaxTable || AH * g.grid_h > kMaxTable || AW * g.grid_w > kMaxTable) {   // adaptive grid beyond the tables
+    const int c0u = blockIdx.y * ch_per_block;
+    roi_untabled_range<kBackward>(feat_or_top, out_or_grad, g, n, c0u, min(C, c0u + ch_per_block), C, S, H, W, AS, AH, AW);
+    return;
   }
   for (int t = threadIdx.x; t < AS * g.grid_s; t += blockDim.x)
     tz[t] = make_sample(g.start_s, g.bin_s, t / g.grid_s, t % g.grid_s, g.grid_s, S, kBackward ? -0.1 : -1.0);
@@ -202,7 +261,11 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
   __syncthreads();
   const RoiGeom g = sg;
   const int nz = AS * g.grid_s, ny = AH * g.grid_h, nx = AW * g.grid_w;
-  if (nz > kMaxTable || ny > kMaxTable || nx > kMaxTable) return;   // as the exact kernel: output stays zero-filled
+  if (nz > kMaxTable || ny > kMaxTable || nx > kMaxTable) {          // adaptive grid beyond the tables: untabled reference order
+    const int c0u = blockIdx.y * ch_per_block;
+    roi_untabled_range<false>(feat, out, g, n, c0u, min(C, c0u + ch_per_block), C, S, H, W, AS, AH, AW);
+    return;
+  }
   for (int t = tid; t < nz; t += 256) tz[t] = make_sample(g.start_s, g.bin_s, t / g.grid_s, t % g.grid_s, g.grid_s, S, -1.0);
   for (int t = tid; t < ny; t += 256) ty[t] = make_sample(g.start_h, g.bin_h, t / g.grid_h, t % g.grid_h, g.grid_h, H, -1.0);
   for (int t = tid; t < nx; t += 256) tx[t] = make_sample(g.start_w, g.bin_w, t / g.grid_w, t % g.grid_w, g.grid_w, W, -1.0);

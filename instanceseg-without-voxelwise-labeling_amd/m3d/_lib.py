@@ -9,7 +9,8 @@ M3D_OK = 0
 _lib = None
 
 SYMBOLS = [
-    "m3d_version", "m3d_error_string", "m3d_last_hip_error",
+    "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option",
+    "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1",
     "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward",
     "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
     "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
@@ -43,11 +44,27 @@ def lib():
         L.m3d_last_hip_error.restype = C.c_char_p
         L.m3d_conv3d_wino2_score.restype = C.c_double
         for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
-                  "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_otsu2d_workspace_bytes",
+                  "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_otsu2d_workspace_bytes",
                   "m3d_cc_workspace_bytes", "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_stem_wino_packed_weight_bytes"):
             getattr(L, n).restype = C.c_size_t
         _lib = L
+        # The library itself never reads the environment (include/m3d.h); this loader - the caller - forwards the
+        # A/B-tooling knobs of tools/*.py once, at load time.
+        for env, name in (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
+                          ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt")):
+            if env in os.environ:
+                set_option(name, int(os.environ[env]))
     return _lib
+
+
+def set_option(name, value):
+    check(lib().m3d_set_option(name.encode(), int(value)), "set_option(%s)" % name)
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().m3d_get_option(name.encode(), C.byref(v)), "get_option(%s)" % name)
+    return v.value
 
 
 def check(rc, what=""):

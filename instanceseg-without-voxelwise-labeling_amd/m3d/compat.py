@@ -17,6 +17,7 @@ backward-data, so lib/modeling/DSN.py and lib/prm/peak_backprop_3d.py run unchan
 import importlib
 import sys
 import types
+import weakref
 
 import numpy as np
 import torch
@@ -144,18 +145,31 @@ class _Legacy2D(object):
 
 # ----------------------------------------------------------------------------- F.conv3d interception
 _orig_conv3d = None
-_pack_cache = {}
+_pack_cache = {}          # (id(parameter), mode) -> (weakref to the parameter, _version, data_ptr, pack)
+STEM_DGRAD = "stem-dgrad"  # pseudo-mode: tap-flipped [C,125] weights of the 5^3 / Cin = 1 stem's backward-data
+
+
+def _make_pack(weight, mode):
+    w = weight.detach()
+    return ops.conv3d_stem5_dgrad_weights(w) if mode == STEM_DGRAD else ops.PackedConv3d(w, mode)
 
 
 def _packed(weight, mode):
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), mode)
-    p = _pack_cache.get(key)
-    if p is None:
-        if len(_pack_cache) > 256:
-            _pack_cache.clear()
-        p = ops.PackedConv3d(weight.detach(), mode)
-        _pack_cache[key] = p
-    return p
+    """MFMA-order pack of `weight`.  Only nn.Parameters are cached, and a cached pack is served only to the SAME live
+    object at the same `_version` and address: the reference's pr_conv3d passes a fresh `F.relu(self.weight).detach()`
+    every call (peak_backprop_3d.py:41) whose address the allocator may later hand to another layer's temporary of the
+    same shape - temporaries are therefore re-packed on every call (7-25 us, small next to the conv)."""
+    if not isinstance(weight, torch.nn.Parameter):
+        return _make_pack(weight, mode)
+    key = (id(weight), mode)
+    ent = _pack_cache.get(key)
+    if ent is not None:
+        ref, ver, ptr, pack = ent
+        if ref() is weight and ver == weight._version and ptr == weight.data_ptr():
+            return pack
+    pack = _make_pack(weight, mode)
+    _pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _pack_cache.pop(k, None)), weight._version, weight.data_ptr(), pack)
+    return pack
 
 
 class _Conv3dFn(torch.autograd.Function):
@@ -169,7 +183,12 @@ class _Conv3dFn(torch.autograd.Function):
     def backward(ctx, gy):
         weight, x = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = _packed(weight, ops.W_DGRAD)(gy) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if weight.shape[2] == 5:          # conv1a: one input channel -> VALU dgrad kernel (csrc/prm.hip)
+                gx = ops.conv3d_stem5_dgrad(gy, _packed(weight, STEM_DGRAD))
+            else:
+                gx = _packed(weight, ops.W_DGRAD)(gy)
         gw = ops.conv3d_wgrad(x, gy, weight.shape[2]) if ctx.needs_input_grad[1] else None
         gb = ops.conv3d_bias_grad(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
@@ -187,7 +206,7 @@ def _qualifies(x, weight, stride, padding, dilation, groups):
         return False
     if k in (1, 3):
         return True
-    return k == 5 and weight.shape[1] == 1 and weight.shape[0] <= 64 and not x.requires_grad
+    return k == 5 and weight.shape[1] == 1 and weight.shape[0] <= 64
 
 
 def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):

@@ -13,17 +13,18 @@ from . import io as mio
 from . import ops, tiling
 
 
-def im_detect_all(det, im, patch=None, overlap=100, dist=None):
+def im_detect_all(det, im, patch=None, overlap=None, dist=None):
     """det: DetectorM3D; im: raw (S,H,W) volume (any dtype).  Returns cls_boxes_total: list (per class) of
     [n,7] float32 arrays (x1,y1,z1,x2,y2,z2,score) in volume coordinates, after the cross-tile nms_3d
     (core/test.py:159).  With `dist` initialised the tiles are sharded round-robin over ranks and their
     detections exchanged by one all_gather (m3d.shard)."""
     from . import shard
     c = det.cfg
-    patch = patch or getattr(c, "in_size", (64, 200, 200))
+    patch = patch or c.in_size                                                # TEST.IN_SIZE
+    overlap = c.crop_ovlp if overlap is None else overlap                     # TEST.CROP_OVLP (core/test.py:87): 100 nuclei, 32 soma
     vol = tiling.norm1(np.asarray(im), np.float32).astype(np.float32)          # blob.py:179-184
     vol, pad_s = tiling.pad_slices(vol, patch[0])                             # core/test.py:79-86
-    sidx, hidx, widx = tiling.tile_grid(vol.shape, patch, overlap)
+    sidx, hidx, widx = tiling.detect_grid(c, vol.shape, patch, overlap)
     tiles = tiling.enumerate_tiles(sidx, hidx, widx)
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
@@ -36,8 +37,7 @@ def im_detect_all(det, im, patch=None, overlap=100, dist=None):
         d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
         off = torch.tensor([w, h, s - pad_s, w, h, s - pad_s, 0], dtype=torch.float32, device=d.device)   # :117-121,140-141
         local.append(d + off)
-    padded, counts = shard.pack_detections(local, c.detections_per_im, device="cuda")
-    allt = shard.all_gather_detections(padded, counts, len(tiles), dist)
+    allt = shard.all_gather_detections(local, c.detections_per_im, len(tiles), dist, device="cuda")   # ONE collective
     dets = torch.cat(allt, 0) if allt else torch.zeros((0, 7), device="cuda")
     keep = ops.nms3d(dets.contiguous(), c.nms)                                 # :159
     res = [np.zeros((0, 7), np.float32) for _ in range(c.num_classes)]
@@ -45,11 +45,13 @@ def im_detect_all(det, im, patch=None, overlap=100, dist=None):
     return res
 
 
-def infer_prm(engine, im, dataset="nuclei", patch=None, overlap=100, out_dir=None, peak_threshold=0.1):
+def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, peak_threshold=0.1):
     """engine: PRMEngine.  Returns a list of per-tile dicts {num, start, dets (float64 [P,7]), prm_u8 (list of
     uint8 volumes, slice padding removed)} for tiles that produced detections (infer_simple.py:209-247)."""
     c = engine.cfg
-    patch = patch or getattr(c, "in_size", (64, 200, 200))
+    patch = patch or c.in_size
+    overlap = c.crop_ovlp if overlap is None else overlap                     # :197
+    dataset = dataset or getattr(c, "dataset", "nuclei")                      # args.dataset (:197,201)
     vol = tiling.norm1(np.asarray(im), np.float64)                            # :180-183
     orig_slices = vol.shape[0]
     vol, pad_s = tiling.pad_slices(vol, patch[0])                             # :188-195
@@ -58,7 +60,7 @@ def infer_prm(engine, im, dataset="nuclei", patch=None, overlap=100, out_dir=Non
     for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
         crop = vol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].copy().astype(np.float32)   # :217
         out = engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=peak_threshold, dense=True)
-        if out is None or out.get("dets") is None:
+        if out is None:
             continue                                                          # :225-226
         dets = out["dets"].cpu().numpy()
         q = ops.prm_quantize_u8(out["prms"]).cpu().numpy()                   # :233-238 on device, then 1 byte per voxel D2H

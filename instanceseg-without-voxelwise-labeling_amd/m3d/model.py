@@ -27,12 +27,52 @@ def dsn_layers(stride):
             ("conv3b", "bn3b", False)]
 
 
+class Probe:
+    """Optional HIP-event spans around named launches (bench.py: live duration of the dominant kernels inside the timed
+    region, on the stream they are launched on).  `det.probe = Probe()` switches it on; None costs nothing."""
+
+    def __init__(self):
+        self.spans = {}
+
+    class _Span:
+        def __init__(self, probe, name):
+            self.p, self.name = probe, name
+
+        def __enter__(self):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+        def __exit__(self, *a):
+            self.e1.record()
+            self.p.spans.setdefault(self.name, []).append((self.e0, self.e1))
+
+    def __call__(self, name):
+        return Probe._Span(self, name)
+
+    def mean_ms(self):
+        """name -> mean duration in ms (call after a device synchronize)."""
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.spans.items()}
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
 class DetectorM3D:
     def __init__(self, params, cfg):
         """params: dict of CUDA fp32 tensors with the reference's state-dict keys; cfg: object with the
         attributes of oracle.Cfg (stride, anchors, pre/post_nms_topN, thresholds, ...)."""
         self.cfg = cfg
         self.P = params
+        self.probe = None
         self.anchors = np.ascontiguousarray(cfg.anchors, dtype=np.float64)
         self.body = []
         for cname, bname, pool in dsn_layers(cfg.stride):
@@ -86,9 +126,14 @@ class DetectorM3D:
         x = conv(x, scale=scale, shift=shift, relu=True)
         return ops.maxpool3d_2x(x) if pool else x
 
+    def span(self, name):
+        return self.probe(name) if self.probe is not None else _NOSPAN
+
     def conv_body(self, x, first=0, last=None):
+        names = dsn_layers(self.cfg.stride)
         for li in range(first, len(self.body) if last is None else last):
-            x = self.body_layer(li, x)
+            with self.span(names[li][0]):
+                x = self.body_layer(li, x)
         return x
 
     def capture_body(self, x, first=0, last=None):
@@ -124,9 +169,11 @@ class DetectorM3D:
     # ---- lib/modeling/fast_rcnn_heads.py:104-117,39-47
     def box_head(self, feat, rois):
         c, P = self.cfg, self.P
-        x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
+        with self.span("roi_align3d"):
+            x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
         x = x.view(x.shape[0], -1)
-        x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"]))
+        with self.span("fc1"):
+            x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"]))
         x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc2.weight"], P["Box_Head.fc2.bias"]))
         cls = torch.softmax(torch.nn.functional.linear(x, P["Box_Outs.cls_score.weight"], P["Box_Outs.cls_score.bias"]), dim=1)
         bbox = torch.nn.functional.linear(x, P["Box_Outs.bbox_pred.weight"], P["Box_Outs.bbox_pred.bias"])

@@ -11,8 +11,8 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1",
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -222,6 +222,24 @@ def reduce_min(x):
     return out
 
 
+def norm1(vol, f32_arith=True, out=None, return_stats=False):
+    """mask = vol > 0; (vol - mean(vol[mask])) / std(vol[mask]) on the device -> fp32 tensor of vol's shape.
+    vol: uint16 (raw) or float32 CUDA tensor.  f32_arith=True mirrors prep_im_for_blob (blob.py:179-184, float32
+    arithmetic); False mirrors infer_simple.py:180-183 (float64, rounded to fp32 once)."""
+    _need_gpu(vol)
+    vol = vol.contiguous()
+    if vol.dtype not in (torch.uint16, torch.float32):
+        raise TypeError("norm1 takes uint16 or float32 volumes")
+    if out is None:
+        out = torch.empty(vol.shape, dtype=torch.float32, device=vol.device)
+    wsb = lib().m3d_norm1_workspace_bytes()
+    ws = torch.empty((wsb // 8,), dtype=torch.float64, device=vol.device)
+    stats = torch.empty((3,), dtype=torch.float64, device=vol.device) if return_stats else None
+    check(lib().m3d_norm1(_ptr(vol), 0 if vol.dtype == torch.uint16 else 1, C.c_int64(vol.numel()), int(bool(f32_arith)),
+                          _ptr(out), _ptr(stats), _ptr(ws), C.c_size_t(wsb), _stream()), "norm1")
+    return (out, stats) if return_stats else out
+
+
 # ------------------------------------------------------------------ Otsu 2D
 def otsu2d_batch(image, prm, offsets, max_gray_range=4096):
     """image, prm: flat uint16 CUDA tensors (crops concatenated); offsets int64 [R+1] CUDA.
@@ -300,6 +318,27 @@ def prm_stem_dgrad(gn, weight, data, data_off, origins):
     check(lib().m3d_prm_stem_dgrad(_ptr(gn), _ptr(weight), _ptr(data), _ptr(data_off), _ptr(origins), P, Cc, Wn, data.shape[0],
                                    data.shape[1], data.shape[2], _ptr(out), _ptr(sums), _stream()), "prm_stem_dgrad")
     return out, sums
+
+
+def conv3d_stem5_dgrad_weights(weight):
+    """weight [C,1,5,5,5] -> [C,125] tap-flipped (no ReLU) for conv3d_stem5_dgrad."""
+    _need_gpu(weight)
+    weight = _f32c(weight)
+    assert tuple(weight.shape[1:]) == (1, 5, 5, 5)
+    wf = torch.empty((weight.shape[0], 125), dtype=torch.float32, device=weight.device)
+    check(lib().m3d_conv3d_stem5_prepare_dgrad_weights(_ptr(weight), weight.shape[0], _ptr(wf), _stream()), "stem5_prepare_dgrad_weights")
+    return wf
+
+
+def conv3d_stem5_dgrad(grad_out, wf):
+    """Backward-data of the 5^3 / Cin=1 stem conv: grad_out [B,C,D,H,W], wf = conv3d_stem5_dgrad_weights(W) -> [B,1,D,H,W]."""
+    _need_gpu(grad_out, wf)
+    grad_out = _f32c(grad_out)
+    B, Cc, D, H, W = grad_out.shape
+    assert wf.shape == (Cc, 125)
+    gin = torch.empty((B, 1, D, H, W), dtype=torch.float32, device=grad_out.device)
+    check(lib().m3d_conv3d_stem5_dgrad(_ptr(grad_out), _ptr(wf), _ptr(gin), B, Cc, D, H, W, _stream()), "conv3d_stem5_dgrad")
+    return gin
 
 
 def prm_scatter(windows, sums, origins, shape):

@@ -109,13 +109,17 @@ class PRMEngine:
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193
     def prm_tile(self, data, peak_threshold=0.1, dense=True):
+        """One tile.  Returns None when the tile yields no RoI or no detection above `peak_threshold` (the reference
+        returns (None,)*5 and its driver `continue`s, infer_simple.py:225-226), else a dict: crm [1,A,s,h,w],
+        peaks int64 [P,5] (b,a,s,h,w), dets float64 [P,7], windows/sums/origins (cone-cropped maps) and, with
+        dense=True, prms [P,S,H,W] (each map divided by its sum)."""
         det, c = self.det, self.cfg
         S, H, W = data.shape[-3:]
         im_info = np.array([S, H, W, 1.0], np.float64)
         feat, prob, deltas, saved, top = self.forward(data)
         rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
         if rois.shape[0] == 0:
-            return None, None, None, None
+            return None                                # nothing survives -> the reference returns five Nones (:190)
         cls, bbox = det.box_head(feat, rois)
         pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
         sc, bx, _, cls_keep = det.box_results_with_nms_and_limit(cls, pred, keep_idx)                          # :124
@@ -127,7 +131,7 @@ class PRMEngine:
         peaks = torch.stack([torch.zeros_like(a), a, pos // (h_ * w_), (pos // w_) % h_, pos % w_], 1)
         valid = sc > peak_threshold                                                                            # :161-162
         if int(valid.sum()) == 0:
-            return None, None, None, None
+            return None                                # no score above peak_threshold (:161-162 never true, :189-190)
         peaks_v = peaks[valid]
         dets = torch.cat([bx[valid], sc[valid].unsqueeze(1)], 1).double()                                      # :163
         win, sums, origins = self.backward_windows(peaks_v[:, 1:].to(torch.int32).contiguous(), saved, top, data)

@@ -3,8 +3,10 @@
 The reference's only multi-GPU inference story is one subprocess per GPU collated through pickle files
 (lib/utils/my_subprocess.py:66-115, lib/core/test_engine.py:139-185).  Tiles never exchange halos
 (lib/core/test.py:91-145): the one real exchange on the path is the concatenation of per-tile detections before
-the cross-tile NMS (lib/core/test.py:150-160).  Here that is ONE all_gather of fixed-shape padded detections
-[items_per_rank, DETECTIONS_PER_IM, 7] + counts (RCCL over xGMI with backend nccl; gloo on CPU for tests)."""
+the cross-tile NMS (lib/core/test.py:150-160).  Here that is ONE all_gather of a fixed-shape buffer
+[items_per_rank, DETECTIONS_PER_IM + 1, 7] fp32 per rank - the padded detections plus one trailer row per item
+whose first element is the detection count (exact in fp32) - so a step issues exactly one collective
+(RCCL over xGMI with backend nccl; gloo on CPU for tests).  64 volumes x 301 x 28 B = 539 KB: latency-bound."""
 import torch
 
 
@@ -17,37 +19,54 @@ def items_per_rank(num_items, world):
     return (num_items + world - 1) // world
 
 
-def pack_detections(dets_list, cap, device=None):
-    """dets_list: per local item a [n_i,7] tensor -> (padded [L,cap,7] fp32, counts [L] int32)."""
+def pack_detections(dets_list, cap, device=None, out=None):
+    """dets_list: per local item a [n_i,7] tensor -> packed [L, cap+1, 7] fp32: rows [0,n_i) the detections (truncated
+    to `cap`), row `cap` = (n_i, 0, ...).  No host synchronisation: counts are written from tensor shapes."""
     L = len(dets_list)
     device = device or (dets_list[0].device if L else "cpu")
-    padded = torch.zeros((L, cap, 7), dtype=torch.float32, device=device)
-    counts = torch.zeros((L,), dtype=torch.int32, device=device)
+    packed = out if out is not None else torch.zeros((L, cap + 1, 7), dtype=torch.float32, device=device)
+    if out is not None:
+        packed.zero_()
+    ns = []
     for i, d in enumerate(dets_list):
         n = min(int(d.shape[0]), cap)
         if n:
-            padded[i, :n] = d[:n].to(torch.float32)
-        counts[i] = n
-    return padded, counts
+            packed[i, :n] = d[:n].to(torch.float32)
+        ns.append(float(n))
+    if L:
+        packed[:, cap, 0] = torch.tensor(ns, dtype=torch.float32).to(packed.device, non_blocking=True)
+    return packed
 
 
-def all_gather_detections(padded, counts, num_items, dist=None):
-    """One collective for the boxes and one tiny one for the counts.  Returns a list of num_items [n_i,7]
-    tensors in GLOBAL item order (item i was produced by rank i % world at local slot i // world)."""
+def unpack_detections(packed):
+    """packed [L, cap+1, 7] (any device) -> list of L [n_i,7] tensors.  One host read of the L counts."""
+    cap = packed.shape[1] - 1
+    counts = packed[:, cap, 0].to("cpu").to(torch.int64).tolist()
+    return [packed[i, :c] for i, c in enumerate(counts)]
+
+
+def all_gather_packed(packed, num_items, dist=None):
+    """THE collective of the path: every rank contributes its [items_per_rank, cap+1, 7] block and receives
+    [world, items_per_rank, cap+1, 7] (one all_gather_into_tensor).  Ranks holding one item fewer pad with an empty item."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return [padded[i, :int(counts[i])] for i in range(min(num_items, padded.shape[0]))]
+        return packed.unsqueeze(0)
     world = dist.get_world_size()
     per = items_per_rank(num_items, world)
-    if padded.shape[0] < per:       # ranks with one item fewer pad to the common shape
-        pad = per - padded.shape[0]
-        padded = torch.cat([padded, padded.new_zeros((pad,) + tuple(padded.shape[1:]))])
-        counts = torch.cat([counts, counts.new_zeros((pad,))])
-    gp = [torch.empty_like(padded) for _ in range(world)]
-    gc = [torch.empty_like(counts) for _ in range(world)]
-    dist.all_gather(gp, padded.contiguous())
-    dist.all_gather(gc, counts.contiguous())
-    out = []
-    for i in range(num_items):
-        r, slot = i % world, i // world
-        out.append(gp[r][slot, :int(gc[r][slot])])
-    return out
+    if packed.shape[0] < per:
+        packed = torch.cat([packed, packed.new_zeros((per - packed.shape[0],) + tuple(packed.shape[1:]))])
+    out = torch.empty((world * per,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)   # dim-0 concatenation
+    dist.all_gather_into_tensor(out, packed.contiguous())
+    return out.view((world, per) + tuple(packed.shape[1:]))
+
+
+def gathered_items(gathered, num_items):
+    """[world, per, cap+1, 7] -> list of num_items [n_i,7] tensors in GLOBAL item order (item i was produced by rank
+    i % world at local slot i // world)."""
+    world, per = gathered.shape[0], gathered.shape[1]
+    flat = unpack_detections(gathered.reshape(world * per, gathered.shape[2], 7))
+    return [flat[(i % world) * per + i // world] for i in range(num_items)]
+
+
+def all_gather_detections(dets_list, cap, num_items, dist=None, device=None):
+    """pack -> one all_gather -> per-item list in global order."""
+    return gathered_items(all_gather_packed(pack_detections(dets_list, cap, device=device), num_items, dist), num_items)

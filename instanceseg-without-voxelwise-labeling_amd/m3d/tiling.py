@@ -44,6 +44,14 @@ def tile_grid(shape, patch, overlap, dataset="nuclei"):
             tile_starts(shape[2], patch[2], overlap))
 
 
+def detect_grid(cfg, shape, patch=None, overlap=None):
+    """Detection-mode tile starts for a (padded) volume: TEST.IN_SIZE / TEST.CROP_OVLP from the config
+    (core/test.py:77,87-90; CROP_OVLP is 100 in the nuclei YAML, the default 32 under the soma YAML, core/config.py:250)."""
+    patch = tuple(patch or cfg.in_size)
+    overlap = cfg.crop_ovlp if overlap is None else overlap
+    return tile_grid(shape, patch, overlap)
+
+
 def enumerate_tiles(sidx, hidx, widx):
     """(num, s, h, w) with num = iss*len_w*len_h + ih*len_w + iw  (infer_simple.py:209-212)."""
     out = []

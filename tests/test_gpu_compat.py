@@ -84,3 +84,75 @@ def test_conv3d_interception_runs_unmodified_module_code(compat):
     # a non-qualifying call (stride 2) falls through to torch's own conv
     z = F.conv3d(x.detach(), conv.weight.detach(), None, 2, 1)
     assert z.shape[-1] == 17
+
+
+def test_pack_cache_never_serves_another_layers_weights(compat):
+    """Two same-shape nn.Conv3d run through the pr_conv3d pattern (fresh relu(W).detach() temporaries, freed between
+    calls so the allocator re-uses their address) alternately: every result must match ITS layer's fp64 conv."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    convs = [nn.Conv3d(16, 16, 3, 1, 1, bias=True).cuda() for _ in range(2)]
+    x = torch.randn(1, 16, 6, 10, 20, device="cuda")
+    for it in range(6):
+        conv = convs[it % 2]
+        wpos = F.relu(conv.weight).detach()                  # same shape, usually the same recycled address
+        n = F.conv3d(x, wpos, None, 1, 1)
+        ref = compat._orig_conv3d(x.double(), wpos.double(), None, 1, 1)
+        assert (n.double() - ref).abs().max().item() < 1e-5, it
+        del wpos, n, ref
+    # in-place update of a cached Parameter (optimizer step / load_state_dict): _version moves, the pack is rebuilt
+    conv = convs[0]
+    y0 = conv(x)
+    with torch.no_grad():
+        conv.weight.mul_(-0.5)
+    y1 = conv(x)
+    ref = compat._orig_conv3d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), 1, 1)
+    assert (y1.double() - ref).abs().max().item() < 1e-5 and (y1 - y0).abs().max().item() > 1e-2
+    # .data re-assignment keeps _version but moves the address
+    conv.weight.data = torch.randn_like(conv.weight)
+    ref = compat._orig_conv3d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), 1, 1)
+    assert (conv(x).double() - ref).abs().max().item() < 1e-5
+    assert all(isinstance(k[0], int) for k in compat._pack_cache)          # only Parameters are cached
+    n_before = len(compat._pack_cache)
+    del conv, convs, y0, y1
+    import gc
+    gc.collect()
+    assert len(compat._pack_cache) < n_before                                # weakref eviction
+
+
+def test_stem_conv_with_input_grad_stays_on_the_hip_path(compat):
+    """The reference's PRM mode: data.requires_grad_() (peak_response_mapping_3d.py:88) then conv1a (5^3, Cin=1, DSN.py:19)
+    through pr_conv3d - forward AND backward-data must come from libm3d (no MIOpen fallback), x.grad vs torch's dgrad."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    conv = nn.Conv3d(1, 32, 5, 1, 2, bias=True).cuda()
+    x = torch.randn(1, 1, 12, 21, 37, device="cuda", requires_grad=True)
+    calls = []
+    orig = compat._orig_conv3d
+    compat._orig_conv3d = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = conv(x)
+        wpos = F.relu(conv.weight).detach()
+        n = F.conv3d(x - x.min().detach(), wpos, None, 1, 2)
+        g = torch.randn_like(n)
+        n.backward(g)
+    finally:
+        compat._orig_conv3d = orig
+    assert not calls, "stem conv fell through to torch's conv"
+    ref_y = orig(x.detach().double(), conv.weight.detach().double(), conv.bias.detach().double(), 1, 2)
+    assert (y.detach().double() - ref_y).abs().max().item() < 1e-5
+    ref_gx = torch.nn.grad.conv3d_input(x.shape, wpos.double(), g.double(), 1, 2)
+    assert (x.grad.double() - ref_gx).abs().max().item() / ref_gx.abs().max().item() < 5e-6
+    # plain autograd through the stem with a Parameter weight: dgrad + wgrad + bias grad
+    conv.zero_grad(); x.grad = None
+    y = conv(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().double().cpu().requires_grad_()
+    wr = conv.weight.detach().double().cpu().requires_grad_()
+    br = conv.bias.detach().double().cpu().requires_grad_()
+    orig(xr, wr, br, 1, 2).backward(g.double().cpu())
+    for got, ref in ((x.grad, xr.grad), (conv.weight.grad, wr.grad), (conv.bias.grad, br.grad)):
+        assert (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-5

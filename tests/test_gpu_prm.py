@@ -89,3 +89,95 @@ def test_infer_prm_tiles_quantised_maps_and_tree(tmp_path):
             assert r["prm_u8"][ch].shape == (12, 24, 24) and d.max() <= 1 and (d > 0).mean() < 5e-3     # fp32 map +-1e-3 -> +-1 level, rarely
         dets, prms = mio.load_prm_instances(str(tmp_path / "img" / "instances" / str(r["num"])))
         assert np.array_equal(dets, r["dets"]) and all(np.array_equal(a, b) for a, b in zip(prms, r["prm_u8"]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# driver boundary: model(**blobs) with the reference's kwargs and return tuple
+def _blobs(crop):
+    """Exactly what tools/infer_simple.py:217-223 builds (host tensors, list-wrapped, float64 im_info)."""
+    im_info = np.hstack((crop.shape, 1.0))[np.newaxis, :]
+    return {"data": [torch.from_numpy(crop[np.newaxis, np.newaxis, :])], "im_info": [torch.from_numpy(im_info)], "im_scale": [1.0]}
+
+
+@pytest.mark.parametrize("tag", ["n", "s"])
+def test_driver_boundary_returns_the_reference_tuple(golden, tag):
+    from m3d.drivers import PeakResponseMapping_3d
+    g = golden("prm_small_" + tag)
+    stride, A = int(g["stride"]), int(g["A"])
+    P = O.make_params(stride=stride, num_anchors=A, mlp_dim=64, seed=int(g["seed"]))
+    cfg = O.Cfg(mlp_dim=64, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=64)
+    model = PeakResponseMapping_3d({"model": P}, cfg).inference()          # checkpoint-style dict, infer_simple.py:142-150
+    res = model(**_blobs(g["vol"][0, 0]))
+    assert isinstance(res, tuple) and len(res) == 5 and res[0] is None     # peak_response_mapping_3d.py:185
+    _, crm, peaks, prms, dets = res
+    assert all(t.is_cuda for t in (crm, peaks, prms, dets))                # :180-182 `.cuda()`
+    assert crm.shape == g["crm"].shape and np.allclose(crm.cpu().numpy(), g["crm"], rtol=1e-4, atol=1e-5)
+    assert peaks.dtype == torch.int64 and np.array_equal(peaks.cpu().numpy(), g["o_peaks"])
+    assert dets.dtype == torch.float64 and np.allclose(dets.cpu().numpy(), g["o_dets"], rtol=1e-4, atol=1e-3)
+    assert prms.shape == g["o_prms"].shape
+    assert np.allclose(prms.cpu().numpy(), g["o_prms"], rtol=2e-3, atol=2e-6 * g["o_prms"].max())
+
+
+def test_empty_tiles_are_skipped_like_the_reference(tmp_path):
+    """A tile with no detection above peak_threshold: the reference returns five Nones (peak_response_mapping_3d.py:189-190)
+    and its driver `continue`s (infer_simple.py:225-226)."""
+    from m3d.drivers import PeakResponseMapping_3d
+    from m3d.infer import infer_prm
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=2)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0, in_size=(16, 24, 24), crop_ovlp=8)
+    model = PeakResponseMapping_3d(P, cfg)
+    rs = np.random.RandomState(3)
+    crop = rs.randn(16, 24, 24).astype(np.float32)
+    # (a) no score can exceed peak_threshold = 2.0
+    res = model(peak_threshold=2.0, **_blobs(crop))
+    assert res == (None, None, None, None, None)
+    assert model.engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=2.0) is None
+    # (b) score threshold so high that box_results keeps nothing (no RoI survives :836)
+    cfg2 = O.Cfg(mlp_dim=32, score_thresh=1.5, in_size=(16, 24, 24), crop_ovlp=8)
+    assert PeakResponseMapping_3d(P, cfg2)(**_blobs(crop)) == (None,) * 5
+    # (c) the whole-volume driver skips such tiles and writes nothing for them
+    im = (rs.rand(16, 40, 40) * 900 + 50).astype(np.uint16)
+    res = infer_prm(model.engine, im, out_dir=str(tmp_path / "img"), peak_threshold=2.0)
+    assert res == [] and not (tmp_path / "img").exists()
+    # (d) an all-zero tile (background-only soma tiles): whatever survives must match the oracle's verdict
+    zero = np.zeros((16, 24, 24), np.float32)
+    ref = O.prm_tile(P, cfg, torch.from_numpy(zero)[None, None])
+    got = model(**_blobs(zero))
+    assert (got[4] is None) == (ref[3] is None)
+    if got[4] is not None:
+        assert np.array_equal(got[2].cpu().numpy(), np.asarray(ref[1]))
+
+
+def test_detection_drivers_have_the_reference_shapes():
+    """Generalized_RCNN return_dict (model_builder.py:228-238), im_detect_bbox (core/test.py:194-263) and im_detect_all
+    (:54-177) with TEST.IN_SIZE / TEST.CROP_OVLP from the config - against the oracle tile by tile."""
+    from m3d.drivers import Generalized_RCNN, im_detect_all, im_detect_bbox
+    from m3d import tiling
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=4)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0, in_size=(16, 24, 24), crop_ovlp=8)
+    model = Generalized_RCNN(P, cfg)
+    rs = np.random.RandomState(5)
+    im = (rs.rand(12, 40, 40) * 900 + 50).astype(np.uint16)
+    vol = tiling.norm1(im, np.float32).astype(np.float32)
+    vol, pad_s = tiling.pad_slices(vol, 16)
+    cube = {"data": vol[:16, :24, :24][None, None].copy(), "im_info": np.array([[16, 24, 24, 1.0]])}
+    rd = model(data=[torch.from_numpy(cube["data"])], im_info=[torch.from_numpy(cube["im_info"])])
+    assert {"blob_conv", "rois", "cls_score", "bbox_pred"} <= set(rd)
+    R = rd["rois"].shape[0]
+    assert rd["rois"].shape == (R, 7) and rd["cls_score"].shape == (R, 2) and rd["bbox_pred"].shape == (R, 12)
+    scores, boxes, sc, blob = im_detect_bbox(model, dict(cube), 1.0)
+    ref = O.detect_tile(P, cfg, torch.from_numpy(cube["data"]))
+    assert isinstance(scores, np.ndarray) and scores.shape == ref["cls"].shape and boxes.shape == ref["pred_boxes"].shape
+    assert np.allclose(scores, ref["cls"], atol=1e-4) and np.allclose(boxes, ref["pred_boxes"], atol=2e-2)
+    cls_boxes, cls_segms, cls_keyps = im_detect_all(model, im)
+    assert cls_keyps is None and cls_segms == [[], []] and cls_boxes[0].shape == (0, 7) and cls_boxes[1].dtype == np.float32
+    sidx, hidx, widx = tiling.tile_grid(vol.shape, (16, 24, 24), 8)
+    alld = []
+    for _, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
+        r = O.detect_tile(P, cfg, torch.from_numpy(vol[s:s + 16, h:h + 24, w:w + 24].copy()[None, None]))
+        alld.append(r["cls_boxes"][1] + np.array([w, h, s - pad_s, w, h, s - pad_s, 0], np.float32))
+    alld = np.vstack(alld)
+    want = alld[O.nms_3d(alld, cfg.nms)]
+    assert abs(len(cls_boxes[1]) - len(want)) <= max(2, len(want) // 20)
+    matched = sum(np.abs(want - g).max(1).min() < 1e-2 for g in cls_boxes[1])
+    assert matched >= 0.95 * len(cls_boxes[1])

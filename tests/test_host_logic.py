@@ -21,6 +21,20 @@ def test_tiling_matches_reference_lists(golden):
     assert tiling.tile_grid((96, 256, 256), (64, 160, 160), 0, "soma") == ([0, 32, 64], [0, 96], [0, 96])
 
 
+def test_detection_tile_grid_reads_crop_ovlp_from_the_config():
+    """core/test.py:87-90 with TEST.CROP_OVLP: 100 under the nuclei YAML, 32 (core/config.py:250) under the soma YAML."""
+    from m3d import tiling
+    from m3d.config import Cfg
+
+    def ref(dim, p, ov):
+        return list(range(0, dim - p, p - ov)) + [dim - p]
+    for cfg, shape in ((Cfg.soma(), (96, 512, 400)), (Cfg.nuclei(), (64, 700, 512))):
+        p = cfg.in_size
+        want = tuple(ref(d, q, cfg.crop_ovlp) for d, q in zip(shape, p))
+        assert tuple(tiling.detect_grid(cfg, shape)) == want
+    assert tiling.detect_grid(Cfg.soma(), (96, 512, 400))[1] == [0, 128, 256, 352]       # step 160 - 32, not 160 - 100
+
+
 def test_norm1_and_quantize():
     from m3d import tiling
     import oracle as O
@@ -48,8 +62,11 @@ def _worker(rank, world, port, q):
     n_items = 5
     mine = shard.partition(n_items, rank, world)
     local = [torch.full((i + 1, 7), float(i)) for i in mine]      # item i has i+1 detections, all valued i
-    padded, counts = shard.pack_detections(local, cap=4)
-    out = shard.all_gather_detections(padded, counts, n_items, dist)
+    calls = []
+    orig = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    out = shard.all_gather_detections(local, 4, n_items, dist)
+    assert len(calls) == 1                                        # exactly ONE collective per exchange (counts ride along)
     q.put((rank, [(int(t.shape[0]), float(t[0, 0])) for t in out]))
     dist.destroy_process_group()
 
@@ -76,3 +93,24 @@ def test_product_anchors_match_reference(golden):
     assert np.array_equal(Cfg.soma().anchors, g["soma"])
     assert Cfg.nuclei().num_anchors == 35 and Cfg.soma().num_anchors == 14
     assert generate_anchors_3d().shape == (6, 6)
+
+
+def test_bench_launcher_starts_n_ranks_itself_and_does_one_gather():
+    """`python bench.py --gpus 2 --backend gloo --dry`: the SAME launcher and exchange code path as the GPU run (bench.py
+    spawns the ranks itself when no external launcher set WORLD_SIZE), stub detect step, rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry"] is True and d["config"]["volumes_per_step"] == 16 and d["steps"] == 2
+    # N = 1 path: no process group, same code
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
