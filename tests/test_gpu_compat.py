@@ -112,7 +112,7 @@ def test_pack_cache_never_serves_another_layers_weights(compat):
     # .data re-assignment keeps _version but moves the address
     conv.weight.data = torch.randn_like(conv.weight)
     ref = compat._orig_conv3d(x.double(), conv.weight.detach().double(), conv.bias.detach().double(), 1, 1)
-    assert (conv(x).double() - ref).abs().max().item() < 1e-5
+    assert (conv(x).double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()      # N(0,1) weights: |y| ~ 40
     assert all(isinstance(k[0], int) for k in compat._pack_cache)          # only Parameters are cached
     n_before = len(compat._pack_cache)
     del conv, convs, y0, y1

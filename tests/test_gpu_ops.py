@@ -503,9 +503,22 @@ def test_rpn_outputs_and_proposals_equal_the_reference_fixture(m3d, golden, tag)
     assert np.allclose(prob.cpu().numpy(), g["crm"], rtol=1e-4, atol=1e-5)
     assert np.allclose(deltas.cpu().numpy(), g["rpn_deltas"], rtol=1e-4, atol=1e-4)
     S, H, W = g["vol"].shape[-3:]
-    rois, probs, kidx = det.proposals(dev(g["crm"]), dev(g["rpn_deltas"]), np.array([S, H, W, 1.0]))
-    assert np.array_equal(kidx.cpu().numpy(), g["keep_idx"])
-    assert np.allclose(rois.cpu().numpy(), g["rois"], rtol=2e-7, atol=1e-5)
+    info = np.array([S, H, W, 1.0])
+    rois, probs, kidx = det.proposals(dev(g["crm"]), dev(g["rpn_deltas"]), info)
+    flat = g["crm"][0].transpose(1, 2, 3, 0).ravel()
+    if len(np.unique(flat)) == flat.size:                 # distinct scores: the reference's own result, bit for bit
+        assert np.array_equal(kidx.cpu().numpy(), g["keep_idx"])
+        assert np.allclose(rois.cpu().numpy(), g["rois"], rtol=2e-7, atol=1e-5)
+    else:
+        # the soma fixture's sigmoid saturates (several scores == 0.9999999): NumPy's unstable argsort()[::-1] leaves the
+        # order of equal scores unspecified (SURVEY 8c caveat i), so the fixture's order is one of several valid ones; the
+        # build's documented tie rule is checked against the oracle, and the fixture as a set of boxes scored the same
+        r0, p0, k0 = O.generate_proposals_3d(g["crm"][0], g["rpn_deltas"][0], info, cfg.anchors, cfg.stride, cfg.pre_nms_topN,
+                                             cfg.post_nms_topN, cfg.rpn_nms_thresh, cfg.rpn_min_size)
+        assert np.array_equal(kidx.cpu().numpy(), k0) and np.allclose(rois.cpu().numpy(), r0, rtol=2e-7, atol=1e-5)
+        both = np.intersect1d(kidx.cpu().numpy(), g["keep_idx"])
+        assert len(both) >= 0.9 * len(g["keep_idx"])
+        assert np.array_equal(np.sort(flat[kidx.cpu().numpy()])[-50:], np.sort(flat[g["keep_idx"]])[-50:])
 
 
 # ------------------------------------------------------------------ RoIAlign adaptive sampling grid beyond the LDS tables
