@@ -226,24 +226,32 @@ def bench_detect(args, rank, world, dist):
     raw_dev = raw_host.cuda()
     im_info = np.array([VOL, VOL, VOL, 1.0], np.float64)
     cap = cfg.detections_per_im
-    stats = {"rois": [], "dets": []}
+    last = {}
 
-    def volume(raw_u16):
-        """One volume: norm1 -> detect -> cross-tile NMS.  Returns [n,7] detections (x1,y1,z1,x2,y2,z2,score)."""
-        x = m3d.norm1(raw_u16, f32_arith=True).view(1, 1, VOL, VOL, VOL)              # blob.py:179-184
+    xbuf = torch.empty((nvol, 1, VOL, VOL, VOL), dtype=torch.float32, device="cuda")
+
+    def batch(raw):
+        """The rank's batch of volumes -> packed detections [nvol, cap+1, 7] on the device (m3d.shard block: rows = detections,
+        trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
+        launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
+        (the proposal counts that size the GEMM)."""
+        for v in range(nvol):
+            m3d.norm1(raw[v], f32_arith=True, out=xbuf[v, 0])                           # blob.py:179-184
         if backbone_only:
-            return det.conv_body(x)
-        out = det.detect_tile(x, im_info)                                              # core/test.py:106-114
-        d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
-        keep = m3d.nms3d(d.contiguous(), cfg.nms)                                      # core/test.py:159 (one tile per volume)
-        stats["rois"].append(int(out["rois"].shape[0])); stats["dets"].append(int(keep.numel()))
-        return d[keep]
+            return det.conv_body(xbuf)
+        r = det.detect_batch(xbuf, im_info, as_dicts=False)                             # core/test.py:106-114 per volume
+        last["num_rois"] = r["num_rois"]
+        if "cls_boxes" not in r:
+            return torch.zeros((nvol, cap + 1, 7), device="cuda")
+        with det.span("cross_tile_nms_pack"):                                           # core/test.py:159 (one tile per volume) + pack
+            return m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
 
     def step_resident():
-        res = [volume(raw_dev[v]) for v in range(nvol)]
+        packed = batch(raw_dev)
         if backbone_only:
-            return res[-1]
-        return shard.all_gather_packed(shard.pack_detections(res, cap, device="cuda"), n_items, dist)   # THE exchange
+            return packed
+        last["packed"] = shard.all_gather_packed(packed, n_items, dist)                 # THE exchange
+        return last["packed"]
 
     # ---- (1) value: raw volumes resident in HBM
     for _ in range(args.warmup):
@@ -280,9 +288,9 @@ def bench_detect(args, rank, world, dist):
             state["i"] += 1
             upload(b ^ 1)                                        # next step's volumes cross PCIe while this step computes
             torch.cuda.current_stream().wait_event(ready[b])
-            res = [volume(bufs[b][v]) for v in range(nvol)]
+            packed = batch(bufs[b])
             freed[b].record()
-            g = shard.all_gather_packed(shard.pack_detections(res, cap, device="cuda"), n_items, dist)
+            g = shard.all_gather_packed(packed, n_items, dist)
             if rank == 0:
                 host_out.copy_(g, non_blocking=True)
                 torch.cuda.current_stream().synchronize()        # detections are on the host when the step ends
@@ -298,13 +306,14 @@ def bench_detect(args, rank, world, dist):
     voxels = n_items * args.steps * VOL ** 3
     # ---- roofline of the dominant hand-written kernel, from the live HIP-event spans of the timed region
     wino = det.wino_mode
-    conv2b_alg = conv_flops(64, 64, 3, (VOL // 2) ** 3)                     # 57.98 GFLOP algorithmic per launch
+    conv2b_alg = nvol * conv_flops(64, 64, 3, (VOL // 2) ** 3)              # 57.98 GFLOP algorithmic per volume, batch in one launch
     kern = {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}
     roof = None
     if "conv2b" in kern_ms:
         ms = kern_ms["conv2b"]
         issued = conv2b_alg * WINO_WORK[wino]
         roof = {"bound": "mfma",
+                "launch": "one launch over the rank's batch of %d volumes" % nvol,
                 "kernel": {2: "conv3d_wino2_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x) + fused BN/ReLU/MaxPool)",
                            1: "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)",
                            0: "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b direct + fused BN/ReLU/MaxPool)"}[wino],
@@ -317,7 +326,7 @@ def bench_detect(args, rank, world, dist):
                         {2: "4/9", 1: "2/3", 0: "1"}[wino]}
         roof.update(pmc_traffic({2: "conv3d_wino2_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
                                  0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
-    body_ms = sum(v for k, v in kern_ms.items() if k.startswith("conv"))
+    body_ms = sum(v for k, v in kern_ms.items() if k.startswith("conv")) / nvol      # spans cover the whole batch
     res = {"metric": METRIC, "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
@@ -328,8 +337,8 @@ def bench_detect(args, rank, world, dist):
                                    % (nvol, "configs[2]" if world == 1 else "configs[4] shape: %d volumes over %d GPUs" % (n_items, world))),
                       "volumes_per_step": n_items, "volumes_per_rank": nvol, "net": "nuclei stride-8 dsn_body, 35 anchors, MLP 1024",
                       "inputs": "raw uint16 volumes resident in HBM at the start of the timed region",
-                      "rois_per_volume": (float(np.mean(stats["rois"])) if stats["rois"] else None),
-                      "dets_per_volume": (float(np.mean(stats["dets"])) if stats["dets"] else None),
+                      "rois_per_volume": (float(np.mean(last["num_rois"])) if "num_rois" in last else None),
+                      "dets_per_volume": (float(last["packed"][:, :, cap, 0].mean().item()) if "packed" in last else None),
                       "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9, "backbone_ms_per_volume": body_ms,
                       "backbone_algorithmic_tflops": backbone_flops(VOL) / (body_ms * 1e-3) / 1e12 if body_ms else None,
                       "kernel_ms_per_launch": kern},

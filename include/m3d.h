@@ -215,6 +215,49 @@ int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, 
 size_t m3d_reduce_min_workspace_bytes(void);
 int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Batched, fused box post-processing: ONE launch per stage for a whole batch of tiles, one workgroup per tile, no host
+ * round trips (csrc/box_fused.hip).  Same results as the per-tile entry points above, item by item.  Every item may
+ * hold at most m3d_fused_max_boxes() (2048) boxes, else M3D_EUNSUPPORTED (use the per-tile entry points).
+ *   m3d_generate_proposals3d_batched  GenerateProposalsOp_3d.forward (lib/modeling/generate_proposals_3d.py:19-192) for
+ *       d_scores [batch,A,S,H,W] / d_deltas [batch,6A,S,H,W]: outputs d_rois [batch,out_rows,7] (column 0 =
+ *       first_batch_index + item), d_probs [batch,out_rows], d_keep_idx [batch,out_rows], d_num [batch].
+ *   m3d_box_results3d_batched         box_results_with_nms_and_limit (lib/core/test.py:806-883) per item: rows
+ *       [d_offsets[b], d_offsets[b+1]) of d_scores [R,nc] / d_boxes [R,6nc] / d_keep_idx [R] (may be NULL) ->
+ *       d_cls_boxes [batch,nc,max_rows,7], d_cls_keep [batch,nc,max_rows] (may be NULL), d_counts [batch,nc].
+ *   m3d_nms3d_batched                 nms_3d / nms_3d_volume (lib/utils/cython_nms_3d.pyx:39-159) per item of d_dets
+ *       (item b at d_dets + b*item_stride_floats, count d_counts[b*count_stride] or max_boxes if d_counts is NULL):
+ *       d_keep [batch,max_boxes] kept indices (ascending), d_num_keep [batch], and/or d_packed [batch,out_cap+1,7] = the
+ *       kept rows, zero padded, with the count in element [out_cap][0] - the block m3d.shard all-gathers
+ *       (lib/core/test.py:150-160). */
+int m3d_fused_max_boxes(void);
+size_t m3d_generate_proposals3d_batched_workspace_bytes(int batch, int A, int S, int H, int W, int pre_nms_topN);
+int m3d_generate_proposals3d_batched(const float* d_scores, const float* d_deltas, int batch, int A, int S, int H, int W,
+                                     const double* anchors, double feat_stride, const double* im_info, int pre_nms_topN,
+                                     int post_nms_topN, float nms_thresh, double min_size, double xform_clip,
+                                     int first_batch_index, int out_rows, float* d_rois, float* d_probs,
+                                     int64_t* d_keep_idx, int32_t* d_num, void* d_ws, size_t ws_bytes, void* stream);
+size_t m3d_box_results3d_batched_workspace_bytes(int batch);
+int m3d_box_results3d_batched(const float* d_scores, const float* d_boxes, const int64_t* d_keep_idx,
+                              const int32_t* d_offsets, int batch, int num_classes, float score_thresh, float nms_thresh,
+                              int detections_per_im, int max_rows_per_item, float* d_cls_boxes, int64_t* d_cls_keep,
+                              int32_t* d_counts, void* d_ws, size_t ws_bytes, void* stream);
+size_t m3d_nms3d_batched_workspace_bytes(int batch);
+int m3d_nms3d_batched(const float* d_dets, size_t item_stride_floats, const int32_t* d_counts, int count_stride, int batch,
+                      int max_boxes, float thresh, int by_volume, int out_cap, float* d_packed, int64_t* d_keep,
+                      int32_t* d_num_keep, void* d_ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fully-connected layer: d_out [M,N] = act(d_x [M,K] . d_weight [N,K]^T + d_bias [N]).  Replaces the cuBLAS SGEMMs of
+ * nn.Linear at lib/modeling/fast_rcnn_heads.py:84-85,114-115 (fc1: K = C*7^3 = 87 808, N = MLP_HEAD_DIM; fc2) and
+ * :15-19,42-45 (cls_score, bbox_pred).  Operands keep PyTorch's layouts (both K-contiguous).  fp32 MFMA split-K GEMM;
+ * partial sums live in d_ws (m3d_linear_workspace_bytes) and are reduced in a fixed order (deterministic).
+ * K must be a multiple of 4 and both operands 16-byte aligned (else M3D_EUNSUPPORTED); d_bias may be NULL; relu != 0
+ * fuses max(.,0). */
+size_t m3d_linear_workspace_bytes(int M, int N, int K);
+int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
+                       int relu, void* d_ws, size_t ws_bytes, void* stream);
+
 /* norm1 pre-processing of a raw volume on the device: mask = im > 0; out = (im - mean(im[mask])) / std(im[mask])
  * (np.std: population).  Replaces the host NumPy code of lib/utils/blob.py:179-184 (float32; f32_arith = 1) and
  * tools/infer_simple.py:180-183 (float64, crops cast to float32 at :217; f32_arith = 0), so the raw uint16 volume is what

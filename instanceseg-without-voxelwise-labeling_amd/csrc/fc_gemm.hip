@@ -1,0 +1,227 @@
+// Fully-connected layers of the box head as an fp32 MFMA split-K GEMM for gfx950:  out[M,N] = act(x[M,K] . W[N,K]^T + b).
+//
+// What it replaces: the cuBLAS SGEMMs behind nn.Linear at lib/modeling/fast_rcnn_heads.py:84-85,114-115 (fc1: K = C*7^3 =
+// 87 808, N = 1024 - 180 GFLOP at 1000 RoIs, the second-largest FLOP block of the pipeline and 360 MB of weights; fc2) and
+// :15-19,42-45 (cls_score / bbox_pred).  Both operands are K-contiguous exactly as PyTorch stores them (x = the RoIAlign
+// output viewed [R, C*343]; W = nn.Linear.weight [out, in]): no transposed copy of the 360 MB matrix is ever made.
+//
+// Roofline: MFMA-bound (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s): 2*M*N*K FLOP vs (M+N)*K*4 bytes read once.
+// Design:
+//  * workgroup tile 128 (rows of x) x 128 (rows of W) x BK = 32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA blocks
+//    (64 accumulator registers), two workgroups per CU so one's staging / barrier hides under the other's MFMAs;
+//  * K is split into `slices`; one workgroup = (slice, tile).  Workgroups that run at the same time on one XCD are given the
+//    SAME slice and neighbouring tiles (blockIdx -> unit remap below), so the x / W panels of a slice are fetched from HBM once
+//    per XCD round and re-used out of that XCD's L2 by the other tiles: HBM traffic stays near (M+N)*K*4 although every
+//    workgroup streams 256 rows x K/slices;
+//  * staging global -> registers -> LDS in 16-byte quads (rows are 128-byte runs: 8 lanes x 16 B), LDS rows padded to 36
+//    floats so the ds_read_b128 fragment reads (lane = row, half-wave = k quad) are conflict-free; double-buffered, one
+//    barrier per chunk, next chunk's global loads issued before the chunk's 64 MFMAs per wave;
+//  * the k index inside an 8-deep group is permuted (lane half h holds k = 4h..4h+3) - identical on both operands, so each
+//    b128 fragment feeds four MFMAs with no shuffles;
+//  * split-K partials go to a caller workspace and are summed in slice order by a second kernel (deterministic; fused with
+//    bias + ReLU).  slices == 1 stores directly.
+#include "m3d_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LS = BK + 4;           // LS: padded LDS row stride (floats)
+constexpr int kStageFloats = (BM + BN) * LS;                       // one buffer
+constexpr int KGmap(int g) { return (g & 3) + 8 * (g >> 2); }      // accumulator register g -> row inside a 32x32 block (+4*(lane>>5))
+
+struct FcArgs {
+  const float* x; const float* w; const float* bias; float* out; float* part;
+  int M, N, K, mt, nt, slices, chunks, relu;
+};
+
+__global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
+  extern __shared__ float lds[];                                   // 2 x [(BM + BN) x LS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- unit = (slice, tile); workgroups dealt to one XCD (blockIdx % 8) get a contiguous run of units
+  const int total = a.mt * a.nt * a.slices;
+  const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
+  const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  const int tiles = a.mt * a.nt;
+  const int slice = u / tiles, tile = u - slice * tiles;
+  const int tm = tile / a.nt, tn = tile - tm * a.nt;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
+
+  // ---- staging: thread -> (row = tid/8 + 32 i, quad = tid%8), i = 0..3 for x and for W
+  const int quad = tid & 7, row0 = tid >> 3;
+  const float* px[4]; const float* pw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rm = min(m0 + row0 + 32 * i, a.M - 1), rn = min(n0 + row0 + 32 * i, a.N - 1);   // clamped: masked at the store
+    px[i] = a.x + (size_t)rm * a.K + 4 * quad;
+    pw[i] = a.w + (size_t)rn * a.K + 4 * quad;
+  }
+  // The loads of chunk c+1 are issued BEFORE chunk c's MFMA loop and nothing touches the loaded registers until commit()
+  // after it - any arithmetic on them (even a K-tail select) makes the compiler wait for the loads in front of the loop.
+  // The main loop therefore covers whole chunks only; a ragged last chunk (K % 32 != 0) is staged once, with the select, at the end.
+  f32x4 sx[4], sw[4];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+    const int k = c * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sx[i] = *reinterpret_cast<const f32x4*>(px[i] + k);
+      sw[i] = *reinterpret_cast<const f32x4*>(pw[i] + k);
+    }
+  };
+  auto commit = [&](float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(buf + (row0 + 32 * i) * LS + 4 * quad) = sx[i];
+      *reinterpret_cast<f32x4*>(buf + (BM + row0 + 32 * i) * LS + 4 * quad) = sw[i];
+    }
+  };
+
+  // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k-quad half h)
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int offA = (wm * 64 + fr) * LS + 4 * fh;
+  const int offB = (BM + wn * 64 + fr) * LS + 4 * fh;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  f32x4 fa[2][2], fb[2][2];                                       // fragment double buffer: group g+1 is read under group g's MFMAs
+  auto read_frags = [&](const float* cur, int g, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[slot][i] = *reinterpret_cast<const f32x4*>(cur + offA + i * 32 * LS + g * 8);
+      fb[slot][i] = *reinterpret_cast<const f32x4*>(cur + offB + i * 32 * LS + g * 8);
+    }
+  };
+  auto compute = [&](const float* cur) __attribute__((always_inline)) {
+    read_frags(cur, 0, 0);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      if (g + 1 < BK / 8) read_frags(cur, g + 1, (g + 1) & 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][kk], fb[g & 1][j][kk], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int full = a.K / BK;                                      // whole chunks in K
+  const int c1f = min(c1, full);                                  // this slice's whole chunks are [c0, c1f)
+  if (c0 < c1f) {
+    fetch(c0);
+    commit(lds);
+  }
+  __syncthreads();
+  for (int c = c0; c < c1f; ++c) {
+    const float* cur = lds + ((c - c0) & 1) * kStageFloats;
+    fetch(c + 1 < c1f ? c + 1 : c);                               // last chunk: harmless re-fetch instead of a branch around the loads
+    __builtin_amdgcn_sched_barrier(0);                            // keep the loads in front of the loop (the scheduler would sink them)
+    compute(cur);
+    commit(lds + ((c + 1 - c0) & 1) * kStageFloats);              // unconditional (after the last chunk nobody reads that buffer)
+    __syncthreads();
+  }
+  if (c1 > c1f) {                                                 // ragged tail chunk of K (only the last slice, only if K % 32 != 0)
+    const bool ok = full * BK + 4 * quad < a.K;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const int k = ok ? full * BK : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 vx = *reinterpret_cast<const f32x4*>(px[i] + k), vw = *reinterpret_cast<const f32x4*>(pw[i] + k);
+      *reinterpret_cast<f32x4*>(lds + (row0 + 32 * i) * LS + 4 * quad) = ok ? vx : z;
+      *reinterpret_cast<f32x4*>(lds + (BM + row0 + 32 * i) * LS + 4 * quad) = ok ? vw : z;
+    }
+    __syncthreads();
+    compute(lds);
+  }
+
+  // ---- epilogue: register g of block (i, j) is out[m0 + wm*64 + i*32 + KG(g) + 4*fh][n0 + wn*64 + j*32 + fr]: for a fixed g the
+  // half-wave writes one 128-byte row segment
+  const bool direct = a.slices == 1;
+  float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + fr;
+    const float b = (direct && a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int m = mb + KGmap(g);
+        if (m < a.M && n < a.N) {
+          float v = acc[i][j][g];
+          if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
+          dst[(size_t)m * a.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// out[e] = act(bias[n] + sum_s part[s][e]), slices summed in index order (deterministic)
+__global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                        float* __restrict__ out, long long MN, int N, int slices, int relu) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long long)gridDim.x * 256) {
+    float v = part[e];
+    for (int s = 1; s < slices; ++s) v += part[(size_t)s * MN + e];
+    if (bias) v += bias[(int)(e % N)];
+    out[e] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+struct Plan { int mt, nt, chunks, slices; };
+
+Plan make_plan(int M, int N, int K) {
+  Plan p;
+  p.mt = (M + BM - 1) / BM; p.nt = (N + BN - 1) / BN; p.chunks = (K + BK - 1) / BK;
+  const double T = (double)p.mt * p.nt, slots = 512.0;            // 256 CUs x 2 resident workgroups
+  const double flop = 2.0 * p.mt * BM * p.nt * BN * (double)K;
+  double best = 1e30; int bs = 1;
+  for (int s = 1; s <= 64 && s <= p.chunks / 4 + 1; ++s) {
+    const double rounds = ceil(T * s / slots), eff = T * s / (rounds * slots);
+    double t = flop / (1.25e14 * eff) + rounds * 4e-6;             // ~80 % of the fp32 MFMA peak in full rounds + per-round fill/drain
+    if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;         // partial write + read, reduce launch
+    if (t < best) { best = t; bs = s; }
+  }
+  p.slices = bs;
+  return p;
+}
+
+}  // namespace
+
+M3D_API size_t m3d_linear_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const Plan p = make_plan(M, N, K);
+  return p.slices > 1 ? (size_t)p.slices * M * N * sizeof(float) : 16;
+}
+
+M3D_API int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
+                               int relu, void* d_ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (M == 0) return M3D_OK;
+  if (!d_x || !d_weight || !d_out) return M3D_EINVAL;
+  if (K % 4 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_weight & 15)) return M3D_EUNSUPPORTED;   // 16-byte row quads
+  const Plan p = make_plan(M, N, K);
+  if (p.slices > 1 && (!d_ws || ws_bytes < (size_t)p.slices * M * N * sizeof(float))) return M3D_EWORKSPACE;
+  FcArgs a{d_x, d_weight, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, p.slices, p.chunks, relu};
+  const size_t lds = sizeof(float) * 2 * kStageFloats;
+  hipStream_t st = m3d::as_stream(stream);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fc_gemm_kernel, dim3(p.mt * p.nt * p.slices), dim3(256), lds, st, a);
+  if (p.slices > 1) {
+    const long long MN = (long long)M * N;
+    long long blocks = (MN + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, p.slices,
+                       relu);
+  }
+  return m3d::check_launch("linear_forward");
+}

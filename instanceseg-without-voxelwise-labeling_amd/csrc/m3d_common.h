@@ -20,7 +20,7 @@ inline int check_launch(const char* what) {
   return M3D_OK;
 }
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int kWave = 64;
 // Explicit tuning options (m3d_set_option): the library never reads the environment.  -1 = "not set" for the tile overrides.
 enum Opt { OPT_XCD_MAP = 0, OPT_TUNE_K3, OPT_TUNE_WINO, OPT_TUNE_WINO2, OPT_TUNE_WINO2_XT, OPT_COUNT };

@@ -13,7 +13,7 @@ from . import io as mio
 from . import ops, tiling
 
 
-def im_detect_all(det, im, patch=None, overlap=None, dist=None):
+def im_detect_all(det, im, patch=None, overlap=None, dist=None, tile_batch=4):
     """det: DetectorM3D; im: raw (S,H,W) volume (any dtype).  Returns cls_boxes_total: list (per class) of
     [n,7] float32 arrays (x1,y1,z1,x2,y2,z2,score) in volume coordinates, after the cross-tile nms_3d
     (core/test.py:159).  With `dist` initialised the tiles are sharded round-robin over ranks and their
@@ -30,13 +30,14 @@ def im_detect_all(det, im, patch=None, overlap=None, dist=None):
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     dvol = torch.from_numpy(vol).cuda()
     local = []
-    for i in shard.partition(len(tiles), rank, world):
-        _, s, h, w = tiles[i]
-        cube = dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].contiguous()[None, None]
-        out = det.detect_tile(cube)
-        d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
-        off = torch.tensor([w, h, s - pad_s, w, h, s - pad_s, 0], dtype=torch.float32, device=d.device)   # :117-121,140-141
-        local.append(d + off)
+    mine = shard.partition(len(tiles), rank, world)
+    for j in range(0, len(mine), tile_batch):                                 # tiles are independent: `tile_batch` of them per pass
+        grp = [tiles[i] for i in mine[j:j + tile_batch]]
+        cubes = torch.stack([dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]] for _, s, h, w in grp])[:, None].contiguous()
+        for (_, s, h, w), out in zip(grp, det.detect_batch(cubes)):
+            d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
+            off = torch.tensor([w, h, s - pad_s, w, h, s - pad_s, 0], dtype=torch.float32, device=d.device)   # :117-121,140-141
+            local.append(d + off)
     allt = shard.all_gather_detections(local, c.detections_per_im, len(tiles), dist, device="cuda")   # ONE collective
     dets = torch.cat(allt, 0) if allt else torch.zeros((0, 7), device="cuda")
     keep = ops.nms3d(dets.contiguous(), c.nms)                                 # :159

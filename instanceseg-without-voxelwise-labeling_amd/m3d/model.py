@@ -7,7 +7,8 @@ lib/modeling/fast_rcnn_heads.py:104-117,39-47 (roi_2mlp_head, fast_rcnn_outputs)
 lib/core/test.py:194-263,806-883 (im_detect_bbox, box_results_with_nms_and_limit).
 The state-dict key layout is the reference's: Conv_Body.conv1a.weight ... Box_Outs.bbox_pred.bias.
 
-Linear layers go to rocBLAS through torch (plain library GEMMs); every other op is a libm3d.so kernel.
+Every op, the linear layers included (split-K fp32 MFMA GEMM, csrc/fc_gemm.hip), is a libm3d.so kernel; torch supplies
+device memory, streams and a few elementwise helpers (sigmoid, softmax, cat).
 """
 import os
 
@@ -102,6 +103,9 @@ class DetectorM3D:
         self.rpn_heads = ops.PackedConv3d(w)
         self.rpn_heads_bias = torch.cat([params["RPN.RPN_cls_score.bias"], params["RPN.RPN_bbox_pred.bias"]]).contiguous()
         self.has_head = "Box_Head.fc1.weight" in params
+        if self.has_head:
+            self.outs_w = torch.cat([params["Box_Outs.cls_score.weight"], params["Box_Outs.bbox_pred.weight"]], 0).contiguous()
+            self.outs_b = torch.cat([params["Box_Outs.cls_score.bias"], params["Box_Outs.bbox_pred.bias"]]).contiguous()
 
     # ---- lib/modeling/DSN.py:57-68
     def body_layer(self, li, x):
@@ -161,10 +165,23 @@ class DetectorM3D:
         logits, deltas = o[:, :self.A], o[:, self.A:]
         return torch.sigmoid(logits), deltas.contiguous()
 
-    def proposals(self, prob, deltas, im_info):
+    def _fused_ok(self, prob):
+        """The one-workgroup-per-tile kernels (csrc/box_fused.hip) hold at most 2048 candidates per tile."""
+        total = prob.shape[-4] * prob.shape[-3] * prob.shape[-2] * prob.shape[-1]
+        k = total if (self.cfg.pre_nms_topN <= 0 or self.cfg.pre_nms_topN >= total) else self.cfg.pre_nms_topN
+        return k <= ops.fused_max_boxes()
+
+    def proposals(self, prob, deltas, im_info, item=0):
+        """One tile: (rois [R,7], probs [R,1], keep_idx [R]) - generate_proposals_3d.py:19-104."""
         c = self.cfg
-        return ops.generate_proposals3d(prob[0].contiguous(), deltas[0], self.anchors, float(c.stride), im_info,
-                                        c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
+        if self._fused_ok(prob):
+            rois, probs, kidx, num = ops.generate_proposals3d_batched(
+                prob[item:item + 1], deltas[item:item + 1], self.anchors, float(c.stride), im_info, c.pre_nms_topN,
+                c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size, first_batch_index=item)
+            r = int(num.item())
+            return rois[0, :r], probs[0, :r].unsqueeze(1), kidx[0, :r]
+        return ops.generate_proposals3d(prob[item].contiguous(), deltas[item], self.anchors, float(c.stride), im_info,
+                                        c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size, batch_index=item)
 
     # ---- lib/modeling/fast_rcnn_heads.py:104-117,39-47
     def box_head(self, feat, rois):
@@ -173,15 +190,28 @@ class DetectorM3D:
             x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
         x = x.view(x.shape[0], -1)
         with self.span("fc1"):
-            x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"]))
-        x = torch.relu(torch.nn.functional.linear(x, P["Box_Head.fc2.weight"], P["Box_Head.fc2.bias"]))
-        cls = torch.softmax(torch.nn.functional.linear(x, P["Box_Outs.cls_score.weight"], P["Box_Outs.cls_score.bias"]), dim=1)
-        bbox = torch.nn.functional.linear(x, P["Box_Outs.bbox_pred.weight"], P["Box_Outs.bbox_pred.bias"])
-        return cls, bbox
+            x = ops.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"], relu=True)          # :114
+        with self.span("fc2"):
+            x = ops.linear(x, P["Box_Head.fc2.weight"], P["Box_Head.fc2.bias"], relu=True)          # :115
+        o = ops.linear(x, self.outs_w, self.outs_b)              # cls_score and bbox_pred share their input: one GEMM (:42,45)
+        nc = c.num_classes
+        cls = torch.softmax(o[:, :nc], dim=1)                                                       # :43-44 (eval)
+        return cls, o[:, nc:].contiguous()
 
     # ---- lib/core/test.py:806-883 (device-side; SOFT_NMS / BBOX_VOTE off)
     def box_results_with_nms_and_limit(self, scores, boxes, scores_keep_idx=None):
         c = self.cfg
+        R = int(scores.shape[0])
+        if 0 < R <= ops.fused_max_boxes():                # one launch, one host read of the per-class counts
+            off = torch.tensor([0, R], dtype=torch.int32, device=scores.device)
+            kin = None if scores_keep_idx is None else scores_keep_idx.to(torch.int64).contiguous()
+            cb, ck, cnt = ops.box_results3d_batched(scores, boxes, kin, off, c.num_classes, c.score_thresh, c.nms, c.detections_per_im, R)
+            n = cnt[0].cpu().tolist()
+            cls_boxes = [cb[0, j, :n[j]] for j in range(c.num_classes)]
+            cls_keep = [ck[0, j, :n[j]] if scores_keep_idx is not None else torch.zeros((0,), dtype=torch.int64, device=scores.device)
+                        for j in range(c.num_classes)]
+            im_results = torch.cat([cls_boxes[j] for j in range(1, c.num_classes)], 0)
+            return im_results[:, -1], im_results[:, :-1], cls_boxes, cls_keep
         cls_boxes = [torch.zeros((0, 7), device=scores.device) for _ in range(c.num_classes)]
         cls_keep = [torch.zeros((0,), dtype=torch.int64, device=scores.device) for _ in range(c.num_classes)]
         for j in range(1, c.num_classes):
@@ -203,20 +233,90 @@ class DetectorM3D:
         im_results = torch.cat([cls_boxes[j] for j in range(1, c.num_classes)], 0)
         return im_results[:, -1], im_results[:, :-1], cls_boxes, cls_keep
 
-    # ---- one tile, detection only: model_builder.py:151-240 + core/test.py:194-263
-    def detect_tile(self, data, im_info=None):
+    # ---- several tiles of equal size at once.  The reference runs one tile per forward (core/test.py:91-145); tiles are
+    # independent, so the convolutions (batch dimension of the kernels), RoIAlign (batch index of each RoI) and the box-head
+    # GEMMs (rows = RoIs of all tiles) run once for the whole batch: the 16^3-class layers fill the chip and the 360 MB fc1
+    # weight matrix is streamed once per batch instead of once per tile.  Per-tile results equal detect_tile's.
+    def detect_batch(self, data, im_info=None, as_dicts=True):
+        """data [B,1,S,H,W].  as_dicts=True: list of B per-tile dicts with detect_tile's keys (two host reads in total: the
+        proposal counts and the detection counts).  as_dicts=False: one dict of batched device tensors (rois [B,rows,7] +
+        num_rois, cls_boxes [B,nc,rows,7] + cls_counts [B,nc], ...) after ONE host read (the proposal counts, which size the
+        box-head GEMM) - what bench.py and the sharded driver consume."""
         c = self.cfg
+        B = data.shape[0]
         S, H, W = data.shape[-3:]
         if im_info is None:
             im_info = np.array([S, H, W, 1.0], np.float64)
         feat = self.conv_body(data)
-        prob, deltas = self.rpn(feat)
-        rois, probs, keep_idx = self.proposals(prob, deltas, im_info)
-        out = dict(feat=feat, rpn_prob=prob, rpn_deltas=deltas, rois=rois, roi_probs=probs, keep_idx=keep_idx)
-        if not self.has_head or rois.shape[0] == 0:
-            return out
+        with self.span("rpn"):
+            prob, deltas = self.rpn(feat)
+        if not self._fused_ok(prob):
+            return self._detect_batch_unfused(feat, prob, deltas, im_info, as_dicts)
+        with self.span("proposals"):
+            rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(
+                prob, deltas, self.anchors, float(c.stride), im_info, c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh,
+                c.rpn_min_size)
+            counts = num.cpu().tolist()                                            # host read 1: sizes the GEMM rows
+        rows = rois_b.shape[1]
+        raw = dict(feat=feat, rpn_prob=prob, rpn_deltas=deltas, rois=rois_b, roi_probs=probs_b, keep_idx=kidx_b, num_rois=counts)
+        total = sum(counts)
+        if self.has_head and total > 0:
+            if B == 1:
+                rois, kidx = rois_b[0, :counts[0]], kidx_b[0, :counts[0]]
+            else:
+                rois = torch.cat([rois_b[b, :counts[b]] for b in range(B)], 0)
+                kidx = torch.cat([kidx_b[b, :counts[b]] for b in range(B)], 0)
+            cls, bbox = self.box_head(feat, rois)                                  # one RoIAlign + one GEMM chain for all tiles
+            pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
+            offs = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+            with self.span("box_results"):
+                cb, ck, cnt = ops.box_results3d_batched(cls, pred, kidx.contiguous(), torch.from_numpy(offs).to(feat.device),
+                                                        c.num_classes, c.score_thresh, c.nms, c.detections_per_im, rows)
+            raw.update(cls=cls, bbox=bbox, pred_boxes=pred, offsets=offs, cls_boxes=cb, cls_keep=ck, cls_counts=cnt)
+        if not as_dicts:
+            return raw
+        outs = [dict(feat=feat[b:b + 1], rpn_prob=prob[b:b + 1], rpn_deltas=deltas[b:b + 1], rois=rois_b[b, :counts[b]],
+                     roi_probs=probs_b[b, :counts[b]].unsqueeze(1), keep_idx=kidx_b[b, :counts[b]]) for b in range(B)]
+        if "cls_boxes" in raw:
+            n = raw["cls_counts"].cpu().tolist()                                   # host read 2
+            for b in range(B):
+                if counts[b] == 0:
+                    continue
+                o0, o1 = int(offs[b]), int(offs[b + 1])
+                cls_boxes = [cb[b, j, :n[b][j]] for j in range(c.num_classes)]
+                cls_keep = [ck[b, j, :n[b][j]] for j in range(c.num_classes)]
+                im = torch.cat([cls_boxes[j] for j in range(1, c.num_classes)], 0)
+                outs[b].update(cls=cls[o0:o1], bbox=bbox[o0:o1], pred_boxes=pred[o0:o1], det_scores=im[:, -1], det_boxes=im[:, :-1],
+                               cls_boxes=cls_boxes, cls_keep=cls_keep)
+        return outs
+
+    def _detect_batch_unfused(self, feat, prob, deltas, im_info, as_dicts):
+        """pre_nms_topN beyond the fused kernels' 2048 candidates per tile: per-tile multi-launch proposal / NMS kernels."""
+        if not as_dicts:
+            raise ops.M3DError("detect_batch(as_dicts=False) needs pre_nms_topN <= %d" % ops.fused_max_boxes())
+        c = self.cfg
+        B = feat.shape[0]
+        props = [self.proposals(prob, deltas, im_info, item=b) for b in range(B)]
+        outs = [dict(feat=feat[b:b + 1], rpn_prob=prob[b:b + 1], rpn_deltas=deltas[b:b + 1], rois=props[b][0], roi_probs=props[b][1],
+                     keep_idx=props[b][2]) for b in range(B)]
+        counts = [int(p[0].shape[0]) for p in props]
+        if not self.has_head or sum(counts) == 0:
+            return outs
+        rois = torch.cat([p[0] for p in props], 0)
         cls, bbox = self.box_head(feat, rois)
         pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
-        sc, bx, cls_boxes, cls_keep = self.box_results_with_nms_and_limit(cls, pred, keep_idx)
-        out.update(cls=cls, bbox=bbox, pred_boxes=pred, det_scores=sc, det_boxes=bx, cls_boxes=cls_boxes, cls_keep=cls_keep)
-        return out
+        o = 0
+        for b in range(B):
+            n = counts[b]
+            if n == 0:
+                continue
+            cb, bb, pb = cls[o:o + n], bbox[o:o + n], pred[o:o + n]
+            sc, bx, cls_boxes, cls_keep = self.box_results_with_nms_and_limit(cb, pb, props[b][2])
+            outs[b].update(cls=cb, bbox=bb, pred_boxes=pb, det_scores=sc, det_boxes=bx, cls_boxes=cls_boxes, cls_keep=cls_keep)
+            o += n
+        return outs
+
+    # ---- one tile, detection only: model_builder.py:151-240 + core/test.py:194-263
+    def detect_tile(self, data, im_info=None):
+        """One tile [1,1,S,H,W] -> dict of every intermediate the parity tests compare (same kernels as detect_batch)."""
+        return self.detect_batch(data, im_info)[0]

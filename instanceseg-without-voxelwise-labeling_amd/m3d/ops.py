@@ -11,7 +11,7 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1",
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "linear",
            "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
@@ -72,6 +72,9 @@ def nms3d(dets, thresh, by_volume=False):
         return torch.zeros((0,), dtype=torch.int64, device=dets.device)
     if dets.dim() != 2 or dets.shape[1] != 7:
         raise ValueError("dets must be [N,7]")
+    if n <= fused_max_boxes():                       # one launch (one workgroup) instead of four
+        r = nms3d_batched(dets.unsqueeze(0), None, thresh, by_volume)
+        return r["keep"][0, :int(r["num"].item())]
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
     num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
     wsb = lib().m3d_nms3d_workspace_bytes(n)
@@ -130,6 +133,97 @@ def generate_proposals3d(scores, deltas, anchors, feat_stride, im_info, pre_nms_
                                          _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()), "generate_proposals3d")
     r = int(num.item())
     return rois[:r], probs[:r].unsqueeze(1), kidx[:r]
+
+
+# ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
+def fused_max_boxes():
+    return int(lib().m3d_fused_max_boxes())
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """One scratch buffer per (stream, stage): the fused stages are launched back to back on a stream, so re-using the
+    buffer is safe, and allocating ~1 MB per tile on every call would cost more than the kernels."""
+    key = (tag, torch.cuda.current_stream().cuda_stream, str(device))
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _ws_cache[key] = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
+    return ws
+
+
+def generate_proposals3d_batched(scores, deltas, anchors, feat_stride, im_info, pre_nms_topN, post_nms_topN, nms_thresh,
+                                 min_size=0.0, first_batch_index=0, xform_clip=BBOX_XFORM_CLIP):
+    """scores [B,A,S,H,W], deltas [B,6A,S,H,W] -> (rois [B,rows,7], probs [B,rows], keep_idx [B,rows], num int32 [B]), all on
+    the device, ONE launch, no host synchronisation; item b's valid rows are [0, num[b])."""
+    _need_gpu(scores, deltas)
+    scores, deltas = _f32c(scores), _f32c(deltas)
+    B, A, S, H, W = scores.shape
+    assert deltas.shape == (B, 6 * A, S, H, W)
+    total = A * S * H * W
+    K = total if (pre_nms_topN <= 0 or pre_nms_topN >= total) else pre_nms_topN
+    rows = K if post_nms_topN <= 0 else min(K, post_nms_topN)
+    dev = scores.device
+    rois = torch.empty((B, rows, 7), dtype=torch.float32, device=dev)
+    probs = torch.empty((B, rows), dtype=torch.float32, device=dev)
+    kidx = torch.empty((B, rows), dtype=torch.int64, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    wsb = lib().m3d_generate_proposals3d_batched_workspace_bytes(B, A, S, H, W, int(pre_nms_topN))
+    ws = _workspace(wsb, dev, "prop")
+    anc = np.ascontiguousarray(anchors, dtype=np.float64)
+    info = np.ascontiguousarray(im_info, dtype=np.float64)
+    check(lib().m3d_generate_proposals3d_batched(_ptr(scores), _ptr(deltas), B, A, S, H, W, anc.ctypes.data_as(C.c_void_p),
+                                                 C.c_double(feat_stride), info.ctypes.data_as(C.c_void_p), int(pre_nms_topN),
+                                                 int(post_nms_topN), C.c_float(np.float32(nms_thresh)), C.c_double(min_size),
+                                                 C.c_double(xform_clip), int(first_batch_index), rows, _ptr(rois), _ptr(probs),
+                                                 _ptr(kidx), _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()),
+          "generate_proposals3d_batched")
+    return rois, probs, kidx, num
+
+
+def box_results3d_batched(scores, boxes, keep_idx, offsets, num_classes, score_thresh, nms_thresh, detections_per_im, max_rows):
+    """scores [R,nc], boxes [R,6nc], keep_idx int64 [R] or None, offsets int32 [B+1] (device) ->
+    (cls_boxes [B,nc,max_rows,7], cls_keep int64 [B,nc,max_rows], counts int32 [B,nc]); ONE launch, no host sync."""
+    _need_gpu(scores, boxes, offsets)
+    scores, boxes = _f32c(scores), _f32c(boxes)
+    assert offsets.dtype == torch.int32 and offsets.is_contiguous()
+    B = offsets.numel() - 1
+    dev = scores.device
+    cls_boxes = torch.empty((B, num_classes, max_rows, 7), dtype=torch.float32, device=dev)
+    cls_keep = torch.empty((B, num_classes, max_rows), dtype=torch.int64, device=dev)
+    counts = torch.empty((B, num_classes), dtype=torch.int32, device=dev)
+    wsb = lib().m3d_box_results3d_batched_workspace_bytes(B)
+    ws = _workspace(wsb, dev, "boxres")
+    if keep_idx is not None:
+        assert keep_idx.dtype == torch.int64 and keep_idx.is_contiguous()
+    check(lib().m3d_box_results3d_batched(_ptr(scores), _ptr(boxes), _ptr(keep_idx), _ptr(offsets), B, int(num_classes),
+                                          C.c_float(np.float32(score_thresh)), C.c_float(np.float32(nms_thresh)),
+                                          int(detections_per_im), int(max_rows), _ptr(cls_boxes), _ptr(cls_keep), _ptr(counts),
+                                          _ptr(ws), C.c_size_t(wsb), _stream()), "box_results3d_batched")
+    return cls_boxes, cls_keep, counts
+
+
+def nms3d_batched(dets, counts, thresh, by_volume=False, pack_cap=None, want_keep=True):
+    """dets [B,n,7] (dim-0 stride arbitrary, inner dims contiguous), counts int32 view [B] (any stride) or None ->
+    dict(keep int64 [B,n], num int32 [B], packed [B,pack_cap+1,7] if pack_cap is not None); ONE launch, no host sync."""
+    _need_gpu(dets)
+    assert dets.dim() == 3 and dets.shape[2] == 7 and dets.dtype == torch.float32 and dets.stride(2) == 1 and dets.stride(1) == 7
+    B, n = dets.shape[0], dets.shape[1]
+    dev = dets.device
+    keep = torch.empty((B, n), dtype=torch.int64, device=dev) if want_keep else None
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    packed = torch.empty((B, pack_cap + 1, 7), dtype=torch.float32, device=dev) if pack_cap is not None else None
+    cstride = 0
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.dim() == 1 and counts.numel() == B
+        cstride = counts.stride(0)
+    wsb = lib().m3d_nms3d_batched_workspace_bytes(B)
+    ws = _workspace(wsb, dev, "nmsb")
+    check(lib().m3d_nms3d_batched(_ptr(dets), C.c_size_t(dets.stride(0)), _ptr(counts), int(cstride), B, n,
+                                  C.c_float(np.float32(thresh)), int(bool(by_volume)), int(pack_cap or 0), _ptr(packed), _ptr(keep),
+                                  _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()), "nms3d_batched")
+    return dict(keep=keep, num=num, packed=packed)
 
 
 # ------------------------------------------------------------------ conv / pool
@@ -219,6 +313,29 @@ def reduce_min(x):
     wsb = lib().m3d_reduce_min_workspace_bytes()
     ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
     check(lib().m3d_reduce_min(_ptr(x), C.c_int64(x.numel()), _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min")
+    return out
+
+
+def linear(x, weight, bias=None, relu=False, out=None):
+    """act(x @ weight.T + bias) on the split-K fp32 MFMA GEMM (m3d_linear_forward): x [M,K], weight [N,K] (nn.Linear layout),
+    bias [N] or None -> [M,N].  fast_rcnn_heads.py:84-85,114-115,15-19."""
+    _need_gpu(x, weight, bias)
+    x, weight = _f32c(x), _f32c(weight)
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError("linear: x is [%d,%d] but weight is %s" % (M, K, tuple(weight.shape)))
+    if bias is not None:
+        bias = _f32c(bias)
+        assert bias.numel() == N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out
+    wsb = lib().m3d_linear_workspace_bytes(M, N, K)
+    ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=x.device)
+    check(lib().m3d_linear_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), M, N, K, int(bool(relu)), _ptr(ws),
+                                   C.c_size_t(wsb), _stream()), "linear_forward")
     return out
 
 

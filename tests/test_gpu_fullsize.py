@@ -215,3 +215,26 @@ def test_config2_four_volumes_128_cubed_detections_equal_the_oracle():
         matched = sum(np.abs(r - row).max(1).min() < 5e-3 for row in g)
         assert matched >= 0.98 * len(g), (matched, len(g))
         assert len(g) <= cfg.detections_per_im
+
+
+def test_detect_batch_equals_per_tile_detection():
+    """DetectorM3D.detect_batch (what bench.py and im_detect_all run): 3 tiles in one batched pass == detect_tile per tile
+    (same proposals kept, same detections; conv tile choices may differ with the batch size -> fp32 noise only)."""
+    from m3d.config import Cfg
+    from m3d.synth import make_params, synth_volume
+    from m3d.model import DetectorM3D
+    from m3d import tiling
+    cfg = Cfg.nuclei(mlp_dim=128, in_size=(32, 64, 64))
+    P = make_params(stride=8, num_anchors=35, mlp_dim=128, seed=2)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    x = torch.stack([torch.from_numpy(tiling.norm1(synth_volume(i, (32, 64, 64)), np.float32).astype(np.float32)) for i in range(3)])[:, None].cuda()
+    outs = det.detect_batch(x)
+    assert len(outs) == 3
+    for b in range(3):
+        one = det.detect_tile(x[b:b + 1].contiguous())
+        got = outs[b]
+        assert (got["feat"] - one["feat"]).abs().max().item() <= 2e-5 * one["feat"].abs().max().item()
+        assert torch.equal(got["keep_idx"], one["keep_idx"]) and torch.allclose(got["rois"][:, 1:], one["rois"][:, 1:], atol=1e-3)
+        assert (got["rois"][:, 0] == b).all()                                   # batch index column (generate_proposals_3d.py:98-100)
+        assert torch.allclose(got["cls"], one["cls"], atol=1e-4) and torch.allclose(got["pred_boxes"], one["pred_boxes"], atol=2e-2)
+        assert got["det_scores"].shape == one["det_scores"].shape and torch.allclose(got["det_boxes"], one["det_boxes"], atol=2e-2)

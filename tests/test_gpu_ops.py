@@ -580,3 +580,108 @@ def test_norm1_on_device_equals_numpy(m3d, shape):
     assert np.abs(got32.cpu().numpy() - ref32).max() <= 2e-5                          # NumPy's fp32 pairwise mean/std vs exact
     f = m3d.norm1(dev(im.astype(np.float32)), f32_arith=True)
     assert torch.equal(f, got32)
+
+
+# ------------------------------------------------------------------ box-head linear layers (fast_rcnn_heads.py:84-85,114-115,15-19)
+@pytest.mark.parametrize("M,N,K,relu", [(1, 2, 32, False), (5, 14, 1024, False), (37, 64, 5488, True), (130, 128, 43904, True),
+                                         (320, 1024, 87808, True), (1283, 1024, 1024, True), (257, 100, 1004, False)])
+def test_linear_split_k_gemm_vs_fp64(m3d, M, N, K, relu):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    got = m3d.linear(x, w, b, relu=relu)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    scale = ref.abs().max().item()
+    assert got.shape == (M, N) and (got.double() - ref).abs().max().item() <= 2e-6 * scale * max(1.0, np.sqrt(K / 1024.0))
+    assert torch.equal(got, m3d.linear(x, w, b, relu=relu))              # deterministic (fixed-order split-K reduction)
+    nb = m3d.linear(x, w, None, relu=False)
+    assert (nb.double() - (x.double() @ w.double().t())).abs().max().item() <= 2e-6 * scale * max(1.0, np.sqrt(K / 1024.0))
+    with pytest.raises(m3d.M3DError):
+        m3d.linear(x[:, :K - 2].contiguous(), w[:, :K - 2].contiguous(), b)     # K % 4 != 0: unsupported, never silently wrong
+    assert m3d.linear(x[:0], w, b).shape == (0, N)
+
+
+# ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
+def test_fused_proposals_batched_bit_exact_with_oracle_and_golden(m3d, golden):
+    """One launch for a batch of tiles == the per-tile reference op, item by item: kept flat indices, probabilities and row
+    order bit for bit (incl. saturated ties), boxes to one fp32 ulp; fixtures of the reference's own GenerateProposalsOp_3d."""
+    g = golden("proposals")
+    for tag, sizes, ratios in (("n", (10, 27, 33, 38, 42, 46, 50), [[1.0, 0.5], [0.5, 0.5], [2., 0.5], [0.2, 0.5], [3., 2.]]),
+                               ("s", (10, 12, 14, 16, 18, 20, 22, 24, 28, 30, 34, 36, 38, 40), [[1.0, 1.0]])):
+        stride = float(g[tag + "_stride"])
+        anchors = O.generate_anchors_3d(stride, sizes, ratios)
+        rois, probs, kidx, num = m3d.generate_proposals3d_batched(dev(g[tag + "_scores"]), dev(g[tag + "_deltas"]), anchors, stride,
+                                                                  g[tag + "_im_info"][0], int(g["pre"]), int(g["post"]), float(g[tag + "_thr"]))
+        n = int(num[0])
+        assert np.array_equal(kidx[0, :n].cpu().numpy(), g[tag + "_keep_idx"])
+        assert np.array_equal(probs[0, :n].cpu().numpy()[:, None], g[tag + "_probs"])
+        assert np.allclose(rois[0, :n].cpu().numpy(), g[tag + "_rois"], rtol=2e-7, atol=1e-5)
+    rs = np.random.RandomState(8)
+    B, A, S, H, W = 3, 35, 16, 16, 16
+    cfg = O.Cfg()
+    sc = rs.uniform(0, 1, (B, A, S, H, W)).astype(np.float32)
+    sc[rs.uniform(0, 1, sc.shape) > 0.995] = 1.0                   # saturated sigmoid: exact ties at the top
+    sc[2] = np.round(sc[2], 2)                                     # item 2: ties everywhere
+    dl = (rs.randn(B, 6 * A, S, H, W) * 0.2).astype(np.float32)
+    info = np.array([128., 128., 128., 1.0])
+    rois, probs, kidx, num = m3d.generate_proposals3d_batched(dev(sc), dev(dl), cfg.anchors, 8., info, 1000, 1000, 0.15, first_batch_index=5)
+    for b in range(B):
+        r0, p0, k0 = O.generate_proposals_3d(sc[b], dl[b], info, cfg.anchors, 8, 1000, 1000, 0.15, 0)
+        n = int(num[b])
+        assert n == len(k0) and np.array_equal(kidx[b, :n].cpu().numpy(), k0), b
+        assert np.array_equal(probs[b, :n].cpu().numpy(), p0.ravel())
+        got = rois[b, :n].cpu().numpy()
+        assert np.all(got[:, 0] == 5 + b) and np.allclose(got[:, 1:], r0[:, 1:], rtol=2e-7, atol=1e-5)
+        # and the multi-launch per-tile entry point gives the very same rows
+        r1, p1, k1 = m3d.generate_proposals3d(dev(sc[b]), dev(dl[b]), cfg.anchors, 8., info, 1000, 1000, 0.15)
+        assert torch.equal(k1, kidx[b, :n]) and torch.equal(r1[:, 1:], rois[b, :n, 1:])
+    # pre_nms_topN beyond one workgroup's capacity is refused, never truncated
+    with pytest.raises(m3d.M3DError):
+        m3d.generate_proposals3d_batched(dev(sc), dev(dl), cfg.anchors, 8., info, 6000, 1000, 0.15)
+
+
+def test_fused_box_results_and_batched_nms_vs_oracle(m3d):
+    """box_results_with_nms_and_limit for three tiles of different sizes in one launch (score threshold, per-class NMS, cap
+    semantics, kept indices) and the batched NMS + pack, against the oracle item by item - with heavy score ties."""
+    rs = np.random.RandomState(12)
+    sizes = [400, 1, 777]
+    nc = 3
+    scores, boxes, keep = [], [], []
+    for R in sizes:
+        s = np.round(rs.uniform(0, 1, (R, nc)), 2).astype(np.float32)
+        c = rs.uniform(0, 100, (R, nc, 3)); e = rs.uniform(4, 40, (R, nc, 3))
+        scores.append(s); boxes.append(np.concatenate((c - e / 2, c + e / 2), 2).reshape(R, 6 * nc).astype(np.float32))
+        keep.append(rs.permutation(100000)[:R].astype(np.int64))
+    offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    S, Bx, Kp = np.vstack(scores), np.vstack(boxes), np.concatenate(keep)
+    for cap_im in (300, 40, 0):
+        cb, ck, cnt = m3d.box_results3d_batched(dev(S), dev(Bx), dev(Kp), dev(offs), nc, 0.05, 0.15, cap_im, max(sizes))
+        cnt = cnt.cpu().numpy()
+        for b, R in enumerate(sizes):
+            sc, bx, cls_boxes, cls_keep = O.box_results_with_nms_and_limit(scores[b], boxes[b], keep[b], num_classes=nc, score_thresh=0.05,
+                                                                           nms_thresh=0.15, detections_per_im=cap_im)
+            assert cnt[b, 0] == 0
+            for j in range(1, nc):
+                n = cnt[b, j]
+                assert n == len(cls_boxes[j]), (cap_im, b, j)
+                assert np.array_equal(cb[b, j, :n].cpu().numpy(), cls_boxes[j]) and np.array_equal(ck[b, j, :n].cpu().numpy(), cls_keep[j])
+    # batched NMS + pack: items of different length inside one padded tensor, by score and by volume
+    n_items, cap_in = 4, 900
+    dets = np.zeros((n_items, cap_in, 7), np.float32)
+    counts = np.array([900, 0, 65, 300], np.int32)
+    for b in range(n_items):
+        c = rs.uniform(0, 100, (cap_in, 3)); e = rs.uniform(4, 40, (cap_in, 3))
+        dets[b] = np.hstack((c - e / 2, c + e / 2, np.round(rs.uniform(0, 1, (cap_in, 1)), 2)))
+    for by_vol in (False, True):
+        r = m3d.nms3d_batched(dev(dets), dev(counts), 0.2, by_volume=by_vol, pack_cap=300)
+        for b in range(n_items):
+            d = dets[b, :counts[b]]
+            ref = (O.nms_3d_volume if by_vol else O.nms_3d)(d, 0.2) if counts[b] else np.zeros((0,), np.int64)
+            n = int(r["num"][b])
+            assert n == len(ref) and np.array_equal(r["keep"][b, :n].cpu().numpy(), ref)
+            p = r["packed"][b].cpu().numpy()
+            m = min(n, 300)
+            assert p[300, 0] == m and np.array_equal(p[:m], d[ref[:m]]) and not p[m:300].any() and not p[300, 1:].any()
