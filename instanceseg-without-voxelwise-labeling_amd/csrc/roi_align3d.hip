@@ -243,17 +243,227 @@ __global__ __launch_bounds__(256) void roi_align3d_kernel(const float* __restric
 // (|diff| <~ 1e-6 * max|f|, tests use 1e-5).  One workgroup = one RoI x a range of channels, processed CH
 // channels at a time so that sub-volume + both intermediates fit in LDS.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kSepLdsFloats = 6 * 1024;    // 24 KB of dynamic LDS -> 6 workgroups (24 waves) per CU
+constexpr int kSepLdsFloats = 8 * 1024;    // 32 KB of dynamic LDS per workgroup, 2048 floats per wave
+constexpr int kSepStageMax = 1536;         // largest sub-volume a wave stages through registers (24 per lane)
+
+// ------------------------------------------------------------------------------------------------------
+// v3 fast path for the shipped geometry (7x7x7 bins, sampling grid 2).  Per axis and bin the two samples' four taps lie on at most
+// four CONSECUTIVE voxels (bins up to 4 voxels wide), so they fold into one base index + four weights; the passes run
+//   X: lanes (row mod 9, pw)   t1[z][y][pw]   = sum_k xw[pw][k]  * f [z][y][xb+k]       taps fixed per lane
+//   Z: lanes (pw, ps)          t2[y][pw][ps]  = sum_k zw[ps][k]  * t1[zb+k][y][pw]      taps fixed per lane
+//   Y: lanes (pw, ps), ph loop out[ph][pw][ps] = sum_k yw[ph][k] * t2[yb+k][pw][ps]     taps wave-uniform (LDS broadcast)
+// so a lane carries 10 tap registers instead of 72, the last pass writes 49 consecutive floats per iteration straight to HBM
+// (7 stores of 196 B per channel, no scattered dwords), and the kernel fits 5 waves per SIMD instead of 2.  Each wave works
+// alone in its LDS slice (no workgroup barriers after the set-up) on TWO channels at a time - two independent dependency chains
+// per pass - and the next channels' sub-volumes arrive by LDS-DMA (global_load_lds_dword) while the current ones are reduced.
+// RoIs that do not fit (wider bins, sub-volume + intermediates beyond the slice) are left to roi_align3d_fwd_sep_kernel.
+// ------------------------------------------------------------------------------------------------------
+struct Fold { int k[4]; float w[4]; };     // positions (relative to the sub-volume origin, clamped to the extent) and weights
+
+__device__ inline bool fold_bin(const AxisSample& s0, const AxisSample& s1, int origin, int extent, float scale, Fold* f) {
+  int base = 1 << 30;
+  if (s0.valid) base = min(base, s0.lo);
+  if (s1.valid) base = min(base, s1.lo);
+  if (base == (1 << 30)) base = origin;
+  bool ok = true;
+  float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+  auto add = [&](int pos, float w) {
+    const int k = pos - base;
+    const float v = w * scale;
+    if (k < 0 || k > 3) ok = false;
+    w0 += k == 0 ? v : 0.f; w1 += k == 1 ? v : 0.f; w2 += k == 2 ? v : 0.f; w3 += k == 3 ? v : 0.f;
+  };
+  if (s0.valid) { add(s0.lo, s0.h); add(s0.hi, s0.l); }
+  if (s1.valid) { add(s1.lo, s1.h); add(s1.hi, s1.l); }
+  if (f) {
+    f->w[0] = w0; f->w[1] = w1; f->w[2] = w2; f->w[3] = w3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f->k[k] = min(base - origin + k, extent - 1);
+  }
+  return ok;
+}
+
+struct V3Dims { int ez, ey, ex, sub, subp, n1, n2, per_ch; };   // subp: sub-volume padded to whole 64-lane DMA pieces
+__device__ inline V3Dims v3_dims(const int* rng) {
+  V3Dims d;
+  d.ez = rng[1] - rng[0] + 1; d.ey = rng[3] - rng[2] + 1; d.ex = rng[5] - rng[4] + 1;
+  d.sub = d.ez * d.ey * d.ex; d.subp = (d.sub + 63) / 64 * 64; d.n1 = d.ez * d.ey * 7; d.n2 = d.ey * 49;
+  d.per_ch = d.subp + d.n1 + d.n2;
+  return d;
+}
+
+// one thread: does the v3 kernel take this RoI?  (tables for 7 bins x 2 samples per axis; rng = valid index ranges)
+__device__ inline bool v3_qualifies(const AxisSample* tz, const AxisSample* ty, const AxisSample* tx, const int* rng) {
+  if (rng[1] < 0 || rng[3] < 0 || rng[5] < 0) return false;
+  const V3Dims d = v3_dims(rng);
+  if (d.per_ch > kSepLdsFloats) return false;              // even one wave with the whole workgroup's LDS cannot hold a channel
+  for (int p = 0; p < 7; ++p) {
+    if (!fold_bin(tz[2 * p], tz[2 * p + 1], rng[0], d.ez, 1.f, nullptr)) return false;
+    if (!fold_bin(ty[2 * p], ty[2 * p + 1], rng[2], d.ey, 1.f, nullptr)) return false;
+    if (!fold_bin(tx[2 * p], tx[2 * p + 1], rng[4], d.ex, 1.f, nullptr)) return false;
+  }
+  return true;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool DUAL>
+__device__ inline void v3_run(const float* __restrict__ fbase /* feature map of the RoI's batch item, channel 0 */, size_t chan_stride,
+                              float* __restrict__ obase /* out + n*C*343 */, float* wl /* this wave's LDS slice */, const Fold* fz,
+                              const Fold* fy, const Fold* fx, const V3Dims d, int HW, int W, int gofs /* z0*HW + y0*W + x0 */,
+                              int c_first, int c_end, int c_step /* channels between two of this wave's channels */) {
+  const int lane = threadIdx.x & 63;
+  constexpr int NQ = DUAL ? 2 : 1;
+  // X-pass lane role
+  const int rx = lane / 7, pw_x = lane % 7;
+  const Fold FX = fx[pw_x];
+  // Z/Y-pass lane role: l = pw*7 + ps
+  const int pw_z = (lane % 49) / 7, ps_z = lane % 7;
+  Fold FZ = fz[ps_z];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) FZ.k[k] *= d.ey * 7;
+  const int nrows = d.ez * d.ey;
+  const float inv_ex = 1.0f / (float)d.ex, inv_ey = 1.0f / (float)d.ey;
+  const int nst = d.subp / 64;
+  auto dma = [&](int c, float* dst) __attribute__((always_inline)) {     // sub-volume of channel c -> LDS, element e = lane + 64 i
+    const float* fc = fbase + (size_t)c * chan_stride + gofs;
+    for (int i = 0; i < nst; ++i) {
+      const int e = min(lane + 64 * i, d.sub - 1);                       // tail lanes re-copy the last element (into the padding)
+      const int r = (int)(((float)e + 0.5f) * inv_ex), x = e - r * d.ex;
+      const int z = (int)(((float)r + 0.5f) * inv_ey), y = r - z * d.ey;
+#ifndef RA_NO_DMA
+      __builtin_amdgcn_global_load_lds(fc + (size_t)z * HW + y * W + x, (lds_ptr_t)(dst + 64 * i), 4, 0, 0);
+#else
+      if (z == 12345) __builtin_amdgcn_global_load_lds(fc + (size_t)z * HW + y * W + x, (lds_ptr_t)(dst + 64 * i), 4, 0, 0);
+#endif
+    }
+  };
+  // LDS slice: per channel q: fsub[subp], t1[n1], t2[n2]
+  float* fs[NQ]; float* t1[NQ]; float* t2[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { fs[q] = wl + q * d.per_ch; t1[q] = fs[q] + d.subp; t2[q] = t1[q] + d.n1; }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (c_first + c_step * q < c_end) dma(c_first + c_step * q, fs[q]);
+  bool first = true;
+  for (int c = c_first; c < c_end; c += c_step * NQ) {
+    // The sub-volumes of this iteration were requested BEFORE the previous iteration's 7*NQ output stores; vector-memory
+    // operations retire in order, so leaving those stores in flight still guarantees the copies have landed.
+    if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (DUAL) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    first = false;
+    if (rx < 9) {                                                        // pass X
+      for (int zy = rx; zy < nrows; zy += 9) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float* row = fs[q] + zy * d.ex;
+          t1[q][zy * 7 + pw_x] = (FX.w[0] * row[FX.k[0]] + FX.w[1] * row[FX.k[1]]) + (FX.w[2] * row[FX.k[2]] + FX.w[3] * row[FX.k[3]]);
+        }
+      }
+    }
+    const bool more = c + c_step * (2 * NQ - 1) < c_end;                 // a FULL next iteration follows (its waits count 7*NQ stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // every read of fsub has returned: the buffers are free
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (c + c_step * (NQ + q) < c_end) dma(c + c_step * (NQ + q), fs[q]);
+    if (lane < 49) {
+      for (int y = 0; y < d.ey; ++y) {                                   // pass Z
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float* col = t1[q] + y * 7 + pw_z;
+          t2[q][y * 49 + lane] = (FZ.w[0] * col[FZ.k[0]] + FZ.w[1] * col[FZ.k[1]]) + (FZ.w[2] * col[FZ.k[2]] + FZ.w[3] * col[FZ.k[3]]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {                                     // pass Y (1/count folded into fy) -> HBM, 49 floats in a row
+      const Fold FY = fy[ph];                                            // wave-uniform: LDS broadcast reads
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float* col = t2[q] + (lane < 49 ? lane : 0);
+        const float v = (FY.w[0] * col[FY.k[0] * 49] + FY.w[1] * col[FY.k[1] * 49]) + (FY.w[2] * col[FY.k[2] * 49] + FY.w[3] * col[FY.k[3] * 49]);
+        // the store is issued by the wave even when this channel does not exist (exec = 0): vmcnt counts per wave instruction
+        const bool on = c + c_step * q < c_end;
+        float* dst = obase + (size_t)(on ? c + c_step * q : c) * 343 + ph * 49 + lane;
+#ifndef RA_NO_STORE
+        if (lane < 49 && on) *dst = v;
+#else
+        if (lane < 49 && on && v == 123.456f) *dst = v;
+#endif
+      }
+    }
+    if (!more) first = true;                                             // a ragged last iteration: wait for everything
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                                 float* __restrict__ out, int C, int S, int H, int W, float scale,
+                                                                 int ch_per_block) {
+  __shared__ AxisSample tz[14], ty[14], tx[14];
+  __shared__ Fold fz[7], fy[7], fx[7];
+  __shared__ RoiGeom sg;
+  __shared__ int rng[6];
+  __shared__ int s_ok;
+  extern __shared__ float dyn[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sg = roi_geom(rois + 7 * n, scale, 7, 7, 7, 2);
+  __syncthreads();
+  const RoiGeom g = sg;
+  if (tid < 14) tz[tid] = make_sample(g.start_s, g.bin_s, tid / 2, tid % 2, 2, S, -1.0);
+  else if (tid >= 64 && tid < 78) ty[tid - 64] = make_sample(g.start_h, g.bin_h, (tid - 64) / 2, (tid - 64) % 2, 2, H, -1.0);
+  else if (tid >= 128 && tid < 142) tx[tid - 128] = make_sample(g.start_w, g.bin_w, (tid - 128) / 2, (tid - 128) % 2, 2, W, -1.0);
+  __syncthreads();
+  if (tid < 3) {
+    const AxisSample* t = tid == 0 ? tz : (tid == 1 ? ty : tx);
+    int lo = 1 << 30, hi = -1;
+    for (int i = 0; i < 14; ++i)
+      if (t[i].valid) { lo = min(lo, t[i].lo); hi = max(hi, t[i].hi); }
+    rng[2 * tid] = lo; rng[2 * tid + 1] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) s_ok = (rng[1] >= 0 && rng[3] >= 0 && rng[5] >= 0) ? 1 : 0;
+  __syncthreads();
+  const V3Dims d = v3_dims(rng);
+  if (tid < 21 && s_ok) {                                   // the 21 (axis, bin) folds in parallel; any failure clears s_ok
+    const int ax = tid / 7, p = tid % 7;
+    bool ok;
+    if (ax == 0) ok = fold_bin(tz[2 * p], tz[2 * p + 1], rng[0], d.ez, 1.f, &fz[p]);
+    else if (ax == 1) ok = fold_bin(ty[2 * p], ty[2 * p + 1], rng[2], d.ey, 0.125f, &fy[p]);      // 1 / (2*2*2 samples)
+    else ok = fold_bin(tx[2 * p], tx[2 * p + 1], rng[4], d.ex, 1.f, &fx[p]);
+    if (!ok || d.per_ch > kSepLdsFloats) atomicAnd(&s_ok, 0);
+  }
+  __syncthreads();
+  if (!s_ok) return;                                        // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI (v3_qualifies)
+  const int wave = tid >> 6;
+  const int c0 = blockIdx.y * ch_per_block, c1 = min(C, c0 + ch_per_block);
+  const int HW = H * W;
+  const float* fbase = feat + (size_t)g.batch * C * S * HW;
+  float* obase = out + (size_t)n * C * 343;
+  const int gofs = rng[0] * HW + rng[2] * W + rng[4];
+  const size_t cs = (size_t)S * HW;
+  // waves that work on this RoI: all 4 with a quarter of the LDS each, or - sub-volume + intermediates too large for that - 2 or 1
+  // with a half / all of it (the other waves leave; big RoIs are few).  Two channels at a time whenever the slice holds them.
+  int nw = 4;
+  while (nw > 1 && d.per_ch > kSepLdsFloats / nw) nw >>= 1;
+  if (wave >= nw) return;
+  const int slice = kSepLdsFloats / nw;
+  float* wl = dyn + (size_t)wave * slice;
+  if (2 * d.per_ch <= slice) v3_run<true>(fbase, cs, obase, wl, fz, fy, fx, d, HW, W, gofs, c0 + wave, c1, nw);
+  else v3_run<false>(fbase, cs, obase, wl, fz, fy, fx, d, HW, W, gofs, c0 + wave, c1, nw);
+}
 
 struct AxisTaps { int lo, hi, n; };        // sub-volume range [lo, hi] and number of taps per bin
 
 template <int kDummy>
 __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
                                                                   float* __restrict__ out, int C, int S, int H, int W, int AS,
-                                                                  int AH, int AW, float scale, int ratio, int ch_per_block) {
+                                                                  int AH, int AW, float scale, int ratio, int ch_per_block,
+                                                                  int skip_v3 /* RoIs the v3 kernel handles are skipped */) {
   __shared__ AxisSample tz[kMaxTable], ty[kMaxTable], tx[kMaxTable];
   __shared__ RoiGeom sg;
   __shared__ int rng[6];
+  __shared__ int s_v3;
   extern __shared__ float dyn[];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
@@ -285,16 +495,17 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
     for (int e = tid; e < (c1 - c0) * bins; e += 256) out[((size_t)n * C + c0) * bins + e] = 0.f;
     return;
   }
+  if (skip_v3) {                                          // same predicate as roi_align3d_fwd_v3_kernel: exactly one of the two runs
+    if (tid == 0) s_v3 = v3_qualifies(tz, ty, tx, rng);
+    __syncthreads();
+    if (s_v3) return;
+  }
   const int z0 = rng[0], y0 = rng[2], x0 = rng[4];
   const int ez = rng[1] - z0 + 1, ey = rng[3] - y0 + 1, ex = rng[5] - x0 + 1;
   const int sub = ez * ey * ex, n1 = ez * ey * AW, n2 = ez * AH * AW;
   const int per_ch = sub + n1 + n2;
   const float inv_count = 1.0f / (float)(g.grid_s * g.grid_h * g.grid_w);
   const int HW = H * W;
-  if (per_ch > kSepLdsFloats) {                          // huge RoI: sub-volume does not fit LDS -> reference order
-    roi_exact_forward_range(feat, out, g, tz, ty, tx, n, c0, c1, C, S, H, W, AS, AH, AW);
-    return;
-  }
   // one pass set over elements [first, first+stride, ...) of one channel held in (fsub, t1, t2)
   auto passes = [&](const float* fsub, float* t1, float* t2, float* oc, int first, int stride, bool block_sync)
                     __attribute__((always_inline)) {
@@ -331,8 +542,24 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
       oc[e] = acc * inv_count;
     }
   };
-  if (4 * per_ch > kSepLdsFloats) {
-    // medium RoI: the whole workgroup cooperates on one channel at a time (block barriers between the passes)
+  const int wave = tid >> 6, lane = tid & 63;
+  constexpr int kSlice = kSepLdsFloats / 4;                  // LDS floats of one wave
+  // register-tap paths (7x7x7 bins, sampling grid 2 - the shipped configs): every lane keeps a FIXED (ph, pw) for the whole RoI, so
+  // all interpolation taps, weights and LDS offsets are precomputed once per RoI; per channel the three passes are bare
+  // {read x4, fma x4, write} bodies.  Every WAVE works alone on one channel at a time in its own LDS slice (LDS operations of one
+  // wave execute in order, so a pass may read what other lanes of the same wave wrote: no workgroup barriers), and the 343 results
+  // of a channel leave through LDS as six fully coalesced 256-byte stores instead of 7 x 49 scattered dwords.
+  //   staged:   the channel's sub-volume is copied into LDS (next channel's copy is fetched into registers meanwhile)
+  //   global-x: sub-volumes too large for that: the x pass reads its taps straight from the (L2-resident) feature map
+  const bool reg_taps = (g.grid_s == 2) & (g.grid_h == 2) & (g.grid_w == 2) & (AS == 7) & (AH == 7) & (AW == 7);
+  const bool staged = sub <= kSepStageMax && per_ch + 343 <= kSlice;
+  const bool globalx = !staged && reg_taps && n1 + n2 + 343 <= kSlice;
+  if (!(staged || globalx)) {
+    if (per_ch > kSepLdsFloats) {                          // sub-volume and intermediates do not fit LDS at all: reference order
+      roi_exact_forward_range(feat, out, g, tz, ty, tx, n, c0, c1, C, S, H, W, AS, AH, AW);
+      return;
+    }
+    // the whole workgroup cooperates on one channel at a time (block barriers between the passes)
     float* fsub = dyn; float* t1 = fsub + sub; float* t2 = t1 + n1;
     for (int c = c0; c < c1; ++c) {
       const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
@@ -343,34 +570,26 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
     }
     return;
   }
-  // small RoI (the common case): every WAVE works alone on one channel at a time in its own LDS slice, no workgroup
-  // barriers (the three short dependent passes are latency-bound).  LDS operations of one wave execute in order, so a
-  // pass may read what other lanes of the same wave wrote.  The next channel's sub-volume is fetched into registers
-  // while the current one is processed.
-  const int wave = tid >> 6, lane = tid & 63;
-  float* fsub = dyn + (size_t)wave * per_ch;             // [ez][ey][ex]
-  float* t1 = fsub + sub;                                // [ez][ey][AW]
-  float* t2 = t1 + n1;                                   // [ez][AH][AW]
-  constexpr int kMaxStage = (kSepLdsFloats / 4 + 63) / 64;   // registers per lane that can hold one sub-volume
+  float* wl = dyn + (size_t)wave * kSlice;
+  float* fsub = wl;                                        // [ez][ey][ex]   (staged only)
+  float* t1 = staged ? fsub + sub : wl;                    // [ez][ey][AW]
+  float* t2 = t1 + n1;                                     // [ez][AH][AW]
+  float* obuf = t2 + n2;                                   // [343] results of one channel in output order
+  constexpr int kMaxStage = kSepStageMax / 64;             // registers per lane that can hold one staged sub-volume
   float stage[kMaxStage];
   int soff[kMaxStage];
 #pragma unroll
   for (int i = 0; i < kMaxStage; ++i) {
     const int e = lane + i * 64;
     soff[i] = -1;
-    if (i * 64 < sub && e < sub) soff[i] = (e / (ey * ex)) * HW + ((e / ex) % ey) * W + e % ex;   // wave-uniform skip
+    if (staged && i * 64 < sub && e < sub) soff[i] = (e / (ey * ex)) * HW + ((e / ex) % ey) * W + e % ex;   // wave-uniform skip
   }
-  auto fetch = [&](int c) __attribute__((always_inline)) {
-    const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+  if (!reg_taps) {                                         // generic grids: table-driven passes, staged sub-volume
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+      const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
 #pragma unroll
-    for (int i = 0; i < kMaxStage; ++i) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
-  };
-  // register-tap fast path (7x7x7 bins, sampling grid 2 — the shipped configs): every lane keeps a FIXED (ph, pw)
-  // for the whole RoI, so all interpolation taps, weights and LDS offsets are precomputed once per RoI; per channel the
-  // three passes are bare {ds_read x4, fma x4, ds_write} bodies (the generic table-driven passes spend 2/3 of their
-  // LDS traffic and most of their VALU work on re-reading the tap tables and re-deriving addresses per element).
-  const bool reg_taps = (g.grid_s == 2) & (g.grid_h == 2) & (g.grid_w == 2) & (AS == 7) & (AH == 7) & (AW == 7);
-  if (!reg_taps) {
+      for (int i = 0; i < kMaxStage; ++i) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
+    };
     if (c0 + wave < c1) fetch(c0 + wave);
     for (int c = c0 + wave; c < c1; c += 4) {
 #pragma unroll
@@ -401,27 +620,39 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
       zo[ps][2 * i] = sz.valid ? (sz.lo - z0) * 49 : 0; zo[ps][2 * i + 1] = sz.valid ? (sz.hi - z0) * 49 : 0;
     }
   const int nrows = ez * ey;
-  const int nst = (sub + 63) / 64;                         // staging registers actually needed (wave-uniform)
-  if (c0 + wave < c1) {
-    const float* fc = feat + ((size_t)g.batch * C + c0 + wave) * S * HW + (size_t)z0 * HW + y0 * W + x0;
+  const int nst = staged ? (sub + 63) / 64 : 0;            // staging registers actually needed (wave-uniform)
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+    const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
 #pragma unroll
     for (int i = 0; i < kMaxStage; ++i) if (i < nst) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
-  }
+  };
+  if (staged && c0 + wave < c1) fetch(c0 + wave);
+  // global-x: this lane's first row (z, y) of the sub-volume and its step of 9 rows
+  const int gz0 = my_rx / ey, gy0 = my_rx % ey;
   for (int c = c0 + wave; c < c1; c += 4) {
+    if (staged) {
 #pragma unroll
-    for (int i = 0; i < kMaxStage; ++i)
-      if (i < nst && soff[i] >= 0) fsub[lane + i * 64] = stage[i];
-    if (c + 4 < c1) {
-      const float* fc = feat + ((size_t)g.batch * C + c + 4) * S * HW + (size_t)z0 * HW + y0 * W + x0;
-#pragma unroll
-      for (int i = 0; i < kMaxStage; ++i) if (i < nst) stage[i] = fc[soff[i] < 0 ? 0 : soff[i]];
-    }
-    if (my_rx < 9) {                                       // pass X: lanes 0..62 <-> (row mod 9, pw)
-      const float* row = fsub + my_rx * ex;
+      for (int i = 0; i < kMaxStage; ++i)
+        if (i < nst && soff[i] >= 0) fsub[lane + i * 64] = stage[i];
+      if (c + 4 < c1) fetch(c + 4);
+      if (my_rx < 9) {                                     // pass X: lanes 0..62 <-> (row mod 9, pw)
+        const float* row = fsub + my_rx * ex;
+        float* dst = t1 + my_rx * 7 + my_pw;
+        for (int zy = my_rx; zy < nrows; zy += 9) {
+          *dst = (xw[0] * row[xo[0]] + xw[1] * row[xo[1]]) + (xw[2] * row[xo[2]] + xw[3] * row[xo[3]]);
+          row += 9 * ex; dst += 63;
+        }
+      }
+    } else if (my_rx < 9) {                                // pass X from the feature map itself
+      const float* fc = feat + ((size_t)g.batch * C + c) * S * HW + (size_t)z0 * HW + y0 * W + x0;
       float* dst = t1 + my_rx * 7 + my_pw;
+      int z = gz0, y = gy0;
       for (int zy = my_rx; zy < nrows; zy += 9) {
+        const float* row = fc + (size_t)z * HW + y * W;
         *dst = (xw[0] * row[xo[0]] + xw[1] * row[xo[1]]) + (xw[2] * row[xo[2]] + xw[3] * row[xo[3]]);
-        row += 9 * ex; dst += 63;
+        dst += 63;
+        y += 9;
+        while (y >= ey) { y -= ey; ++z; }
       }
     }
     if (lane < 49) {
@@ -431,11 +662,17 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
         *dst = (yw[0] * col[yo[0]] + yw[1] * col[yo[1]]) + (yw[2] * col[yo[2]] + yw[3] * col[yo[3]]);
         col += ey * 7; dst += 49;
       }
-      const float* cz = t2 + lane;                         // pass Z (+ 1/count folded into the weights)
-      float* oc = out + ((size_t)n * C + c) * 343 + lane * 7;
+      const float* cz = t2 + lane;                         // pass Z (+ 1/count folded into the weights) -> obuf in output order
+      float* ob = obuf + lane * 7;
 #pragma unroll
       for (int ps = 0; ps < 7; ++ps)
-        oc[ps] = (zw[ps][0] * cz[zo[ps][0]] + zw[ps][1] * cz[zo[ps][1]]) + (zw[ps][2] * cz[zo[ps][2]] + zw[ps][3] * cz[zo[ps][3]]);
+        ob[ps] = (zw[ps][0] * cz[zo[ps][0]] + zw[ps][1] * cz[zo[ps][1]]) + (zw[ps][2] * cz[zo[ps][2]] + zw[ps][3] * cz[zo[ps][3]]);
+    }
+    float* oc = out + ((size_t)n * C + c) * 343;           // 343 contiguous floats: 6 coalesced stores
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int e = lane + 64 * k;
+      if (e < 343) oc[e] = obuf[e];
     }
   }
 }
@@ -459,8 +696,15 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
   const bool backward = (mode == 2);
   if (mode == 0) {
     const size_t lds = sizeof(float) * kSepLdsFloats;
-    hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, grid, block, lds, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
-                       scale, ratio, cpb);
+    const int v3 = (ratio == 2 && AS == 7 && AH == 7 && AW == 7) ? 1 : 0;      // the shipped geometry: two launches, each RoI in one
+    if (v3) {                       // 32 channels per workgroup: big RoIs run on 1-2 waves, so their work is cut finer
+      const int cpb3 = 32;
+      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
+                         H, W, scale, cpb3);
+    }
+    // complement pass (v3: only the RoIs v3 declined - wide bins, huge sub-volumes - so one workgroup per RoI, all channels)
+    hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, 1) : grid, block, lds, m3d::as_stream(stream), a, rois, o, C, S, H, W,
+                       AS, AH, AW, scale, ratio, v3 ? C : cpb, v3);
   } else if (!backward)
     hipLaunchKernelGGL(roi_align3d_kernel<false>, grid, block, 0, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
                        scale, ratio, cpb, (int*)nullptr);

@@ -43,7 +43,9 @@ def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_rati
     features, rois = _f32c(features), _f32c(rois)
     B, Cc, S, H, W = features.shape
     R = rois.shape[0]
-    out = torch.zeros((R, Cc, AS, AH, AW), dtype=torch.float32, device=features.device)   # roi_align_3d.py:24
+    # functions/roi_align_3d.py:24 zero-fills before the call; every forward kernel here writes every output element
+    # (RoIs without a valid sample included), so the 351 MB memset is not repeated
+    out = torch.empty((R, Cc, AS, AH, AW), dtype=torch.float32, device=features.device)
     fn = lib().m3d_roi_align3d_forward_exact if exact else lib().m3d_roi_align3d_forward
     check(fn(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
                                         _ptr(features), B, Cc, S, H, W, _ptr(rois), R, int(rois.shape[1]) if rois.dim() == 2 else 0,
