@@ -418,6 +418,364 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   }
 }
 
+// eta-split variant (conv3d_wino2e_kernel): same tile, 8 waves - waves w and w + 4 share a SIMD and split the 16 (eta, xi)
+// accumulator blocks by eta half.
+template <int CC, int XT, int WZ, int WY, bool POOL>
+struct W2CfgE {
+  static constexpr int NT = 512;
+  static constexpr int PP = CC / 2;
+  static constexpr int YT = 32 / XT;
+  static constexpr int TX = 2 * XT, TY = 2 * YT * WY, TZ = WZ;
+  static constexpr int EP = XT + 2;
+  static constexpr int QR = EP / 2;                            // 16-byte quads per row
+  // row pitch: the YT y-pairs of a block sit 2*HXP floats apart; 2*HXP = XT (mod 32) puts them on disjoint banks
+  static constexpr int HXP = (YT == 1) ? 2 * EP : ((2 * EP - XT / 2 + 15) / 16 * 16 + XT / 2);
+  static constexpr int HY = TY + 2, HZ = TZ + 2;
+  static constexpr int CS = HXP * HY * HZ;
+  static constexpr int IN_ELEMS = CC * CS;
+  static constexpr int NQUAD = CC * HZ * HY * QR;
+  static constexpr int W_SEG = WT2 * 64;                       // one cout block
+  static constexpr int W_ELEMS = PP * W_SEG;
+  static constexpr int NI = (NQUAD + NT - 1) / NT;
+  static constexpr int NW4 = (W_ELEMS / 4 + NT - 1) / NT;
+  static constexpr int DUMP = IN_ELEMS + W_ELEMS;              // 2 x 8-byte dump slots behind each buffer (branch-free staging)
+  static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS + ((EP + 2 + 3) / 4) * 4;
+  static constexpr int XCH_FLOATS = 4 * 64 * 64;               // eta-half exchange: 4 wave pairs x 64 floats x 64 lanes
+  static constexpr int RED_FLOATS = XCH_FLOATS + (POOL ? 4 * 16 * 64 : 0);
+  static constexpr int SMEM_FLOATS = 2 * LDS_FLOATS > RED_FLOATS ? 2 * LDS_FLOATS : RED_FLOATS;
+  static_assert(WZ * WY == 4, "4 wave pairs per workgroup, one pair per SIMD");
+  static_assert(!POOL || WZ == 2, "fused pool: the z pair lives in waves wz = 0, 1");
+  static_assert(HXP % 2 == 0, "8-byte LDS stores");
+  static_assert((W_ELEMS / 4) % NT == 0, "weight staging is branch-free: whole float4 rounds");
+};
+
+
+template <int CC, int XT, int WZ, int WY, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+                                                              float* __restrict__ out, int cin, int cout, int D, int H, int W,
+                                                              int tiles_x, int tiles_y, int tiles_z, int ncb_total, W2Epi ep) {
+  using C = W2CfgE<CC, XT, WZ, WY, POOL>;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int eh = wave8 >> 2, wave = wave8 & 3;          // eta half (waves w and w + 4 sit on the same SIMD), wave position in the tile
+  const int wz = wave / WY, wy = wave % WY;
+
+  int bid = blockIdx.x;
+  const int co_tiles = (cout + 31) / 32;
+  int cot;
+  // XCD-contiguous order with the cout tile FASTEST: the co_tiles workgroups that share one input tile run next to
+  // each other on the same XCD, so the slab is fetched into one L2 once (these layers are input-dominated: measured
+  // 225 MB -> see profiles/r01_pmc_traffic.json per conv2b launch when the cout tiles sat on different XCDs)
+  if (ep.xcd_map) bid = xcd_contiguous2(bid, gridDim.x);
+  cot = bid % co_tiles; bid /= co_tiles;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  // z tiles in groups of 4 inside the y sweep: the tiles an XCD works on at the same time form a compact (y, z) block whose
+  // halo planes stay in its 4 MB L2 (a full-y, single-z slab order re-fetches every z halo plane for the next slab)
+  constexpr int ZG = 4;
+  int ty, tz;
+  {
+    const int n_full = tiles_z / ZG, full = n_full * ZG * tiles_y;
+    if (bid < full) {
+      const int zl = bid % ZG; bid /= ZG;
+      ty = bid % tiles_y; tz = (bid / tiles_y) * ZG + zl;
+    } else {
+      const int zr = tiles_z - n_full * ZG, rem = bid - full;
+      ty = rem / zr; tz = n_full * ZG + rem % zr;
+    }
+  }
+  const int b = blockIdx.y;
+  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const size_t DHW = (size_t)D * H * W;
+  const float* in_b = in + (size_t)b * cin * DHW;
+
+  // ---- input staging descriptors: 16-byte quads, see conv3d_wino.hip
+  int gq[C::NI], mq[C::NI], lq[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    const int e = tid + i * C::NT;
+    gq[i] = 0; mq[i] = 0; lq[i] = C::DUMP;          // quads beyond the tile: masked to zero, written to a dump slot
+    if (e < C::NQUAD) {
+      const int q = e % C::QR;
+      const int row = e / C::QR;
+      const int hy = row % C::HY, hz = (row / C::HY) % C::HZ, ci = row / (C::HY * C::HZ);
+      const int z = z0 + hz - 1, y = y0 + hy - 1, xf = x0 - 1 + 4 * q;
+      const bool rok = (z >= 0) & (z < D) & (y >= 0) & (y < H);
+      int m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
+      long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
+      if (rok && lin < 0) { lin = 0; m |= 16; }
+      mq[i] = m;
+      gq[i] = rok ? (int)(lin * 4) : 0;
+      lq[i] = row * C::HXP + 2 * q;
+    }
+  }
+  // weights and input quads are staged one after the other through the SAME registers (weights: loads in step 0,
+  // LDS writes in step 2; input: loads in step 2, writes in step NS-2)
+  constexpr int NSTG = C::NI > C::NW4 ? C::NI : C::NW4;
+  f32x4 stg[NSTG];
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
+  const int nchunk_all = (cin + CC - 1) / CC;
+  const int c_begin = ep.ksplit > 1 ? (int)blockIdx.z * ep.cps : 0;
+  const int nchunk = ep.ksplit > 1 ? min(nchunk_all, c_begin + ep.cps) : nchunk_all;     // one past this slice's last chunk
+  if (ep.ksplit > 1) out += (size_t)blockIdx.z * ep.slice_stride;
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
+  const size_t w_pair_stride4 = (size_t)ncb_total * WT2 * 64 / 4;
+  const size_t w_tile_off4 = (size_t)cot * WT2 * 64 / 4;
+  auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
+    if (idx < C::NI) {
+      const int voff = gq[idx] + chunk * (int)(CC * DHW * sizeof(float));
+      stg[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
+    } else {
+      const int i = idx - C::NI;
+      const int e = tid + i * C::NT;
+      const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
+      stg[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
+    }
+  };
+  auto commit1 = [&](int idx, float* dst_in, float* dst_w) __attribute__((always_inline)) {
+    if (idx < C::NI) {                                 // branch-free: the K loop must stay one scheduling region
+      const int m = mq[idx];
+      const f32x4 v = stg[idx];
+      const bool sh = (m & 16) != 0;
+      const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
+      const f32x2 ev = {(m & 2) ? v1 : 0.f, (m & 8) ? v3 : 0.f};
+      const f32x2 ov = {(m & 1) ? v0 : 0.f, (m & 4) ? v2 : 0.f};
+      *reinterpret_cast<f32x2*>(dst_in + lq[idx]) = ev;
+      *reinterpret_cast<f32x2*>(dst_in + lq[idx] + C::EP) = ov;
+    } else {
+      const int i = idx - C::NI;
+      reinterpret_cast<f32x4*>(dst_w)[tid + i * C::NT] = stg[i];
+    }
+  };
+
+  f32x16 acc[2][4];   // [eta - 2 * eh][xi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[a][x][g] = 0.f;
+
+  const int jt = (lane & 31) % XT, ju = (lane & 31) / XT;
+  // B base: channel half, the wave's z plane, halo row 2*(wy*YT + ju) (= output row pair's y-1), E[jt]
+  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HXP) + 2 * (wy * C::YT + ju) * C::HXP + jt;
+
+  constexpr int NS = 3 * C::PP;                        // K steps per chunk: dz x channel pair
+  static_assert(NS % 2 == 0 && NS >= 4, "the fragment rings are indexed statically across the chunk loop");
+  // y transform of this eta half from three of the four halo rows:  cA = U - V,  cB = sgn * P + V
+  //   eh = 0 (eta 0, 1): U = row 0, V = row 2, P = row 1, sgn = +1   (d0 - d2, d1 + d2)
+  //   eh = 1 (eta 2, 3): U = row 2, V = row 1, P = row 3, sgn = -1   (d2 - d1, d1 - d3)
+  const int rowU = (eh ? 2 : 0) * C::HXP, rowV = (eh ? 1 : 2) * C::HXP, rowP = (eh ? 3 : 1) * C::HXP;
+  const float sgnP = eh ? -1.f : 1.f;
+  auto read_raw = [&](const float* in_k, int s, float (&r)[3][4]) __attribute__((always_inline)) {
+    const int dz = s / C::PP, pp = s % C::PP;
+    const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP);
+    const float* pu = p + rowU; const float* pv = p + rowV; const float* pq = p + rowP;
+    r[0][0] = pu[0]; r[0][1] = pu[1]; r[0][2] = pu[C::EP]; r[0][3] = pu[C::EP + 1];      // (E[t], E[t+1], O[t], O[t+1])
+    r[1][0] = pv[0]; r[1][1] = pv[1]; r[1][2] = pv[C::EP]; r[1][3] = pv[C::EP + 1];
+    r[2][0] = pq[0]; r[2][1] = pq[1]; r[2][2] = pq[C::EP]; r[2][3] = pq[C::EP + 1];
+  };
+  auto transform = [&](const float (&r)[3][4], float (&bf)[2][4]) __attribute__((always_inline)) {
+    float c[2][4];                                     // rows combined (y transform), still raw in x
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      c[0][v] = r[0][v] - r[1][v];
+      c[1][v] = sgnP * r[2][v] + r[1][v];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {                      // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
+      bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
+    }
+  };
+  auto load_a = [&](const float* w_k, int s, float (&af)[8]) __attribute__((always_inline)) {     // w_k points at this half's 8 slots
+    const int dz = s / C::PP, pp = s % C::PP;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
+  };
+
+  // ---- prologue: chunk 0 -> buffer 0, first fragments
+#pragma unroll
+  for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, c_begin);
+#pragma unroll
+  for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, lds, lds + C::IN_ELEMS);
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) issue(i, c_begin);
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) commit1(i, lds, lds + C::IN_ELEMS);
+  __syncthreads();
+  float raw[2][3][4], bfq[2][2][4], afq[2][8];
+  read_raw(lds + b_base, 0, raw[0]);
+  read_raw(lds + b_base, 1, raw[1]);
+  load_a(lds + C::IN_ELEMS + lane + eh * 8 * 64, 0, afq[0]);
+  transform(raw[0], bfq[0]);
+
+  // ---- K loop, software-pipelined ACROSS chunks.  With one wave per SIMD nothing hides a refill of the fragment
+  // pipeline after the chunk barrier, so the barrier sits at the end of step NS-2 (all staging writes of the next chunk
+  // are done by then and every LDS read of the current chunk has been issued and waited for) and the last step's 16
+  // MFMAs cover the first fragment reads of the next chunk.
+  constexpr int SW = 0, SX = (NS - 2) / 2;             // weights: loads in step SW, writes in step SX; input: loads SX, writes NS-2
+  for (int chunk = c_begin; chunk < nchunk; ++chunk) {
+    const float* cur_in = lds + ((chunk - c_begin) & 1) * C::LDS_FLOATS;
+    const float* cur_w = cur_in + C::IN_ELEMS;
+    float* nxt_in = lds + ((chunk - c_begin + 1) & 1) * C::LDS_FLOATS;
+    float* nxt_w = nxt_in + C::IN_ELEMS;
+    const int nchk = min(chunk + 1, nchunk - 1);
+    const float* in_k = cur_in + b_base;
+    const float* w_k = cur_w + lane + eh * 8 * 64;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
+      if (s + 2 < NS) read_raw(in_k, s + 2, raw[s & 1]);
+      if (s + 1 < NS) load_a(w_k, s + 1, afq[(s + 1) & 1]);
+      if (s == NS - 1) {                               // next chunk's first fragments (its buffer is complete: barrier below)
+        read_raw(nxt_in + b_base, 0, raw[0]);
+        read_raw(nxt_in + b_base, 1, raw[1]);
+        load_a(nxt_w + lane + eh * 8 * 64, 0, afq[0]);
+        transform(raw[0], bfq[0]);
+      }
+#if !(M3D_EXP & 1)
+      if (s == SW) {
+#pragma unroll
+        for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, nchk);
+      }
+      if (s == SX) {
+#pragma unroll
+        for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, nxt_in, nxt_w);
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) issue(i, nchk);
+      }
+#endif
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          acc[a][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][a * 4 + x], bfq[s & 1][a][x], acc[a][x], 0, 0, 0);
+#if !(M3D_EXP & 1)
+      if (s == NS - 2) {
+#pragma unroll
+        for (int i = 0; i < C::NI; ++i) commit1(i, nxt_in, nxt_w);
+      }
+#endif
+      // Two waves per SIMD: the partner's MFMAs fill the pipe while this wave issues its LDS / VALU / VMEM work, which is still
+      // spread between the step's 8 MFMAs so that neither wave presents a long MFMA-free stretch.
+#ifndef M3D_SGE
+#define M3D_SGE 3, 6, 1, 1     /* per MFMA slot: DS reads, VALU, DS writes, VMEM reads */
+#endif
+#ifndef M3D_SGE_OFF
+      {
+        constexpr int sg[4] = {M3D_SGE};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, sg[0], 0);     // DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, sg[1], 0);     // VALU
+          __builtin_amdgcn_sched_group_barrier(0x200, sg[2], 0);     // DS write
+          __builtin_amdgcn_sched_group_barrier(0x020, sg[3], 0);     // VMEM read
+        }
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#if !(M3D_EXP & 2)
+      if (s == NS - 2) __syncthreads();
+#endif
+    }
+  }
+  __syncthreads();                                     // the pool exchange below reuses the staging area
+
+  // ---- inverse transform: over xi in the lane, over eta across the two halves:  y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3
+  // half 1 (eta 2, 3) hands (m2, -m2 - m3) for both columns to half 0 through LDS; half 0 finishes and stores.
+  f32x16 yv[2][2];
+  {
+    f32x16 p0[2], p1[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      p0[a] = acc[a][0] + acc[a][1] + acc[a][2];
+      p1[a] = acc[a][1] - acc[a][2] - acc[a][3];
+    }
+    float* xch = lds + (size_t)wave * 64 * 64 + lane;      // final barrier of the chunk loop has passed: staging area is free
+    if (eh == 1) {
+      const f32x16 a0 = p0[0], a1 = -p0[0] - p0[1], b0 = p1[0], b1 = -p1[0] - p1[1];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        xch[g * 64] = a0[g]; xch[(16 + g) * 64] = a1[g]; xch[(32 + g) * 64] = b0[g]; xch[(48 + g) * 64] = b1[g];
+      }
+    }
+    __syncthreads();
+    if (eh == 1) return;
+    yv[0][0] = p0[0] + p0[1]; yv[1][0] = p0[1];
+    yv[0][1] = p1[0] + p1[1]; yv[1][1] = p1[1];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      yv[0][0][g] += xch[g * 64]; yv[1][0][g] += xch[(16 + g) * 64]; yv[0][1][g] += xch[(32 + g) * 64]; yv[1][1][g] += xch[(48 + g) * 64];
+    }
+  }
+  const int co0 = cot * 32 + 4 * (lane >> 5);
+  const int z = z0 + wz;
+  const int x = x0 + 2 * jt;
+  const int y = y0 + 2 * (wy * C::YT + ju);
+
+  if constexpr (POOL) {
+    // conv + scale/shift + ReLU + MaxPool3d(2,2): the (y, x) 2x2 footprint is in the lane; the z pair is wave wz = 0 / 1
+    float pooled[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = min(co0 + (g & 3) + 8 * (g >> 2), cout - 1);
+      const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float v = yv[r][c][g] * sc + sh;
+          if (ep.relu) v = fmaxf(v, 0.f);
+          m = fmaxf(m, v);
+        }
+      pooled[g] = m;
+    }
+    float* red = lds + C::XCH_FLOATS + (size_t)wy * 16 * 64 + lane;   // behind the eta exchange area
+    if (wz == 1) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) red[g * 64] = pooled[g];
+    }
+    __syncthreads();
+    if (wz == 1) return;
+    const int PD = D / 2, PH = H / 2, PW = W / 2;
+    const int zp = z0 >> 1, yp = y >> 1, xp = x >> 1;
+    if (zp >= PD || yp >= PH || xp >= PW) return;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = co0 + (g & 3) + 8 * (g >> 2);
+      if (co < cout)
+        out[((size_t)b * cout + co) * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = fmaxf(pooled[g], red[g * 64]);
+    }
+    return;
+  }
+
+  if (!(z < D && y < H && x < W)) return;
+  const bool pair_ok = ((W & 1) == 0);
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int co = co0 + (g & 3) + 8 * (g >> 2);
+    if (co >= cout) continue;
+    const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (y + r >= H) continue;
+      float v0 = yv[r][0][g] * sc + sh, v1 = yv[r][1][g] * sc + sh;
+      if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      float* o = out + ((size_t)b * cout + co) * DHW + ((size_t)z * H + y + r) * W + x;
+      if (pair_ok) {
+        *reinterpret_cast<f32x2*>(o) = f32x2{v0, v1};
+      } else {
+        o[0] = v0;
+        if (x + 1 < W) o[1] = v1;
+      }
+    }
+  }
+}
+
 // split-K epilogue: out = act(scale * sum_s partial[s] + shift), fixed summation order
 __global__ __launch_bounds__(256) void wino2_reduce_kernel(const float* __restrict__ ws, int ksplit, size_t slice_stride,
                                                            float* __restrict__ out, int cout, size_t DHW, size_t total,
@@ -436,7 +794,7 @@ inline int xcd_map_enabled2() {
 }
 
 template <int CC, int XT, int WZ, int WY, bool POOL = false>
-int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
+int launch_wino2_one(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
                  int ksplit = 1) {
   using C = W2Cfg<CC, XT, WZ, WY, POOL>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
@@ -453,6 +811,37 @@ int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, i
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B, ksplit), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
                      tiles_z, ncb_total, ep);
   return m3d::check_launch("conv3d_wino2");
+}
+
+
+// eta-split variant: 8 waves, two per SIMD
+template <int CC, int XT, int WZ, int WY, bool POOL = false>
+int launch_wino2e(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
+                  int ksplit = 1) {
+  using C = W2CfgE<CC, XT, WZ, WY, POOL>;
+  const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
+  const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;
+  const int co_tiles = (cout + 31) / 32;
+  const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
+  if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
+  ep.xcd_map = xcd_map_enabled2();
+  const size_t lds = sizeof(float) * C::SMEM_FLOATS;
+  if (lds > 160 * 1024) return M3D_EUNSUPPORTED;
+  auto kern = conv3d_wino2e_kernel<CC, XT, WZ, WY, POOL>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B, ksplit), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
+                     tiles_z, ncb_total, ep);
+  return m3d::check_launch("conv3d_wino2e");
+}
+
+// tune_wino2 >= 100 selects the one-wave-per-SIMD kernels (A/B measurements); default: the eta-split kernels
+template <int CC, int XT, int WZ, int WY, bool POOL = false>
+int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
+                 int ksplit = 1) {
+  if (m3d::opt(m3d::OPT_TUNE_WINO2) >= 100)
+    return launch_wino2_one<CC, XT, WZ, WY, POOL>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
+  return launch_wino2e<CC, XT, WZ, WY, POOL>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
 }
 
 }  // namespace
@@ -536,7 +925,7 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  const int variant = m3d::opt(m3d::OPT_TUNE_WINO2);
+  const int variant = m3d::opt(m3d::OPT_TUNE_WINO2) % 100;      // +100: one-wave-per-SIMD kernels (launch_wino2)
 #define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
   M3D_W2(1, 4, 32, 4, 1)
@@ -545,7 +934,7 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
   M3D_W2(4, 4, 16, 4, 1)
   M3D_W2(5, 4, 16, 1, 4)
 #undef M3D_W2
-  if (variant >= 0) return M3D_EUNSUPPORTED;
+  if (variant >= 0 && variant != 99) return M3D_EUNSUPPORTED;    // 99 / 199: library tile choice
   const int xt = choose_xt(batch, cin, cout, depth, height, width);
   if (xt == 32) return launch_wino2<4, 32, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   if (xt == 16) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);

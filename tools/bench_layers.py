@@ -12,14 +12,15 @@ L = [("conv1a", 1, 32, 5, size), ("conv2a", 32, 64, 3, size // 2), ("conv2b", 64
      ("conv4b", 256, 256, 3, size // 8), ("rpn_conv", 256, 256, 3, size // 8), ("rpn_heads", 256, 245, 1, size // 8)]
 tot_t, tot_f, tot_w = 0.0, 0.0, 0.0
 only = os.environ.get('LAYERS')
+BATCH = int(os.environ.get("BATCH", "1"))
 for name, cin, cout, k, s in L:
     if only and name not in only.split(','):
         continue
-    x = torch.randn(1, cin, s, s, s, device="cuda")
+    x = torch.randn(BATCH, cin, s, s, s, device="cuda")
     w = torch.randn(cout, cin, k, k, k, device="cuda") * 0.05
     conv = m3d.PackedConv3d(w)
     sc = torch.rand(cout, device="cuda"); sh = torch.rand(cout, device="cuda")
-    out = torch.empty(1, cout, s, s, s, device="cuda")
+    out = torch.empty(BATCH, cout, s, s, s, device="cuda")
     fused = name in ("conv1a", "conv2b") and os.environ.get("FUSED", "1") == "1"   # as the real pipeline runs them
     run = (lambda: conv.pooled(x, scale=sc, shift=sh, relu=True)) if fused else (lambda: conv(x, scale=sc, shift=sh, relu=True, out=out))
     if fused:
@@ -33,7 +34,7 @@ for name, cin, cout, k, s in L:
         run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    fl = 2.0 * cin * cout * k ** 3 * s ** 3
+    fl = 2.0 * cin * cout * k ** 3 * s ** 3 * BATCH
     tot_t += ms; tot_f += fl
     line = "%-12s cin %3d cout %3d k%d %3d^3  direct %8.3f ms %6.2f TFLOP/s (%.1f%%)" % (name, cin, cout, k, s, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100)
     msw = ms
