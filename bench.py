@@ -304,28 +304,47 @@ def bench_detect(args, rank, world, dist):
     if rank != 0:
         return
     voxels = n_items * args.steps * VOL ** 3
-    # ---- roofline of the dominant hand-written kernel, from the live HIP-event spans of the timed region
+    # ---- rooflines of the two largest hand-written kernels, from the live HIP-event spans of the timed region; `roofline` is
+    # the one with the longer launch (the dominant kernel of the step)
     wino = det.wino_mode
     conv2b_alg = nvol * conv_flops(64, 64, 3, (VOL // 2) ** 3)              # 57.98 GFLOP algorithmic per volume, batch in one launch
     kern = {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}
-    roof = None
+    roofs = {}
     if "conv2b" in kern_ms:
         ms = kern_ms["conv2b"]
         issued = conv2b_alg * WINO_WORK[wino]
-        roof = {"bound": "mfma",
-                "launch": "one launch over the rank's batch of %d volumes" % nvol,
-                "kernel": {2: "conv3d_wino2_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x) + fused BN/ReLU/MaxPool)",
-                           1: "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)",
-                           0: "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b direct + fused BN/ReLU/MaxPool)"}[wino],
-                "achieved": issued / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": issued / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
-                "issued_gflop_per_launch": issued / 1e9, "algorithmic_gflop_per_launch": conv2b_alg / 1e9,
-                "algorithmic_equivalent_tflops": conv2b_alg / (ms * 1e-3) / 1e12,
-                "note": "achieved/frac count the MFMA FLOPs the kernel ISSUES (Winograd: %s of the algorithmic 2*Cin*Cout*27 per voxel); "
-                        "algorithmic_equivalent_tflops is the direct-convolution FLOP count over the same time" %
-                        {2: "4/9", 1: "2/3", 0: "1"}[wino]}
-        roof.update(pmc_traffic({2: "conv3d_wino2_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
-                                 0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
+        r = {"bound": "mfma",
+             "launch": "one launch over the rank's batch of %d volumes" % nvol,
+             "kernel": {2: "conv3d_wino2e_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x), eta-split 8 waves + fused BN/ReLU/MaxPool)",
+                        1: "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)",
+                        0: "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b direct + fused BN/ReLU/MaxPool)"}[wino],
+             "achieved": issued / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": issued / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
+             "issued_gflop_per_launch": issued / 1e9, "algorithmic_gflop_per_launch": conv2b_alg / 1e9,
+             "algorithmic_equivalent_tflops": conv2b_alg / (ms * 1e-3) / 1e12,
+             "note": "achieved/frac count the MFMA FLOPs the kernel ISSUES (Winograd: %s of the algorithmic 2*Cin*Cout*27 per voxel); "
+                     "algorithmic_equivalent_tflops is the direct-convolution FLOP count over the same time" %
+                     {2: "4/9", 1: "2/3", 0: "1"}[wino]}
+        r.update(pmc_traffic({2: "conv3d_wino2e_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
+                              0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
+        roofs["conv2b"] = r
+    if "fc1" in kern_ms and "num_rois" in last:
+        ms = kern_ms["fc1"]
+        M = int(sum(last["num_rois"]))
+        Kf, Nf = 256 * 343, cfg.mlp_dim
+        fl = 2.0 * M * Nf * Kf
+        r = {"bound": "mfma", "launch": "one launch over the RoIs of the rank's %d volumes (M = %d rows)" % (nvol, M),
+             "kernel": "fc_gemm_kernel (Box_Head.fc1: [M,87808] x [1024,87808]^T, split-K fp32 MFMA GEMM; + fc_reduce_kernel)",
+             "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms, "algorithmic_gflop_per_launch": fl / 1e9,
+             "algorithmic_bytes_per_launch": (M + Nf) * Kf * 4.0 + M * Nf * 4.0,
+             "note": "every multiply-add of the GEMM is issued (no Winograd): achieved = 2*M*N*K / time of the GEMM + its split-K reduction"}
+        r.update(pmc_traffic("fc_gemm_kernel"))
+        roofs["fc1"] = r
+    roof = None
+    if roofs:
+        dom = max(roofs, key=lambda k: roofs[k]["kernel_ms"])
+        roof = roofs[dom]
     body_ms = sum(v for k, v in kern_ms.items() if k.startswith("conv")) / nvol      # spans cover the whole batch
     res = {"metric": METRIC, "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -342,7 +361,7 @@ def bench_detect(args, rank, world, dist):
                       "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9, "backbone_ms_per_volume": body_ms,
                       "backbone_algorithmic_tflops": backbone_flops(VOL) / (body_ms * 1e-3) / 1e12 if body_ms else None,
                       "kernel_ms_per_launch": kern},
-           "roofline": roof}
+           "roofline": roof, "rooflines": roofs}
     if e2e is not None:
         res["e2e_host_to_host"] = e2e
     if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only

@@ -34,17 +34,28 @@ constexpr int KGmap(int g) { return (g & 3) + 8 * (g >> 2); }      // accumulato
 struct FcArgs {
   const float* x; const float* w; const float* bias; float* out; float* part;
   int M, N, K, mt, nt, slices, chunks, relu;
+  int mt_full;            // row tiles run by the full-tile path; mt - mt_full (0 or 1) ragged last tile runs the cheap tail path
+  int full_per_xcd, tail_per_xcd;   // units of each kind given to one XCD (grid = 8 * (full_per_xcd + tail_per_xcd))
 };
 
 __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
   extern __shared__ float lds[];                                   // 2 x [(BM + BN) x LS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- unit = (slice, tile); workgroups dealt to one XCD (blockIdx % 8) get a contiguous run of units
-  const int total = a.mt * a.nt * a.slices;
-  const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
-  const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  const int tiles = a.mt * a.nt;
-  const int slice = u / tiles, tile = u - slice * tiles;
+  // ---- unit = (slice, tile).  Workgroups dealt to one XCD (blockIdx % 8) get a contiguous run of full-tile units (same slice,
+  // neighbouring tiles: their x / W panels are shared through that XCD's L2) FOLLOWED by its share of the cheap ragged-tail units:
+  // dispatched last, the short workgroups fill the slots that are left instead of pushing full tiles into a second round.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tiles_full = a.mt_full * a.nt, nfull = tiles_full * a.slices, ntail = (a.mt - a.mt_full) * a.nt * a.slices;
+  int slice, tile;
+  if (idx < a.full_per_xcd) {
+    const int u = xcd * a.full_per_xcd + idx;
+    if (u >= nfull) return;
+    slice = u / tiles_full; tile = u - slice * tiles_full;
+  } else {
+    const int v = xcd * a.tail_per_xcd + (idx - a.full_per_xcd);
+    if (idx - a.full_per_xcd >= a.tail_per_xcd || v >= ntail) return;
+    slice = v / a.nt; tile = tiles_full + (v - slice * a.nt);
+  }
   const int tm = tile / a.nt, tn = tile - tm * a.nt;
   const int m0 = tm * BM, n0 = tn * BN;
   const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
@@ -77,6 +88,82 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
       *reinterpret_cast<f32x4*>(buf + (BM + row0 + 32 * i) * LS + 4 * quad) = sw[i];
     }
   };
+
+  const int full = a.K / BK;                                      // whole chunks in K
+  const int c1f = min(c1, full);                                  // this slice's whole chunks are [c0, c1f)
+  const bool direct = a.slices == 1;
+  float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
+
+  // ---- ragged last row tile (M % 128 in 1..64): only nb = 1 or 2 of its four 32-row blocks hold rows, so the four waves split
+  // the COLUMNS instead - wave w owns row block w >> (nb == 2 ? 1 : 2)... one (nb = 1) or two (nb = 2) MFMA blocks per wave - and the
+  // tile costs a quarter / a half of a full one (M = 1281 RoIs: 10.25 tile times instead of 11).  Separate, simple loop: the
+  // full-tile path below keeps its registers and schedule.
+  const int nb = min(4, (a.M - m0 + 31) / 32);
+  if (tm >= a.mt_full) {                                           // nb is 1 or 2 here (make_plan)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int rbk = nb == 2 ? (wave >> 1) : 0;                    // row block of this wave
+    const int cb0 = nb == 2 ? 2 * (wave & 1) : wave;              // first column block; nb == 2: also cb0 + 1
+    const int ncb = nb == 2 ? 2 : 1;
+    const int oA = (rbk * 32 + fr) * LS + 4 * fh, oB = (BM + cb0 * 32 + fr) * LS + 4 * fh;
+    f32x16 t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t[j][g] = 0.f;
+    auto tail_compute = [&](const float* cur) __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(cur + oA + g * 8);
+        const f32x4 fb0 = *reinterpret_cast<const f32x4*>(cur + oB + g * 8);
+        const f32x4 fb1 = *reinterpret_cast<const f32x4*>(cur + oB + 32 * LS + g * 8);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb0[kk], t[0], 0, 0, 0);
+          if (ncb == 2) t[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb1[kk], t[1], 0, 0, 0);
+        }
+      }
+    };
+    if (c0 < c1f) { fetch(c0); commit(lds); }
+    __syncthreads();
+    for (int c = c0; c < c1f; ++c) {
+      const float* cur = lds + ((c - c0) & 1) * kStageFloats;
+      fetch(c + 1 < c1f ? c + 1 : c);
+      __builtin_amdgcn_sched_barrier(0);
+      tail_compute(cur);
+      commit(lds + ((c + 1 - c0) & 1) * kStageFloats);
+      __syncthreads();
+    }
+    if (c1 > c1f) {                                               // ragged tail chunk of K
+      const bool ok = full * BK + 4 * quad < a.K;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const int k = ok ? full * BK : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 vx = *reinterpret_cast<const f32x4*>(px[i] + k), vw = *reinterpret_cast<const f32x4*>(pw[i] + k);
+        *reinterpret_cast<f32x4*>(lds + (row0 + 32 * i) * LS + 4 * quad) = ok ? vx : z;
+        *reinterpret_cast<f32x4*>(lds + (BM + row0 + 32 * i) * LS + 4 * quad) = ok ? vw : z;
+      }
+      __syncthreads();
+      tail_compute(lds);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j >= ncb) continue;
+      const int n = n0 + (cb0 + j) * 32 + fr;
+      const float b = (direct && a.bias && n < a.N) ? a.bias[n] : 0.f;
+      const int mb = m0 + rbk * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int m = mb + KGmap(g);
+        if (m < a.M && n < a.N) {
+          float v = t[j][g];
+          if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
+          dst[(size_t)m * a.N + n] = v;
+        }
+      }
+    }
+    return;
+  }
 
   // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k-quad half h)
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
@@ -113,8 +200,6 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
     }
   };
 
-  const int full = a.K / BK;                                      // whole chunks in K
-  const int c1f = min(c1, full);                                  // this slice's whole chunks are [c0, c1f)
   if (c0 < c1f) {
     fetch(c0);
     commit(lds);
@@ -144,8 +229,6 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
 
   // ---- epilogue: register g of block (i, j) is out[m0 + wm*64 + i*32 + KG(g) + 4*fh][n0 + wn*64 + j*32 + fr]: for a fixed g the
   // half-wave writes one 128-byte row segment
-  const bool direct = a.slices == 1;
-  float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + fr;
@@ -177,21 +260,29 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
   }
 }
 
-struct Plan { int mt, nt, chunks, slices; };
+struct Plan { int mt, nt, chunks, slices, mt_full, full_per_xcd, tail_per_xcd; };
 
 Plan make_plan(int M, int N, int K) {
   Plan p;
   p.mt = (M + BM - 1) / BM; p.nt = (N + BN - 1) / BN; p.chunks = (K + BK - 1) / BK;
-  const double T = (double)p.mt * p.nt, slots = 512.0;            // 256 CUs x 2 resident workgroups
-  const double flop = 2.0 * p.mt * BM * p.nt * BN * (double)K;
+  const int rem_blocks = ((M - (p.mt - 1) * BM) + 31) / 32;       // 32-row blocks of the last row tile
+  p.mt_full = (rem_blocks <= 2) ? p.mt - 1 : p.mt;                // a last tile with 1-2 blocks runs the tail path (1/4, 1/2 tile time)
+  const double tail_cost = rem_blocks == 1 ? 0.45 : 0.6;          // measured: the staging of 128 W rows per chunk does not shrink
+  const double slots = 64.0;                                      // per XCD: 32 CUs x 2 resident workgroups
+  const double flop = 2.0 * BM * BN * (double)K;                  // one full tile over all of K
   double best = 1e30; int bs = 1;
   for (int s = 1; s <= 64 && s <= p.chunks / 4 + 1; ++s) {
-    const double rounds = ceil(T * s / slots), eff = T * s / (rounds * slots);
-    double t = flop / (1.25e14 * eff) + rounds * 4e-6;             // ~80 % of the fp32 MFMA peak in full rounds + per-round fill/drain
-    if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;         // partial write + read, reduce launch
+    const double longs = ceil((double)p.mt_full * p.nt * s / 8.0), shorts = ceil((double)(p.mt - p.mt_full) * p.nt * s / 8.0);
+    double rounds = ceil(longs / slots);                            // full-tile rounds; the short tail workgroups use what is left
+    const double spare = rounds * slots - longs;
+    if (shorts > spare) rounds += tail_cost * ceil((shorts - spare) / slots);
+    double t = rounds * flop / s / (1.25e14 / 512.0) + ceil(rounds) * 4e-6;   // a workgroup's time at ~80 % of the per-slot MFMA rate
+    if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;          // partial write + read, reduce launch
     if (t < best) { best = t; bs = s; }
   }
   p.slices = bs;
+  p.full_per_xcd = (p.mt_full * p.nt * bs + 7) / 8;
+  p.tail_per_xcd = ((p.mt - p.mt_full) * p.nt * bs + 7) / 8;
   return p;
 }
 
@@ -211,11 +302,12 @@ M3D_API int m3d_linear_forward(const float* d_x, const float* d_weight, const fl
   if (K % 4 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_weight & 15)) return M3D_EUNSUPPORTED;   // 16-byte row quads
   const Plan p = make_plan(M, N, K);
   if (p.slices > 1 && (!d_ws || ws_bytes < (size_t)p.slices * M * N * sizeof(float))) return M3D_EWORKSPACE;
-  FcArgs a{d_x, d_weight, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, p.slices, p.chunks, relu};
+  FcArgs a{d_x, d_weight, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, p.slices, p.chunks, relu, p.mt_full, p.full_per_xcd,
+           p.tail_per_xcd};
   const size_t lds = sizeof(float) * 2 * kStageFloats;
   hipStream_t st = m3d::as_stream(stream);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(fc_gemm_kernel, dim3(p.mt * p.nt * p.slices), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(fc_gemm_kernel, dim3(8 * (p.full_per_xcd + p.tail_per_xcd)), dim3(256), lds, st, a);
   if (p.slices > 1) {
     const long long MN = (long long)M * N;
     long long blocks = (MN + 255) / 256;

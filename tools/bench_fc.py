@@ -28,7 +28,7 @@ def main():
     for K in (87808, 43904, 1024):
         w = torch.randn(N, K, device="cuda") / K ** 0.5
         b = torch.randn(N, device="cuda")
-        for M in (64, 128, 320, 640, 1000, 1280, 2560):
+        for M in (64, 128, 320, 640, 1000, 1280, 1281, 1313, 2560):
             x = torch.randn(M, K, device="cuda")
             t_own = timeit(lambda: m3d.linear(x, w, b, relu=True))
             t_lib = timeit(lambda: torch.relu(torch.nn.functional.linear(x, w, b)))

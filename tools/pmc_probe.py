@@ -20,11 +20,14 @@ for _ in range(2):
     y.copy_(x)                                   # 16 B/lane reads + writes
 torch.cuda.synchronize()
 del x, y
-cfg = Cfg.nuclei()
-P = make_params(stride=8, num_anchors=35, seed=0)
+from m3d.synth import synth_volume
+cfg = Cfg.nuclei(in_size=(128, 128, 128))
+P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0)
 det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
-vol = torch.randn(1, 1, 128, 128, 128, device="cuda")
+# the bench's step: a batch of 4 synthetic 128^3 volumes through the whole detection pipeline (bench.py --workload detect)
+x = torch.stack([m3d.norm1(torch.from_numpy(synth_volume(i, (128, 128, 128))).cuda()) for i in range(4)])[:, None].contiguous()
 for _ in range(3):
-    det.conv_body(vol)
+    r = det.detect_batch(x, as_dicts=False)
+    m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=300, want_keep=False)
 torch.cuda.synchronize()
-print("pmc_probe done; calibration bytes", N_CAL * 4)
+print("pmc_probe done; calibration bytes", N_CAL * 4, "rois", r["num_rois"])

@@ -23,7 +23,7 @@ def main():
         ks = [k for k in d if frag in k[0]]
         return max(ks, key=lambda k: sum(d[k]) / len(d[k])) if ks else None
     k_min = find(fetch, "min_partial_kernel")
-    others = [k for k in fetch if "min_partial" not in k[0] and "conv3d" not in k[0]]
+    others = [k for k in fetch if "copyBuffer" in k[0] or "direct_copy" in k[0]]
     k_cpy = max(others, key=lambda k: sum(fetch[k]) / len(fetch[k])) if others else None      # the 1.25 GiB torch copy
     f_dword = cal_bytes / (sum(fetch[k_min]) / len(fetch[k_min]))
     f_vec = cal_bytes / (sum(fetch[k_cpy]) / len(fetch[k_cpy])) if k_cpy else None
@@ -32,11 +32,11 @@ def main():
            "fetch_factor_16B_loads": f_vec, "write_size_over_known": w_chk,
            "kernels": {"dword": k_min[0][:80], "vec": k_cpy[0][:80] if k_cpy else None}}, "kernels": []}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k]) / len(fetch[k])):
-        if "conv3d" not in k[0] or "pack" in k[0]:
+        if not any(t in k[0] for t in ("conv3d", "fc_gemm", "fc_reduce", "roi_align3d", "proposals_stage", "nms_mask_tiles", "norm1")) or "pack" in k[0]:
             continue
         fr = sum(fetch[k]) / len(fetch[k])
         wr = sum(write[k]) / len(write[k]) if k in write else None
-        res["kernels"].append({"kernel": k[0].split("(float")[0].replace("void (anonymous namespace)::", ""), "grid": k[1],
+        res["kernels"].append({"kernel": k[0].split("(float")[0].split("((anonymous")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), "grid": k[1],
                                "launches": len(fetch[k]), "fetch_raw": fr, "fetch_corrected": fr * f_dword, "write": wr,
                                "traffic": fr * f_dword + (wr or 0)})
     json.dump(res, open(out, "w"), indent=1)
