@@ -280,6 +280,7 @@ Plan make_plan(int M, int N, int K) {
     if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;          // partial write + read, reduce launch
     if (t < best) { best = t; bs = s; }
   }
+  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) bs = ts < p.chunks ? ts : p.chunks;   // A/B tooling only
   p.slices = bs;
   p.full_per_xcd = (p.mt_full * p.nt * bs + 7) / 8;
   p.tail_per_xcd = ((p.mt - p.mt_full) * p.nt * bs + 7) / 8;
