@@ -32,3 +32,15 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+def cfg0_params(mlp_dim=1024, seed=0):
+    """Weights of the configs[0] fixture (tests/golden/gen_cfg0.py): the bench weights with the RPN class scores de-saturated.
+    The synthetic kaiming x2 cls weights push thousands of sigmoid outputs to the same float (0.9999999, 1.0), and NumPy's
+    unstable argsort()[::-1] leaves the order of equal scores unspecified (SURVEY 8c caveat i): a bit-exact fixture needs
+    distinct scores near the top."""
+    from m3d.synth import make_params
+    P = make_params(stride=8, num_anchors=35, mlp_dim=mlp_dim, seed=seed)
+    P["RPN.RPN_cls_score.weight"] = P["RPN.RPN_cls_score.weight"] * 0.02
+    P["RPN.RPN_cls_score.bias"] = P["RPN.RPN_cls_score.bias"] - 1.0
+    return P

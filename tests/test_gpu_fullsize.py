@@ -238,3 +238,37 @@ def test_detect_batch_equals_per_tile_detection():
         assert (got["rois"][:, 0] == b).all()                                   # batch index column (generate_proposals_3d.py:98-100)
         assert torch.allclose(got["cls"], one["cls"], atol=1e-4) and torch.allclose(got["pred_boxes"], one["pred_boxes"], atol=2e-2)
         assert got["det_scores"].shape == one["det_scores"].shape and torch.allclose(got["det_boxes"], one["det_boxes"], atol=2e-2)
+
+
+def test_config0_64_cubed_equals_the_reference_run(golden):
+    """BASELINE.json configs[0]: the reference's own CPU run on one 1x64^3 volume (tests/golden/cfg0_64.npz, gen_cfg0.py) against
+    the HIP path: detection mode (scores, decoded boxes, kept detections) and the full PRM tuple (peaks, dets, every map)."""
+    from m3d.config import Cfg
+    from m3d.synth import make_params, synth_volume
+    from m3d.drivers import Generalized_RCNN, PeakResponseMapping_3d, im_detect_bbox, box_results_with_nms_and_limit
+    from m3d import tiling
+    g = golden("cfg0_64")
+    n = int(g["size"])
+    cfg = Cfg.nuclei(in_size=(n, n, n))
+    from conftest import cfg0_params
+    P = cfg0_params(1024, int(g["seed_params"]))
+    vol = tiling.norm1(synth_volume(int(g["seed_volume"]), (n, n, n)), np.float32).astype(np.float32)
+    model = Generalized_RCNN(P, cfg)
+    cube = {"data": vol[None, None].copy(), "im_info": np.array([[n, n, n, 1.0]])}
+    scores, boxes, _, blob = im_detect_bbox(model, cube, 1.0)
+    feat = blob.cpu().numpy()
+    assert np.allclose(feat.sum(1)[0], g["feat_sum_c"], rtol=1e-4, atol=1e-4 * float(g["feat_absmax"]))
+    assert np.allclose(feat.ravel()[::997], g["feat_sample"], rtol=1e-4, atol=1e-4 * float(g["feat_absmax"]))
+    assert scores.shape == g["d_scores"].shape and np.allclose(scores, g["d_scores"], atol=1e-4)
+    assert np.allclose(boxes, g["d_pred_boxes"], rtol=1e-4, atol=2e-2)
+    _, _, cls_boxes, _ = box_results_with_nms_and_limit(model, scores, boxes)
+    assert cls_boxes[1].shape == g["d_cls1"].shape and np.allclose(cls_boxes[1], g["d_cls1"], rtol=1e-4, atol=2e-2)
+    pm = PeakResponseMapping_3d(P, cfg).inference()
+    _, crm, peaks, prms, dets = pm(data=[torch.from_numpy(cube["data"])], im_info=[torch.from_numpy(cube["im_info"])], im_scale=[1.0])
+    assert np.allclose(crm.cpu().numpy(), g["crm"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(peaks.cpu().numpy(), g["p_peaks"]) and np.allclose(dets.cpu().numpy(), g["p_dets"], rtol=1e-4, atol=2e-2)
+    pr = prms.cpu().numpy()
+    assert np.allclose(pr.sum((1, 2, 3)), g["p_prm_sum"], atol=1e-4)
+    assert (pr.reshape(len(pr), -1).argmax(1) == g["p_prm_argmax"]).mean() >= 0.9          # ties between neighbouring voxels may flip
+    for ax, key in (((2, 3), "p_prm_z"), ((1, 3), "p_prm_y"), ((1, 2), "p_prm_x")):
+        assert np.allclose(pr.sum(ax), g[key], rtol=3e-3, atol=3e-6)

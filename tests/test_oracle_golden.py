@@ -151,3 +151,35 @@ def _raw_grad(O, P, saved, peak, shape):
             gx = torch.nn.grad.conv3d_input(rec["xo"].shape, F.relu(P[rec["name"] + ".weight"]), gn, 1, rec["pad"])
             g = rec["xo"] * gx
     return g
+
+
+def test_config0_64_cubed_reference_run(golden):
+    """BASELINE.json configs[0] (tests/golden/gen_cfg0.py: the reference's own code on one 1x64^3 volume, nuclei YAML, MLP 1024):
+    the oracle reproduces its detection-mode outputs and the first peak response maps."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "instanceseg-without-voxelwise-labeling_amd"))
+    from m3d.synth import make_params, synth_volume
+    import torch
+    g = golden("cfg0_64")
+    n = int(g["size"])
+    from conftest import cfg0_params
+    P = cfg0_params(1024, int(g["seed_params"]))
+    vol = torch.from_numpy(O.norm1(synth_volume(int(g["seed_volume"]), (n, n, n)), np.float32).astype(np.float32)).view(1, 1, n, n, n)
+    cfg = O.Cfg()
+    r = O.detect_tile(P, cfg, vol)
+    feat = r["feat"].numpy()
+    assert np.allclose(feat.sum(1)[0], g["feat_sum_c"], rtol=1e-4, atol=1e-4 * float(g["feat_absmax"]))
+    assert np.allclose(feat.ravel()[::997], g["feat_sample"], rtol=1e-4, atol=1e-5 * float(g["feat_absmax"]))
+    assert r["cls"].shape == g["d_scores"].shape and np.allclose(r["cls"], g["d_scores"], atol=1e-5)
+    assert np.allclose(r["pred_boxes"], g["d_pred_boxes"], rtol=1e-5, atol=1e-3)
+    assert r["cls_boxes"][1].shape == g["d_cls1"].shape and np.allclose(r["cls_boxes"][1], g["d_cls1"], rtol=1e-5, atol=1e-3)
+    # PRM mode: class response map, kept peaks / detections, and three of the 38 peak response maps (the oracle needs ~2 s per map)
+    cfgp = O.Cfg(score_thresh=0.05)
+    f2, prob, d2, saved = O.prm_forward(P, cfgp, vol)
+    assert np.allclose(prob.numpy(), g["crm"], rtol=1e-5, atol=1e-6)
+    for i in (0, len(g["p_peaks"]) // 2, len(g["p_peaks"]) - 1):
+        prm = O.prm_backward(P, saved, g["p_peaks"][i], prob.shape)[0].numpy()
+        assert abs(prm.sum() - g["p_prm_sum"][i]) < 1e-4 and int(prm.argmax()) == int(g["p_prm_argmax"][i])
+        for ax, key in (((1, 2), "p_prm_z"), ((0, 2), "p_prm_y"), ((0, 1), "p_prm_x")):
+            assert np.allclose(prm.sum(ax), g[key][i], rtol=2e-3, atol=2e-6)
