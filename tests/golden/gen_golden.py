@@ -5,7 +5,7 @@ Run in the build container only (needs /root/reference and oracle/_ref built by 
     python tests/golden/gen_golden.py
 The fixtures are data (inputs + the reference's outputs); no reference source is stored.  Weights are
 not stored: they are re-created from a seed by oracle.make_params (same torch build on the GPU box).
-Fixture list follows SURVEY.md 8c (1)-(11).
+Fixture list follows SURVEY.md 8c (1)-(10); (11) tiling: gen_tiling.py; configs[0] 64^3 run: gen_cfg0.py.
 """
 import os
 import sys
@@ -209,24 +209,8 @@ def main():
         oz["kb%d" % i] = np.array([k, bm], np.int64)
     save("otsu", **oz)
 
-    # (11) tiling index lists as the reference expressions evaluate (infer_simple.py:188-212)
-    tl = {}
-    for i, (shape, patch, ov) in enumerate([((59, 350, 350), (64, 200, 200), 100), ((64, 200, 200), (64, 200, 200), 100),
-                                            ((100, 256, 256), (64, 200, 200), 100), ((100, 256, 256), (64, 160, 160), 32)]):
-        slices, height, width = shape
-        if slices < patch[0]:
-            pad_s = np.int64((patch[0] - slices) / 2)
-            slices = patch[0]
-        else:
-            pad_s = 0
-        sidx = list(range(0, slices - patch[0], patch[0] - ov)) + [slices - patch[0]]
-        hidx = list(range(0, height - patch[1], patch[1] - ov)) + [height - patch[1]]
-        widx = list(range(0, width - patch[2], patch[2] - ov)) + [width - patch[2]]
-        tl["shape%d" % i] = np.array(shape); tl["patch%d" % i] = np.array(patch); tl["ov%d" % i] = np.int64(ov)
-        tl["pad%d" % i] = np.int64(pad_s)
-        tl["s%d" % i], tl["h%d" % i], tl["w%d" % i] = np.array(sidx), np.array(hidx), np.array(widx)
-    tl["n"] = np.int64(4)
-    save("tiling", **tl)
+    # (11) tiling index lists: tests/golden/gen_tiling.py (executes the reference's own statements, infer_simple.py:180-212 and
+    # core/test.py:76-90, from where they lie)
 
 
 if __name__ == "__main__":

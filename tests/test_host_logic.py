@@ -8,16 +8,22 @@ import torch
 
 
 def test_tiling_matches_reference_lists(golden):
+    """Product host logic (m3d.tiling) against the reference's own tiling statements exec'd on synthetic volumes
+    (tests/golden/gen_tiling.py): padding, tile starts of both drivers and both dataset rules, tile ids, norm1 + padding values."""
     from m3d import tiling
     g = golden("tiling")
     for i in range(int(g["n"])):
-        shape, patch, ov = g["shape%d" % i], g["patch%d" % i], int(g["ov%d" % i])
+        shape, patch, ov, ds = g["shape%d" % i], tuple(int(v) for v in g["patch%d" % i]), int(g["ov%d" % i]), str(g["ds%d" % i])
         im, pad_s = tiling.pad_slices(np.zeros(shape, np.float32), patch[0])
-        assert pad_s == int(g["pad%d" % i])
-        s, h, w = tiling.tile_grid(im.shape, patch, ov)
-        assert (s, h, w) == (list(g["s%d" % i]), list(g["h%d" % i]), list(g["w%d" % i]))
-    nums = [t[0] for t in tiling.enumerate_tiles([0], [0, 100, 150], [0, 100, 150])]
-    assert nums == list(range(9))
+        assert pad_s == int(g["pad%d" % i]) and tuple(im.shape) == tuple(g["pshape%d" % i]) == tuple(g["d_pshape%d" % i])
+        s, h, w = tiling.tile_grid(im.shape, patch, ov, ds)                                  # infer_simple.py:196-204
+        assert (list(s), list(h), list(w)) == (list(g["s%d" % i]), list(g["h%d" % i]), list(g["w%d" % i]))
+        assert [list(t) for t in tiling.enumerate_tiles(s, h, w)] == g["nums%d" % i].tolist()   # :209-212
+        ds_, dh, dw = tiling.tile_grid(im.shape, patch, ov)                                  # core/test.py:87-90 (always the nuclei rule)
+        assert (list(ds_), list(dh), list(dw)) == (list(g["d_s%d" % i]), list(g["d_h%d" % i]), list(g["d_w%d" % i]))
+        if g["seed_im%d" % i].size:
+            vol, _ = tiling.pad_slices(tiling.norm1(g["seed_im%d" % i], np.float64), patch[0])   # :180-195
+            assert np.array_equal(vol, g["pim%d" % i])
     assert tiling.tile_grid((96, 256, 256), (64, 160, 160), 0, "soma") == ([0, 32, 64], [0, 96], [0, 96])
 
 

@@ -84,15 +84,21 @@ def test_otsu(golden):
 
 
 def test_tiling(golden):
+    """tests/golden/tiling.npz = the reference's own statements exec'd (gen_tiling.py: infer_simple.py:180-212, core/test.py:76-90)."""
     g = golden("tiling")
     for i in range(int(g["n"])):
-        shape, patch, ov = g["shape%d" % i], g["patch%d" % i], int(g["ov%d" % i])
+        shape, patch, ov, ds = g["shape%d" % i], g["patch%d" % i], int(g["ov%d" % i]), str(g["ds%d" % i])
         im = np.zeros(shape, np.float32)
         im, pad_s = O.pad_slices(im, patch[0])
-        assert pad_s == int(g["pad%d" % i])
-        assert O.tile_starts(im.shape[0], patch[0], ov) == list(g["s%d" % i])
-        assert O.tile_starts(im.shape[1], patch[1], ov) == list(g["h%d" % i])
-        assert O.tile_starts(im.shape[2], patch[2], ov) == list(g["w%d" % i])
+        assert pad_s == int(g["pad%d" % i]) == int(g["d_pad%d" % i]) and tuple(im.shape) == tuple(g["pshape%d" % i])
+        if ds == "nuclei":
+            assert O.tile_starts(im.shape[0], patch[0], ov) == list(g["s%d" % i]) == list(g["d_s%d" % i])
+            assert O.tile_starts(im.shape[1], patch[1], ov) == list(g["h%d" % i]) == list(g["d_h%d" % i])
+            assert O.tile_starts(im.shape[2], patch[2], ov) == list(g["w%d" % i]) == list(g["d_w%d" % i])
+        if g["seed_im%d" % i].size:                       # small case: the padded, normalised volume itself
+            raw = g["seed_im%d" % i]
+            vol, _ = O.pad_slices(O.norm1(raw, np.float64), patch[0])
+            assert np.array_equal(vol, g["pim%d" % i])
 
 
 @pytest.mark.parametrize("tag", ["n", "s"])
