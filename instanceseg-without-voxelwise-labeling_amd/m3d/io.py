@@ -30,8 +30,42 @@ def _lib():
         for f in (lib.m3d_tiff_lzw_encode, lib.m3d_tiff_lzw_decode):
             f.restype = C.c_size_t
             f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.m3d_rle3d_encode.restype = C.c_size_t
+        lib.m3d_rle3d_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.m3d_rle3d_decode.restype = C.c_int
+        lib.m3d_rle3d_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _io = lib
     return _io
+
+
+# ---------------------------------------------------------------------------- 3D run-length masks
+def binary_mask_to_rle(binary_mask):
+    """lib/utils/cython_mask_3d.pyx:19-52 (= lib/utils/mask_3d.py:15-47): uint8 [S,H,W] -> {'counts': [...], 'size': [S,H,W]};
+    the container of instance masks in lib/core/test.py:164-173.  Like the Cython original, only uint8 3-D arrays are accepted."""
+    m = np.asarray(binary_mask)
+    if m.ndim != 3:
+        raise ValueError("Buffer has wrong number of dimensions (expected 3, got %d)" % m.ndim)
+    if m.dtype != np.uint8:
+        raise ValueError("Buffer dtype mismatch, expected 'DTYPE_t' but got '%s'" % m.dtype)
+    m = np.ascontiguousarray(m)
+    S, H, W = m.shape
+    cap = 1024
+    while True:
+        counts = np.empty((cap,), np.int64)
+        n = _lib().m3d_rle3d_encode(m.ctypes.data, S, H, W, counts.ctypes.data, cap)
+        if n <= cap:
+            return {"counts": [int(v) for v in counts[:n]], "size": [S, H, W]}
+        cap = int(n)
+
+
+def rle_to_binary_mask(rle):
+    """lib/utils/cython_mask_3d.pyx:54-84: {'counts', 'size'} -> uint8 [S,H,W] of 0/1."""
+    counts = np.ascontiguousarray(rle["counts"], dtype=np.int64)
+    S, H, W = (int(v) for v in rle["size"])
+    out = np.zeros((S, H, W), np.uint8)
+    if _lib().m3d_rle3d_decode(counts.ctypes.data, counts.size, S, H, W, out.ctypes.data) != 0:
+        raise AssertionError("sum(counts) != prod(size)")           # cython_mask_3d.pyx:63
+    return out
 
 
 def lzw_encode(raw):
