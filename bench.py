@@ -246,11 +246,18 @@ def bench_detect(args, rank, world, dist):
         with det.span("cross_tile_nms_pack"):                                           # core/test.py:159 (one tile per volume) + pack
             return m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
 
+    # `--backend gloo` (rehearsal of the N > 1 code path on a one-GPU box: ranks share the card, the exchange goes through host
+    # memory) moves the packed block to the CPU for the collective; nccl (RCCL over xGMI) gathers device to device.
+    via_host = dist is not None and args.backend == "gloo"
+
+    def exchange(packed):
+        return shard.all_gather_packed(packed.cpu() if via_host else packed, n_items, dist)            # THE exchange
+
     def step_resident():
         packed = batch(raw_dev)
         if backbone_only:
             return packed
-        last["packed"] = shard.all_gather_packed(packed, n_items, dist)                 # THE exchange
+        last["packed"] = exchange(packed)
         return last["packed"]
 
     # ---- (1) value: raw volumes resident in HBM
@@ -258,7 +265,7 @@ def bench_detect(args, rank, world, dist):
         step_resident()
     det.probe = Probe()
     dt = timed_loop(step_resident, args.steps, 0, dist, torch.cuda.synchronize)
-    dt = sync_max_time(dt, dist, "cuda")
+    dt = sync_max_time(dt, dist, "cpu" if via_host else "cuda")
     torch.cuda.synchronize()
     kern_ms = det.probe.mean_ms()
     det.probe = None
@@ -290,13 +297,13 @@ def bench_detect(args, rank, world, dist):
             torch.cuda.current_stream().wait_event(ready[b])
             packed = batch(bufs[b])
             freed[b].record()
-            g = shard.all_gather_packed(packed, n_items, dist)
+            g = exchange(packed)
             if rank == 0:
                 host_out.copy_(g, non_blocking=True)
                 torch.cuda.current_stream().synchronize()        # detections are on the host when the step ends
             return g
         dt2 = timed_loop(step_host, args.steps, max(1, args.warmup // 2), dist, torch.cuda.synchronize)
-        dt2 = sync_max_time(dt2, dist, "cuda")
+        dt2 = sync_max_time(dt2, dist, "cpu" if via_host else "cuda")
         e2e = {"value": n_items * args.steps * VOL ** 3 / dt2, "unit": "voxels/s", "ms_per_step": dt2 / args.steps * 1e3,
                "includes": "H2D of the raw uint16 volumes (pinned, copy stream, double-buffered) + D2H of the gathered [%d,%d,7] detections"
                            % (n_items, cap + 1)}
@@ -354,7 +361,7 @@ def bench_detect(args, rank, world, dist):
                                    "detection-mode infer_simple: raw u16 volume -> norm1 -> dsn_body -> RPN -> proposals -> RoIAlign3D -> 2-MLP head "
                                    "-> decode -> NMS -> cross-tile NMS, batch of %d x (1x128^3) per rank, one all_gather of detections per step [%s]"
                                    % (nvol, "configs[2]" if world == 1 else "configs[4] shape: %d volumes over %d GPUs" % (n_items, world))),
-                      "volumes_per_step": n_items, "volumes_per_rank": nvol, "net": "nuclei stride-8 dsn_body, 35 anchors, MLP 1024",
+                      "volumes_per_step": n_items, "volumes_per_rank": nvol, "backend": (args.backend if world > 1 else None), "net": "nuclei stride-8 dsn_body, 35 anchors, MLP 1024",
                       "inputs": "raw uint16 volumes resident in HBM at the start of the timed region",
                       "rois_per_volume": (float(np.mean(last["num_rois"])) if "num_rois" in last else None),
                       "dets_per_volume": (float(last["packed"][:, :, cap, 0].mean().item()) if "packed" in last else None),
@@ -423,7 +430,7 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback); --dry rehearses the launcher on CPU")
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())   # more ranks than GPUs only in the gloo rehearsal below
         if world > 1:
             import torch.distributed as dist
             if args.backend == "nccl":
