@@ -126,6 +126,11 @@ int m3d_conv3d_pack_weights(const float* d_weight /*[cout,cin,k,k,k]*/, int cin,
 int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
+/* 3x3x3 "same" convolution with dilation 2 / padding 2 (dilation 1 = m3d_conv3d_forward): the convolutions of the mask head
+ * (lib/modeling/mask_rcnn_heads.py:148-151 with MRCNN.DILATION = 2, lib/core/config.py:767).  d_packed: m3d_conv3d_pack_weights. */
+int m3d_conv3d_forward_dilated(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                               int height, int width, int k, int dilation, const float* d_scale, const float* d_shift, int relu,
+                               void* stream);
 
 /* 3x3x3 forward convolution with the Winograd F(2,3) transform along x (csrc/conv3d_wino.hip): the same operation as
  * m3d_conv3d_forward for k = 3, plain weights, no input offset / PRM multiply, at 2/3 of the MFMA work.  Results

@@ -203,11 +203,11 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
   return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1, int DIL = 1>
 struct Cfg {
   static constexpr int NT = 256 * KS;                    // threads per workgroup (KS = in-workgroup split of K)
   static constexpr int PP = CC / 2 / KS;                  // channel pairs per chunk handled by one K-split group
-  static constexpr int P = K / 2;
+  static constexpr int P = (K / 2) * DIL;                 // halo = padding = dilation * (K / 2) ("same" convolution)
   static constexpr int K3 = K * K * K;
   static constexpr int YB = 32 / XB;
   // rows of a wave: r -> (zz = r / RY, yy = r % RY).  POOL: 2 z-levels x 2 y-rows = one pooling footprint.
@@ -228,11 +228,11 @@ struct Cfg {
   static_assert(KS == 1 || 4 * NCB * ROWS * 16 * 64 <= 2 * LDS_FLOATS, "split-K reduction buffer fits the staging area");
 };
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL, int KS>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL, int KS, int DIL = 1>
 __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                           float* __restrict__ out, int cin, int cout, int D, int H, int W,
                                                           int tiles_x, int tiles_y, int tiles_z, int ncb_total, Epilogue ep) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS, DIL>;
   extern __shared__ float lds[];
   float* lds_in = lds;
   float* lds_w = lds + C::IN_ELEMS;
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256 * KS, 2) void conv3d_mfma_kernel(const float* _
         const int dz = tap / (K * K), dy = (tap / K) % K, dx = tap % K;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
-          b[r] = in_k[(r / C::RY) * (C::HY * C::HX) + (r % C::RY) * C::YB * C::HX + pp * 2 * C::CS + dz * (C::HY * C::HX) +
-                      dy * C::HX + dx];
+          b[r] = in_k[(r / C::RY) * (C::HY * C::HX) + (r % C::RY) * C::YB * C::HX + pp * 2 * C::CS + DIL * (dz * (C::HY * C::HX) +
+                      dy * C::HX + dx)];
 #pragma unroll
         for (int c = 0; c < NCB; ++c) a[c] = w_k[pp * C::W_SEG + (c * C::K3 + tap) * 64];
       };
@@ -551,10 +551,10 @@ inline int xcd_map_enabled() {   // M3D_XCD_MAP=0 restores the plain round-robin
   return m3d::opt(m3d::OPT_XCD_MAP) != 0;
 }
 
-template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1>
+template <int K, int CC, int XB, int ROWS, int NCB, int WZ, int WY, bool POOL = false, int KS = 1, int DIL = 1>
 int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, Epilogue ep,
                hipStream_t st) {
-  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
+  using C = Cfg<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS, DIL>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
   const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;   // as packed (padded to 2 blocks)
   const int co_tiles = ((cout + 31) / 32 + NCB - 1) / NCB;
@@ -562,7 +562,8 @@ int launch_cfg(const float* in, const float* wp, float* out, int B, int cin, int
   if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
   ep.xcd_map = xcd_map_enabled();
   const size_t lds = sizeof(float) * 2 * C::LDS_FLOATS;   // double-buffered
-  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS>;
+  auto kern = conv3d_mfma_kernel<K, CC, XB, ROWS, NCB, WZ, WY, POOL, KS, DIL>;
+  if (lds > 160 * 1024) return M3D_EUNSUPPORTED;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
@@ -715,6 +716,23 @@ M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* 
                                const float* d_shift, int relu, const float* d_mul, void* stream) {
   Epilogue ep{d_scale, d_shift, d_mul, d_in_offset, relu, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
   return conv_dispatch(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
+}
+
+/* 3x3x3 "same" convolution with dilation 2 (padding 2): the convs of the mask head, lib/modeling/mask_rcnn_heads.py:148-151 with
+ * MRCNN.DILATION = 2 (lib/core/config.py:767).  Same packed weights as m3d_conv3d_forward; small maps (the 7^3 / 14^3 RoI grids). */
+M3D_API int m3d_conv3d_forward_dilated(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
+                                       int height, int width, int k, int dilation, const float* d_scale, const float* d_shift, int relu,
+                                       void* stream) {
+  if (dilation == 1)
+    return m3d_conv3d_forward(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, k, nullptr, d_scale, d_shift, relu, nullptr,
+                              stream);
+  if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (k != 3 || dilation != 2) return M3D_EUNSUPPORTED;
+  if ((size_t)min(cin, 4) * depth * height * width >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
+  Epilogue ep{d_scale, d_shift, nullptr, nullptr, relu, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+  // 8 x 8 x 4 voxel tile, 64 output channels per workgroup: the RoI grids are 7 or 14 voxels wide
+  return launch_cfg<3, 4, 8, 2, 2, 4, 1, false, 1, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep,
+                                                        m3d::as_stream(stream));
 }
 
 M3D_API int m3d_conv3d_forward_windowed(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,

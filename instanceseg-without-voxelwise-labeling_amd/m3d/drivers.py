@@ -19,6 +19,7 @@ import torch
 from . import ops, tiling
 from .model import DetectorM3D
 from .prm import PRMEngine
+from .mask_head import MaskHeadM3D, im_detect_mask as _im_detect_mask
 
 
 def _first(x):
@@ -53,8 +54,17 @@ class Generalized_RCNN(object):
     def __init__(self, state_dict, cfg, device="cuda"):
         self.cfg = cfg
         self.device = torch.device(device)
-        self.det = DetectorM3D(_to_params(state_dict, self.device), cfg)
+        params = _to_params(state_dict, self.device)
+        self.det = DetectorM3D(params, cfg)
         self.training = False
+        # MODEL.MASK_ON checkpoints carry a mask branch (model_builder.py:111-116); both shipped configs have it off
+        self.mask_head = MaskHeadM3D(params, cfg) if "Mask_Head.upconv.weight" in params else None
+
+    def mask_net(self, blob_conv, rpn_blob):
+        """model_builder.py:327-331."""
+        if self.mask_head is None:
+            raise AttributeError("this checkpoint has no Mask_Head / Mask_Outs weights (MODEL.MASK_ON False)")
+        return self.mask_head.mask_net(blob_conv, rpn_blob)
 
     # nn.Module look-alikes the reference drivers call on the model
     def eval(self):
@@ -93,6 +103,14 @@ class Generalized_RCNN(object):
                 "cls_score": out["cls"] if "cls" in out else torch.zeros((R, nc), device=dev),          # :233
                 "bbox_pred": out["bbox"] if "bbox" in out else torch.zeros((R, 6 * nc), device=dev),    # :234
                 "_m3d": out}
+
+
+def im_detect_mask(model, im_scale, boxes, blob_conv):
+    """lib/core/test.py:439-476 with the reference's signature (model = Generalized_RCNN, possibly behind .module)."""
+    net = model.module if hasattr(model, "module") else model
+    if net.mask_head is None:
+        raise AttributeError("this checkpoint has no Mask_Head / Mask_Outs weights (MODEL.MASK_ON False)")
+    return _im_detect_mask(net.mask_head, im_scale, boxes, blob_conv)
 
 
 class PeakResponseMapping_3d(Generalized_RCNN):

@@ -269,7 +269,7 @@ class PackedConv3d:
               "conv3d_forward_pool2")
         return (out, am) if return_argmax else out
 
-    def __call__(self, x, scale=None, shift=None, relu=False, in_offset=None, mul=None, out=None):
+    def __call__(self, x, scale=None, shift=None, relu=False, in_offset=None, mul=None, out=None, dilation=1):
         _need_gpu(x)
         x = _f32c(x)
         B, Cin, D, H, W = x.shape
@@ -280,6 +280,12 @@ class PackedConv3d:
         for t in (scale, shift):
             if t is not None:
                 assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.cout and t.is_contiguous()
+        if dilation != 1:                                     # mask head (mask_rcnn_heads.py:148-151): padding = dilation
+            assert in_offset is None and mul is None
+            check(lib().m3d_conv3d_forward_dilated(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, self.k,
+                                                   int(dilation), _ptr(scale), _ptr(shift), int(bool(relu)), _stream()),
+                  "conv3d_forward_dilated")
+            return out
         if mul is not None:
             assert mul.shape == out.shape and mul.is_contiguous() and mul.dtype == torch.float32
         check(lib().m3d_conv3d_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, self.k,

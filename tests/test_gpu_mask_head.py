@@ -1,0 +1,108 @@
+"""GPU: mask branch (dilated convs, ConvTranspose3d as 1x1x1 conv + voxel shuffle, classifier) against torch fp64 on the CPU.
+Reference: lib/modeling/mask_rcnn_heads.py:132-193,20-68; lib/core/test.py:439-476.  Tolerance: fp32 MFMA accumulation vs fp64,
+rtol 1e-4 of the layer's largest magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask_params(cin, dim, nc, convs, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    c = cin
+    for i in range(convs):
+        P["Mask_Head.conv_fcn.%d.weight" % (2 * i)] = torch.randn((dim, c, 3, 3, 3), generator=g) * (2.0 / (27 * c)) ** 0.5
+        P["Mask_Head.conv_fcn.%d.bias" % (2 * i)] = torch.randn((dim,), generator=g) * 0.1
+        c = dim
+    P["Mask_Head.upconv.weight"] = torch.randn((dim, dim, 2, 2, 2), generator=g) * (2.0 / dim) ** 0.5
+    P["Mask_Head.upconv.bias"] = torch.randn((dim,), generator=g) * 0.1
+    P["Mask_Outs.classify.weight"] = torch.randn((nc, dim, 1, 1, 1), generator=g) * (1.0 / dim) ** 0.5
+    P["Mask_Outs.classify.bias"] = torch.randn((nc,), generator=g) * 0.1
+    return P
+
+
+def _ref_from_pooled(P, x, convs, dil):
+    x = x.double()
+    for i in range(convs):
+        x = F.relu(F.conv3d(x, P["Mask_Head.conv_fcn.%d.weight" % (2 * i)].double(), P["Mask_Head.conv_fcn.%d.bias" % (2 * i)].double(),
+                            padding=dil, dilation=dil))
+    x = F.relu(F.conv_transpose3d(x, P["Mask_Head.upconv.weight"].double(), P["Mask_Head.upconv.bias"].double(), stride=2))
+    y = F.conv3d(x, P["Mask_Outs.classify.weight"].double(), P["Mask_Outs.classify.bias"].double())
+    return x, torch.sigmoid(y)
+
+
+@pytest.mark.parametrize("dil,res,convs", [(2, 7, 4), (2, 14, 2), (1, 7, 3), (2, 5, 1)])
+def test_dilated_conv_stack_and_upconv(dil, res, convs):
+    import m3d
+    from m3d.mask_head import MaskHeadM3D
+    cin, dim, nc, R = 48, 40, 2, 5
+    P = _mask_params(cin, dim, nc, convs, seed=res * 10 + dil)
+    head = MaskHeadM3D({k: v.cuda() for k, v in P.items()}, O.Cfg(mlp_dim=64), roi_res=res, dilation=dil, resolution=2 * res)
+    feat = torch.randn((1, cin, 8, 9, 10), generator=torch.Generator().manual_seed(3))
+    rois = torch.tensor([[0, 3, 2, 1, 60, 50, 40], [0, 0, 0, 0, 79, 71, 63], [0, 10, 10, 10, 14, 13, 12],
+                         [0, 30.5, 20.25, 8, 70, 69, 50], [0, 5, 40, 30, 25, 60, 62]], dtype=torch.float32)
+    pooled = m3d.roi_align3d_forward(feat.cuda(), rois.cuda(), res, res, res, 1.0 / 8, 0)
+    up_ref, prob_ref = _ref_from_pooled(P, pooled.cpu(), convs, dil)
+    up = head.head(feat.cuda(), rois.cuda())
+    prob = head.outputs(up)
+    assert tuple(up.shape) == (R, dim, 2 * res, 2 * res, 2 * res) and tuple(prob.shape) == (R, nc, 2 * res, 2 * res, 2 * res)
+    assert np.allclose(up.cpu().numpy(), up_ref.numpy(), rtol=1e-4, atol=1e-4 * float(up_ref.abs().max()))
+    assert np.allclose(prob.cpu().numpy(), prob_ref.numpy(), rtol=1e-4, atol=1e-5)
+    out = head.mask_net(feat.cuda(), {"mask_rois": rois.numpy()})
+    assert torch.equal(out, prob)
+
+
+def test_dilated_conv_rejects_what_it_does_not_implement():
+    import m3d
+    from m3d._lib import M3DError
+    w = torch.randn((8, 8, 3, 3, 3)).cuda()
+    conv = m3d.PackedConv3d(w)
+    x = torch.randn((1, 8, 7, 7, 7)).cuda()
+    with pytest.raises(M3DError):
+        conv(x, dilation=3)
+    y = conv(x, dilation=1)
+    assert torch.equal(y, conv(x))
+
+
+def test_im_detect_mask_shapes_and_empty():
+    from m3d.mask_head import MaskHeadM3D, im_detect_mask
+    cfg = O.Cfg(mlp_dim=64)
+    P = _mask_params(32, 16, cfg.num_classes, 2, seed=1)
+    head = MaskHeadM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    feat = torch.randn((1, 32, 8, 8, 8)).cuda()
+    empty = im_detect_mask(head, [1.0], np.zeros((0, 6), np.float32), feat)
+    assert empty.shape == (0, 14, 14, 14) and empty.dtype == np.float32            # core/test.py:457-459
+    boxes = np.array([[2, 3, 4, 40, 41, 42], [10, 0, 5, 63, 63, 30], [20, 20, 20, 29, 31, 33]], np.float32)
+    m = im_detect_mask(head, [1.0], boxes, feat)
+    assert m.shape == (3, cfg.num_classes, 14, 14, 14) and m.dtype == np.float32
+    assert (m > 0).all() and (m < 1).all()
+    one = im_detect_mask(head, [1.0], boxes[:1], feat)                              # squeeze() then reshape (:469-474)
+    assert one.shape == (1, cfg.num_classes, 14, 14, 14) and np.allclose(one[0], m[0], rtol=1e-5, atol=1e-6)
+
+
+def test_driver_mask_net_and_im_detect_mask():
+    """model.module.mask_net(blob_conv, {'mask_rois': ...}) and im_detect_mask(model, im_scale, boxes, blob_conv) as the
+    reference's drivers call them (core/test.py:165-168,468)."""
+    from m3d.drivers import Generalized_RCNN, im_detect_mask
+    cfg = O.Cfg(mlp_dim=64)
+    P = O.make_params(stride=8, num_anchors=cfg.anchors.shape[0], mlp_dim=64, seed=5)
+    plain = Generalized_RCNN(P, cfg)
+    with pytest.raises(AttributeError):
+        plain.mask_net(None, {})
+    body_dim = P["Conv_Body.conv4b.weight"].shape[0] if "Conv_Body.conv4b.weight" in P else 256
+    P = dict(P)
+    P.update(_mask_params(body_dim, 32, cfg.num_classes, 2, seed=9))
+    model = Generalized_RCNN(P, cfg)
+    vol = torch.randn((1, 1, 64, 64, 64), generator=torch.Generator().manual_seed(2))
+    out = model(data=[vol], im_info=[torch.tensor([[64, 64, 64, 1.0]])])
+    boxes = np.array([[4, 4, 4, 40, 44, 48], [0, 10, 20, 63, 50, 60]], np.float32)
+    masks = im_detect_mask(model, [1.0], boxes, out["blob_conv"])
+    assert masks.shape == (2, cfg.num_classes, 14, 14, 14)
+    rois = np.hstack([np.zeros((2, 1), np.float32), boxes])
+    direct = model.module.mask_net(out["blob_conv"], {"mask_rois": rois}).cpu().numpy()
+    assert np.array_equal(direct, masks)
