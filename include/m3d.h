@@ -302,6 +302,26 @@ int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float* d_data
                        int width, float* d_out, float* d_sums, void* stream);
 int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
                     int depth, int height, int width, float* d_dense, void* stream);
+
+/* Round 2: the stem step of the peak back-propagation on the matrix cores, with the prepare step fused (replaces
+ * m3d_prm_prepare(pool = 1, border = 2) + m3d_prm_stem_dgrad for 32 stem channels and even window sizes; same results up to
+ * fp32 summation order).
+ *   m3d_prm_den_pool   peak-independent denominator map of a conv + MaxPool3d(2,2) layer, once per tile: d_den [C,UD,UH,UW] =
+ *                      |N| + 1e-10 at the argmax child where the pooled activation is > 0 and N >= 1e-10, else 0
+ *                      (lib/prm/peak_backprop_3d.py:30-33 with the ReLU mask and the max-unpool routing folded in).
+ *   m3d_prm_stem_mfma_prepare_weights  conv1a weight [32,1,5,5,5] -> d_wa [80,64]: tap-flipped relu(W) in MFMA A-operand order.
+ *   m3d_prm_stem_dgrad_fused_supported 1 when the fused kernel has a configuration for (channels, up_size).
+ *   m3d_prm_stem_dgrad_fused  d_gup [P,32,U,U,U] (gradient w.r.t. the pooled stem output), d_origin_up int32 [P,3] (pooled
+ *                      coordinates) -> d_out [P,Wn,Wn,Wn] (Wn = 2U + 4) = clamp((data - offset) * dgrad, min 0), d_sums [P],
+ *                      d_origins_out int32 [P,3] = 2 * origin_up - 2   (peak_response_mapping_3d.py:169-171). */
+int m3d_prm_den_pool(const uint8_t* d_argmax, const float* d_xnext, const float* d_norm, int channels, int up_depth, int up_height,
+                     int up_width, int depth, int height, int width, float* d_den, void* stream);
+int m3d_prm_stem_mfma_prepare_weights(const float* d_weight, int channels, float* d_wa, void* stream);
+int m3d_prm_stem_dgrad_fused_supported(int channels, int up_size);
+int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size,
+                             const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
+                             int up_width, const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height,
+                             int width, float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
 /* Backward-data of the 5^3 / Cin = 1 stem conv for autograd (what cuDNN dgrad computes for conv1a when the input requires
  * grad: the reference's PRM mode, lib/prm/peak_response_mapping_3d.py:88 + lib/prm/peak_backprop_3d.py:37-44, lib/modeling/DSN.py:19).
  *   m3d_conv3d_stem5_prepare_dgrad_weights  d_weight [C,1,5,5,5] -> d_wf [C,125], taps flipped (no ReLU: the caller passes

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "linear",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -443,6 +443,51 @@ def prm_stem_dgrad(gn, weight, data, data_off, origins):
     check(lib().m3d_prm_stem_dgrad(_ptr(gn), _ptr(weight), _ptr(data), _ptr(data_off), _ptr(origins), P, Cc, Wn, data.shape[0],
                                    data.shape[1], data.shape[2], _ptr(out), _ptr(sums), _stream()), "prm_stem_dgrad")
     return out, sums
+
+
+def prm_den_pool(argmax, xnext, norm):
+    """Peak-independent denominator map of a conv + MaxPool3d(2,2) layer: argmax uint8 / xnext [C,UD,UH,UW] (pool argmax and
+    pooled activation), norm [C,D,H,W] (norm conv) -> den [C,UD,UH,UW] = |N| + 1e-10 at the argmax child where xnext > 0 and
+    N >= 1e-10, else 0 (peak_backprop_3d.py:30-33 + ReLU / max-unpool routing)."""
+    _need_gpu(argmax, xnext, norm)
+    assert argmax.dtype == torch.uint8 and argmax.shape == xnext.shape
+    Cc, UD, UH, UW = xnext.shape
+    den = torch.empty_like(xnext)
+    check(lib().m3d_prm_den_pool(_ptr(argmax.contiguous()), _ptr(_f32c(xnext)), _ptr(_f32c(norm)), Cc, UD, UH, UW, norm.shape[1],
+                                 norm.shape[2], norm.shape[3], _ptr(den), _stream()), "prm_den_pool")
+    return den
+
+
+def prm_stem_mfma_weights(weight):
+    """conv1a.weight [32,1,5,5,5] -> MFMA A-operand pack [80,64] of the tap-flipped relu(W) for prm_stem_dgrad_fused."""
+    _need_gpu(weight)
+    weight = _f32c(weight)
+    assert tuple(weight.shape[1:]) == (1, 5, 5, 5)
+    wa = torch.empty((80, 64), dtype=torch.float32, device=weight.device)
+    check(lib().m3d_prm_stem_mfma_prepare_weights(_ptr(weight), weight.shape[0], _ptr(wa), _stream()), "prm_stem_mfma_prepare_weights")
+    return wa
+
+
+def prm_stem_dgrad_fused_supported(channels, up_size):
+    return bool(lib().m3d_prm_stem_dgrad_fused_supported(int(channels), int(up_size)))
+
+
+def prm_stem_dgrad_fused(gup, origin_up, den, argmax, scale, wa, data, data_off):
+    """Max-unpool + ReLU + BN + PostHook + backward-data of conv1a + PreHook in one MFMA kernel.  gup [P,32,U,U,U] (gradient
+    w.r.t. the pooled stem output), origin_up int32 [P,3] (pooled coordinates), den = prm_den_pool(...), argmax uint8
+    [32,UD,UH,UW], scale [32] or None, wa = prm_stem_mfma_weights(W), data [D,H,W] ->
+    (windows [P,Wn,Wn,Wn] clamped (Wn = 2U + 4), sums [P], origins int32 [P,3])."""
+    _need_gpu(gup, origin_up, den, argmax, wa, data, data_off)
+    P, Cc, U = gup.shape[0], gup.shape[1], gup.shape[2]
+    Wn = 2 * U + 4
+    out = torch.empty((P, Wn, Wn, Wn), dtype=torch.float32, device=gup.device)
+    sums = torch.empty((P,), dtype=torch.float32, device=gup.device)
+    oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
+    check(lib().m3d_prm_stem_dgrad_fused(_ptr(_f32c(gup)), _ptr(origin_up), P, Cc, U, _ptr(den), _ptr(argmax), _ptr(scale),
+                                         den.shape[1], den.shape[2], den.shape[3], _ptr(wa), _ptr(data), _ptr(data_off),
+                                         data.shape[0], data.shape[1], data.shape[2], _ptr(out), _ptr(sums), _ptr(oo), _stream()),
+          "prm_stem_dgrad_fused")
+    return out, sums, oo
 
 
 def conv3d_stem5_dgrad_weights(weight):

@@ -14,7 +14,7 @@ from .model import DetectorM3D
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True):
         self.det = det
         self.cfg = det.cfg
         self.peak_chunk = peak_chunk or None          # 0 / None: size the batches from window_budget
@@ -30,6 +30,10 @@ class PRMEngine:
         w = P["RPN.RPN_conv.weight"]
         self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU))
         self.stem_wf = ops.prm_stem_prepare_weights(P["Conv_Body.conv1a.weight"])
+        # stem step on the matrix cores with the un-pool/prepare fused (csrc/prm_stem_mfma.hip); fused_stem=False keeps the
+        # two-kernel VALU path (prepare + m3d_prm_stem_dgrad), which the tests compare it with
+        self.fused_stem = fused_stem and P["Conv_Body.conv1a.weight"].shape[0] == 32
+        self.stem_wa = ops.prm_stem_mfma_weights(P["Conv_Body.conv1a.weight"]) if self.fused_stem else None
         self.w_cls = P["RPN.RPN_cls_score.weight"]
         self.cls_norm_conv = ops.PackedConv3d(self.w_cls, ops.W_RELU)
         self.w_cls2d = self.w_cls.reshape(self.w_cls.shape[0], self.w_cls.shape[1]).contiguous()
@@ -52,6 +56,8 @@ class PRMEngine:
                     xn, am = y, None
             saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
                               xnext=xn[0], k=L["k"], dgrad=L["dgrad"], weight=L["weight"]))
+            if L["k"] == 5 and L["pool"] and self.fused_stem:
+                saved[-1]["den"] = ops.prm_den_pool(am[0], xn[0], n[0])          # peak-independent part of the prepare step
             x = xn
         feat = x
         off = ops.reduce_min(feat)
@@ -77,7 +83,14 @@ class PRMEngine:
         the big-window tail (38^3..84^3) is processed in peak chunks to bound the working set."""
         budget = self.window_budget
 
+        def fused(rec, g):
+            return self.fused_stem and rec["k"] == 5 and "den" in rec and ops.prm_stem_dgrad_fused_supported(g.shape[1], g.shape[2])
+
         def run_layer(rec, g, origin, border):
+            if fused(rec, g):                    # un-pool + prepare + stem dgrad + PreHook in one MFMA kernel
+                w, s, origin = ops.prm_stem_dgrad_fused(g, origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa, data[0, 0],
+                                                        rec["off"])
+                return (w, s), origin
             gn, origin = ops.prm_prepare(g, origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
             if rec["k"] == 5:                    # conv1a: 5^3, one input channel -> VALU stem dgrad
                 w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
@@ -93,6 +106,8 @@ class PRMEngine:
             P, Cc, U = g.shape[0], rec["n"].shape[0], g.shape[2]
             Wn = (2 if rec["pool"] else 1) * U + 2 * border
             per_peak = 4 * Wn ** 3 * max(Cc, rec["x"].shape[0]) * 2      # prepare output + conv output
+            if fused(rec, g):
+                per_peak = 4 * Wn ** 3                                    # the un-pooled window is never materialised
             chunk = self.peak_chunk if self.peak_chunk else max(1, min(P, int(budget // per_peak)))
             if chunk >= P:
                 g2, o2 = run_layer(rec, g, origin, border)

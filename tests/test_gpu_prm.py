@@ -62,6 +62,35 @@ def test_prm_vs_oracle_border_peaks():
         assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
 
 
+@pytest.mark.parametrize("stride,shape", [(8, (24, 40, 32)), (4, (16, 24, 40)), (8, (40, 104, 96))])
+def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
+    """csrc/prm_stem_mfma.hip (un-pool + prepare + stem dgrad on the matrix cores) against m3d_prm_prepare + the VALU
+    m3d_prm_stem_dgrad: same origins, windows equal up to fp32 summation order.  Peaks at the corners (windows sticking
+    out of the tile on every side), in the middle, and a tile large enough for complete 84^3 / 40^3 windows."""
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    A = 35 if stride == 8 else 14
+    P = O.make_params(stride=stride, num_anchors=A, mlp_dim=64, seed=11)
+    cfg = O.Cfg(mlp_dim=64, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=64)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    fused, plain = PRMEngine(det), PRMEngine(det, fused_stem=False)
+    assert fused.fused_stem and not plain.fused_stem
+    data = torch.randn((1, 1) + shape, generator=torch.Generator().manual_seed(4)).cuda()
+    feat, prob, deltas, saved, top = fused.forward(data)
+    assert "den" in saved[0]
+    s_, h_, w_ = prob.shape[-3:]
+    pk = torch.tensor([(0, 0, 0, 0), (A - 1, s_ - 1, h_ - 1, w_ - 1), (3, s_ // 2, h_ // 2, w_ // 2), (5, 0, h_ - 1, w_ // 2),
+                       (1, s_ - 1, 0, 1), (2, s_ // 2, h_ // 2 + 1, w_ // 2 - 1), (7, 1, 1, 1)], dtype=torch.int32).cuda()
+    w1, s1, o1 = fused.backward_windows(pk, saved, top, data)
+    w0, s0, o0 = plain.backward_windows(pk, saved, top, data)
+    assert w1.shape == w0.shape and torch.equal(o1, o0)
+    a, b = w1.cpu().numpy(), w0.cpu().numpy()
+    assert b.max() > 0
+    for i in range(pk.shape[0]):
+        assert np.allclose(a[i], b[i], rtol=1e-4, atol=1e-6 * b[i].max()), i
+    assert np.allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-4)
+
+
 def test_infer_prm_tiles_quantised_maps_and_tree(tmp_path):
     """m3d.infer.infer_prm (tools/infer_simple.py:176-247): norm1, slice padding, tiling, per-tile PRM, uint8 quantisation on
     device, instance tree on disk - every tile against the oracle run on the same crop."""
