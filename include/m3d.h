@@ -322,6 +322,23 @@ int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin_up, int
                              const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
                              int up_width, const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height,
                              int width, float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
+
+/* Strip layout for window batches: the P windows of n^3 voxels side by side along x, one separator column after each -
+ * [C, n, n, P*(n+1)] instead of [P, C, n, n, n] - so that m3d_conv3d_wino2_forward convolves the whole batch as ONE wide volume
+ * (its 64-wide tiles fit 38 / 40-voxel windows badly, a 2 600-voxel strip well).  That kernel has no PreHook epilogue, so the
+ * consumer of its output applies the multiply by (X - offset) of peak_backprop_3d.py:16-18:
+ *   m3d_prm_prepare_ex           m3d_prm_prepare with in_strip / out_strip (0 batch-major, 1 strip) and d_up_offset (non-null: d_gup
+ *                                is a bare backward-data result, multiplied here by (d_xnext - *d_up_offset)); writes the zero separators.
+ *   m3d_prm_stem_dgrad_fused_ex  m3d_prm_stem_dgrad_fused with gup_strip and (d_xnext [32,UD,UH,UW], d_up_offset) for the same purpose. */
+int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool, int border,
+                       const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width, const float* d_scale,
+                       const float* d_norm, int depth, int height, int width, int in_strip, int out_strip, const float* d_up_offset,
+                       float* d_out, int32_t* d_origin_out, void* stream);
+int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const float* d_xnext, const float* d_up_offset,
+                                const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den,
+                                const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
+                                const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
+                                float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
 /* Backward-data of the 5^3 / Cin = 1 stem conv for autograd (what cuDNN dgrad computes for conv1a when the input requires
  * grad: the reference's PRM mode, lib/prm/peak_response_mapping_3d.py:88 + lib/prm/peak_backprop_3d.py:37-44, lib/modeling/DSN.py:19).
  *   m3d_conv3d_stem5_prepare_dgrad_weights  d_weight [C,1,5,5,5] -> d_wf [C,125], taps flipped (no ReLU: the caller passes

@@ -50,6 +50,13 @@ struct PrepParams {
   int P, C, U, Wn, border, pool;
   int D, H, W;             // this layer's resolution
   int UD, UH, UW;          // X_{L+1} resolution
+  // element (p, c, z, y, x) of gup / out sits at p*ps + c*cs + z*zs + y*ys + x.  Batch-major [P,C,n,n,n]: ps = C n^3, cs = n^3,
+  // zs = n^2, ys = n.  Strip [C,n,n,P*(n+1)] (the windows side by side along x, one separator column after each - the layout the
+  // Winograd kernel convolves as ONE wide volume): ps = n + 1, cs = n^2 L, zs = n L, ys = L with L = P (n + 1).
+  long long ips, ics, ops, ocs;
+  int izs, iys, ozs, oys;
+  int out_sep;             // strip output: the separator columns are zero-filled here
+  const float* xoff;       // non-null: gup is a bare backward-data result; the PreHook multiply by (X_{L+1} - *xoff) happens here
 };
 
 // One thread per output voxel (no pooling between this layer and the upper one).  grid = (ceil(Wn^3/256), C, P):
@@ -68,13 +75,17 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   if ((iz >= 0) & (iz < q.U) & (iy >= 0) & (iy < q.U) & (ix >= 0) & (ix < q.U) & (qz >= 0) & (qz < q.D) & (qy >= 0) & (qy < q.H) &
       (qx >= 0) & (qx < q.W)) {
     const size_t pos = (((size_t)c * q.D + qz) * q.H + qy) * q.W + qx;
-    g = q.gup[(((size_t)p * q.C + c) * q.U + iz) * q.U * q.U + (size_t)iy * q.U + ix];
-    if (!(q.xnext[pos] > 0.f)) g = 0.f;                                    // ReLU backward (output > 0)
+    g = q.gup[(size_t)p * q.ips + (size_t)c * q.ics + (size_t)iz * q.izs + (size_t)iy * q.iys + ix];
+    const float xn = q.xnext[pos];
+    if (q.xoff) g = (xn - *q.xoff) * g;                                    // PreHook of the layer above, peak_backprop_3d.py:16-18
+    if (!(xn > 0.f)) g = 0.f;                                              // ReLU backward (output > 0)
     if (q.scale) g = g * q.scale[c];                                       // eval-mode BatchNorm backward
     const float n = q.norm[pos];
     g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                          // PostHook, peak_backprop_3d.py:30-33
   }
-  q.out[((size_t)p * q.C + c) * w3 + e] = g;
+  float* o = q.out + (size_t)p * q.ops + (size_t)c * q.ocs + (size_t)z * q.ozs + (size_t)y * q.oys + x;
+  o[0] = g;
+  if (q.out_sep && x == q.Wn - 1) o[1] = 0.f;
 }
 
 // MaxPool3d(2,2) between this layer and the upper one: one thread per 2x2x2 output block, i.e. per UPPER voxel (plus a
@@ -99,8 +110,10 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
   if ((bz >= 0) & (bz < q.U) & (by >= 0) & (by < q.U) & (bx >= 0) & (bx < q.U) & (az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) &
       (ax >= 0) & (ax < q.UW)) {
     const size_t upos = (((size_t)c * q.UD + az) * q.UH + ay) * q.UW + ax;
-    float g = q.gup[(((size_t)p * q.C + c) * q.U + bz) * q.U * q.U + (size_t)by * q.U + bx];
-    if (!(q.xnext[upos] > 0.f)) g = 0.f;                                           // ReLU backward on the pooled value
+    float g = q.gup[(size_t)p * q.ips + (size_t)c * q.ics + (size_t)bz * q.izs + (size_t)by * q.iys + bx];
+    const float xn = q.xnext[upos];
+    if (q.xoff) g = (xn - *q.xoff) * g;                                            // PreHook of the layer above
+    if (!(xn > 0.f)) g = 0.f;                                                      // ReLU backward on the pooled value
     if (q.scale) g = g * q.scale[c];
     const int child = q.argmax[upos];                                              // max-unpool routing
     const int qz = 2 * az + (child >> 2), qy = 2 * ay + ((child >> 1) & 1), qx = 2 * ax + (child & 1);
@@ -109,11 +122,15 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
       vals[child] = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);
     }
   }
-  float* o = q.out + ((size_t)p * q.C + c) * q.Wn * q.Wn * q.Wn;
+  float* o = q.out + (size_t)p * q.ops + (size_t)c * q.ocs;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int wz = 2 * bz + (k >> 2) + q.border, wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
-    if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) o[((size_t)wz * q.Wn + wy) * q.Wn + wx] = vals[k];
+    if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
+      float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
+      d[0] = vals[k];
+      if (q.out_sep && wx == q.Wn - 1) d[1] = 0.f;
+    }
   }
 }
 
@@ -305,10 +322,12 @@ M3D_API int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_p
   return m3d::check_launch("prm_seed");
 }
 
-M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
-                            int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
-                            const float* d_scale, const float* d_norm, int depth, int height, int width, float* d_out,
-                            int32_t* d_origin_out, void* stream) {
+// in_strip / out_strip: 0 = batch-major [P,C,n,n,n], 1 = strip [C,n,n,P*(n+1)] (see PrepParams).  d_up_offset non-null: d_gup is the
+// bare backward-data of the layer above (no PreHook multiply in its epilogue) and the multiply by (d_xnext - *d_up_offset) is done here.
+M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                               int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                               const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip,
+                               int out_strip, const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream) {
   if (num_peaks < 0 || channels <= 0 || up_size <= 0 || border < 0) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
   if (!d_gup || !d_origin_up || !d_xnext || !d_norm || !d_out || !d_origin_out || (pool && !d_argmax)) return M3D_EINVAL;
@@ -317,6 +336,19 @@ M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int 
   q.norm = d_norm; q.out = d_out; q.origin_out = d_origin_out; q.P = num_peaks; q.C = channels; q.U = up_size;
   q.Wn = (pool ? 2 : 1) * up_size + 2 * border; q.border = border; q.pool = pool ? 1 : 0;
   q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
+  q.xoff = d_up_offset; q.out_sep = out_strip ? 1 : 0;
+  auto strides = [&](int n, int strip, long long* ps, long long* cs, int* zs, int* ys) {
+    if (strip) {
+      const long long L = (long long)num_peaks * (n + 1);
+      if ((long long)n * L >= 0x7FFFFFFFll) return false;
+      *ps = n + 1; *cs = (long long)n * n * L; *zs = (int)(n * L); *ys = (int)L;
+    } else {
+      *ps = (long long)channels * n * n * n; *cs = (long long)n * n * n; *zs = n * n; *ys = n;
+    }
+    return true;
+  };
+  if (!strides(up_size, in_strip, &q.ips, &q.ics, &q.izs, &q.iys) || !strides(q.Wn, out_strip, &q.ops, &q.ocs, &q.ozs, &q.oys))
+    return M3D_EUNSUPPORTED;
   if (channels > 65535 || num_peaks > 65535) return M3D_EUNSUPPORTED;
   if (pool) {
     if (border > 2) return M3D_EUNSUPPORTED;      // the one-block shell covers borders of 1 or 2 voxels
@@ -328,6 +360,14 @@ M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int 
                        m3d::as_stream(stream), q);
   }
   return m3d::check_launch("prm_prepare");
+}
+
+M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                            int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                            const float* d_scale, const float* d_norm, int depth, int height, int width, float* d_out,
+                            int32_t* d_origin_out, void* stream) {
+  return m3d_prm_prepare_ex(d_gup, d_origin_up, num_peaks, channels, up_size, pool, border, d_argmax, d_xnext, up_depth, up_height,
+                            up_width, d_scale, d_norm, depth, height, width, 0, 0, nullptr, d_out, d_origin_out, stream);
 }
 
 M3D_API int m3d_prm_stem_prepare_weights(const float* d_weight, int channels, float* d_wf, void* stream) {

@@ -85,6 +85,11 @@ struct StemMArgs {
   int* origins_out;        // [P, 3]
   int P, U, ZW;
   int UD, UH, UW, D, H, W;
+  // gup element (p, c, z, y, x) at p*gps + c*gcs + z*gzs + y*gys + x (batch-major or strip layout, see prm.hip PrepParams)
+  long long gps;
+  int gcs, gzs, gys;
+  const float* xnext;      // with up_off: [32, UD, UH, UW] pooled stem activation - gup is a bare backward-data result and the PreHook
+  const float* up_off;     // multiply by (xnext - *up_off) of the layer above happens in the staging
 };
 
 constexpr int kNB = 5;       // MFMA column blocks per wave and fine row
@@ -140,9 +145,8 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   // ---- staging of one chunk (4 channels) of one coarse row.  A thread's cells keep their (channel-in-chunk, coarse plane,
   // coarse x) for the whole kernel; only the coarse row and the chunk move.
   constexpr int ncell = 4 * NBZ * U;
-  constexpr int U3 = U * U * U;
   const int M3 = q.UD * q.UH * q.UW;
-  const float* const gp = q.gup + (size_t)p * 32 * U3;
+  const float* const gp = q.gup + (size_t)p * q.gps;
   int cg[kNCell], cm[kNCell], cl[kNCell], ccv[kNCell];                // gup / map / LDS offsets of the cell (-1: always zero)
 #pragma unroll
   for (int i = 0; i < kNCell; ++i) {
@@ -152,23 +156,25 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     const int bz = (z0 >> 1) - 2 + bzl;
     const int az = uz0 + bz, ax = ux0 + bx;
     const bool ok = (e < ncell) & (bz >= 0) & (bz < U) & (az >= 0) & (az < q.UD) & (ax >= 0) & (ax < q.UW);
-    cg[i] = ok ? (cc * U + bz) * U * U + bx : -1;
+    cg[i] = ok ? cc * q.gcs + bz * q.gzs + bx : -1;
     cm[i] = ok ? (cc * q.UD + az) * q.UH * q.UW + ax : 0;
     cl[i] = e < ncell ? cc * CS + (2 * bzl) * 2 * NX + 2 * bx : -1;
     ccv[i] = e < ncell ? cc : 0;
   }
   // fetch issues loads only: any arithmetic on a loaded value would make the compiler wait for it before the MFMA run
-  float sg[kNCell], sd[kNCell], ss[kNCell];
+  float sg[kNCell], sd[kNCell], ss[kNCell], sx[kNCell];
   int sa[kNCell];
   float a_next[10], a_cur[10];
   bool fetched_rowok = false;
   const float* const scp = q.scale ? q.scale : q.wA;                   // any readable address when there is no scale
+  const float* const xnp = q.up_off ? q.xnext : q.den;
+  const float up_off = q.up_off ? *q.up_off : 0.f;
   auto fetch = [&](int g) __attribute__((always_inline)) {
     const int by = g >> 3, ch = g & 7;
     const int ay = uy0 + by;
     const bool rowok = (ay >= 0) & (ay < q.UH);
     fetched_rowok = rowok;
-    const int go = ch * 4 * U3 + by * U, mo = ch * 4 * M3 + (rowok ? ay : 0) * q.UW;
+    const int go = ch * 4 * q.gcs + by * q.gys, mo = ch * 4 * M3 + (rowok ? ay : 0) * q.UW;
 #pragma unroll
     for (int i = 0; i < kNCell; ++i) {
       const bool ok = rowok & (cg[i] >= 0);
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
       sd[i] = q.den[mi];
       sa[i] = q.argmax[mi];
       ss[i] = scp[4 * ch + ccv[i]];
+      sx[i] = xnp[mi];
     }
   };
   auto fetch_a = [&](int g) __attribute__((always_inline)) {
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     for (int i = 0; i < kNCell; ++i) {
       if (cl[i] >= 0) {
         const bool ok = fetched_rowok & (cg[i] >= 0);
-        const float g = q.scale ? sg[i] * ss[i] : sg[i];                         // eval-BatchNorm backward
+        float g = q.up_off ? (sx[i] - up_off) * sg[i] : sg[i];                   // PreHook of conv2a, peak_backprop_3d.py:16-18
+        g = q.scale ? g * ss[i] : g;                                             // eval-BatchNorm backward
         const float v = (ok & (sd[i] > 0.f)) ? g / sd[i] : 0.f;                  // PostHook division, peak_backprop_3d.py:30-33
         const int child = sa[i];
         float* cell = dst + cl[i];
@@ -449,8 +457,8 @@ M3D_API int m3d_prm_stem_dgrad_fused_supported(int channels, int up_size) {
   return channels == 32 && stem_plan(up_size, &pl) ? 1 : 0;
 }
 
-M3D_API int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size,
-                                     const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
+M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const float* d_xnext, const float* d_up_offset,
+                                        const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
                                      int up_width, const float* d_wa, const float* d_data, const float* d_data_offset, int depth,
                                      int height, int width, float* d_out, float* d_sums, int32_t* d_origins_out, void* stream) {
   if (num_peaks < 0 || channels <= 0 || up_size <= 0) return M3D_EINVAL;
@@ -466,6 +474,18 @@ M3D_API int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin
   q.gup = d_gup; q.origin_up = d_origin_up; q.den = d_den; q.argmax = d_argmax; q.scale = d_scale; q.wA = d_wa; q.data = d_data;
   q.data_off = d_data_offset; q.out = d_out; q.sums = d_sums; q.origins_out = d_origins_out; q.P = num_peaks; q.U = up_size;
   q.ZW = pl.zw; q.UD = up_depth; q.UH = up_height; q.UW = up_width; q.D = depth; q.H = height; q.W = width;
+  if ((d_up_offset != nullptr) != (d_xnext != nullptr)) return M3D_EINVAL;
+  q.xnext = d_xnext; q.up_off = d_up_offset;
+  {
+    const long long n = up_size, L = (long long)num_peaks * (n + 1);
+    if (gup_strip) {
+      if (n * n * L >= 0x7FFFFFFFll / 32) return M3D_EUNSUPPORTED;     // 32-bit offsets inside the gradient tensor
+      q.gps = n + 1; q.gcs = (int)(n * n * L); q.gzs = (int)(n * L); q.gys = (int)L;
+    } else {
+      q.gps = 32 * n * n * n; q.gcs = (int)(n * n * n); q.gzs = (int)(n * n); q.gys = (int)n;
+    }
+  }
+  if ((long long)32 * up_depth * up_height * up_width >= 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
   auto launch = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     hipLaunchKernelGGL(kern, dim3(pl.nslab, num_peaks), dim3(kNT), pl.lds, st, q);
@@ -473,4 +493,13 @@ M3D_API int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin
   if (up_size == 40) launch(prm_stem_dgrad_mfma_kernel<40, 2>);
   else launch(prm_stem_dgrad_mfma_kernel<18, 4>);
   return m3d::check_launch("prm_stem_dgrad_fused");
+}
+
+M3D_API int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size,
+                                     const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
+                                     int up_width, const float* d_wa, const float* d_data, const float* d_data_offset, int depth,
+                                     int height, int width, float* d_out, float* d_sums, int32_t* d_origins_out, void* stream) {
+  return m3d_prm_stem_dgrad_fused_ex(d_gup, 0, nullptr, nullptr, d_origin_up, num_peaks, channels, up_size, d_den, d_argmax, d_scale,
+                                     up_depth, up_height, up_width, d_wa, d_data, d_data_offset, depth, height, width, d_out, d_sums,
+                                     d_origins_out, stream);
 }

@@ -14,9 +14,13 @@ from .model import DetectorM3D
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16):
         self.det = det
         self.cfg = det.cfg
+        # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
+        # side by side along x): 4/9 of the MFMA work and tiles that fit; strip_wino=False keeps the direct kernel everywhere
+        self.strip_wino = bool(strip_wino)
+        self.strip_min = int(strip_min)
         self.peak_chunk = peak_chunk or None          # 0 / None: size the batches from window_budget
         self.window_budget = window_budget
         P = det.P
@@ -26,7 +30,8 @@ class PRMEngine:
             w = P["Conv_Body.%s.weight" % cname]
             self.layers.append(dict(name=cname, conv=conv, scale=scale, shift=shift, pool=pool, k=w.shape[2],
                                     norm_conv=ops.PackedConv3d(w, ops.W_RELU),
-                                    dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU), weight=w))
+                                    dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU),
+                                    dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None, weight=w))
         w = P["RPN.RPN_conv.weight"]
         self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU))
         self.stem_wf = ops.prm_stem_prepare_weights(P["Conv_Body.conv1a.weight"])
@@ -37,6 +42,13 @@ class PRMEngine:
         self.w_cls = P["RPN.RPN_cls_score.weight"]
         self.cls_norm_conv = ops.PackedConv3d(self.w_cls, ops.W_RELU)
         self.w_cls2d = self.w_cls.reshape(self.w_cls.shape[0], self.w_cls.shape[1]).contiguous()
+
+    @staticmethod
+    def _dgrad_wino(w):
+        """backward-data of a 'same' 3^3 conv with relu(W) (peak_backprop_3d.py:41-42) as a forward conv: taps flipped, channel
+        roles swapped; packed for the F(2x2,3x3) kernel."""
+        wd = torch.relu(w).flip(2, 3, 4).transpose(0, 1).contiguous()
+        return ops.WinoConv3d(wd, two_d=True)
 
     # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
     def forward(self, data):
@@ -55,7 +67,7 @@ class PRMEngine:
                 else:
                     xn, am = y, None
             saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
-                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], weight=L["weight"]))
+                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], weight=L["weight"]))
             if L["k"] == 5 and L["pool"] and self.fused_stem:
                 saved[-1]["den"] = ops.prm_den_pool(am[0], xn[0], n[0])          # peak-independent part of the prepare step
             x = xn
@@ -80,46 +92,75 @@ class PRMEngine:
 
         All peaks go through a layer in ONE launch while the layer's window batch stays under `window_budget`
         bytes (the stride-8/4 layers have 3^3..18^3 windows: per-launch latency, not work, dominates there);
-        the big-window tail (38^3..84^3) is processed in peak chunks to bound the working set."""
+        the big-window tail (38^3..84^3) is processed in peak chunks to bound the working set.
+
+        A window batch travels as a dict: t (tensor), strip (layout, see ops.prm_prepare), P, C, U, and up_off - the input
+        offset of the layer that produced it when that layer ran without its PreHook epilogue (the Winograd path), so that
+        the consumer multiplies by (X - up_off)."""
         budget = self.window_budget
 
-        def fused(rec, g):
-            return self.fused_stem and rec["k"] == 5 and "den" in rec and ops.prm_stem_dgrad_fused_supported(g.shape[1], g.shape[2])
+        def fused(rec, wb):
+            return self.fused_stem and rec["k"] == 5 and "den" in rec and ops.prm_stem_dgrad_fused_supported(wb["C"], wb["U"])
 
-        def run_layer(rec, g, origin, border):
-            if fused(rec, g):                    # un-pool + prepare + stem dgrad + PreHook in one MFMA kernel
-                w, s, origin = ops.prm_stem_dgrad_fused(g, origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa, data[0, 0],
-                                                        rec["off"])
+        def wino(rec, Wn):
+            return self.strip_wino and rec["k"] == 3 and rec.get("dgrad_wino") is not None and Wn >= self.strip_min
+
+        def run_layer(rec, wb, origin, border):
+            dims = (wb["P"], wb["C"], wb["U"])
+            if fused(rec, wb):                   # un-pool + prepare + stem dgrad + PreHook in one MFMA kernel
+                w, s, origin = ops.prm_stem_dgrad_fused(wb["t"], origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa,
+                                                        data[0, 0], rec["off"], strip=wb["strip"],
+                                                        xnext=rec["xnext"] if wb["up_off"] is not None else None,
+                                                        up_off=wb["up_off"], dims=dims)
                 return (w, s), origin
-            gn, origin = ops.prm_prepare(g, origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"])
+            Wn = (2 if rec["pool"] else 1) * wb["U"] + 2 * border
+            strip = wino(rec, Wn)
+            gn, origin = ops.prm_prepare(wb["t"], origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"],
+                                         in_strip=wb["strip"], out_strip=strip, up_off=wb["up_off"], dims=dims)
             if rec["k"] == 5:                    # conv1a: 5^3, one input channel -> VALU stem dgrad
                 w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
                 return (w, s), origin
-            return ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin), origin
+            cout = rec["x"].shape[0]
+            if strip:                            # F(2x2,3x3) over the whole strip; its PreHook multiply moves to the consumer
+                y = rec["dgrad_wino"](gn.unsqueeze(0))[0]
+                return dict(t=y, strip=True, P=wb["P"], C=cout, U=Wn, up_off=rec["off"]), origin
+            y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
+            return dict(t=y, strip=False, P=wb["P"], C=cout, U=Wn, up_off=None), origin
 
-        def tail(layers, g, origin):
+        def take(wb, c0, c1):
+            """peaks [c0, c1) of a window batch"""
+            if wb["strip"]:
+                n = wb["U"] + 1
+                t = wb["t"][..., c0 * n:c1 * n].contiguous()
+            else:
+                t = wb["t"][c0:c1].contiguous()
+            return dict(wb, t=t, P=c1 - c0)
+
+        def tail(layers, wb, origin):
             """Run the remaining layers (top -> bottom) on the given peak subset."""
-            if not layers:
-                return g, origin
             rec = layers[0]
             border = 2 if rec["k"] == 5 else 1
-            P, Cc, U = g.shape[0], rec["n"].shape[0], g.shape[2]
+            P, Cc, U = wb["P"], rec["n"].shape[0], wb["U"]
             Wn = (2 if rec["pool"] else 1) * U + 2 * border
-            per_peak = 4 * Wn ** 3 * max(Cc, rec["x"].shape[0]) * 2      # prepare output + conv output
-            if fused(rec, g):
+            cmax = max(Cc, rec["x"].shape[0])
+            per_peak = 4 * Wn ** 3 * cmax * 2                            # prepare output + conv output
+            if fused(rec, wb):
                 per_peak = 4 * Wn ** 3                                    # the un-pooled window is never materialised
             chunk = self.peak_chunk if self.peak_chunk else max(1, min(P, int(budget // per_peak)))
+            if wino(rec, Wn):                                             # 32-bit offsets inside one strip
+                chunk = max(1, min(chunk, (2 ** 31 - 1) // (4 * cmax * Wn * Wn * (Wn + 1))))
             if chunk >= P:
-                g2, o2 = run_layer(rec, g, origin, border)
-                return (g2, o2) if rec["k"] == 5 else tail(layers[1:], g2, o2)
-            outs = [tail(layers, g[c0:c0 + chunk].contiguous(), origin[c0:c0 + chunk].contiguous()) for c0 in range(0, P, chunk)]
+                out, o2 = run_layer(rec, wb, origin, border)
+                return (out, o2) if rec["k"] == 5 else tail(layers[1:], out, o2)
+            outs = [tail(layers, take(wb, c0, min(P, c0 + chunk)), origin[c0:c0 + chunk].contiguous()) for c0 in range(0, P, chunk)]
             wins = torch.cat([o[0][0] for o in outs]); sums = torch.cat([o[0][1] for o in outs]); orig = torch.cat([o[1] for o in outs])
             return (wins, sums), orig
 
         pk = peaks_ashw.contiguous()
         g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
         origin = pk[:, 1:4].contiguous()
-        (win, sums), origins = tail(list(reversed(saved)), g, origin)
+        wb = dict(t=g, strip=False, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
+        (win, sums), origins = tail(list(reversed(saved)), wb, origin)
         return win, sums, origins
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193
