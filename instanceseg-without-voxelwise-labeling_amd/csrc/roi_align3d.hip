@@ -496,7 +496,16 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
     return;
   }
   if (skip_v3) {                                          // same predicate as roi_align3d_fwd_v3_kernel: exactly one of the two runs
-    if (tid == 0) s_v3 = v3_qualifies(tz, ty, tx, rng);
+    if (tid == 0) s_v3 = 1;
+    __syncthreads();
+    if (tid < 21) {                                       // v3_qualifies, its 21 (axis, bin) folds in parallel
+      const V3Dims d = v3_dims(rng);
+      const int ax = tid / 7, p = tid % 7;
+      const bool ok = ax == 0 ? fold_bin(tz[2 * p], tz[2 * p + 1], rng[0], d.ez, 1.f, nullptr)
+                    : ax == 1 ? fold_bin(ty[2 * p], ty[2 * p + 1], rng[2], d.ey, 1.f, nullptr)
+                              : fold_bin(tx[2 * p], tx[2 * p + 1], rng[4], d.ex, 1.f, nullptr);
+      if (!ok || d.per_ch > kSepLdsFloats) atomicAnd(&s_v3, 0);
+    }
     __syncthreads();
     if (s_v3) return;
   }
@@ -702,9 +711,14 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
       hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
                          H, W, scale, cpb3);
     }
-    // complement pass (v3: only the RoIs v3 declined - wide bins, huge sub-volumes - so one workgroup per RoI, all channels)
-    hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, 1) : grid, block, lds, m3d::as_stream(stream), a, rois, o, C, S, H, W,
-                       AS, AH, AW, scale, ratio, v3 ? C : cpb, v3);
+    // complement pass (v3: only the RoIs v3 declined - wide bins, huge sub-volumes; the other workgroups leave after the set-up).
+    // Those RoIs are few and heavy (45 us each on one workgroup: soma tile, 25 of 274 RoIs = 1.1 ms), so their channels are cut
+    // into enough chunks for ~4096 workgroups in all.
+    int cchunks = 1;
+    while ((long)R * cchunks < 4096 && cchunks * 8 < C) cchunks *= 2;
+    const int ccpb = (C + cchunks - 1) / cchunks;
+    hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, (C + ccpb - 1) / ccpb) : grid, block, lds, m3d::as_stream(stream), a,
+                       rois, o, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3);
   } else if (!backward)
     hipLaunchKernelGGL(roi_align3d_kernel<false>, grid, block, 0, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
                        scale, ratio, cpb, (int*)nullptr);
