@@ -59,33 +59,42 @@ struct PrepParams {
   const float* xoff;       // non-null: gup is a bare backward-data result; the PreHook multiply by (X_{L+1} - *xoff) happens here
 };
 
-// One thread per output voxel (no pooling between this layer and the upper one).  grid = (ceil(Wn^3/256), C, P):
-// no 64-bit div/mod chains, channel and peak come from the block index.
+// One thread per output voxel (no pooling between this layer and the upper one).  grid = (chunks, C, P): a workgroup walks
+// its share of the (p, c) window in strides of 256 voxels - a million 256-voxel workgroups were bound by the dispatch rate, not
+// by memory - and channel and peak come from the block index (no 64-bit div/mod chains).
 __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   const int w3 = q.Wn * q.Wn * q.Wn;
-  const int e = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y, p = blockIdx.z;
   const int oz = q.origin_up[3 * p] - q.border, oy = q.origin_up[3 * p + 1] - q.border, ox = q.origin_up[3 * p + 2] - q.border;
-  if (e == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
-  if (e >= w3) return;
-  const int x = e % q.Wn, y = (e / q.Wn) % q.Wn, z = e / (q.Wn * q.Wn);
-  const int iz = z - q.border, iy = y - q.border, ix = x - q.border;       // inner (un-padded) window coords == upper coords
-  const int qz = oz + z, qy = oy + y, qx = ox + x;                         // position in this layer's tensor (== X_{L+1})
-  float g = 0.f;
-  if ((iz >= 0) & (iz < q.U) & (iy >= 0) & (iy < q.U) & (ix >= 0) & (ix < q.U) & (qz >= 0) & (qz < q.D) & (qy >= 0) & (qy < q.H) &
-      (qx >= 0) & (qx < q.W)) {
-    const size_t pos = (((size_t)c * q.D + qz) * q.H + qy) * q.W + qx;
-    g = q.gup[(size_t)p * q.ips + (size_t)c * q.ics + (size_t)iz * q.izs + (size_t)iy * q.iys + ix];
-    const float xn = q.xnext[pos];
-    if (q.xoff) g = (xn - *q.xoff) * g;                                    // PreHook of the layer above, peak_backprop_3d.py:16-18
-    if (!(xn > 0.f)) g = 0.f;                                              // ReLU backward (output > 0)
-    if (q.scale) g = g * q.scale[c];                                       // eval-mode BatchNorm backward
-    const float n = q.norm[pos];
-    g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                          // PostHook, peak_backprop_3d.py:30-33
+  if (blockIdx.x == 0 && threadIdx.x == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+  const float sc = q.scale ? q.scale[c] : 1.f;
+  const float xoff = q.xoff ? *q.xoff : 0.f;
+  const float* gup = q.gup + (size_t)p * q.ips + (size_t)c * q.ics;
+  const float* xnext = q.xnext + (size_t)c * q.D * q.H * q.W;
+  const float* norm = q.norm + (size_t)c * q.D * q.H * q.W;
+  float* out = q.out + (size_t)p * q.ops + (size_t)c * q.ocs;
+  const float inv_w = 1.0f / (float)q.Wn;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
+    const int r = (int)(((float)e + 0.5f) * inv_w), x = e - r * q.Wn;      // exact for e < 2^22 (Wn <= 100)
+    const int z = (int)(((float)r + 0.5f) * inv_w), y = r - z * q.Wn;
+    const int iz = z - q.border, iy = y - q.border, ix = x - q.border;       // inner (un-padded) window coords == upper coords
+    const int qz = oz + z, qy = oy + y, qx = ox + x;                         // position in this layer's tensor (== X_{L+1})
+    float g = 0.f;
+    if ((iz >= 0) & (iz < q.U) & (iy >= 0) & (iy < q.U) & (ix >= 0) & (ix < q.U) & (qz >= 0) & (qz < q.D) & (qy >= 0) & (qy < q.H) &
+        (qx >= 0) & (qx < q.W)) {
+      const size_t pos = ((size_t)qz * q.H + qy) * q.W + qx;
+      g = gup[(size_t)iz * q.izs + (size_t)iy * q.iys + ix];
+      const float xn = xnext[pos];
+      if (q.xoff) g = (xn - xoff) * g;                                       // PreHook of the layer above, peak_backprop_3d.py:16-18
+      if (!(xn > 0.f)) g = 0.f;                                              // ReLU backward (output > 0)
+      if (q.scale) g = g * sc;                                               // eval-mode BatchNorm backward
+      const float n = norm[pos];
+      g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                          // PostHook, peak_backprop_3d.py:30-33
+    }
+    float* o = out + (size_t)z * q.ozs + (size_t)y * q.oys + x;
+    o[0] = g;
+    if (q.out_sep && x == q.Wn - 1) o[1] = 0.f;
   }
-  float* o = q.out + (size_t)p * q.ops + (size_t)c * q.ocs + (size_t)z * q.ozs + (size_t)y * q.oys + x;
-  o[0] = g;
-  if (q.out_sep && x == q.Wn - 1) o[1] = 0.f;
 }
 
 // MaxPool3d(2,2) between this layer and the upper one: one thread per 2x2x2 output block, i.e. per UPPER voxel (plus a
@@ -94,42 +103,50 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
 // and the eight outputs are written as four 8-byte stores.  grid = (ceil((U+2)^3/256), C, P).
 __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
   const int UB = q.U + 2;                                                  // blocks per axis incl. the shell
-  const int e = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y, p = blockIdx.z;
   const int uz0 = q.origin_up[3 * p], uy0 = q.origin_up[3 * p + 1], ux0 = q.origin_up[3 * p + 2];
   const int oz = 2 * uz0 - q.border, oy = 2 * uy0 - q.border, ox = 2 * ux0 - q.border;
-  if (e == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
-  if (e >= UB * UB * UB) return;
-  // block b covers inner coordinates 2*(b-1) .. 2*(b-1)+1 shifted so that every window voxel belongs to one block:
-  // window coordinate w = inner + border; blocks are aligned to the INNER grid (pooling windows).
-  const int bx = e % UB - 1, by = (e / UB) % UB - 1, bz = e / (UB * UB) - 1;      // upper-window voxel index, -1 .. U
-  float vals[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) vals[k] = 0.f;
-  const int az = uz0 + bz, ay = uy0 + by, ax = ux0 + bx;                          // upper tensor position
-  if ((bz >= 0) & (bz < q.U) & (by >= 0) & (by < q.U) & (bx >= 0) & (bx < q.U) & (az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) &
-      (ax >= 0) & (ax < q.UW)) {
-    const size_t upos = (((size_t)c * q.UD + az) * q.UH + ay) * q.UW + ax;
-    float g = q.gup[(size_t)p * q.ips + (size_t)c * q.ics + (size_t)bz * q.izs + (size_t)by * q.iys + bx];
-    const float xn = q.xnext[upos];
-    if (q.xoff) g = (xn - *q.xoff) * g;                                            // PreHook of the layer above
-    if (!(xn > 0.f)) g = 0.f;                                                      // ReLU backward on the pooled value
-    if (q.scale) g = g * q.scale[c];
-    const int child = q.argmax[upos];                                              // max-unpool routing
-    const int qz = 2 * az + (child >> 2), qy = 2 * ay + ((child >> 1) & 1), qx = 2 * ax + (child & 1);
-    if ((qz < q.D) & (qy < q.H) & (qx < q.W)) {
-      const float n = q.norm[(((size_t)c * q.D + qz) * q.H + qy) * q.W + qx];
-      vals[child] = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);
-    }
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+  const float sc = q.scale ? q.scale[c] : 1.f;
+  const float xoff = q.xoff ? *q.xoff : 0.f;
+  const float* gup = q.gup + (size_t)p * q.ips + (size_t)c * q.ics;
+  const size_t umap = (size_t)c * q.UD * q.UH * q.UW;
+  const float* norm = q.norm + (size_t)c * q.D * q.H * q.W;
   float* o = q.out + (size_t)p * q.ops + (size_t)c * q.ocs;
+  const float inv_u = 1.0f / (float)UB;
+  const int ub3 = UB * UB * UB;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < ub3; e += gridDim.x * 256) {
+    // block b covers inner coordinates 2*(b-1) .. 2*(b-1)+1 shifted so that every window voxel belongs to one block:
+    // window coordinate w = inner + border; blocks are aligned to the INNER grid (pooling windows).
+    const int r = (int)(((float)e + 0.5f) * inv_u), bx = e - r * UB - 1;           // upper-window voxel index, -1 .. U
+    const int rz = (int)(((float)r + 0.5f) * inv_u), by = r - rz * UB - 1, bz = rz - 1;
+    float vals[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int wz = 2 * bz + (k >> 2) + q.border, wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
-    if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
-      float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
-      d[0] = vals[k];
-      if (q.out_sep && wx == q.Wn - 1) d[1] = 0.f;
+    for (int k = 0; k < 8; ++k) vals[k] = 0.f;
+    const int az = uz0 + bz, ay = uy0 + by, ax = ux0 + bx;                          // upper tensor position
+    if ((bz >= 0) & (bz < q.U) & (by >= 0) & (by < q.U) & (bx >= 0) & (bx < q.U) & (az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) &
+        (ax >= 0) & (ax < q.UW)) {
+      const size_t upos = umap + ((size_t)az * q.UH + ay) * q.UW + ax;
+      float g = gup[(size_t)bz * q.izs + (size_t)by * q.iys + bx];
+      const float xn = q.xnext[upos];
+      if (q.xoff) g = (xn - xoff) * g;                                               // PreHook of the layer above
+      if (!(xn > 0.f)) g = 0.f;                                                      // ReLU backward on the pooled value
+      if (q.scale) g = g * sc;
+      const int child = q.argmax[upos];                                              // max-unpool routing
+      const int qz = 2 * az + (child >> 2), qy = 2 * ay + ((child >> 1) & 1), qx = 2 * ax + (child & 1);
+      if ((qz < q.D) & (qy < q.H) & (qx < q.W)) {
+        const float n = norm[((size_t)qz * q.H + qy) * q.W + qx];
+        vals[child] = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int wz = 2 * bz + (k >> 2) + q.border, wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
+      if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
+        float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
+        d[0] = vals[k];
+        if (q.out_sep && wx == q.Wn - 1) d[1] = 0.f;
+      }
     }
   }
 }
@@ -353,11 +370,17 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
   if (pool) {
     if (border > 2) return M3D_EUNSUPPORTED;      // the one-block shell covers borders of 1 or 2 voxels
     const int ub = up_size + 2;
-    hipLaunchKernelGGL(prm_prepare_pool_kernel, dim3((ub * ub * ub + 255) / 256, channels, num_peaks), dim3(256), 0,
-                       m3d::as_stream(stream), q);
+    if (ub > 100) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
+    const int blocks = (ub * ub * ub + 255) / 256;
+    int chunks = (int)((16384 + (long long)channels * num_peaks - 1) / ((long long)channels * num_peaks));
+    chunks = chunks < 1 ? 1 : (chunks > blocks ? blocks : chunks);
+    hipLaunchKernelGGL(prm_prepare_pool_kernel, dim3(chunks, channels, num_peaks), dim3(256), 0, m3d::as_stream(stream), q);
   } else {
-    hipLaunchKernelGGL(prm_prepare_kernel, dim3((q.Wn * q.Wn * q.Wn + 255) / 256, channels, num_peaks), dim3(256), 0,
-                       m3d::as_stream(stream), q);
+    if (q.Wn > 100) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
+    const int blocks = (q.Wn * q.Wn * q.Wn + 255) / 256;
+    int chunks = (int)((16384 + (long long)channels * num_peaks - 1) / ((long long)channels * num_peaks));   // >= 16 k workgroups
+    chunks = chunks < 1 ? 1 : (chunks > blocks ? blocks : chunks);
+    hipLaunchKernelGGL(prm_prepare_kernel, dim3(chunks, channels, num_peaks), dim3(256), 0, m3d::as_stream(stream), q);
   }
   return m3d::check_launch("prm_prepare");
 }

@@ -14,12 +14,16 @@ from .model import DetectorM3D
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True):
         self.det = det
         self.cfg = det.cfg
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
         # side by side along x): 4/9 of the MFMA work and tiles that fit; strip_wino=False keeps the direct kernel everywhere
         self.strip_wino = bool(strip_wino)
+        # forward: the RESPONSE convs of the un-pooled layers may take the detection path's Winograd kernels (values differ from the
+        # direct kernel by ~1e-6 relative); the NORM convs never do - their exact zeros (sums of non-negative products) gate the
+        # PostHook's `N < 1e-10` test, and a Winograd 1e-8 in place of a 0 would be divided by
+        self.wino_forward = bool(wino_forward) and det.use_wino
         self.strip_min = int(strip_min)
         self.peak_chunk = peak_chunk or None          # 0 / None: size the batches from window_budget
         self.window_budget = window_budget
@@ -55,13 +59,17 @@ class PRMEngine:
         det = self.det
         saved = []
         x = data
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             off = ops.reduce_min(x)
             n = L["norm_conv"](x, in_offset=off)
             if L["pool"] and L["conv"].supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
                 xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
-                y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
+                wn = det.body_wino[li] if self.wino_forward else None
+                if wn is not None and not L["pool"] and wn.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
+                    y = wn(x, scale=L["scale"], shift=L["shift"], relu=True)        # response conv: F(2x2,3x3) as in detection mode
+                else:
+                    y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
                 if L["pool"]:
                     xn, am = ops.maxpool3d_2x(y, return_argmax=True)
                 else:
@@ -73,7 +81,11 @@ class PRMEngine:
             x = xn
         feat = x
         off = ops.reduce_min(feat)
-        h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
+        wn = det.rpn_conv_wino if self.wino_forward else None
+        if wn is not None and wn.supports(feat.shape[-1], (feat.shape[0],) + tuple(feat.shape[2:])):
+            h = wn(feat, shift=det.rpn_conv_bias, relu=True)
+        else:
+            h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
         n = self.rpn["norm_conv"](feat, in_offset=off)
         saved.append(dict(x=feat[0], off=off, n=n[0], scale=None, pool=False, argmax=None, xnext=h[0], k=3,
                           dgrad=self.rpn["dgrad"]))
