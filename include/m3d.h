@@ -339,6 +339,17 @@ int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const float* 
                                 const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
                                 const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
                                 float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
+
+/* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
+ * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on
+ * dgrad-packed weights: d_gn [P, cout_fwd, win^3] -> d_out [P, cin_fwd, win^3] = (d_full[co][origin + v] - *d_full_offset) *
+ * sum relu(W)[ci][co][26 - t] * gn[p, ci][v + t - 1]  (lib/prm/peak_backprop_3d.py:16-18,41-42).  d_weight: the forward conv's
+ * [cout_fwd, cin_fwd, 3, 3, 3]; pack once per model. */
+size_t m3d_prm_small_dgrad_packed_bytes(int cout_fwd, int cin_fwd);
+int m3d_prm_small_dgrad_pack(const float* d_weight, int cout_fwd, int cin_fwd, float* d_packed, void* stream);
+int m3d_prm_small_dgrad(const float* d_gn, const float* d_packed, int num_peaks, int cout_fwd, int cin_fwd, int win,
+                        const float* d_full, const float* d_full_offset, const int32_t* d_origins, int depth, int height, int width,
+                        float* d_out, void* stream);
 /* Backward-data of the 5^3 / Cin = 1 stem conv for autograd (what cuDNN dgrad computes for conv1a when the input requires
  * grad: the reference's PRM mode, lib/prm/peak_response_mapping_3d.py:88 + lib/prm/peak_backprop_3d.py:37-44, lib/modeling/DSN.py:19).
  *   m3d_conv3d_stem5_prepare_dgrad_weights  d_weight [C,1,5,5,5] -> d_wf [C,125], taps flipped (no ReLU: the caller passes

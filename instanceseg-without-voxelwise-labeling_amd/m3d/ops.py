@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "linear",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -395,6 +395,33 @@ def conv3d_windowed(packed, x, full, full_off, origins):
                                             _ptr(full), _ptr(full_off), _ptr(origins), full.shape[1], full.shape[2],
                                             full.shape[3], _stream()), "conv3d_forward_windowed")
     return out
+
+
+class SmallWindowDgrad:
+    """Backward-data of a 3^3 conv with relu(W) on batches of 3^3 / 5^3 / 7^3 windows, all peaks in one dense GEMM
+    (csrc/prm_small.hip); weight = the forward conv's [cout, cin, 3, 3, 3], packed once."""
+    SIZES = (3, 5, 7)
+
+    def __init__(self, weight):
+        _need_gpu(weight)
+        w = _f32c(weight)
+        assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+        self.cout_fwd, self.cin_fwd = int(w.shape[0]), int(w.shape[1])
+        nbytes = lib().m3d_prm_small_dgrad_packed_bytes(self.cout_fwd, self.cin_fwd)
+        self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
+        check(lib().m3d_prm_small_dgrad_pack(_ptr(w), self.cout_fwd, self.cin_fwd, _ptr(self.packed), _stream()), "prm_small_dgrad_pack")
+
+    def __call__(self, gn, full, full_off, origins):
+        """gn [P, cout_fwd, n, n, n]; full [cin_fwd, D, H, W]; origins int32 [P,3] -> [P, cin_fwd, n, n, n]."""
+        _need_gpu(gn, full, full_off, origins)
+        gn = _f32c(gn)
+        P, Cc, n = gn.shape[0], gn.shape[1], gn.shape[2]
+        assert Cc == self.cout_fwd and n in self.SIZES and full.shape[0] == self.cin_fwd
+        out = torch.empty((P, self.cin_fwd, n, n, n), dtype=torch.float32, device=gn.device)
+        check(lib().m3d_prm_small_dgrad(_ptr(gn), _ptr(self.packed), P, self.cout_fwd, self.cin_fwd, n, _ptr(_f32c(full)), _ptr(full_off),
+                                        _ptr(origins), full.shape[1], full.shape[2], full.shape[3], _ptr(out), _stream()),
+              "prm_small_dgrad")
+        return out
 
 
 def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off):

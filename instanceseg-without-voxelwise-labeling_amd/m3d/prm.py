@@ -14,7 +14,7 @@ from .model import DetectorM3D
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True):
         self.det = det
         self.cfg = det.cfg
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
@@ -35,9 +35,11 @@ class PRMEngine:
             self.layers.append(dict(name=cname, conv=conv, scale=scale, shift=shift, pool=pool, k=w.shape[2],
                                     norm_conv=ops.PackedConv3d(w, ops.W_RELU),
                                     dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU),
-                                    dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None, weight=w))
+                                    dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None,
+                                    dgrad_small=ops.SmallWindowDgrad(w) if (small_gemm and w.shape[2] == 3) else None, weight=w))
         w = P["RPN.RPN_conv.weight"]
-        self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU))
+        self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU),
+                        dgrad_small=ops.SmallWindowDgrad(w) if small_gemm else None)
         self.stem_wf = ops.prm_stem_prepare_weights(P["Conv_Body.conv1a.weight"])
         # stem step on the matrix cores with the un-pool/prepare fused (csrc/prm_stem_mfma.hip); fused_stem=False keeps the
         # two-kernel VALU path (prepare + m3d_prm_stem_dgrad), which the tests compare it with
@@ -75,7 +77,8 @@ class PRMEngine:
                 else:
                     xn, am = y, None
             saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
-                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], weight=L["weight"]))
+                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_small=L["dgrad_small"],
+                              weight=L["weight"]))
             if L["k"] == 5 and L["pool"] and self.fused_stem:
                 saved[-1]["den"] = ops.prm_den_pool(am[0], xn[0], n[0])          # peak-independent part of the prepare step
             x = xn
@@ -88,7 +91,7 @@ class PRMEngine:
             h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
         n = self.rpn["norm_conv"](feat, in_offset=off)
         saved.append(dict(x=feat[0], off=off, n=n[0], scale=None, pool=False, argmax=None, xnext=h[0], k=3,
-                          dgrad=self.rpn["dgrad"]))
+                          dgrad=self.rpn["dgrad"], dgrad_small=self.rpn["dgrad_small"]))
         off_h = ops.reduce_min(h)
         o = det.rpn_heads(h, shift=det.rpn_heads_bias)
         prob = torch.sigmoid(o[:, :det.A]).contiguous()
@@ -136,7 +139,11 @@ class PRMEngine:
             if strip:                            # F(2x2,3x3) over the whole strip; its PreHook multiply moves to the consumer
                 y = rec["dgrad_wino"](gn.unsqueeze(0))[0]
                 return dict(t=y, strip=True, P=wb["P"], C=cout, U=Wn, up_off=rec["off"]), origin
-            y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
+            small = rec.get("dgrad_small")
+            if small is not None and Wn in small.SIZES:      # 3^3 / 5^3 / 7^3: all peaks in one dense GEMM (csrc/prm_small.hip)
+                y = small(gn, rec["x"], rec["off"], origin)
+            else:
+                y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
             return dict(t=y, strip=False, P=wb["P"], C=cout, U=Wn, up_off=None), origin
 
         def take(wb, c0, c1):

@@ -73,8 +73,8 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     P = O.make_params(stride=stride, num_anchors=A, mlp_dim=64, seed=11)
     cfg = O.Cfg(mlp_dim=64, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=64)
     det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
-    plain = PRMEngine(det, fused_stem=False, strip_wino=False)          # prepare + direct MFMA dgrad + VALU stem everywhere
-    fused = PRMEngine(det, strip_wino=False)                            # + MFMA stem with the prepare step fused
+    plain = PRMEngine(det, fused_stem=False, strip_wino=False, small_gemm=False, wino_forward=False)   # round-1 path: prepare +
+    fused = PRMEngine(det, strip_wino=False)                            # direct MFMA dgrad + VALU stem.  fused: + MFMA stem, small GEMM
     strip = PRMEngine(det)                                              # + F(2x2,3x3) on the strip layout for windows >= 16^3
     mixed = PRMEngine(det, fused_stem=False)                            # strip layers feeding the VALU stem (layout hand-over)
     assert fused.fused_stem and not plain.fused_stem and strip.strip_wino and not fused.strip_wino
@@ -100,6 +100,35 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     w2, s2, o2 = chunked.backward_windows(pk, saved, top, data)
     w1, s1, o1 = strip.backward_windows(pk, saved, top, data)
     assert torch.equal(o2, o1) and np.allclose(w2.cpu().numpy(), w1.cpu().numpy(), rtol=1e-5, atol=1e-7 * b.max())
+
+
+@pytest.mark.parametrize("win,cout_f,cin_f,P", [(3, 64, 48, 37), (5, 40, 64, 11), (7, 24, 32, 5), (5, 6, 3, 1)])
+def test_small_window_gemm_equals_the_direct_windowed_kernel(win, cout_f, cin_f, P):
+    """csrc/prm_small.hip against m3d_conv3d_forward_windowed on dgrad-packed relu(W): same sums in another order."""
+    import m3d
+    g = torch.Generator().manual_seed(win * 100 + P)
+    w = torch.randn((cout_f, cin_f, 3, 3, 3), generator=g).cuda()
+    gn = torch.rand((P, cout_f, win, win, win), generator=g).cuda()
+    D, H, W = 9, 11, 13
+    full = torch.randn((cin_f, D, H, W), generator=g).cuda()
+    off = full.min().reshape(1)
+    origins = torch.stack([torch.randint(-win, D, (P,), generator=g), torch.randint(-win, H, (P,), generator=g),
+                           torch.randint(-win, W, (P,), generator=g)], 1).to(torch.int32).cuda()
+    ref = m3d.conv3d_windowed(m3d.PackedConv3d(w, m3d.W_DGRAD_RELU), gn, full, off, origins)
+    out = m3d.SmallWindowDgrad(w)(gn, full, off, origins)
+    assert out.shape == ref.shape
+    assert np.allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+    # fp64 spot check of one peak (dgrad of a zero-padded 'same' conv with relu(W), times (X - off) inside the volume)
+    gx = torch.nn.functional.conv_transpose3d(gn[:1].double().cpu(), torch.relu(w).double().cpu(), padding=1)[0]
+    o = origins[0].cpu().tolist()
+    exp = torch.zeros_like(gx)
+    for z in range(win):
+        for y in range(win):
+            for x in range(win):
+                q = (o[0] + z, o[1] + y, o[2] + x)
+                if 0 <= q[0] < D and 0 <= q[1] < H and 0 <= q[2] < W:
+                    exp[:, z, y, x] = gx[:, z, y, x] * (full[:, q[0], q[1], q[2]].double().cpu() - float(off))
+    assert np.allclose(out[0].cpu().numpy(), exp.numpy(), rtol=1e-4, atol=1e-5 * float(exp.abs().max()) + 1e-30)
 
 
 def test_infer_prm_tiles_quantised_maps_and_tree(tmp_path):
