@@ -34,6 +34,7 @@ constexpr int KGmap(int g) { return (g & 3) + 8 * (g >> 2); }      // accumulato
 struct FcArgs {
   const float* x; const float* w; const float* bias; float* out; float* part;
   int M, N, K, mt, nt, slices, chunks, relu;
+  int slices_tail;        // K slices of the ragged last row tile's units (its own count: they are shorter and fill the left-over slots)
   int mt_full;            // row tiles run by the full-tile path; mt - mt_full (0 or 1) ragged last tile runs the cheap tail path
   int full_per_xcd, tail_per_xcd;   // units of each kind given to one XCD (grid = 8 * (full_per_xcd + tail_per_xcd))
 };
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
   // neighbouring tiles: their x / W panels are shared through that XCD's L2) FOLLOWED by its share of the cheap ragged-tail units:
   // dispatched last, the short workgroups fill the slots that are left instead of pushing full tiles into a second round.
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int tiles_full = a.mt_full * a.nt, nfull = tiles_full * a.slices, ntail = (a.mt - a.mt_full) * a.nt * a.slices;
+  const int tiles_full = a.mt_full * a.nt, nfull = tiles_full * a.slices, ntail = (a.mt - a.mt_full) * a.nt * a.slices_tail;
   int slice, tile;
   if (idx < a.full_per_xcd) {
     const int u = xcd * a.full_per_xcd + idx;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
   }
   const int tm = tile / a.nt, tn = tile - tm * a.nt;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
+  const int nsl = tile >= tiles_full ? a.slices_tail : a.slices;
+  const int c0 = (int)((long long)slice * a.chunks / nsl), c1 = (int)((long long)(slice + 1) * a.chunks / nsl);
 
   // ---- staging: thread -> (row = tid/8 + 32 i, quad = tid%8), i = 0..3 for x and for W
   const int quad = tid & 7, row0 = tid >> 3;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
 
   const int full = a.K / BK;                                      // whole chunks in K
   const int c1f = min(c1, full);                                  // this slice's whole chunks are [c0, c1f)
-  const bool direct = a.slices == 1;
+  const bool direct = nsl == 1;
   float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
 
   // ---- ragged last row tile (M % 128 in 1..64): only nb = 1 or 2 of its four 32-row blocks hold rows, so the four waves split
@@ -249,18 +251,22 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
   }
 }
 
-// out[e] = act(bias[n] + sum_s part[s][e]), slices summed in index order (deterministic)
+// out[e] = act(bias[n] + sum_s part[s][e]), slices summed in index order (deterministic).  Rows below m_full were cut into
+// `slices` K ranges, the ragged last row tile into `slices_tail`; a part with one slice was stored directly (bias + act applied).
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                        float* __restrict__ out, long long MN, int N, int slices, int relu) {
+                                                        float* __restrict__ out, long long MN, int N, int slices, int slices_tail,
+                                                        long long full_elems /* m_full * N */, int relu) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long long)gridDim.x * 256) {
+    const int ns = e < full_elems ? slices : slices_tail;
+    if (ns == 1) continue;
     float v = part[e];
-    for (int s = 1; s < slices; ++s) v += part[(size_t)s * MN + e];
+    for (int s = 1; s < ns; ++s) v += part[(size_t)s * MN + e];
     if (bias) v += bias[(int)(e % N)];
     out[e] = relu ? fmaxf(v, 0.f) : v;
   }
 }
 
-struct Plan { int mt, nt, chunks, slices, mt_full, full_per_xcd, tail_per_xcd; };
+struct Plan { int mt, nt, chunks, slices, slices_tail, mt_full, full_per_xcd, tail_per_xcd; };
 
 Plan make_plan(int M, int N, int K) {
   Plan p;
@@ -270,20 +276,35 @@ Plan make_plan(int M, int N, int K) {
   const double tail_cost = rem_blocks == 1 ? 0.45 : 0.6;          // measured: the staging of 128 W rows per chunk does not shrink
   const double slots = 64.0;                                      // per XCD: 32 CUs x 2 resident workgroups
   const double flop = 2.0 * BM * BN * (double)K;                  // one full tile over all of K
-  double best = 1e30; int bs = 1;
-  for (int s = 1; s <= 64 && s <= p.chunks / 4 + 1; ++s) {
-    const double longs = ceil((double)p.mt_full * p.nt * s / 8.0), shorts = ceil((double)(p.mt - p.mt_full) * p.nt * s / 8.0);
-    double rounds = ceil(longs / slots);                            // full-tile rounds; the short tail workgroups use what is left
-    const double spare = rounds * slots - longs;
-    if (shorts > spare) rounds += tail_cost * ceil((shorts - spare) / slots);
-    double t = rounds * flop / s / (1.25e14 / 512.0) + ceil(rounds) * 4e-6;   // a workgroup's time at ~80 % of the per-slot MFMA rate
+  const double rate = 1.25e14 / 512.0;                            // a workgroup's share of ~80 % of the MFMA rate
+  const int ntail_tiles = (p.mt - p.mt_full) * p.nt;
+  const int smax = p.chunks / 4 + 1 < 64 ? p.chunks / 4 + 1 : 64;
+  double best = 1e30; int bs = 1, bt = 1;
+  // The full tiles choose the slice count as if they were alone.  The ragged last row tile gets its OWN count: its units are
+  // staging-bound (0.45 / 0.6 of a full unit per chunk), so they are cut fine enough to be no longer than a full unit and, when
+  // the slots the full units leave free allow it, so that everything is resident at once - M = 1281: 80 x 6 + 8 x 4 = the 512
+  // slots, 1.82 ms; one common count (5: 440 units) left 14 % of the slots idle: 1.88 ms, and 6 + 6 = 528 units 2.2 ms
+  // (tools/sweep_fc_tail.py).
+  const int nlong = p.mt_full ? p.mt_full * p.nt : ntail_tiles;    // no full tile at all: the tail tiles are the whole problem
+  for (int s = 1; s <= smax; ++s) {
+    const double longs = ceil((double)nlong * s / 8.0), rounds = ceil(longs / slots);
+    double t = rounds * (p.mt_full ? 1.0 : tail_cost) * flop / s / rate + rounds * 4e-6;
     if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;          // partial write + read, reduce launch
     if (t < best) { best = t; bs = s; }
   }
-  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) bs = ts < p.chunks ? ts : p.chunks;   // A/B tooling only
-  p.slices = bs;
+  bt = bs;
+  if (p.mt_full && ntail_tiles) {
+    const double longs = ceil((double)nlong * bs / 8.0);
+    const int spare = (int)(ceil(longs / slots) * slots - longs);
+    const int need = (int)ceil(tail_cost * bs), fit = spare * 8 / ntail_tiles;
+    bt = fit >= need ? (fit < 2 * bs ? fit : 2 * bs) : 2 * bs;
+    bt = bt < 1 ? 1 : (bt > smax ? smax : bt);
+  }
+  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) bs = bt = ts < p.chunks ? ts : p.chunks;   // A/B tooling only
+  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES_TAIL); ts > 0) bt = ts < p.chunks ? ts : p.chunks;
+  p.slices = bs; p.slices_tail = ntail_tiles ? bt : 1;
   p.full_per_xcd = (p.mt_full * p.nt * bs + 7) / 8;
-  p.tail_per_xcd = ((p.mt - p.mt_full) * p.nt * bs + 7) / 8;
+  p.tail_per_xcd = (ntail_tiles * p.slices_tail + 7) / 8;
   return p;
 }
 
@@ -292,7 +313,8 @@ Plan make_plan(int M, int N, int K) {
 M3D_API size_t m3d_linear_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const Plan p = make_plan(M, N, K);
-  return p.slices > 1 ? (size_t)p.slices * M * N * sizeof(float) : 16;
+  const int sm = p.slices > p.slices_tail ? p.slices : p.slices_tail;
+  return sm > 1 ? (size_t)sm * M * N * sizeof(float) : 16;
 }
 
 M3D_API int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
@@ -302,19 +324,20 @@ M3D_API int m3d_linear_forward(const float* d_x, const float* d_weight, const fl
   if (!d_x || !d_weight || !d_out) return M3D_EINVAL;
   if (K % 4 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_weight & 15)) return M3D_EUNSUPPORTED;   // 16-byte row quads
   const Plan p = make_plan(M, N, K);
-  if (p.slices > 1 && (!d_ws || ws_bytes < (size_t)p.slices * M * N * sizeof(float))) return M3D_EWORKSPACE;
-  FcArgs a{d_x, d_weight, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, p.slices, p.chunks, relu, p.mt_full, p.full_per_xcd,
-           p.tail_per_xcd};
+  const int sm = p.slices > p.slices_tail ? p.slices : p.slices_tail;
+  if (sm > 1 && (!d_ws || ws_bytes < (size_t)sm * M * N * sizeof(float))) return M3D_EWORKSPACE;
+  FcArgs a{d_x, d_weight, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, p.slices, p.chunks, relu, p.slices_tail, p.mt_full,
+           p.full_per_xcd, p.tail_per_xcd};
   const size_t lds = sizeof(float) * 2 * kStageFloats;
   hipStream_t st = m3d::as_stream(stream);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(fc_gemm_kernel, dim3(8 * (p.full_per_xcd + p.tail_per_xcd)), dim3(256), lds, st, a);
-  if (p.slices > 1) {
+  if (sm > 1) {
     const long long MN = (long long)M * N;
     long long blocks = (MN + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, p.slices,
-                       relu);
+                       p.slices_tail, (long long)(p.mt_full < p.mt ? p.mt_full * BM : M) * N, relu);
   }
   return m3d::check_launch("linear_forward");
 }

@@ -55,7 +55,8 @@ def lib():
         # The library itself never reads the environment (include/m3d.h); this loader - the caller - forwards the
         # A/B-tooling knobs of tools/*.py once, at load time.
         for env, name in (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
-                          ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices")):
+                          ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
+                          ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail")):
             if env in os.environ:
                 set_option(name, int(os.environ[env]))
     return _lib
