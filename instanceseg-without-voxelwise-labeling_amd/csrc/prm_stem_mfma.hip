@@ -119,6 +119,15 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   const int oz = 2 * uz0 - 2, oy = 2 * uy0 - 2, ox = 2 * ux0 - 2;     // origin of the output window in data coordinates
   if (slab == 0 && tid == 0) { q.origins_out[3 * p] = oz; q.origins_out[3 * p + 1] = oy; q.origins_out[3 * p + 2] = ox; }
 
+  // A slab whose output planes all lie outside the volume is zero (the PreHook factor is zero there): nothing to compute.  The
+  // nuclei tile is 64 planes deep against 84-plane windows, so about a quarter of the slabs go this way.
+  if (oz + z0 >= q.D || oz + z0 + TZ <= 0) {
+    const int zend = z0 + TZ < Wn ? z0 + TZ : Wn;
+    const size_t base = ((size_t)p * Wn + z0) * Wn * Wn, cnt = (size_t)(zend - z0) * Wn * Wn;
+    for (size_t e = (size_t)tid * 4; e < cnt; e += (size_t)kNT * 4)
+      *reinterpret_cast<float4*>(q.out + base + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   if (r == 0) {
     for (int e = l; e < 25 * ZWn; e += 64) tq[e] = 0.f;               // the never-written borders of the shifted rows stay zero
     for (int e = l; e < 5 * ZWn; e += 64) roll[e] = 0.f;
@@ -358,12 +367,13 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     const int ch = g & 7, by = g >> 3;
     const float* tile = sm + (g & 1) * BUF;
     float* next = sm + ((g + 1) & 1) * BUF;
+    const bool row_in = (uy0 + by >= 0) & (uy0 + by < q.UH);            // a coarse row outside the map stages zeros: skip its MFMAs
     if (g + 1 < steps) fetch_a(g + 1);
     if (r == 0) {
       if (ch == 0) zero_acc();
       if (g + 1 < steps) fetch(g + 1);
       if (ch == 7) prefetch_data(2 * by);
-      mfma_step(tile);
+      if (row_in) mfma_step(tile);
       if (!(STEM_EXP & 1) && ch == 7) fold(2 * by);
       if (g + 1 < steps) commit(next);
     } else {
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
       if (g + 1 < steps) commit(next);
       if (g + 2 < steps) fetch(g + 2);
       if (ch == 7) prefetch_data(2 * by + 1);
-      mfma_step(tile);
+      if (row_in) mfma_step(tile);
     }
 #pragma unroll
     for (int s = 0; s < 10; ++s) a_cur[s] = a_next[s];
