@@ -168,10 +168,23 @@ def run_dry(args, rank, world, dist):
 
 
 # ------------------------------------------------------------------------------------------------ PRM workloads
+def cone_limited_gflop_per_peak(stride):
+    """Algorithmic FLOPs of one peak's back-propagation when every layer only computes its receptive-field window:
+    window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per voxel."""
+    if stride == 8:
+        L = [(256, 256, 3, 3), (256, 256, 3, 5), (256, 128, 3, 7), (128, 128, 3, 16), (128, 64, 3, 18), (64, 64, 3, 38), (64, 32, 3, 40),
+             (32, 1, 5, 84)]
+    else:
+        L = [(128, 128, 3, 3), (128, 128, 3, 5), (128, 64, 3, 7), (64, 64, 3, 16), (64, 32, 3, 18), (32, 1, 5, 40)]
+    return sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n in L) / 1e9
+
+
 def bench_prm(args, rank, world, dist):
-    """configs[3]: PRM_ON soma tile 1x64x160x160: forward (2 convs per layer) + batched peak back-propagation."""
+    """configs[3]: PRM_ON soma tile 1x64x160x160: forward (2 convs per layer) + batched peak back-propagation + per-detection
+    Otsu binarisation down to instance labels."""
     import numpy as np
     import torch
+    import m3d
     from m3d.model import DetectorM3D
     from m3d.prm import PRMEngine
     from m3d.config import Cfg
@@ -183,25 +196,52 @@ def bench_prm(args, rank, world, dist):
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
     S, H, W = cfg.in_size
     vol = torch.from_numpy(tiling.norm1(synth_volume(rank, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
-    npk = []
+    from m3d import binarize
+    raw = torch.from_numpy(synth_volume(rank, (S, H, W)).astype(np.uint16)).cuda()
+    mode = "nuclei" if nuclei else "soma"
+    npk, nlab = [], []
 
     def step():
+        """one tile: PRM forward + box head + peak back-propagation -> uint8 quantisation (from the windows; no dense float maps) -> per-detection crop +
+        normalisation -> 2D-Otsu -> largest component (+ hole fill / closing) -> instance labels (binarization_*.py loop body)"""
         out = eng.prm_tile(vol, dense=False)
         npk.append(0 if out is None else int(out["peaks"].shape[0]))
+        if out is not None:
+            labels, painted = binarize.segment_tile(raw, (out["windows"], out["sums"], out["origins"]), out["dets"], mode=mode)
+            nlab.append(painted)
     dt = timed_loop(step, args.steps, args.warmup, dist, torch.cuda.synchronize)
     dt = sync_max_time(dt, dist, "cuda")
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    e[0].record(); eng.forward(vol); e[1].record(); torch.cuda.synchronize()
-    fwd_ms = e[0].elapsed_time(e[1])
+    ev = lambda: torch.cuda.Event(enable_timing=True)     # noqa: E731
+    e = [ev() for _ in range(6)]
+    e[0].record(); eng.forward(vol); e[1].record()
+    out = eng.prm_tile(vol, dense=False); e[2].record()
+    e[3].record()
+    q = m3d.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], (S, H, W))
+    boxes = binarize.det_boxes_int(out["dets"].cpu().numpy(), (S, H, W), mode)
+    torch.cuda.synchronize()
+    e[4].record(); r = binarize._tile_instance_masks(raw, q, boxes, mode, 8192); e[5].record(); torch.cuda.synchronize()
+    fwd_ms, prm_ms, otsu_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[4].elapsed_time(e[5])
+    nroi = 0 if r is None else int(r[3].numel())
+    # cone-limited algorithmic work of the back-propagation (SURVEY 8a-12): receptive-field windows per layer, dgrad with relu(W)
+    cone = cone_limited_gflop_per_peak(cfg.stride)
     if rank == 0:
         print(json.dumps({"metric": "voxels/sec end-to-end infer_simple (PRM_ON tile)", "value": world * args.steps * S * H * W / dt,
                           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation%s" %
+                          "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation + per-detection 2D-Otsu -> instance labels%s" %
                                                  (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
                                                   "" if nuclei else " [configs[3]]")), "peaks_per_tile": npk[-1],
-                                     "prm_forward_ms": fwd_ms}}))
+                                     "prm_forward_ms": fwd_ms, "prm_tile_ms": prm_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0},
+                          "roofline": {"bound": "mfma", "kernel": "peak back-propagation (all window convs + stem), cone-limited algorithmic FLOPs",
+                                       "achieved": npk[-1] * cone / max(prm_ms - fwd_ms, 1e-6), "peak": 157.3, "unit": "TFLOP/s",
+                                       "frac": npk[-1] * cone / max(prm_ms - fwd_ms, 1e-6) / 157.3,
+                                       "cone_limited_gflop_per_peak": cone, "backward_ms": prm_ms - fwd_ms,
+                                       "note": "backward_ms also holds proposals, RoIAlign and the box head of the tile; Winograd issues 4/9 "
+                                               "of the 3^3 window convs' multiplies, so this is an algorithmic-equivalent figure"},
+                          "otsu": {"rois": nroi, "ms": otsu_ms, "rois_per_s": nroi / otsu_ms * 1e3 if otsu_ms > 0 else None,
+                                   "what": "crop + normalise + 2D-Otsu + largest component%s for the tile's detections" %
+                                           (" + hole fill + 6-closing" if nuclei else "")}}))
 
 
 # ------------------------------------------------------------------------------------------------ detect / backbone

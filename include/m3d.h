@@ -375,6 +375,18 @@ int m3d_roi_normalize(const uint16_t* d_image, const uint8_t* d_prm_u8, const in
                       const int64_t* d_offsets, int num_rois, int depth, int height, int width, int mode,
                       uint16_t* d_out_image, uint16_t* d_out_prm, void* stream);
 
+/* Round 2: element-parallel forms of the two functions above, results identical.
+ *   m3d_prm_quantize_windows_u8  the uint8 maps straight from the cone-cropped windows the back-propagation returns (d_windows
+ *       [P, win^3] un-normalised, d_sums [P], d_origins int32 [P,3]): equals m3d_prm_quantize_u8 of the maps m3d_prm_scatter would
+ *       build, without ever materialising them (tools/infer_simple.py:233-238).  d_ws: 16 * num_peaks bytes.
+ *   m3d_roi_normalize_ws         m3d_roi_normalize over a (chunks, RoI) grid; total_voxels = d_offsets[num_rois];
+ *       d_ws: 24 * num_rois bytes. */
+int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
+                                int depth, int height, int width, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
+int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,
+                         int num_rois, int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
+                         uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Per-RoI 2D-Otsu binarisation.  Replaces otsu.otsu_py_2d_fast (tools/otsu.py:199-284) for uint16 inputs
  * (the callers normalise to uint16: tools/binarization_soma.py:85-91, binarization_nuclei.py:110-121).

@@ -31,7 +31,7 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
     ok = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
          (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
-    q = ops.prm_quantize_u8(prms)                                           # what the reference reads back from its TIFFs
+    q = _quantised(prms, (S, H, W))                                         # what the reference reads back from its TIFFs
     idx = np.nonzero(ok)[0]
     out = [(boxes[i], None, 0, 0) for i in range(len(boxes))]
     if len(idx) == 0:
@@ -75,22 +75,30 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range):
     return cc, offs, bsel, idx_t, (st_otsu == 0) & (st_cc == 0) & nonempty
 
 
+def _quantised(prms, shape):
+    """uint8 maps from dense float maps [P,S,H,W], or straight from the back-propagation's cone-cropped windows when `prms` is the
+    triple (windows, sums, origins) of PRMEngine.prm_tile(dense=False) - the dense float maps are then never built."""
+    if isinstance(prms, (tuple, list)):
+        return ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape)
+    return ops.prm_quantize_u8(prms)
+
+
 def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_id=1):
     """The reference's per-detection loop body for one tile, entirely on device.
-    image_u16 [S,H,W] uint16 CUDA, prms float32 [P,S,H,W] CUDA, dets [P,7] in tile coordinates, ALREADY in the
+    image_u16 [S,H,W] uint16 CUDA, prms float32 [P,S,H,W] CUDA (or the (windows, sums, origins) triple), dets [P,7] in tile coordinates, ALREADY in the
     order the reference loops over them (soma: NMS-kept, score-descending, binarization_soma.py:56-61; nuclei: NMS
     order filtered by score > 0.4, binarization_nuclei.py:80-86).  Detection d gets mask id first_id + d whether or not
     it ends up painted (mask_id is incremented before the `continue`, binarization_soma.py:66).
     Returns (labels int32 [S,H,W] CUDA, painted bool [P] CUDA): labels holds, per voxel, the id of the first
     detection whose final mask covers it; painted[d] says whether id d occurs at all (`mask_id in np.unique(seg)`)."""
     S, H, W = image_u16.shape
-    P = int(prms.shape[0])
+    P = int((prms[0] if isinstance(prms, (tuple, list)) else prms).shape[0])
     dev = image_u16.device
     painted = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P == 0:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
-    r = _tile_instance_masks(image_u16, ops.prm_quantize_u8(prms), boxes, mode, max_gray_range)
+    r = _tile_instance_masks(image_u16, _quantised(prms, (S, H, W)), boxes, mode, max_gray_range)
     if r is None:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     cc, offs, bsel, idx_t, ok = r

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "linear",
-           "otsu2d_batch", "prm_quantize_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -567,6 +567,20 @@ def prm_quantize_u8(prms):
     return out
 
 
+def prm_quantize_windows_u8(windows, sums, origins, shape):
+    """The uint8 maps of prm_quantize_u8(prm_scatter(windows, sums, origins, shape)) without the dense float maps: windows
+    float32 [P,Wn,Wn,Wn] (un-normalised, clamped), sums [P], origins int32 [P,3], shape = (D,H,W) -> uint8 [P,D,H,W]."""
+    _need_gpu(windows, sums, origins)
+    windows = _f32c(windows)
+    P, Wn = windows.shape[0], windows.shape[1]
+    D, H, W = (int(v) for v in shape)
+    out = torch.empty((P, D, H, W), dtype=torch.uint8, device=windows.device)
+    ws = torch.empty((max(16 * P, 16),), dtype=torch.uint8, device=windows.device)
+    check(lib().m3d_prm_quantize_windows_u8(_ptr(windows), _ptr(_f32c(sums)), _ptr(origins.contiguous()), P, Wn, D, H, W, _ptr(out),
+                                            _ptr(ws), C.c_size_t(ws.numel()), _stream()), "prm_quantize_windows_u8")
+    return out
+
+
 def roi_normalize(image_u16, prm_u8, boxes, mode):
     """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
     Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch."""
@@ -581,8 +595,12 @@ def roi_normalize(image_u16, prm_u8, boxes, mode):
     total = int(offs[-1]) if R else 0
     oi = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
     op = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
-    check(lib().m3d_roi_normalize(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
-                                  R, D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _stream()), "roi_normalize")
+    if R == 0:
+        return oi, op, offs
+    ws = torch.empty((24 * R,), dtype=torch.uint8, device=image_u16.device)
+    check(lib().m3d_roi_normalize_ws(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
+                                     R, C.c_int64(total), D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _ptr(ws),
+                                     C.c_size_t(ws.numel()), _stream()), "roi_normalize")
     return oi, op, offs
 
 

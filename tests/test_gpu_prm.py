@@ -250,3 +250,23 @@ def test_detection_drivers_have_the_reference_shapes():
     assert abs(len(cls_boxes[1]) - len(want)) <= max(2, len(want) // 20)
     matched = sum(np.abs(want - g).max(1).min() < 1e-2 for g in cls_boxes[1])
     assert matched >= 0.95 * len(cls_boxes[1])
+
+
+def test_quantised_maps_from_windows_equal_the_dense_route():
+    """m3d_prm_quantize_windows_u8 == m3d_prm_quantize_u8(m3d_prm_scatter(...)), bit for bit (windows inside, across and covering
+    the whole tile; infer_simple.py:233-238)."""
+    import m3d
+    g = torch.Generator().manual_seed(7)
+    for (D, H, W), Wn in (((20, 30, 26), 12), ((8, 9, 10), 12), ((16, 16, 16), 8)):
+        P = 6
+        win = (torch.rand((P, Wn, Wn, Wn), generator=g) * (torch.rand((P, Wn, Wn, Wn), generator=g) > 0.3)).cuda()
+        org = torch.stack([torch.randint(-Wn + 2, D - 1, (P,), generator=g), torch.randint(-Wn + 2, H - 1, (P,), generator=g),
+                           torch.randint(-Wn + 2, W - 1, (P,), generator=g)], 1).to(torch.int32)
+        org[0] = torch.tensor([-1, -1, -1])                               # (8,9,10) tile: this window covers the whole tile
+        org = org.cuda()
+        win[0] += 0.25                                                     # ... and has a non-zero minimum there
+        sums = win.reshape(P, -1).sum(1)
+        dense = m3d.prm_scatter(win, sums, org, (D, H, W))
+        ref = m3d.prm_quantize_u8(dense)
+        out = m3d.prm_quantize_windows_u8(win, sums, org, (D, H, W))
+        assert torch.equal(out, ref), (D, H, W, Wn)
