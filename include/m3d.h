@@ -378,7 +378,8 @@ int m3d_roi_normalize(const uint16_t* d_image, const uint8_t* d_prm_u8, const in
 /* Round 2: element-parallel forms of the two functions above, results identical.
  *   m3d_prm_quantize_windows_u8  the uint8 maps straight from the cone-cropped windows the back-propagation returns (d_windows
  *       [P, win^3] un-normalised, d_sums [P], d_origins int32 [P,3]): equals m3d_prm_quantize_u8 of the maps m3d_prm_scatter would
- *       build, without ever materialising them (tools/infer_simple.py:233-238).  d_ws: 16 * num_peaks bytes.
+ *       build, without ever materialising them (tools/infer_simple.py:233-238).  d_ws: 16 * num_peaks bytes; on return
+ *       int32 word 3 of each 16-byte record is 1 when the peak's uint8 map has a non-zero voxel.
  *   m3d_roi_normalize_ws         m3d_roi_normalize over a (chunks, RoI) grid; total_voxels = d_offsets[num_rois];
  *       d_ws: 24 * num_rois bytes. */
 int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,

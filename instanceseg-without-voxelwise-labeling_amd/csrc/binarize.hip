@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void winq_stats_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict__ win, const float* __restrict__ sums,
                                                          const int* __restrict__ origins, int Wn, int D, int H, int W,
-                                                         const WinQ* __restrict__ st, uint8_t* __restrict__ out) {
+                                                         WinQ* __restrict__ st, uint8_t* __restrict__ out) {
   const int p = blockIdx.y, w3 = Wn * Wn * Wn;
   const int oz = origins[3 * p], oy = origins[3 * p + 1], ox = origins[3 * p + 2];
   const float sum = sums[p];
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict
   const float mx = __uint_as_float(s.fmax_bits) - mn;                // max(fm - min)
   const float* wp = win + (size_t)p * w3;
   uint8_t* o = out + (size_t)p * D * H * W;
+  int any = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
     const int x = e % Wn, y = (e / Wn) % Wn, z = e / (Wn * Wn);
     const int qz = oz + z, qy = oy + y, qx = ox + x;
@@ -164,9 +165,12 @@ __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict
       v = v - mn;
       v = v / mx;
       v = v * 255.f;
-      o[((size_t)qz * H + qy) * W + qx] = (uint8_t)v;
+      const uint8_t u = (uint8_t)v;
+      o[((size_t)qz * H + qy) * W + qx] = u;
+      any |= u;
     }
   }
+  if (__ballot(any != 0) && (threadIdx.x & 63) == 0) atomicOr(&st[p].pad, 1);      // the map is not all zero (binarization_soma.py:74-76)
 }
 
 struct RoiStat { int gmax, gmin, pmax, pmin, g2max, g2min; };
@@ -313,7 +317,7 @@ M3D_API int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_s
   hipLaunchKernelGGL(winq_stats_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q);
   hipLaunchKernelGGL(winq_apply_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
-                     width, (const WinQ*)q, d_out);
+                     width, q, d_out);
   return m3d::check_launch("prm_quantize_windows_u8");
 }
 

@@ -40,9 +40,19 @@ __device__ inline int uf_find(const int* parent, int x) {
   while ((p = parent[x]) != x) x = p;
   return x;
 }
+// find with path halving: parents only ever move towards the root, so the unsynchronised shortcut stores are benign
+__device__ inline int uf_find_halve(int* parent, int x) {
+  while (true) {
+    const int p = parent[x];
+    if (p == x) return x;
+    const int gp = parent[p];
+    if (gp != p) parent[x] = gp;
+    x = p;
+  }
+}
 __device__ inline void uf_union(int* parent, int a, int b) {
   while (true) {
-    a = uf_find(parent, a); b = uf_find(parent, b);
+    a = uf_find_halve(parent, a); b = uf_find_halve(parent, b);
     if (a == b) return;
     if (a < b) { const int t = a; a = b; b = t; }      // a > b: hang root a under b
     const int old = atomicMin(&parent[a], b);
@@ -59,7 +69,8 @@ __global__ __launch_bounds__(kT) void cc_init_kernel(CcArgs a) {
   const uint8_t* m = a.mask + q.beg;
   for (int v = blockIdx.x * kT + threadIdx.x; v < q.V; v += gridDim.x * kT) {
     const bool fg = (m[v] != 0) != (a.invert != 0);
-    a.parent[q.beg + v] = fg ? v : -1;
+    const bool left = fg && (v % q.ex) > 0 && ((m[v - 1] != 0) != (a.invert != 0));
+    a.parent[q.beg + v] = fg ? (left ? v - 1 : v) : -1;                 // x runs start out linked: no atomics for the commonest merge
     a.counts[q.beg + v] = 0;
   }
 }
@@ -69,28 +80,39 @@ __global__ __launch_bounds__(kT) void cc_union_kernel(CcArgs a) {
   const RoiView q = roi_view(a.offsets, a.dims, r);
   if (!q.ok) return;
   int* parent = a.parent + q.beg;
+  const uint8_t* m = a.mask + q.beg;
+  const bool inv = a.invert != 0;
   const int sy = q.ex, sz = q.ex * q.ey;
+  auto fg = [&](int n) __attribute__((always_inline)) { return (m[n] != 0) != inv; };
   for (int v = blockIdx.x * kT + threadIdx.x; v < q.V; v += gridDim.x * kT) {
-    if (parent[v] < 0) continue;
+    if (!fg(v)) continue;
     const int x = v % q.ex, y = (v / q.ex) % q.ey, z = v / sz;
-    // the 13 neighbours that precede v in raster order (26-connectivity)
-    if (x > 0 && parent[v - 1] >= 0) uf_union(parent, v, v - 1);
+    const bool xl = x > 0, xr = x + 1 < q.ex;
+    // Of the 13 neighbours that precede v in raster order (26-connectivity) only one per group that is connected WITHOUT v needs a
+    // union: a row's centre voxel is x-adjacent to both its sides (runs are linked by cc_init_kernel), the centre of the previous
+    // plane's 3x3 block is adjacent to all eight others.  Foreground tests read the mask bytes, not the parent words.
+    // same plane, previous row
     if (y > 0) {
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = x + dx;
-        if (xx >= 0 && xx < q.ex && parent[v - sy + dx] >= 0) uf_union(parent, v, v - sy + dx);
+      const int c = v - sy;
+      if (fg(c)) uf_union(parent, v, c);
+      else {
+        if (xl && fg(c - 1) && !fg(v - 1)) uf_union(parent, v, c - 1);          // with v-1 set, v-1's own centre is c-1
+        if (xr && fg(c + 1)) uf_union(parent, v, c + 1);
       }
     }
     if (z > 0) {
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= q.ey) continue;
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int xx = x + dx;
-          const int n = v - sz + dy * sy + dx;
-          if (xx >= 0 && xx < q.ex && parent[n] >= 0) uf_union(parent, v, n);
+      const int cc = v - sz;
+      if (fg(cc)) uf_union(parent, v, cc);
+      else {
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int yy = y + dy;
+          if (yy < 0 || yy >= q.ey) continue;
+          const int c = cc + dy * sy;
+          if (dy != 0 && fg(c)) uf_union(parent, v, c);
+          else {
+            if (xl && fg(c - 1)) uf_union(parent, v, c - 1);
+            if (xr && fg(c + 1)) uf_union(parent, v, c + 1);
+          }
         }
       }
     }
@@ -108,7 +130,7 @@ __global__ __launch_bounds__(kT) void cc_count_kernel(CcArgs a) {
     const int v = (it * gridDim.x + blockIdx.x) * kT + threadIdx.x;
     int root = -1;
     if (v < q.V && parent[v] >= 0) {
-      root = uf_find(parent, v);
+      root = uf_find_halve(parent, v);
       parent[v] = root;                                                      // flatten: cc_write_kernel's find is one step
     }
     // one atomic per distinct root of the wave instead of one per voxel: the inverted (hole-filling) pass has ONE huge

@@ -31,7 +31,7 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
     ok = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
          (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
-    q = _quantised(prms, (S, H, W))                                         # what the reference reads back from its TIFFs
+    q, _ = _quantised(prms, (S, H, W))                                      # what the reference reads back from its TIFFs
     idx = np.nonzero(ok)[0]
     out = [(boxes[i], None, 0, 0) for i in range(len(boxes))]
     if len(idx) == 0:
@@ -49,7 +49,7 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     return out
 
 
-def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range):
+def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all=None):
     """Device pipeline for the detections of one tile: crop + normalise -> 2D-Otsu -> largest 26-connected component
     (-> hole fill -> 6-closing for nuclei).  image_u16 [S,H,W] CUDA, q uint8 [P,S,H,W] CUDA (quantised PRMs),
     boxes int32 ndarray [P,6] inclusive tile coordinates.  Returns (masks uint8 flat, offsets, boxes CUDA int32 [n,6],
@@ -63,7 +63,7 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range):
         return None
     idx_t = torch.from_numpy(idx).to(dev)
     bsel = torch.from_numpy(boxes[idx]).to(dev)
-    qs = q[idx_t].contiguous()
+    qs = q if len(idx) == q.shape[0] else q[idx_t].contiguous()          # every detection has a valid crop: no 200 MB gather
     oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode)
     mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
     dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
@@ -71,7 +71,7 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range):
     if mode == "nuclei":
         cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
         cc = ops.binary_closing6_batch(cc, offs, dims)
-    nonempty = qs.reshape(len(idx), -1).amax(1) > 0                                       # binarization_soma.py:74-76
+    nonempty = nonempty_all[idx_t] if nonempty_all is not None else qs.reshape(len(idx), -1).amax(1) > 0   # binarization_soma.py:74-76
     return cc, offs, bsel, idx_t, (st_otsu == 0) & (st_cc == 0) & nonempty
 
 
@@ -79,8 +79,8 @@ def _quantised(prms, shape):
     """uint8 maps from dense float maps [P,S,H,W], or straight from the back-propagation's cone-cropped windows when `prms` is the
     triple (windows, sums, origins) of PRMEngine.prm_tile(dense=False) - the dense float maps are then never built."""
     if isinstance(prms, (tuple, list)):
-        return ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape)
-    return ops.prm_quantize_u8(prms)
+        return ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
+    return ops.prm_quantize_u8(prms), None
 
 
 def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_id=1):
@@ -98,7 +98,8 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     if P == 0:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
-    r = _tile_instance_masks(image_u16, _quantised(prms, (S, H, W)), boxes, mode, max_gray_range)
+    q, nonempty = _quantised(prms, (S, H, W))
+    r = _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty)
     if r is None:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     cc, offs, bsel, idx_t, ok = r

@@ -567,9 +567,10 @@ def prm_quantize_u8(prms):
     return out
 
 
-def prm_quantize_windows_u8(windows, sums, origins, shape):
+def prm_quantize_windows_u8(windows, sums, origins, shape, return_nonempty=False):
     """The uint8 maps of prm_quantize_u8(prm_scatter(windows, sums, origins, shape)) without the dense float maps: windows
-    float32 [P,Wn,Wn,Wn] (un-normalised, clamped), sums [P], origins int32 [P,3], shape = (D,H,W) -> uint8 [P,D,H,W]."""
+    float32 [P,Wn,Wn,Wn] (un-normalised, clamped), sums [P], origins int32 [P,3], shape = (D,H,W) -> uint8 [P,D,H,W]
+    (+ bool [P]: the map has a non-zero voxel)."""
     _need_gpu(windows, sums, origins)
     windows = _f32c(windows)
     P, Wn = windows.shape[0], windows.shape[1]
@@ -578,6 +579,8 @@ def prm_quantize_windows_u8(windows, sums, origins, shape):
     ws = torch.empty((max(16 * P, 16),), dtype=torch.uint8, device=windows.device)
     check(lib().m3d_prm_quantize_windows_u8(_ptr(windows), _ptr(_f32c(sums)), _ptr(origins.contiguous()), P, Wn, D, H, W, _ptr(out),
                                             _ptr(ws), C.c_size_t(ws.numel()), _stream()), "prm_quantize_windows_u8")
+    if return_nonempty:
+        return out, ws[:16 * P].view(torch.int32).view(P, 4)[:, 3] != 0
     return out
 
 

@@ -270,3 +270,24 @@ def test_quantised_maps_from_windows_equal_the_dense_route():
         ref = m3d.prm_quantize_u8(dense)
         out = m3d.prm_quantize_windows_u8(win, sums, org, (D, H, W))
         assert torch.equal(out, ref), (D, H, W, Wn)
+
+
+def test_segment_tile_from_windows_equals_the_dense_route():
+    """binarize.segment_tile fed with the (windows, sums, origins) triple == fed with the dense maps (labels and painted flags)."""
+    import m3d
+    from m3d import binarize
+    g = torch.Generator().manual_seed(3)
+    D, H, W, Wn, P = 24, 40, 36, 16, 5
+    img = torch.randint(50, 4000, (D, H, W), generator=g).to(torch.uint16).cuda()
+    win = torch.rand((P, Wn, Wn, Wn), generator=g).cuda()
+    win[4] = 0.0                                                           # an empty map: skipped (binarization_soma.py:74-76)
+    org = torch.tensor([[2, 3, 4], [-5, 10, 20], [10, 30, 25], [6, 6, 6], [1, 1, 1]], dtype=torch.int32).cuda()
+    sums = win.reshape(P, -1).sum(1).clamp(min=1e-6)
+    dets = torch.tensor([[6, 5, 4, 17, 16, 15, 0.9], [22, 12, 0, 33, 22, 9, 0.8], [27, 32, 12, 35, 39, 22, 0.7],
+                         [8, 8, 8, 19, 19, 19, 0.6], [3, 3, 3, 12, 12, 12, 0.5]], dtype=torch.float64)
+    dense = m3d.prm_scatter(win, sums, org, (D, H, W))
+    for mode in ("soma", "nuclei"):
+        l0, p0 = binarize.segment_tile(img, dense, dets, mode=mode)
+        l1, p1 = binarize.segment_tile(img, (win, sums, org), dets, mode=mode)
+        assert torch.equal(l0, l1) and torch.equal(p0, p1), mode
+        assert not bool(p1[4])
