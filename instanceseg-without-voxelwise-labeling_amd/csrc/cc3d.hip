@@ -67,11 +67,26 @@ __global__ __launch_bounds__(kT) void cc_init_kernel(CcArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.key[r] = 0ull; if (!q.ok && a.status) a.status[r] = 2; }
   if (!q.ok) return;
   const uint8_t* m = a.mask + q.beg;
-  for (int v = blockIdx.x * kT + threadIdx.x; v < q.V; v += gridDim.x * kT) {
-    const bool fg = (m[v] != 0) != (a.invert != 0);
-    const bool left = fg && (v % q.ex) > 0 && ((m[v - 1] != 0) != (a.invert != 0));
-    a.parent[q.beg + v] = fg ? (left ? v - 1 : v) : -1;                 // x runs start out linked: no atomics for the commonest merge
-    a.counts[q.beg + v] = 0;
+  const bool inv = a.invert != 0;
+  const int lane = threadIdx.x & 63;
+  const int nloop = (q.V + gridDim.x * kT - 1) / (gridDim.x * kT);           // same trip count for the whole wave (ballots below)
+  for (int it = 0; it < nloop; ++it) {
+    const int v = (it * gridDim.x + blockIdx.x) * kT + threadIdx.x;         // a wave holds 64 consecutive voxels
+    const bool in = v < q.V;
+    const bool fg = in && ((m[v] != 0) != inv);
+    const int x = in ? v % q.ex : 0;
+    // x runs start out linked WITHOUT atomics and almost flat: every voxel points at the first voxel of its run inside the wave;
+    // a run that continues from the previous wave points one voxel to the left of the wave (whose parent is that run's start there)
+    const unsigned long long fgm = __ballot(fg);
+    const bool left = lane ? ((fgm >> (lane - 1)) & 1ull) != 0 : (fg && x > 0 && ((m[v - 1] != 0) != inv));
+    const bool start = fg && (x == 0 || !left);
+    const unsigned long long below = __ballot(start) & ((2ull << lane) - 1ull);
+    if (in) {
+      int p = -1;
+      if (fg) p = below ? (v - lane) + (63 - __clzll((long long)below)) : (v - lane) - 1;
+      a.parent[q.beg + v] = p;
+      a.counts[q.beg + v] = 0;
+    }
   }
 }
 
