@@ -60,11 +60,12 @@ def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, 
     results = []
     for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
         crop = vol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].copy().astype(np.float32)   # :217
-        out = engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=peak_threshold, dense=True)
+        out = engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=peak_threshold, dense=False)
         if out is None:
             continue                                                          # :225-226
         dets = out["dets"].cpu().numpy()
-        q = ops.prm_quantize_u8(out["prms"]).cpu().numpy()                   # :233-238 on device, then 1 byte per voxel D2H
+        # :233-238 on device, straight from the cone-cropped windows (no dense float maps), then 1 byte per voxel D2H
+        q = ops.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], crop.shape[-3:]).cpu().numpy()
         u8 = [q[ch][pad_s:pad_s + orig_slices] if pad_s else q[ch] for ch in range(q.shape[0])]   # :239-240
         rec = dict(num=num, start=(s, h, w), dets=dets, prm_u8=u8, peaks=out["peaks"].cpu().numpy())
         results.append(rec)
