@@ -348,6 +348,15 @@ def bench_detect(args, rank, world, dist):
                "includes": "H2D of the raw uint16 volumes (pinned, copy stream, double-buffered) + D2H of the gathered [%d,%d,7] detections"
                            % (n_items, cap + 1)}
 
+    # ---- (3) N > 1: the same per-rank batches WITHOUT the exchange, so that the collective's cost (and the effect of the larger
+    # per-rank batch of configs[4] on the single-GPU rate) can be read off the line
+    no_xchg = None
+    if dist is not None and not backbone_only:
+        dt3 = timed_loop(lambda: batch(raw_dev), args.steps, 1, dist, torch.cuda.synchronize)
+        dt3 = sync_max_time(dt3, dist, "cpu" if via_host else "cuda")
+        no_xchg = {"value": n_items * args.steps * VOL ** 3 / dt3, "unit": "voxels/s", "ms_per_step": dt3 / args.steps * 1e3,
+                   "what": "all ranks' batches of %d volumes, no all_gather (max over ranks)" % nvol}
+
     if rank != 0:
         return
     voxels = n_items * args.steps * VOL ** 3
@@ -411,6 +420,8 @@ def bench_detect(args, rank, world, dist):
            "roofline": roof, "rooflines": roofs}
     if e2e is not None:
         res["e2e_host_to_host"] = e2e
+    if no_xchg is not None:
+        res["without_exchange"] = no_xchg
     if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
         # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's restatement of the same per-volume pipeline)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
