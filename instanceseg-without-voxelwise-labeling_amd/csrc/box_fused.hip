@@ -280,11 +280,27 @@ struct PropFusedArgs {
 
 struct PropScratch { u64* keys; float* boxes; unsigned char* valid; float* dets; int64_t* flat_idx; char* nms; };
 
+// Multi-workgroup radix select (round 2): the four score-digit histograms, the two list counters and the list of the keys inside
+// the threshold bucket live behind the per-item scratch.
+struct SelCtrl { unsigned int count, ncand, pad[62]; };
+struct SelScratch { unsigned int* hist /*[4][256]*/; SelCtrl* ctrl; u64* cand /*[total]*/; };
+
 __host__ __device__ inline size_t prop_nms_offset(int K) {
   return m3d::align_up(sizeof(u64) * K, 256) + m3d::align_up(sizeof(float) * 6 * K, 256) + m3d::align_up((size_t)K, 256) +
          m3d::align_up(sizeof(float) * 7 * K, 256) + m3d::align_up(sizeof(int64_t) * K, 256);
 }
-__host__ __device__ inline size_t prop_item_bytes(int K) { return prop_nms_offset(K) + nms_scratch_bytes() + 256; }
+__host__ __device__ inline size_t prop_sel_offset(int K) { return prop_nms_offset(K) + nms_scratch_bytes() + 256; }
+__host__ __device__ inline size_t prop_item_bytes(int K, long long total) {
+  return prop_sel_offset(K) + 4096 + sizeof(SelCtrl) + m3d::align_up(sizeof(u64) * (size_t)total, 256) + 256;
+}
+__device__ inline SelScratch sel_carve(char* item, int K) {
+  SelScratch s;
+  char* w = item + prop_sel_offset(K);
+  s.hist = (unsigned int*)w; w += 4096;
+  s.ctrl = (SelCtrl*)w; w += sizeof(SelCtrl);
+  s.cand = (u64*)w;
+  return s;
+}
 
 __device__ inline PropScratch prop_carve(char* w, int K) {
   PropScratch s;
@@ -295,6 +311,114 @@ __device__ inline PropScratch prop_carve(char* w, int K) {
   s.flat_idx = (int64_t*)w; w += m3d::align_up(sizeof(int64_t) * K, 256);
   s.nms = w;
   return s;
+}
+
+// ---- state of the select after the score digits whose histograms exist.  Same arithmetic as the single-workgroup `pick`:
+// at a level, tot = keys under the prefix; tot <= remaining: all of them are selected (all_sel); else the digit d with
+// count(bins > d) < remaining <= count(bins >= d) joins the prefix, remaining -= count(bins > d), bucket = hist[d].
+// The sweeps stop after level p when all_sel, or p >= 1 and the bucket fits the LDS candidate list, or p == 3 (score resolved).
+struct SelState { unsigned int prefix32; unsigned int remaining, bucket; int nd /* digits in the prefix */; int all_sel, stop; };
+
+// wave 0 of the calling workgroup; nlev histograms are complete.  Result through `out` (LDS); caller barriers.
+__device__ inline void sel_replay(const unsigned int* __restrict__ hist, int nlev, int K, SelState* out) {
+  const int lane = threadIdx.x & 63;
+  unsigned int prefix = 0u, rem = (unsigned int)K, bucket = 0u;
+  int nd = 0, all_sel = 0, stop = 0;
+  for (int p = 0; p < nlev && !stop; ++p) {
+    unsigned int h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = hist[p * 256 + 4 * lane + q];
+    const unsigned int mine = (h[0] + h[1]) + (h[2] + h[3]);
+    unsigned int suf = mine;                                         // sum over lanes >= lane (bins >= 4 * lane)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned int v = (unsigned int)__shfl_down((int)suf, off, 64);
+      if (lane + off < 64) suf += v;
+    }
+    const unsigned int tot = (unsigned int)__shfl((int)suf, 0, 64);
+    if (tot <= rem) { all_sel = 1; stop = 1; break; }
+    const unsigned int above = suf - mine;
+    const bool here = above < rem && rem <= above + mine;            // exactly one lane
+    unsigned int d = 0u, nb = 0u, nr = 0u;
+    if (here) {
+      unsigned int r = rem - above;
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        if (r != 0u) {
+          if (h[q] >= r) { d = (unsigned int)(4 * lane + q); nb = h[q]; nr = r; r = 0u; }
+          else r -= h[q];
+        }
+      }
+    }
+    const int src = __ffsll((long long)__ballot(here)) - 1;
+    d = (unsigned int)__shfl((int)d, src, 64); nb = (unsigned int)__shfl((int)nb, src, 64); nr = (unsigned int)__shfl((int)nr, src, 64);
+    prefix |= d << (24 - 8 * p); rem = nr; bucket = nb; nd = p + 1;
+    if ((p >= 1 && bucket <= (unsigned int)kCandMax) || p == 3) stop = 1;
+  }
+  if (lane == 0) { out->prefix32 = prefix; out->remaining = rem; out->bucket = bucket; out->nd = nd; out->all_sel = all_sel; out->stop = stop; }
+}
+
+constexpr int kSelT = 256;
+
+__global__ void prop_sel_init_kernel(PropFusedArgs a) {
+  const SelScratch ss = sel_carve(a.ws + (size_t)blockIdx.x * a.ws_item, a.K);
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) ss.hist[i] = 0u;
+  if (threadIdx.x == 0) { ss.ctrl->count = 0u; ss.ctrl->ncand = 0u; }
+}
+
+// histogram of score digit `level` over the keys under the prefix of the levels before it; grid (chunks, items)
+__global__ __launch_bounds__(kSelT) void prop_sel_hist_kernel(PropFusedArgs a, int level) {
+  __shared__ unsigned int lh[256];
+  __shared__ SelState st;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long long total = (long long)a.p.A * a.p.S * a.p.H * a.p.W;
+  const float* scores = a.scores + (size_t)b * total;
+  const SelScratch ss = sel_carve(a.ws + (size_t)b * a.ws_item, a.K);
+  lh[tid] = 0u;
+  if (tid < 64) sel_replay(ss.hist, level, a.K, &st);
+  __syncthreads();
+  if (st.stop) return;
+  const unsigned int pfx = st.prefix32;
+  const int sh_digit = 24 - 8 * level, sh_top = 32 - 8 * level;       // digit of this level; bits above it = the prefix digits
+  for (long long e = (long long)blockIdx.x * kSelT + tid; e < total; e += (long long)gridDim.x * kSelT) {
+    const unsigned int sb = score_bits(scores[e]);
+    if (level == 0 || (sb >> sh_top) == (pfx >> sh_top)) hist_add(lh, (sb >> sh_digit) & 255u);
+  }
+  __syncthreads();
+  const unsigned int v = lh[tid];
+  if (v) atomicAdd(&ss.hist[level * 256 + tid], v);
+}
+
+// keys above the threshold bucket -> the selected list, keys inside it -> the candidate list; grid (chunks, items)
+__global__ __launch_bounds__(kSelT) void prop_sel_compact_kernel(PropFusedArgs a) {
+  __shared__ SelState st;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int A = a.p.A, SHW = a.p.S * a.p.H * a.p.W, K = a.K;
+  const long long total = (long long)A * SHW;
+  const float* scores = a.scores + (size_t)b * total;
+  char* item = a.ws + (size_t)b * a.ws_item;
+  const PropScratch ps = prop_carve(item, K);
+  const SelScratch ss = sel_carve(item, K);
+  if (tid < 64) sel_replay(ss.hist, 4, K, &st);
+  __syncthreads();
+  const int sh = 32 - 8 * st.nd;
+  const unsigned int pfx = st.nd ? (st.prefix32 >> sh) : 0u;
+  const bool all_sel = st.all_sel != 0;
+  for (long long e = (long long)blockIdx.x * kSelT + tid; e < total; e += (long long)gridDim.x * kSelT) {
+    const unsigned int sb = score_bits(scores[e]);
+    const unsigned int top = st.nd ? (sb >> sh) : 0u;
+    if (top < pfx) continue;
+    const int an = (int)(e / SHW), pos = (int)(e - (long long)an * SHW);
+    const unsigned int flat = (unsigned int)pos * (unsigned int)A + (unsigned int)an;     // generate_proposals_3d.py:121,129
+    const u64 key = ((u64)sb << 32) | (u64)(0xFFFFFFFFu - flat);
+    if (top > pfx || all_sel) {
+      const unsigned int slot = atomicAdd(&ss.ctrl->count, 1u);
+      if (slot < (unsigned int)K) ps.keys[slot] = key;
+    } else {
+      const unsigned int slot = atomicAdd(&ss.ctrl->ncand, 1u);
+      ss.cand[slot] = key;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) {
@@ -308,11 +432,19 @@ __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) 
   const PropScratch ps = prop_carve(a.ws + (size_t)b * a.ws_item, K);
   const NmsScratch sc = nms_scratch_carve(ps.nms);
 
-  // ---- top-K of the 64-bit keys (score bits, ~flat index) by radix-256 select (generate_proposals_3d.py:135-146).  The flat
-  // (S,H,W,A) index only breaks ties, so the first passes sweep the A*S*H*W scores with 32-bit keys and no index arithmetic; as
-  // soon as the bucket holding the K-th key has <= kCandMax members ONE more sweep appends every key above the bucket to the
-  // output and moves the bucket's 64-bit keys into LDS, where the remaining passes run: 3 sweeps in all for typical score maps.
-  if (tid == 0) { L.prefix = 0ull; L.remaining = (unsigned)K; L.done = 0u; L.count = 0u; L.bucket = 0u; L.ncand = 0u; }
+  // ---- top-K of the 64-bit keys (score bits, ~flat index) by radix-256 select (generate_proposals_3d.py:135-146).  The sweeps
+  // over the A*S*H*W scores ran before this kernel, on many workgroups (prop_sel_hist_kernel x 4, prop_sel_compact_kernel): the
+  // keys above the threshold bucket are already in ps.keys, the bucket's own keys in ss.cand.  What is left is to take the
+  // `remaining` largest keys of the bucket - in LDS when it fits (the usual case), else by more radix passes over the list.
+  const SelScratch ss = sel_carve(a.ws + (size_t)b * a.ws_item, K);
+  __shared__ SelState st;
+  if (tid < 64) sel_replay(ss.hist, 4, K, &st);
+  __syncthreads();
+  const int ncand_g = st.all_sel ? 0 : (int)ss.ctrl->ncand;
+  if (tid == 0) {
+    L.prefix = (u64)st.prefix32 << 32; L.remaining = st.remaining; L.done = st.all_sel ? 1u : 0u;
+    L.count = min(ss.ctrl->count, (unsigned int)K); L.bucket = st.bucket; L.ncand = 0u;
+  }
   __syncthreads();
   STAMP(0);
   auto pick = [&](int shift) __attribute__((always_inline)) {       // wave 0: digit of the K-th key at this level
@@ -346,24 +478,18 @@ __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) 
       }
     }
   };
-  // visits every (anchor a, position pos) with its score; flat index = pos * A + a (generate_proposals_3d.py:121,129)
+  // visits every key of the threshold bucket (global list)
   auto sweep = [&](auto&& f) __attribute__((always_inline)) {
-    for (int an = 0; an < A; ++an) {
-      const float* sa = scores + (size_t)an * SHW;
-      for (int p0 = tid; p0 < SHW; p0 += 4 * kWG) {
-        float sv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int pos = p0 + u * kWG; sv[u] = sa[pos < SHW ? pos : 0]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int pos = p0 + u * kWG;
-          if (pos < SHW) f(score_bits(sv[u]), (unsigned int)pos * (unsigned int)A + (unsigned int)an);
-        }
-      }
-    }
+    for (int e = tid; e < ncand_g; e += kWG) f(ss.cand[e]);
   };
   bool in_lds = false;
-  for (int pass = 0; pass < 8; ++pass) {
+  if (!st.all_sel && ncand_g <= kCandMax) {                           // the bucket fits: its keys move into LDS right away
+    for (int e = tid; e < ncand_g; e += kWG) L.cand[e] = ss.cand[e];
+    if (tid == 0) L.ncand = (unsigned int)ncand_g;
+    in_lds = true;
+    __syncthreads();
+  }
+  for (int pass = st.nd; pass < 8; ++pass) {                         // the digits below the st.nd resolved ones
     if (L.done) break;                                               // uniform: read after a barrier
     if (tid < 256) L.hist[tid] = 0u;
     __syncthreads();
@@ -375,25 +501,17 @@ __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) 
         const u64 key = L.cand[e];
         if ((key >> (shift + 8)) == (prefix >> (shift + 8))) hist_add(L.hist, (unsigned int)(key >> shift) & 255u);
       }
-    } else if (pass < 4) {                                           // score bits only
-      const unsigned int p32 = (unsigned int)(prefix >> 32);
-      const int s32 = shift - 32;
-      sweep([&](unsigned int sb, unsigned int) {
-        if (pass == 0 || (sb >> (s32 + 8)) == (p32 >> (s32 + 8))) hist_add(L.hist, (sb >> s32) & 255u);
-      });
-    } else {                                                         // > kCandMax exact score ties at the threshold: index digits
-      sweep([&](unsigned int sb, unsigned int flat) {
-        const u64 key = ((u64)sb << 32) | (u64)(0xFFFFFFFFu - flat);
+    } else {                                                         // > kCandMax exact score ties at the threshold: list sweeps
+      sweep([&](u64 key) {
         if ((key >> (shift + 8)) == (prefix >> (shift + 8))) hist_add(L.hist, (unsigned int)(key >> shift) & 255u);
       });
     }
     __syncthreads();
     if (tid < 64) pick(shift);
     __syncthreads();
-    if (!in_lds && !L.done && pass >= 1 && L.bucket <= (unsigned)kCandMax) {
+    if (!in_lds && !L.done && L.bucket <= (unsigned)kCandMax) {
       const u64 pfx = L.prefix >> shift;
-      sweep([&](unsigned int sb, unsigned int flat) {
-        const u64 key = ((u64)sb << 32) | (u64)(0xFFFFFFFFu - flat);
+      sweep([&](u64 key) {
         const u64 top = key >> shift;
         if (top > pfx) {
           const unsigned int slot = atomicAdd(&L.count, 1u);
@@ -419,9 +537,8 @@ __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) 
         if (slot < (unsigned)K) ps.keys[slot] = key;
       }
     }
-  } else {
-    sweep([&](unsigned int sb, unsigned int flat) {
-      const u64 key = ((u64)sb << 32) | (u64)(0xFFFFFFFFu - flat);
+  } else if (!st.all_sel) {
+    sweep([&](u64 key) {
       if (key >= thr) {
         const unsigned int slot = atomicAdd(&L.count, 1u);
         if (slot < (unsigned)K) ps.keys[slot] = key;
@@ -693,7 +810,7 @@ M3D_API size_t m3d_generate_proposals3d_batched_workspace_bytes(int batch, int A
   long long K = (pre_nms_topN <= 0 || pre_nms_topN >= total) ? total : pre_nms_topN;
   if (K <= 0) K = 1;
   if (K > kFusedMax) K = kFusedMax;
-  return (size_t)(batch > 0 ? batch : 1) * prop_item_bytes((int)K) + 256;
+  return (size_t)(batch > 0 ? batch : 1) * prop_item_bytes((int)K, total) + 256;
 }
 
 M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float* d_deltas, int batch, int A, int S, int H, int W,
@@ -709,10 +826,10 @@ M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float*
   const long long Kll = (pre_nms_topN <= 0 || pre_nms_topN >= total) ? total : pre_nms_topN;   // :135
   if (Kll > kFusedMax) return M3D_EUNSUPPORTED;        // larger pre-NMS sets: the multi-launch m3d_generate_proposals3d
   const int K = (int)Kll;
-  if (ws_bytes < (size_t)batch * prop_item_bytes(K) + 256) return M3D_EWORKSPACE;
+  if (ws_bytes < (size_t)batch * prop_item_bytes(K, (long long)A * S * H * W) + 256) return M3D_EWORKSPACE;
   PropFusedArgs a;
   a.scores = d_scores; a.deltas = d_deltas; a.rois = d_rois; a.probs = d_probs; a.keep_idx = d_keep_idx; a.num = d_num;
-  a.ws = (char*)m3d::align_up((size_t)d_ws, 256); a.ws_item = prop_item_bytes(K);
+  a.ws = (char*)m3d::align_up((size_t)d_ws, 256); a.ws_item = prop_item_bytes(K, (long long)A * S * H * W);
   a.K = K; a.post = post_nms_topN; a.cap_out = out_rows; a.nms_thresh = nms_thresh; a.first_batch_index = first_batch_index;
   PropParams& p = a.p;
   for (int i = 0; i < 6 * A; ++i) p.anchors[i] = anchors[i];
@@ -721,6 +838,15 @@ M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float*
   for (int i = 0; i < 6; ++i) p.xf.w[i] = 1.0;                            // :149-150
   p.xf.clip = xform_clip; p.xf.cs = im_info[0]; p.xf.ch = im_info[1]; p.xf.cw = im_info[2];   // :154
   hipStream_t st = m3d::as_stream(stream);
+  {   // the score sweeps of the radix select on many workgroups: ~4 k scores per workgroup and pass
+    const long long total = (long long)A * S * H * W;
+    long long ch = (total + 4095) / 4096;
+    const int chunks = (int)(ch < 1 ? 1 : (ch > 128 ? 128 : ch));
+    hipLaunchKernelGGL(prop_sel_init_kernel, dim3(batch), dim3(256), 0, st, a);
+    for (int level = 0; level < 4; ++level)
+      hipLaunchKernelGGL(prop_sel_hist_kernel, dim3(chunks, batch), dim3(kSelT), 0, st, a, level);
+    hipLaunchKernelGGL(prop_sel_compact_kernel, dim3(chunks, batch), dim3(kSelT), 0, st, a);
+  }
   hipLaunchKernelGGL(proposals_stage1_kernel, dim3(batch), dim3(kWG), 0, st, a);
   if (nms_thresh > 0) launch_mask(a.ws, a.ws_item, prop_nms_offset(K), batch, K, nms_thresh, st);
   hipLaunchKernelGGL(proposals_stage3_kernel, dim3(batch), dim3(kWG), 0, st, a);

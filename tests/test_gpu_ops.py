@@ -638,6 +638,23 @@ def test_fused_proposals_batched_bit_exact_with_oracle_and_golden(m3d, golden):
         # and the multi-launch per-tile entry point gives the very same rows
         r1, p1, k1 = m3d.generate_proposals3d(dev(sc[b]), dev(dl[b]), cfg.anchors, 8., info, 1000, 1000, 0.15)
         assert torch.equal(k1, kidx[b, :n]) and torch.equal(r1[:, 1:], rois[b, :n, 1:])
+    # far more exact ties at the threshold than the select's LDS candidate list holds (4096): the radix passes go on over the
+    # flat-index digits of the bucket's list; and a map with fewer anchors than pre_nms_topN above... (everything selected)
+    sc2 = np.full((2, A, S, H, W), 0.5, np.float32)
+    sc2[0].reshape(-1)[rs.permutation(A * S * H * W)[:300]] = 0.75
+    sc2[1, :, :, :, 8:] = 0.25
+    rois, probs, kidx, num = m3d.generate_proposals3d_batched(dev(sc2), dev(dl[:2]), cfg.anchors, 8., info, 1000, 1000, 0.15)
+    for b in range(2):
+        r0, p0, k0 = O.generate_proposals_3d(sc2[b], dl[b], info, cfg.anchors, 8, 1000, 1000, 0.15, 0)
+        n = int(num[b])
+        assert n == len(k0) and np.array_equal(kidx[b, :n].cpu().numpy(), k0), b
+        assert np.array_equal(probs[b, :n].cpu().numpy(), p0.ravel())
+    small = rs.uniform(0, 1, (1, A, 2, 3, 2)).astype(np.float32)                       # 420 anchors < pre_nms_topN
+    dsm = (rs.randn(1, 6 * A, 2, 3, 2) * 0.2).astype(np.float32)
+    rois, probs, kidx, num = m3d.generate_proposals3d_batched(dev(small), dev(dsm), cfg.anchors, 8., np.array([16., 24., 16., 1.0]), 1000, 1000, 0.15)
+    r0, p0, k0 = O.generate_proposals_3d(small[0], dsm[0], np.array([16., 24., 16., 1.0]), cfg.anchors, 8, 1000, 1000, 0.15, 0)
+    n = int(num[0])
+    assert n == len(k0) and np.array_equal(kidx[0, :n].cpu().numpy(), k0)
     # pre_nms_topN beyond one workgroup's capacity is refused, never truncated
     with pytest.raises(m3d.M3DError):
         m3d.generate_proposals3d_batched(dev(sc), dev(dl), cfg.anchors, 8., info, 6000, 1000, 0.15)
