@@ -275,8 +275,7 @@ def bench_detect(args, rank, world, dist):
         trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
         launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
         (the proposal counts that size the GEMM)."""
-        for v in range(nvol):
-            m3d.norm1(raw[v], f32_arith=True, out=xbuf[v, 0])                           # blob.py:179-184
+        m3d.norm1_batched(raw, f32_arith=True, out=xbuf)                                # blob.py:179-184, per volume statistics
         if backbone_only:
             return det.conv_body(xbuf)
         r = det.detect_batch(xbuf, im_info, as_dicts=False)                             # core/test.py:106-114 per volume

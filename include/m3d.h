@@ -271,6 +271,10 @@ int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_b
 size_t m3d_norm1_workspace_bytes(void);
 int m3d_norm1(const void* d_in, int in_dtype, int64_t n, int f32_arith, float* d_out, double* d_stats, void* d_ws,
               size_t ws_bytes, void* stream);
+/* batch volumes of n voxels each, contiguous; each with its own statistics (one launch per pass for the whole batch).
+ * d_stats [batch,3] or null; d_ws: batch * m3d_norm1_workspace_bytes() */
+int m3d_norm1_batched(const void* d_in, int in_dtype, int batch, int64_t n, int f32_arith, float* d_out, double* d_stats, void* d_ws,
+                      size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Peak-response back-propagation on cropped windows (all kept peaks of a tile as one batch).  Replaces the

@@ -34,6 +34,7 @@ __device__ inline double reduce_partials(const double* __restrict__ part, double
 template <typename T>
 __global__ __launch_bounds__(256) void norm1_sum_kernel(const T* __restrict__ in, long long n, double* __restrict__ ws) {
   __shared__ double sm[4];
+  in += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * 3 * kBlocks;          // blockIdx.y: volume of the batch
   double s = 0.0, c = 0.0;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)kBlocks * 256) {
     const double v = load_as_double(in, e);
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void norm1_sum_kernel(const T* __restrict__ in
 template <typename T>
 __global__ __launch_bounds__(256) void norm1_var_kernel(const T* __restrict__ in, long long n, double* __restrict__ ws) {
   __shared__ double sm[4];
+  in += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * 3 * kBlocks;
   const double mean = reduce_partials(ws, sm) / reduce_partials(ws + kBlocks, sm);
   double q = 0.0;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)kBlocks * 256) {
@@ -63,6 +65,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void norm1_apply_kernel(const T* __restrict__ in, long long n, const double* __restrict__ ws,
                                                           int f32_arith, float* __restrict__ out, double* __restrict__ stats) {
   __shared__ double sm[4];
+  in += (size_t)blockIdx.y * n; ws += (size_t)blockIdx.y * 3 * kBlocks; out += (size_t)blockIdx.y * n;
+  if (stats) stats += 3 * blockIdx.y;
   const double cnt = reduce_partials(ws + kBlocks, sm);
   const double mean = reduce_partials(ws, sm) / cnt;
   const double sd = sqrt(reduce_partials(ws + 2 * kBlocks, sm) / cnt);      // np.std: population (ddof = 0)
@@ -75,13 +79,13 @@ __global__ __launch_bounds__(256) void norm1_apply_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-int run(const T* in, long long n, int f32_arith, float* out, double* ws, double* stats, hipStream_t st) {
-  hipLaunchKernelGGL(norm1_sum_kernel<T>, dim3(kBlocks), dim3(256), 0, st, in, n, ws);
-  hipLaunchKernelGGL(norm1_var_kernel<T>, dim3(kBlocks), dim3(256), 0, st, in, n, ws);
+int run(const T* in, int batch, long long n, int f32_arith, float* out, double* ws, double* stats, hipStream_t st) {
+  hipLaunchKernelGGL(norm1_sum_kernel<T>, dim3(kBlocks, batch), dim3(256), 0, st, in, n, ws);
+  hipLaunchKernelGGL(norm1_var_kernel<T>, dim3(kBlocks, batch), dim3(256), 0, st, in, n, ws);
   long long blocks = (n + 256 * 8 - 1) / (256 * 8);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(norm1_apply_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, in, n, (const double*)ws, f32_arith, out, stats);
+  hipLaunchKernelGGL(norm1_apply_kernel<T>, dim3((unsigned)blocks, batch), dim3(256), 0, st, in, n, (const double*)ws, f32_arith, out, stats);
   return m3d::check_launch("norm1");
 }
 
@@ -94,7 +98,19 @@ M3D_API int m3d_norm1(const void* d_in, int in_dtype, int64_t n, int f32_arith, 
   if (!d_in || !d_out || !d_ws || n <= 0) return M3D_EINVAL;
   if (ws_bytes < m3d_norm1_workspace_bytes()) return M3D_EWORKSPACE;
   hipStream_t st = m3d::as_stream(stream);
-  if (in_dtype == 0) return run((const uint16_t*)d_in, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
-  if (in_dtype == 1) return run((const float*)d_in, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
+  if (in_dtype == 0) return run((const uint16_t*)d_in, 1, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
+  if (in_dtype == 1) return run((const float*)d_in, 1, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
+  return M3D_EINVAL;
+}
+
+/* `batch` volumes of n voxels each, contiguous in d_in and d_out; every volume is normalised with its OWN mean / std
+ * (blob.py:179-184 is called per image).  d_stats: [batch, 3] or null.  d_ws: batch * m3d_norm1_workspace_bytes(). */
+M3D_API int m3d_norm1_batched(const void* d_in, int in_dtype, int batch, int64_t n, int f32_arith, float* d_out, double* d_stats,
+                              void* d_ws, size_t ws_bytes, void* stream) {
+  if (!d_in || !d_out || !d_ws || n <= 0 || batch <= 0 || batch > 65535) return M3D_EINVAL;
+  if (ws_bytes < (size_t)batch * m3d_norm1_workspace_bytes()) return M3D_EWORKSPACE;
+  hipStream_t st = m3d::as_stream(stream);
+  if (in_dtype == 0) return run((const uint16_t*)d_in, batch, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
+  if (in_dtype == 1) return run((const float*)d_in, batch, (long long)n, f32_arith, d_out, (double*)d_ws, d_stats, st);
   return M3D_EINVAL;
 }

@@ -10,7 +10,7 @@ _lib = None
 
 SYMBOLS = [
     "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option",
-    "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1",
+    "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1", "m3d_norm1_batched",
     "m3d_linear_workspace_bytes", "m3d_linear_forward",
     "m3d_fused_max_boxes", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
     "m3d_box_results3d_batched_workspace_bytes", "m3d_box_results3d_batched", "m3d_nms3d_batched_workspace_bytes", "m3d_nms3d_batched",

@@ -11,7 +11,7 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "linear",
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear",
            "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
@@ -363,6 +363,24 @@ def norm1(vol, f32_arith=True, out=None, return_stats=False):
     check(lib().m3d_norm1(_ptr(vol), 0 if vol.dtype == torch.uint16 else 1, C.c_int64(vol.numel()), int(bool(f32_arith)),
                           _ptr(out), _ptr(stats), _ptr(ws), C.c_size_t(wsb), _stream()), "norm1")
     return (out, stats) if return_stats else out
+
+
+def norm1_batched(vols, f32_arith=True, out=None):
+    """norm1 of every volume of a batch [B, ...] with its own statistics, one launch per pass for the whole batch."""
+    _need_gpu(vols)
+    vols = vols.contiguous()
+    if vols.dtype not in (torch.uint16, torch.float32):
+        raise TypeError("norm1 takes uint16 or float32 volumes")
+    B = vols.shape[0]
+    n = vols[0].numel()
+    if out is None:
+        out = torch.empty(vols.shape, dtype=torch.float32, device=vols.device)
+    assert out.is_contiguous() and out.numel() == vols.numel() and out.dtype == torch.float32
+    wsb = lib().m3d_norm1_workspace_bytes() * B
+    ws = torch.empty((wsb // 8,), dtype=torch.float64, device=vols.device)
+    check(lib().m3d_norm1_batched(_ptr(vols), 0 if vols.dtype == torch.uint16 else 1, B, C.c_int64(n), int(bool(f32_arith)),
+                                  _ptr(out), None, _ptr(ws), C.c_size_t(wsb), _stream()), "norm1_batched")
+    return out
 
 
 # ------------------------------------------------------------------ Otsu 2D

@@ -580,6 +580,10 @@ def test_norm1_on_device_equals_numpy(m3d, shape):
     assert np.abs(got32.cpu().numpy() - ref32).max() <= 2e-5                          # NumPy's fp32 pairwise mean/std vs exact
     f = m3d.norm1(dev(im.astype(np.float32)), f32_arith=True)
     assert torch.equal(f, got32)
+    # a batch in one launch per pass: every volume with its own statistics, bit-identical to the one-volume calls
+    im2 = (im.astype(np.int64) * 3 // 2 + 17).astype(np.uint16)
+    b = m3d.norm1_batched(dev(np.stack([im, im2])), f32_arith=True)
+    assert torch.equal(b[0], got32) and torch.equal(b[1], m3d.norm1(dev(im2), f32_arith=True))
 
 
 # ------------------------------------------------------------------ box-head linear layers (fast_rcnn_heads.py:84-85,114-115,15-19)
