@@ -306,6 +306,7 @@ __device__ inline bool v3_qualifies(const AxisSample* tz, const AxisSample* ty, 
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned int kDeclinedBits = 0x7FC0DEADu;      // quiet NaN with a payload: arithmetic only ever yields 0x7FC00000 / 0xFFC00000
 
 template <bool DUAL>
 __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of the RoI's batch item, channel 0 */, size_t chan_stride,
@@ -399,7 +400,7 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
 
 __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
                                                                  float* __restrict__ out, int C, int S, int H, int W, float scale,
-                                                                 int ch_per_block) {
+                                                                 int ch_per_block, int mark_declined) {
   __shared__ AxisSample tz[14], ty[14], tx[14];
   __shared__ Fold fz[7], fy[7], fx[7];
   __shared__ RoiGeom sg;
@@ -434,7 +435,17 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __
     if (!ok || d.per_ch > kSepLdsFloats) atomicAnd(&s_ok, 0);
   }
   __syncthreads();
-  if (!s_ok) return;                                        // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI (v3_qualifies)
+  if (!s_ok) {
+    // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI.  It is told so through the output itself: a NaN payload no
+    // arithmetic produces, at the first element of every 8th channel of this workgroup's range (= every place a channel chunk of
+    // the complement pass can start).  The complement workgroups of all other RoIs then leave after ONE load instead of
+    // repeating the whole set-up (5 000 such workgroups cost 43 us per detection step).
+    if (mark_declined && tid < 4) {
+      const int c = blockIdx.y * ch_per_block + 8 * tid;
+      if (c < C && 8 * tid < ch_per_block) out[((size_t)n * C + c) * 343] = __uint_as_float(kDeclinedBits);
+    }
+    return;
+  }
   const int wave = tid >> 6;
   const int c0 = blockIdx.y * ch_per_block, c1 = min(C, c0 + ch_per_block);
   const int HW = H * W;
@@ -467,6 +478,8 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
   extern __shared__ float dyn[];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
+  if (skip_v3 == 2 &&                                       // v3 marked the RoIs it declined (see there); everyone else is done
+      __float_as_uint(out[((size_t)n * C + (size_t)blockIdx.y * ch_per_block) * (AS * AH * AW)]) != kDeclinedBits) return;
   if (tid == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio);
   __syncthreads();
   const RoiGeom g = sg;
@@ -706,19 +719,20 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
   if (mode == 0) {
     const size_t lds = sizeof(float) * kSepLdsFloats;
     const int v3 = (ratio == 2 && AS == 7 && AH == 7 && AW == 7) ? 1 : 0;      // the shipped geometry: two launches, each RoI in one
-    if (v3) {                       // 32 channels per workgroup: big RoIs run on 1-2 waves, so their work is cut finer
-      const int cpb3 = 32;
-      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
-                         H, W, scale, cpb3);
-    }
-    // complement pass (v3: only the RoIs v3 declined - wide bins, huge sub-volumes; the other workgroups leave after the set-up).
-    // Those RoIs are few and heavy (45 us each on one workgroup: soma tile, 25 of 274 RoIs = 1.1 ms), so their channels are cut
-    // into enough chunks for ~4096 workgroups in all.
+    // complement pass (v3: only the RoIs v3 declined - wide bins, huge sub-volumes).  Those RoIs are few and heavy (45 us each on
+    // one workgroup: soma tile, 25 of 274 RoIs = 1.1 ms), so their channels are cut into enough chunks for ~4096 workgroups in all.
     int cchunks = 1;
     while ((long)R * cchunks < 4096 && cchunks * 8 < C) cchunks *= 2;
     const int ccpb = (C + cchunks - 1) / cchunks;
+    // v3 marks the RoIs it declines in the output (every 8th channel of its 32); usable when the complement chunks start there
+    const int marks = (C % 32 == 0 && ccpb % 8 == 0) ? 1 : 0;
+    if (v3) {                       // 32 channels per workgroup: big RoIs run on 1-2 waves, so their work is cut finer
+      const int cpb3 = 32;
+      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
+                         H, W, scale, cpb3, marks);
+    }
     hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, (C + ccpb - 1) / ccpb) : grid, block, lds, m3d::as_stream(stream), a,
-                       rois, o, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3);
+                       rois, o, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3 ? (marks ? 2 : 1) : 0);
   } else if (!backward)
     hipLaunchKernelGGL(roi_align3d_kernel<false>, grid, block, 0, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
                        scale, ratio, cpb, (int*)nullptr);

@@ -129,6 +129,21 @@ def test_roi_align_forward_bit_exact(m3d, shape, R, res, ratio):
     assert np.array_equal(fast == 0, ref == 0) or np.abs(fast[ref == 0]).max() < 1e-6
 
 
+@pytest.mark.parametrize("C", [64, 96, 40])
+def test_roi_align_fast_and_complement_kernels_share_the_rois(m3d, C):
+    """ratio 2, 7^3 bins: RoIs with bins wider than 4 voxels are declined by the fast kernel and done by the complement pass
+    (C % 32 == 0 with 8-aligned chunks: the hand-over goes through a marker in the output; otherwise through the predicate)."""
+    rs = np.random.RandomState(C)
+    f = rs.randn(1, C, 12, 14, 16).astype(np.float32)
+    R = 60
+    c = rs.uniform(0, 120, (R, 3)); s = np.where(rs.uniform(0, 1, (R, 1)) < 0.4, rs.uniform(240, 420, (R, 3)), rs.uniform(4, 60, (R, 3)))
+    rois = np.hstack((np.zeros((R, 1)), c - s / 2, c + s / 2)).astype(np.float32)
+    ref = O.roi_align_3d_forward(f, rois, 7, 7, 7, 0.125, 2)
+    fast = m3d.roi_align3d_forward(dev(f), dev(rois), 7, 7, 7, 0.125, 2).cpu().numpy()
+    assert not np.isnan(fast).any()
+    assert np.abs(fast - ref).max() <= 1e-5 * np.abs(f).max()
+
+
 def test_roi_align_bad_cols_and_empty(m3d):
     f = torch.zeros((1, 2, 4, 4, 4), device="cuda")
     with pytest.raises(m3d.M3DError):
