@@ -323,6 +323,16 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
   Fold FZ = fz[ps_z];
 #pragma unroll
   for (int k = 0; k < 4; ++k) FZ.k[k] *= d.ey * 7;
+  // the Y folds are wave-uniform and the same for every channel: scalar registers, not 56 LDS broadcast reads per iteration (the
+  // kernel is bound by the CU's LDS instruction rate: ~170 wave-level LDS operations per channel pair with 16-20 waves per CU)
+  float yw[7][4]; int yk[7][4];
+#pragma unroll
+  for (int ph = 0; ph < 7; ++ph)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      yw[ph][k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fy[ph].w[k])));
+      yk[ph][k] = __builtin_amdgcn_readfirstlane(fy[ph].k[k]) * 49;
+    }
   const int nrows = d.ez * d.ey;
   const float inv_ex = 1.0f / (float)d.ex, inv_ey = 1.0f / (float)d.ey;
   const int nst = d.subp / 64;
@@ -379,11 +389,10 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
     }
 #pragma unroll
     for (int ph = 0; ph < 7; ++ph) {                                     // pass Y (1/count folded into fy) -> HBM, 49 floats in a row
-      const Fold FY = fy[ph];                                            // wave-uniform: LDS broadcast reads
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const float* col = t2[q] + (lane < 49 ? lane : 0);
-        const float v = (FY.w[0] * col[FY.k[0] * 49] + FY.w[1] * col[FY.k[1] * 49]) + (FY.w[2] * col[FY.k[2] * 49] + FY.w[3] * col[FY.k[3] * 49]);
+        const float v = (yw[ph][0] * col[yk[ph][0]] + yw[ph][1] * col[yk[ph][1]]) + (yw[ph][2] * col[yk[ph][2]] + yw[ph][3] * col[yk[ph][3]]);
         // the store is issued by the wave even when this channel does not exist (exec = 0): vmcnt counts per wave instruction
         const bool on = c + c_step * q < c_end;
         float* dst = obase + (size_t)(on ? c + c_step * q : c) * 343 + ph * 49 + lane;
@@ -398,70 +407,104 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
   }
 }
 
-__global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
-                                                                 float* __restrict__ out, int C, int S, int H, int W, float scale,
-                                                                 int ch_per_block, int mark_declined) {
-  __shared__ AxisSample tz[14], ty[14], tx[14];
-  __shared__ Fold fz[7], fy[7], fx[7];
-  __shared__ RoiGeom sg;
-  __shared__ int rng[6];
-  __shared__ int s_ok;
-  extern __shared__ float dyn[];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) sg = roi_geom(rois + 7 * n, scale, 7, 7, 7, 2);
+// The per-RoI set-up of the v3 path (geometry, 7 x 2 sample tables per axis, valid ranges, the 21 folds); 256 threads, barriers
+// inside.  Returns through shared memory: sg, rng, s_ok (1: the v3 kernel takes the RoI), fz / fy / fx.
+struct V3Shared {
+  AxisSample tz[14], ty[14], tx[14];
+  Fold fz[7], fy[7], fx[7];
+  RoiGeom sg;
+  int rng[6];
+  int s_ok;
+};
+__device__ inline V3Dims v3_setup(const float* __restrict__ rois, int n, float scale, int S, int H, int W, V3Shared& sh) {
+  const int tid = threadIdx.x;
+  if (tid == 0) sh.sg = roi_geom(rois + 7 * n, scale, 7, 7, 7, 2);
   __syncthreads();
-  const RoiGeom g = sg;
-  if (tid < 14) tz[tid] = make_sample(g.start_s, g.bin_s, tid / 2, tid % 2, 2, S, -1.0);
-  else if (tid >= 64 && tid < 78) ty[tid - 64] = make_sample(g.start_h, g.bin_h, (tid - 64) / 2, (tid - 64) % 2, 2, H, -1.0);
-  else if (tid >= 128 && tid < 142) tx[tid - 128] = make_sample(g.start_w, g.bin_w, (tid - 128) / 2, (tid - 128) % 2, 2, W, -1.0);
+  const RoiGeom g = sh.sg;
+  if (tid < 14) sh.tz[tid] = make_sample(g.start_s, g.bin_s, tid / 2, tid % 2, 2, S, -1.0);
+  else if (tid >= 64 && tid < 78) sh.ty[tid - 64] = make_sample(g.start_h, g.bin_h, (tid - 64) / 2, (tid - 64) % 2, 2, H, -1.0);
+  else if (tid >= 128 && tid < 142) sh.tx[tid - 128] = make_sample(g.start_w, g.bin_w, (tid - 128) / 2, (tid - 128) % 2, 2, W, -1.0);
   __syncthreads();
   if (tid < 3) {
-    const AxisSample* t = tid == 0 ? tz : (tid == 1 ? ty : tx);
+    const AxisSample* t = tid == 0 ? sh.tz : (tid == 1 ? sh.ty : sh.tx);
     int lo = 1 << 30, hi = -1;
     for (int i = 0; i < 14; ++i)
       if (t[i].valid) { lo = min(lo, t[i].lo); hi = max(hi, t[i].hi); }
-    rng[2 * tid] = lo; rng[2 * tid + 1] = hi;
+    sh.rng[2 * tid] = lo; sh.rng[2 * tid + 1] = hi;
   }
   __syncthreads();
-  if (tid == 0) s_ok = (rng[1] >= 0 && rng[3] >= 0 && rng[5] >= 0) ? 1 : 0;
+  if (tid == 0) sh.s_ok = (sh.rng[1] >= 0 && sh.rng[3] >= 0 && sh.rng[5] >= 0) ? 1 : 0;
   __syncthreads();
-  const V3Dims d = v3_dims(rng);
-  if (tid < 21 && s_ok) {                                   // the 21 (axis, bin) folds in parallel; any failure clears s_ok
+  const V3Dims d = v3_dims(sh.rng);
+  if (tid < 21 && sh.s_ok) {                                // the 21 (axis, bin) folds in parallel; any failure clears s_ok
     const int ax = tid / 7, p = tid % 7;
     bool ok;
-    if (ax == 0) ok = fold_bin(tz[2 * p], tz[2 * p + 1], rng[0], d.ez, 1.f, &fz[p]);
-    else if (ax == 1) ok = fold_bin(ty[2 * p], ty[2 * p + 1], rng[2], d.ey, 0.125f, &fy[p]);      // 1 / (2*2*2 samples)
-    else ok = fold_bin(tx[2 * p], tx[2 * p + 1], rng[4], d.ex, 1.f, &fx[p]);
-    if (!ok || d.per_ch > kSepLdsFloats) atomicAnd(&s_ok, 0);
+    if (ax == 0) ok = fold_bin(sh.tz[2 * p], sh.tz[2 * p + 1], sh.rng[0], d.ez, 1.f, &sh.fz[p]);
+    else if (ax == 1) ok = fold_bin(sh.ty[2 * p], sh.ty[2 * p + 1], sh.rng[2], d.ey, 0.125f, &sh.fy[p]);      // 1 / (2*2*2 samples)
+    else ok = fold_bin(sh.tx[2 * p], sh.tx[2 * p + 1], sh.rng[4], d.ex, 1.f, &sh.fx[p]);
+    if (!ok || d.per_ch > kSepLdsFloats) atomicAnd(&sh.s_ok, 0);
   }
   __syncthreads();
-  if (!s_ok) {
-    // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI.  It is told so through the output itself: a NaN payload no
-    // arithmetic produces, at the first element of every 8th channel of this workgroup's range (= every place a channel chunk of
-    // the complement pass can start).  The complement workgroups of all other RoIs then leave after ONE load instead of
-    // repeating the whole set-up (5 000 such workgroups cost 43 us per detection step).
-    if (mark_declined && tid < 4) {
-      const int c = blockIdx.y * ch_per_block + 8 * tid;
-      if (c < C && 8 * tid < ch_per_block) out[((size_t)n * C + c) * 343] = __uint_as_float(kDeclinedBits);
-    }
-    return;
+  return d;
+}
+
+// waves that work on a RoI: all 4 with a quarter of the LDS each, or - sub-volume + intermediates too large for that - 2 or 1 with
+// a half / all of it
+__device__ inline int v3_waves(const V3Dims& d) {
+  int nw = 4;
+  while (nw > 1 && d.per_ch > kSepLdsFloats / nw) nw >>= 1;
+  return nw;
+}
+
+// Work split of the forward pass, decided once per RoI and handed to the workgroups THROUGH THE OUTPUT: a NaN payload no arithmetic
+// produces, at the first element of every 8th channel (the places a channel chunk can start; real results overwrite them).
+//   small   (all four waves fit; 94 % of the detection RoIs): ONE workgroup does all channels - the set-up (geometry, tables,
+//           folds: several barriers) is paid once per RoI instead of once per 32 channels;
+//   medium  (1-2 waves fit): one workgroup per 8 channels, so the few long RoIs are cut fine and do not form the tail;
+//   declined (bins wider than 4 voxels / sub-volume beyond the LDS): the complement pass (roi_align3d_fwd_sep_kernel) does it.
+// Every other workgroup of the (RoI, C/8) grid leaves after one load.
+constexpr unsigned int kSmallBits = 0x7FC05A11u, kMedBits = 0x7FC03ED0u;
+
+__global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict__ rois, float* __restrict__ out, int C, int S, int H,
+                                                        int W, float scale) {
+  __shared__ V3Shared sh;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const V3Dims d = v3_setup(rois, n, scale, S, H, W, sh);
+  const unsigned int cls = !sh.s_ok ? kDeclinedBits : (v3_waves(d) == 4 ? kSmallBits : kMedBits);
+  for (int k = tid; 8 * k < C; k += 256) out[((size_t)n * C + 8 * k) * 343] = __uint_as_float(cls);
+}
+
+// marks = 1: grid (R, C / 8), work split read from the markers.  marks = 0 (C not a multiple of 32): grid (R, ceil(C / ch_per_block)),
+// every workgroup does the set-up and takes its ch_per_block channels if the RoI qualifies.
+__global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                                 float* __restrict__ out, int C, int S, int H, int W, float scale,
+                                                                 int ch_per_block, int marks) {
+  __shared__ V3Shared sh;
+  extern __shared__ float dyn[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int c0 = blockIdx.y * ch_per_block, c1 = min(C, c0 + ch_per_block);
+  if (marks) {
+    const unsigned int m = __float_as_uint(out[((size_t)n * C + 8 * blockIdx.y) * 343]);
+    if (m == kMedBits) { c0 = 8 * blockIdx.y; c1 = min(C, c0 + 8); }
+    else if (m == kSmallBits && blockIdx.y == 0) { c0 = 0; c1 = C; }
+    else return;
   }
+  const V3Dims d = v3_setup(rois, n, scale, S, H, W, sh);
+  if (!sh.s_ok) return;                                     // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI
+  const RoiGeom g = sh.sg;
   const int wave = tid >> 6;
-  const int c0 = blockIdx.y * ch_per_block, c1 = min(C, c0 + ch_per_block);
   const int HW = H * W;
   const float* fbase = feat + (size_t)g.batch * C * S * HW;
   float* obase = out + (size_t)n * C * 343;
-  const int gofs = rng[0] * HW + rng[2] * W + rng[4];
+  const int gofs = sh.rng[0] * HW + sh.rng[2] * W + sh.rng[4];
   const size_t cs = (size_t)S * HW;
-  // waves that work on this RoI: all 4 with a quarter of the LDS each, or - sub-volume + intermediates too large for that - 2 or 1
-  // with a half / all of it (the other waves leave; big RoIs are few).  Two channels at a time whenever the slice holds them.
-  int nw = 4;
-  while (nw > 1 && d.per_ch > kSepLdsFloats / nw) nw >>= 1;
+  // Two channels at a time whenever the wave's LDS slice holds them.
+  const int nw = v3_waves(d);
   if (wave >= nw) return;
   const int slice = kSepLdsFloats / nw;
   float* wl = dyn + (size_t)wave * slice;
-  if (2 * d.per_ch <= slice) v3_run<true>(fbase, cs, obase, wl, fz, fy, fx, d, HW, W, gofs, c0 + wave, c1, nw);
-  else v3_run<false>(fbase, cs, obase, wl, fz, fy, fx, d, HW, W, gofs, c0 + wave, c1, nw);
+  if (2 * d.per_ch <= slice) v3_run<true>(fbase, cs, obase, wl, sh.fz, sh.fy, sh.fx, d, HW, W, gofs, c0 + wave, c1, nw);
+  else v3_run<false>(fbase, cs, obase, wl, sh.fz, sh.fy, sh.fx, d, HW, W, gofs, c0 + wave, c1, nw);
 }
 
 struct AxisTaps { int lo, hi, n; };        // sub-volume range [lo, hi] and number of taps per bin
@@ -724,12 +767,16 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
     int cchunks = 1;
     while ((long)R * cchunks < 4096 && cchunks * 8 < C) cchunks *= 2;
     const int ccpb = (C + cchunks - 1) / cchunks;
-    // v3 marks the RoIs it declines in the output (every 8th channel of its 32); usable when the complement chunks start there
+    // the per-RoI work split travels through markers in the output (every 8th channel); usable when all chunk starts fall there
     const int marks = (C % 32 == 0 && ccpb % 8 == 0) ? 1 : 0;
-    if (v3) {                       // 32 channels per workgroup: big RoIs run on 1-2 waves, so their work is cut finer
+    if (v3 && marks) {              // work split per RoI through markers in the output (roi_class_kernel)
+      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, C, S, H, W, scale);
+      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, C, S, H, W, scale,
+                         8, 1);
+    } else if (v3) {                // 32 channels per workgroup
       const int cpb3 = 32;
       hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
-                         H, W, scale, cpb3, marks);
+                         H, W, scale, cpb3, 0);
     }
     hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, (C + ccpb - 1) / ccpb) : grid, block, lds, m3d::as_stream(stream), a,
                        rois, o, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3 ? (marks ? 2 : 1) : 0);
