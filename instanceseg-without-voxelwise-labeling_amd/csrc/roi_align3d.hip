@@ -287,7 +287,10 @@ struct V3Dims { int ez, ey, ex, sub, subp, n1, n2, per_ch; };   // subp: sub-vol
 __device__ inline V3Dims v3_dims(const int* rng) {
   V3Dims d;
   d.ez = rng[1] - rng[0] + 1; d.ey = rng[3] - rng[2] + 1; d.ex = rng[5] - rng[4] + 1;
-  d.sub = d.ez * d.ey * d.ex; d.subp = (d.sub + 63) / 64 * 64; d.n1 = d.ez * d.ey * 7; d.n2 = d.ey * 49;
+  // The four taps of a fold are consecutive voxels, read UNCLAMPED as base + 0..3 so that the compiler pairs them into ds_read2_b32
+  // (the kernel is bound by the LDS instruction rate); taps past the extent have weight 0 and must only hit finite memory: the
+  // sub-volume is padded by >= 3 floats (the DMA's tail lanes re-copy the last voxel there) and t2 by three zeroed rows.
+  d.sub = d.ez * d.ey * d.ex; d.subp = (d.sub + 3 + 63) / 64 * 64; d.n1 = d.ez * d.ey * 7; d.n2 = (d.ey + 3) * 49;
   d.per_ch = d.subp + d.n1 + d.n2;
   return d;
 }
@@ -325,14 +328,13 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
   for (int k = 0; k < 4; ++k) FZ.k[k] *= d.ey * 7;
   // the Y folds are wave-uniform and the same for every channel: scalar registers, not 56 LDS broadcast reads per iteration (the
   // kernel is bound by the CU's LDS instruction rate: ~170 wave-level LDS operations per channel pair with 16-20 waves per CU)
-  float yw[7][4]; int yk[7][4];
+  float yw[7][4]; int yk[7];
 #pragma unroll
-  for (int ph = 0; ph < 7; ++ph)
+  for (int ph = 0; ph < 7; ++ph) {
+    yk[ph] = __builtin_amdgcn_readfirstlane(fy[ph].k[0]) * 49;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      yw[ph][k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fy[ph].w[k])));
-      yk[ph][k] = __builtin_amdgcn_readfirstlane(fy[ph].k[k]) * 49;
-    }
+    for (int k = 0; k < 4; ++k) yw[ph][k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fy[ph].w[k])));
+  }
   const int nrows = d.ez * d.ey;
   const float inv_ex = 1.0f / (float)d.ex, inv_ey = 1.0f / (float)d.ey;
   const int nst = d.subp / 64;
@@ -354,8 +356,10 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { fs[q] = wl + q * d.per_ch; t1[q] = fs[q] + d.subp; t2[q] = t1[q] + d.n1; }
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
+  for (int q = 0; q < NQ; ++q) {
+    for (int e = lane; e < 3 * 49; e += 64) t2[q][d.ey * 49 + e] = 0.f;      // the rows the unclamped Y taps may touch
     if (c_first + c_step * q < c_end) dma(c_first + c_step * q, fs[q]);
+  }
   bool first = true;
   for (int c = c_first; c < c_end; c += c_step * NQ) {
     // The sub-volumes of this iteration were requested BEFORE the previous iteration's 7*NQ output stores; vector-memory
@@ -368,8 +372,8 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
       for (int zy = rx; zy < nrows; zy += 9) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const float* row = fs[q] + zy * d.ex;
-          t1[q][zy * 7 + pw_x] = (FX.w[0] * row[FX.k[0]] + FX.w[1] * row[FX.k[1]]) + (FX.w[2] * row[FX.k[2]] + FX.w[3] * row[FX.k[3]]);
+          const float* row = fs[q] + zy * d.ex + FX.k[0];
+          t1[q][zy * 7 + pw_x] = (FX.w[0] * row[0] + FX.w[1] * row[1]) + (FX.w[2] * row[2] + FX.w[3] * row[3]);
         }
       }
     }
@@ -392,7 +396,8 @@ __device__ inline void v3_run(const float* __restrict__ fbase /* feature map of 
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const float* col = t2[q] + (lane < 49 ? lane : 0);
-        const float v = (yw[ph][0] * col[yk[ph][0]] + yw[ph][1] * col[yk[ph][1]]) + (yw[ph][2] * col[yk[ph][2]] + yw[ph][3] * col[yk[ph][3]]);
+        const float* cy = col + yk[ph];
+        const float v = (yw[ph][0] * cy[0] + yw[ph][1] * cy[49]) + (yw[ph][2] * cy[98] + yw[ph][3] * cy[147]);
         // the store is issued by the wave even when this channel does not exist (exec = 0): vmcnt counts per wave instruction
         const bool on = c + c_step * q < c_end;
         float* dst = obase + (size_t)(on ? c + c_step * q : c) * 343 + ph * 49 + lane;
