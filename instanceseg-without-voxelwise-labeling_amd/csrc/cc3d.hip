@@ -109,7 +109,9 @@ __global__ __launch_bounds__(kT) void cc_union_kernel(CcArgs a) {
     // same plane, previous row
     if (y > 0) {
       const int c = v - sy;
-      if (fg(c)) uf_union(parent, v, c);
+      // inside two overlapping runs only the FIRST voxel of the overlap links them (v-1 and c-1 set: v-1 did, or its own left
+      // neighbour): in a solid region that is one union per row pair instead of one per voxel
+      if (fg(c)) { if (!(xl && fg(v - 1) && fg(c - 1))) uf_union(parent, v, c); }
       else {
         if (xl && fg(c - 1) && !fg(v - 1)) uf_union(parent, v, c - 1);          // with v-1 set, v-1's own centre is c-1
         if (xr && fg(c + 1)) uf_union(parent, v, c + 1);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(kT) void cc_union_kernel(CcArgs a) {
     }
     if (z > 0) {
       const int cc = v - sz;
-      if (fg(cc)) uf_union(parent, v, cc);
+      if (fg(cc)) { if (!(xl && fg(v - 1) && fg(cc - 1))) uf_union(parent, v, cc); }
       else {
         for (int dy = -1; dy <= 1; ++dy) {
           const int yy = y + dy;
