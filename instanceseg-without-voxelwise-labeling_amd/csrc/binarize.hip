@@ -123,10 +123,12 @@ __global__ __launch_bounds__(256) void winq_stats_kernel(const float* __restrict
   const int oz = origins[3 * p], oy = origins[3 * p + 1], ox = origins[3 * p + 2];
   const float sum = sums[p];
   const float* wp = win + (size_t)p * w3;
+  const float inv_w = 1.0f / (float)Wn;
   float mn = INFINITY, mx = 0.f;
   int cnt = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
-    const int x = e % Wn, y = (e / Wn) % Wn, z = e / (Wn * Wn);
+    const int r = (int)(((float)e + 0.5f) * inv_w), x = e - r * Wn;          // exact for Wn <= 100 (host-checked)
+    const int z = (int)(((float)r + 0.5f) * inv_w), y = r - z * Wn;
     const int qz = oz + z, qy = oy + y, qx = ox + x;
     if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
       const float f = wp[e] / sum;                         // prm / prm.sum(), peak_response_mapping_3d.py:171
@@ -156,9 +158,11 @@ __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict
   const float mx = __uint_as_float(s.fmax_bits) - mn;                // max(fm - min)
   const float* wp = win + (size_t)p * w3;
   uint8_t* o = out + (size_t)p * D * H * W;
+  const float inv_w = 1.0f / (float)Wn;
   int any = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
-    const int x = e % Wn, y = (e / Wn) % Wn, z = e / (Wn * Wn);
+    const int r = (int)(((float)e + 0.5f) * inv_w), x = e - r * Wn;          // exact for Wn <= 100 (host-checked)
+    const int z = (int)(((float)r + 0.5f) * inv_w), y = r - z * Wn;
     const int qz = oz + z, qy = oy + y, qx = ox + x;
     if ((qz >= 0) & (qz < D) & (qy >= 0) & (qy < H) & (qx >= 0) & (qx < W)) {
       float v = wp[e] / sum;
@@ -191,8 +195,10 @@ __global__ __launch_bounds__(256) void roi_stats_kernel(const uint16_t* __restri
   if (!roi_box(boxes, offsets, r, x1, y1, z1, ex, ey, V)) return;
   const uint8_t* pm = prm + (size_t)r * D * H * W;
   int gmax = 0, gmin = 65535, pmax = 0, pmin = 255;
-  for (long long e = blockIdx.x * 256 + threadIdx.x; e < V; e += gridDim.x * 256) {
-    const int x = x1 + (int)(e % ex), y = y1 + (int)((e / ex) % ey), z = z1 + (int)(e / ((long long)ex * ey));
+  const int Vi = (int)V, exy = ex * ey;                              // 32-bit index arithmetic: a crop is a sub-box of one tile
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < Vi; e += gridDim.x * 256) {
+    const int zq = e / exy, rq = e - zq * exy, yq = rq / ex;
+    const int x = x1 + (rq - yq * ex), y = y1 + yq, z = z1 + zq;
     const size_t idx = ((size_t)z * H + y) * W + x;
     const int g = image[idx], p = pm[idx];
     gmax = max(gmax, g); gmin = min(gmin, g); pmax = max(pmax, p); pmin = min(pmin, p);
@@ -222,8 +228,10 @@ __global__ __launch_bounds__(256) void roi_apply1_kernel(const uint16_t* __restr
   const double gmaxd = (double)s.gmax, pmaxd = (double)s.pmax;
   const bool stretch = (s.gmax - s.gmin + 1) < 400;
   int g2max = 0, g2min = 65535;
-  for (long long e = blockIdx.x * 256 + threadIdx.x; e < V; e += gridDim.x * 256) {
-    const int x = x1 + (int)(e % ex), y = y1 + (int)((e / ex) % ey), z = z1 + (int)(e / ((long long)ex * ey));
+  const int Vi = (int)V, exy = ex * ey;                              // 32-bit index arithmetic: a crop is a sub-box of one tile
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < Vi; e += gridDim.x * 256) {
+    const int zq = e / exy, rq = e - zq * exy, yq = rq / ex;
+    const int x = x1 + (rq - yq * ex), y = y1 + yq, z = z1 + zq;
     const size_t idx = ((size_t)z * H + y) * W + x;
     if (mode == 0) {
       double f = (double)image[idx] / gmaxd * 300.0;                  // binarization_soma.py:86-87
@@ -257,8 +265,10 @@ __global__ __launch_bounds__(256) void roi_apply2_kernel(const uint8_t* __restri
   const RoiStat s = st[r];
   const double pmaxd = (double)s.pmax, pmind = (double)s.pmin;
   const double span = (double)(uint16_t)((uint16_t)s.g2max - (uint16_t)s.g2min), base = (double)s.g2min;
-  for (long long e = blockIdx.x * 256 + threadIdx.x; e < V; e += gridDim.x * 256) {
-    const int x = x1 + (int)(e % ex), y = y1 + (int)((e / ex) % ey), z = z1 + (int)(e / ((long long)ex * ey));
+  const int Vi = (int)V, exy = ex * ey;                              // 32-bit index arithmetic: a crop is a sub-box of one tile
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < Vi; e += gridDim.x * 256) {
+    const int zq = e / exy, rq = e - zq * exy, yq = rq / ex;
+    const int x = x1 + (rq - yq * ex), y = y1 + yq, z = z1 + zq;
     const size_t idx = ((size_t)z * H + y) * W + x;
     const double q = ((double)pm[idx] - pmind) / (pmaxd - pmind) * span + base;
     op[e] = (uint16_t)rint(q);
@@ -306,7 +316,7 @@ M3D_API int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_s
   if (num_peaks == 0) return M3D_OK;
   if (!d_windows || !d_sums || !d_origins || !d_out || !d_ws) return M3D_EINVAL;
   if (ws_bytes < sizeof(WinQ) * (size_t)num_peaks) return M3D_EWORKSPACE;
-  if (num_peaks > 65535 || (long long)win * win * win >= 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
+  if (num_peaks > 65535 || win > 100) return M3D_EUNSUPPORTED;      // float-reciprocal index split in the kernels
   hipStream_t st = m3d::as_stream(stream);
   WinQ* q = (WinQ*)d_ws;
   (void)hipMemsetAsync(d_out, 0, (size_t)num_peaks * depth * height * width, st);
@@ -328,7 +338,7 @@ M3D_API int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u
   if (num_rois == 0) return M3D_OK;
   if (!d_image || !d_prm_u8 || !d_boxes || !d_offsets || !d_out_image || !d_out_prm || !d_ws) return M3D_EINVAL;
   if (ws_bytes < sizeof(RoiStat) * (size_t)num_rois) return M3D_EWORKSPACE;
-  if (num_rois > 65535) return M3D_EUNSUPPORTED;
+  if (num_rois > 65535 || (long long)depth * height * width >= 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
   RoiStat* rs = (RoiStat*)d_ws;
   long long per = (total_voxels / num_rois + 255) / 256, want = (8192 + num_rois - 1) / num_rois;
