@@ -64,7 +64,7 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all
     idx_t = torch.from_numpy(idx).to(dev)
     bsel = torch.from_numpy(boxes[idx]).to(dev)
     qs = q if len(idx) == q.shape[0] else q[idx_t].contiguous()          # every detection has a valid crop: no 200 MB gather
-    oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode)
+    oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode, boxes_host=boxes[idx])
     mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
     dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
     cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))

@@ -602,18 +602,20 @@ def prm_quantize_windows_u8(windows, sums, origins, shape, return_nonempty=False
     return out
 
 
-def roi_normalize(image_u16, prm_u8, boxes, mode):
+def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None):
     """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
-    Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch."""
+    Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch.
+    boxes_host: the same boxes as an ndarray when the caller has them (saves the device read-back that sizes the crops)."""
     _need_gpu(image_u16, prm_u8, boxes)
     assert image_u16.dtype == torch.uint16 and prm_u8.dtype == torch.uint8 and boxes.dtype == torch.int32
     R = boxes.shape[0]
     D, H, W = image_u16.shape
-    b = boxes.cpu().numpy().astype(np.int64)
+    b = (np.asarray(boxes_host) if boxes_host is not None else boxes.cpu().numpy()).astype(np.int64)
     sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
     assert R == 0 or (sizes.min() > 0 and b[:, :3].min() >= 0 and b[:, 3].max() < W and b[:, 4].max() < H and b[:, 5].max() < D)
-    offs = torch.from_numpy(np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)).to(image_u16.device)
-    total = int(offs[-1]) if R else 0
+    offs_h = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    offs = torch.from_numpy(offs_h).to(image_u16.device)
+    total = int(offs_h[-1]) if R else 0
     oi = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
     op = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
     if R == 0:
