@@ -965,7 +965,9 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
                                            void* stream) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2) return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
-  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 48) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 24) return M3D_EUNSUPPORTED;
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
+  if (width < 48)         // 32-wide tiles (conv3b on 32^3 maps): the pool of the 16^3-class layers is fused as well
+    return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
   return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
 }

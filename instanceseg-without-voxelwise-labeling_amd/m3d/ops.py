@@ -683,9 +683,8 @@ class WinoConv3d(object):
                         int(bool(relu)), _stream()), "conv3d_wino_forward")
         return out
 
-    @staticmethod
-    def supports_pool(width):
-        return width >= 48
+    def supports_pool(self, width):
+        return width >= (24 if self.two_d else 48)
 
     def pooled(self, x, scale=None, shift=None, relu=False, out=None):
         """conv + scale/shift + ReLU + MaxPool3d(2,2) in one launch; returns [B,cout,D//2,H//2,W//2]."""
