@@ -86,10 +86,22 @@ def f_proposals(rs):
     assert np.array_equal(k1.cpu().numpy(), k0), ("proposals idx", A, S, H, W, pre, post, thr, mode)
     assert np.array_equal(p1.cpu().numpy(), p0)
     assert np.allclose(r1.cpu().numpy(), r0, rtol=3e-7, atol=1e-4)
+    if min(pre, A * S * H * W) <= m3d.fused_max_boxes():       # the batched fused path (multi-workgroup radix select)
+        B = int(rs.randint(1, 4))
+        scb = np.stack([sc] + [np.roll(sc, i + 1, axis=1) for i in range(B - 1)])
+        dlb = np.stack([dl] * B)
+        rb, pb, kb, nb = m3d.generate_proposals3d_batched(dev(scb), dev(dlb), cfg.anchors, float(st), info, pre, post, thr)
+        n0 = int(nb[0])
+        assert n0 == len(k0) and np.array_equal(kb[0, :n0].cpu().numpy(), k0), ("proposals batched idx", A, S, H, W, pre, post, thr, mode)
+        assert np.array_equal(pb[0, :n0].cpu().numpy(), p0.ravel())
+        for b in range(1, B):
+            rr, pp, kk = O.generate_proposals_3d(scb[b], dl, info, cfg.anchors, st, pre, post, thr, 0)
+            n = int(nb[b])
+            assert n == len(kk) and np.array_equal(kb[b, :n].cpu().numpy(), kk), ("proposals batched item", b)
 
 
 def f_roialign(rs):
-    B, Cc = int(rs.randint(1, 3)), int(rs.choice([1, 3, 16, 64]))
+    B, Cc = int(rs.randint(1, 3)), int(rs.choice([1, 3, 16, 32, 64, 96]))
     S, H, W = int(rs.randint(1, 18)), int(rs.randint(1, 28)), int(rs.randint(1, 28))
     f = rs.randn(B, Cc, S, H, W).astype(np.float32)
     R = int(rs.randint(1, 60))
@@ -142,7 +154,7 @@ def f_cc(rs):
     n = int(rs.randint(1, 10))
     masks = []
     for _ in range(n):
-        shp = tuple(int(v) for v in rs.randint(1, 34, 3))
+        shp = tuple(int(v) for v in rs.randint(1, 34 if rs.rand() < 0.85 else 90, 3))
         p = rs.choice([0.03, 0.1, 0.2, 0.35, 0.6, 0.95])
         m = (rs.rand(*shp) < p)
         if rs.rand() < 0.3:
@@ -251,7 +263,32 @@ def f_prm(rs):
     assert np.allclose(got, pr, rtol=5e-3, atol=5e-6 * scale, equal_nan=True), ("prm maps", S, H, W, soma)
 
 
-ops = [("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
+def f_quant_segment(rs):
+    """uint8 maps from the cone-cropped windows == from the dense maps; segment_tile fed either way gives the same labels."""
+    from m3d import binarize
+    D, H, W = int(rs.randint(4, 30)), int(rs.randint(4, 40)), int(rs.randint(4, 40))
+    Wn = int(rs.choice([4, 8, 12, 40]))
+    P = int(rs.randint(1, 7))
+    win = (rs.rand(P, Wn, Wn, Wn) * (rs.rand(P, Wn, Wn, Wn) > rs.choice([0.0, 0.3, 0.9]))).astype(np.float32)
+    if rs.rand() < 0.3:
+        win[0] = 0
+    org = np.stack([rs.randint(-Wn + 1, D, P), rs.randint(-Wn + 1, H, P), rs.randint(-Wn + 1, W, P)], 1).astype(np.int32)
+    if rs.rand() < 0.3:
+        org[-1] = -1                                 # may cover the whole tile
+    sums = np.maximum(win.reshape(P, -1).sum(1), 1e-6).astype(np.float32)
+    w_, s_, o_ = dev(win), dev(sums), dev(org)
+    dense = m3d.prm_scatter(w_, s_, o_, (D, H, W))
+    assert torch.equal(m3d.prm_quantize_windows_u8(w_, s_, o_, (D, H, W)), m3d.prm_quantize_u8(dense)), ("quantise", D, H, W, Wn)
+    img = dev(rs.randint(0, 3000, (D, H, W)).astype(np.uint16))
+    c = np.stack([rs.uniform(0, W, P), rs.uniform(0, H, P), rs.uniform(0, D, P)], 1); e = rs.uniform(2, 24, (P, 3))
+    dets = np.hstack((c - e / 2, c + e / 2, rs.uniform(0.4, 1, (P, 1))))
+    mode = "soma" if rs.rand() < 0.5 else "nuclei"
+    l0, p0 = binarize.segment_tile(img, dense, dets, mode=mode)
+    l1, p1 = binarize.segment_tile(img, (w_, s_, o_), dets, mode=mode)
+    assert torch.equal(l0, l1) and torch.equal(p0, p1), ("segment", D, H, W, Wn, mode)
+
+
+ops = [("quantise/segment", f_quant_segment), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
        ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
