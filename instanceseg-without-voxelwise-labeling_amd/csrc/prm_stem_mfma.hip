@@ -92,7 +92,6 @@ struct StemMArgs {
   const float* up_off;     // multiply by (xnext - *up_off) of the layer above happens in the staging
 };
 
-constexpr int kNB = 5;       // MFMA column blocks per wave and fine row
 constexpr int kNCell = 2;    // coarse cells staged per thread and chunk
 constexpr int kNT = 512;     // 8 waves: wave (w, r) owns the planes of w and fine row r of the row pair
 
@@ -101,7 +100,7 @@ constexpr int kNT = 512;     // 8 waves: wave (w, r) owns the planes of w and fi
 // r = 1: fold, commit, MFMAs - and one half's MFMAs cover the other half's staging.
 // U (window size in pooled cells) and ZW (output planes per wave) are compile-time: every LDS offset of the MFMA run is then an
 // immediate of its ds_read.  The reference's two nets give U = 40 (stride 8) and U = 18 (stride 4).
-template <int U, int ZW>
+template <int U, int ZW, int NB>
 __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q) {
   extern __shared__ float sm[];
   const int tid = threadIdx.x, wv = tid >> 6, w = wv & 3, r = wv >> 2, l = tid & 63, h = l >> 5, nl = l & 31;
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   constexpr int CS = TZH * 2 * NX;         // floats per channel of a tile buffer: [TZH planes][2 fine rows][NX]
   constexpr int BUF = 4 * CS;
   constexpr int ZWn = ZW * Wn;
-  static_assert(4 * NBZ * U <= kNT * kNCell && 32 * kNB >= ZW * NX && Wn % 4 == 0, "tile shape");
+  static_assert(4 * NBZ * U <= kNT * kNCell && 32 * NB >= ZW * NX && Wn % 4 == 0, "tile shape");
   float* const tq = sm + 2 * BUF + w * (25 * ZWn);                    // per plane group [25][ZW][Wn], shifted by dx; the two row
   float* const roll = sm + 2 * BUF + 4 * (25 * ZWn) + w * (5 * ZWn);  // waves of a group use it in turn.  roll: [5][ZW][Wn]
   float* const dump = sm + 2 * BUF + 4 * (30 * ZWn) + 4 * wv;         // wave-private slot for T rows 25..31 / columns past the row
@@ -134,9 +133,9 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   }
 
   // ---- per-lane constants of the MFMA side
-  int bbase[kNB], tbase[kNB];
+  int bbase[NB], tbase[NB];
 #pragma unroll
-  for (int j = 0; j < kNB; ++j) {
+  for (int j = 0; j < NB; ++j) {
     int n = 32 * j + nl;
     const bool ok = n < ZW * NX;
     n = ok ? n : 0;
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     }
   };
 
-  f32x16 acc[kNB];
+  f32x16 acc[NB];
   float local = 0.f;
   const float off = *q.data_off;
 
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   // fold the T rows of fine input row yi (the accumulators) into the rolling output rows yi .. yi+4
   auto fold = [&](int yi) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < kNB; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 13; ++e) {
         const int o = tbase[j] + toff[e];
@@ -325,15 +324,15 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
   };
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < kNB; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
   };
   // 10 groups (dz, cp) of 5 MFMAs (column blocks); the B values of group k+1 are read while group k runs
   auto mfma_step = [&](const float* tile) __attribute__((always_inline)) {
-    float bv[2][kNB];
+    float bv[2][NB];
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) bv[0][j] = tile[bbase[j]];
+    for (int j = 0; j < NB; ++j) bv[0][j] = tile[bbase[j]];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -341,10 +340,10 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
       if (k + 1 < 10) {
         const int o1 = ((k + 1) & 1) * 2 * CS + ((k + 1) >> 1) * 2 * NX;
 #pragma unroll
-        for (int j = 0; j < kNB; ++j) bv[(k + 1) & 1][j] = tile[bbase[j] + o1];
+        for (int j = 0; j < NB; ++j) bv[(k + 1) & 1][j] = tile[bbase[j] + o1];
       }
 #pragma unroll
-      for (int j = 0; j < kNB; ++j) {
+      for (int j = 0; j < NB; ++j) {
         if (!(STEM_EXP & 8)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[dz * 2 + cp], bv[k & 1][j], acc[j], 0, 0, 0);
         else acc[j][0] += bv[k & 1][j];
       }
@@ -453,7 +452,7 @@ struct StemPlan { int zw, nslab; size_t lds; };
 bool stem_plan(int U, StemPlan* pl) {
   if (U != 40 && U != 18) return false;                               // the two instantiations below
   const int NX = 2 * U, Wn = NX + 4;
-  const int zw = U == 40 ? 2 : 4;
+  const int zw = U == 40 ? 2 : 3;                                     // planes per wave (see the instantiations)
   const int TZ = 4 * zw, TZH = TZ + 4;
   const size_t floats = (size_t)2 * 4 * TZH * 2 * NX + (size_t)4 * 30 * zw * Wn + 32;
   pl->zw = zw; pl->nslab = (Wn + TZ - 1) / TZ; pl->lds = floats * sizeof(float);
@@ -500,8 +499,11 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     hipLaunchKernelGGL(kern, dim3(pl.nslab, num_peaks), dim3(kNT), pl.lds, st, q);
   };
-  if (up_size == 40) launch(prm_stem_dgrad_mfma_kernel<40, 2>);
-  else launch(prm_stem_dgrad_mfma_kernel<18, 4>);
+  // U = 40: 2 planes x 80 columns = 5 full blocks per wave, 11 slabs of 8 planes.  U = 18: 3 planes x 36 columns in 4 blocks (84 %),
+  // 4 slabs of 12 planes - 128 peaks give 512 workgroups = two full rounds of the 256 CUs (4 planes in 5 blocks: 384 workgroups,
+  // a ragged second round)
+  if (up_size == 40) launch(prm_stem_dgrad_mfma_kernel<40, 2, 5>);
+  else launch(prm_stem_dgrad_mfma_kernel<18, 3, 4>);
   return m3d::check_launch("prm_stem_dgrad_fused");
 }
 
