@@ -172,19 +172,33 @@ def read_tiff_stack(path):
     return np.stack(pages) if pages else np.zeros((0, 0, 0), np.uint8)
 
 
+def _parallel(fn, items):
+    """One file per peak response map: the LZW codec is C behind ctypes (the GIL is released during the call), so the maps of a
+    tile are encoded / decoded on a small thread pool; results in input order."""
+    if len(items) < 4:
+        return [fn(it) for it in items]
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    with ThreadPoolExecutor(max_workers=max(1, min(16, n))) as ex:
+        return list(ex.map(fn, items))
+
+
 def save_prm_instances(save_path, prms_u8, dets):
     """tools/infer_simple.py:233-247: one `{ch}.tif` per peak response map (already quantised to uint8 and un-padded)
     and `dets.npy` (float64 [P,7])."""
     os.makedirs(save_path, exist_ok=True)
-    for ch, fm in enumerate(prms_u8):
-        write_tiff_stack(os.path.join(save_path, "%d.tif" % ch), np.asarray(fm, dtype=np.uint8))
+    _parallel(lambda a: write_tiff_stack(os.path.join(save_path, "%d.tif" % a[0]), np.asarray(a[1], dtype=np.uint8)),
+              list(enumerate(prms_u8)))
     np.save(os.path.join(save_path, "dets.npy"), np.asarray(dets))
 
 
 def load_prm_instances(instance_path):
     """What tools/binarization_*.py read per tile: dets.npy and the n `{i}.tif` stacks (binarization_nuclei.py:60-69,95)."""
     dets = np.load(os.path.join(instance_path, "dets.npy"))
-    prms = [read_tiff_stack(os.path.join(instance_path, "%d.tif" % i)) for i in range(dets.shape[0])]
+    prms = _parallel(lambda i: read_tiff_stack(os.path.join(instance_path, "%d.tif" % i)), list(range(dets.shape[0])))
     return dets, prms
 
 
