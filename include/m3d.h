@@ -169,6 +169,11 @@ int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float*
 int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                    int depth, int height, int width, const float* d_scale, const float* d_shift,
                                    int relu, void* stream);
+/* the same with the pool's argmax (uint8 [batch, cout, D/2, H/2, W/2], dz*4 + dy*2 + dx of the first maximum: the rule of
+ * m3d_maxpool3d_2x_forward) - the response conv of the pooled layers in PRM mode */
+int m3d_conv3d_wino2_forward_pool2_argmax(const float* d_in, const float* d_packed, float* d_out, unsigned char* d_argmax, int batch,
+                                          int cin, int cout, int depth, int height, int width, const float* d_scale,
+                                          const float* d_shift, int relu, void* stream);
 
 /* conv1a (5x5x5, one input channel; DSN.py:19,58) with Winograd F(2,5) along x (csrc/conv3d_stem_wino.hip): 0.62x the MFMA
  * work of the direct stem kernel; own packed layout; pool != 0 fuses MaxPool3d(2,2) and writes [batch,cout,D/2,H/2,W/2].

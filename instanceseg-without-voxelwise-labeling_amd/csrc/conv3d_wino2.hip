@@ -70,6 +70,7 @@ struct W2Epi {
   // channel chunks [s*cps, (s+1)*cps) and writes its un-scaled partial result to out + s*slice_stride
   int ksplit, cps;
   size_t slice_stride;
+  unsigned char* argmax;   // fused-pool kernels instantiated with AM: index 0..7 = (dz, dy, dx) of each pooled value's first maximum
 };
 
 __device__ __forceinline__ int xcd_contiguous2(int bid, int n) {
@@ -450,7 +451,7 @@ struct W2CfgE {
 };
 
 
-template <int CC, int XT, int WZ, int WY, bool POOL>
+template <int CC, int XT, int WZ, int WY, bool POOL, bool AM = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                               float* __restrict__ out, int cin, int cout, int D, int H, int W,
                                                               int tiles_x, int tiles_y, int tiles_z, int ncb_total, W2Epi ep) {
@@ -719,25 +720,36 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
   if constexpr (POOL) {
     // conv + scale/shift + ReLU + MaxPool3d(2,2): the (y, x) 2x2 footprint is in the lane; the z pair is wave wz = 0 / 1
     float pooled[16];
+    int pidx[16];                                      // AM: (dy, dx) of the first maximum inside the lane's 2x2 patch
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int co = min(co0 + (g & 3) + 8 * (g >> 2), cout - 1);
       const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
       float m = -INFINITY;
+      int mi = 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           float v = yv[r][c][g] * sc + sh;
           if (ep.relu) v = fmaxf(v, 0.f);
-          m = fmaxf(m, v);
+          if constexpr (AM) {
+            if (v > m) { m = v; mi = 2 * r + c; }      // strict >: the first maximum in (dz, dy, dx) order, as maxpool2_fwd_kernel
+          } else {
+            m = fmaxf(m, v);
+          }
         }
       pooled[g] = m;
+      pidx[g] = mi;
     }
     float* red = lds + C::XCH_FLOATS + (size_t)wy * 16 * 64 + lane;   // behind the eta exchange area
+    float* redi = red + 2 * 16 * 64;                   // the second half of the pool exchange area: the indices
     if (wz == 1) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g) red[g * 64] = pooled[g];
+      for (int g = 0; g < 16; ++g) {
+        red[g * 64] = pooled[g];
+        if constexpr (AM) redi[g * 64] = __int_as_float(pidx[g]);
+      }
     }
     __syncthreads();
     if (wz == 1) return;
@@ -747,8 +759,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int co = co0 + (g & 3) + 8 * (g >> 2);
-      if (co < cout)
-        out[((size_t)b * cout + co) * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = fmaxf(pooled[g], red[g * 64]);
+      if (co < cout) {
+        const size_t o = ((size_t)b * cout + co) * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp;
+        const float up = red[g * 64];
+        if constexpr (AM) {
+          const bool upper = up > pooled[g];            // the z + 1 plane only wins when strictly larger
+          out[o] = upper ? up : pooled[g];
+          ep.argmax[o] = (unsigned char)(upper ? 4 + __float_as_int(redi[g * 64]) : pidx[g]);
+        } else {
+          out[o] = fmaxf(pooled[g], up);
+        }
+      }
     }
     return;
   }
@@ -815,7 +836,7 @@ int launch_wino2_one(const float* in, const float* wp, float* out, int B, int ci
 
 
 // eta-split variant: 8 waves, two per SIMD
-template <int CC, int XT, int WZ, int WY, bool POOL = false>
+template <int CC, int XT, int WZ, int WY, bool POOL = false, bool AM = false>
 int launch_wino2e(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
                   int ksplit = 1) {
   using C = W2CfgE<CC, XT, WZ, WY, POOL>;
@@ -827,7 +848,7 @@ int launch_wino2e(const float* in, const float* wp, float* out, int B, int cin, 
   ep.xcd_map = xcd_map_enabled2();
   const size_t lds = sizeof(float) * C::SMEM_FLOATS;
   if (lds > 160 * 1024) return M3D_EUNSUPPORTED;
-  auto kern = conv3d_wino2e_kernel<CC, XT, WZ, WY, POOL>;
+  auto kern = conv3d_wino2e_kernel<CC, XT, WZ, WY, POOL, AM>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B, ksplit), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W, tiles_x, tiles_y,
@@ -970,4 +991,19 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
   if (width < 48)         // 32-wide tiles (conv3b on 32^3 maps): the pool of the 16^3-class layers is fused as well
     return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
   return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
+}
+
+/* m3d_conv3d_wino2_forward_pool2 that also returns the pool's argmax (uint8 [batch, cout, D/2, H/2, W/2], index = dz*4 + dy*2 + dx
+ * of the first maximum, the rule of m3d_maxpool3d_2x_forward): the response conv of the pooled layers in PRM mode. */
+M3D_API int m3d_conv3d_wino2_forward_pool2_argmax(const float* d_in, const float* d_packed, float* d_out, unsigned char* d_argmax,
+                                                  int batch, int cin, int cout, int depth, int height, int width, const float* d_scale,
+                                                  const float* d_shift, int relu, void* stream) {
+  if (!d_in || !d_packed || !d_out || !d_argmax || batch <= 0 || cin <= 0 || cout <= 0 || depth < 2 || height < 2 || width < 2)
+    return M3D_EINVAL;
+  const size_t DHW = (size_t)depth * height * width;
+  if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 24) return M3D_EUNSUPPORTED;
+  W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0, d_argmax};
+  hipStream_t st = m3d::as_stream(stream);
+  if (width < 48) return launch_wino2e<4, 16, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  return launch_wino2e<4, 32, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
 }

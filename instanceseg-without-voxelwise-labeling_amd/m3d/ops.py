@@ -686,14 +686,23 @@ class WinoConv3d(object):
     def supports_pool(self, width):
         return width >= (24 if self.two_d else 48)
 
-    def pooled(self, x, scale=None, shift=None, relu=False, out=None):
-        """conv + scale/shift + ReLU + MaxPool3d(2,2) in one launch; returns [B,cout,D//2,H//2,W//2]."""
+    def pooled(self, x, scale=None, shift=None, relu=False, out=None, return_argmax=False):
+        """conv + scale/shift + ReLU + MaxPool3d(2,2) in one launch; returns [B,cout,D//2,H//2,W//2] (+ the pool's uint8 argmax,
+        2-D kernel only)."""
         _need_gpu(x)
         x = _f32c(x)
         B, cin, D, H, W = x.shape
         assert cin == self.cin
         if out is None:
             out = torch.empty((B, self.cout, D // 2, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        if return_argmax:
+            assert self.two_d
+            am = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+            check(lib().m3d_conv3d_wino2_forward_pool2_argmax(_ptr(x), _ptr(self.packed), _ptr(out), _ptr(am), B, cin, self.cout, D, H, W,
+                                                              _ptr(scale) if scale is not None else None,
+                                                              _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),
+                  "conv3d_wino2_forward_pool2_argmax")
+            return out, am
         check(self._pool(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                          _ptr(scale) if scale is not None else None,
                          _ptr(shift) if shift is not None else None, int(bool(relu)), _stream()),

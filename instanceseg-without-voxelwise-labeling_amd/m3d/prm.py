@@ -64,7 +64,11 @@ class PRMEngine:
         for li, L in enumerate(self.layers):
             off = ops.reduce_min(x)
             n = L["norm_conv"](x, in_offset=off)
-            if L["pool"] and L["conv"].supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
+            wnp = det.body_wino[li] if (self.wino_forward and L["pool"] and L["k"] == 3) else None
+            if wnp is not None and wnp.two_d and wnp.supports_pool(x.shape[-1]) and x[0].numel() * 4 < 0x7FFFFFFF and \
+                    wnp.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
+                xn, am = wnp.pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)     # F(2x2,3x3) + pool + argmax
+            elif L["pool"] and L["conv"].supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
                 xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
                 wn = det.body_wino[li] if self.wino_forward else None

@@ -256,6 +256,33 @@ def test_conv3d_winograd_vs_fp64(m3d, B, cin, cout, D, H, W, two_d):
         assert (yp - refp).abs().max().item() / refp.abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 64, 64, 6, 8, 64), (2, 32, 40, 4, 10, 70), (1, 128, 128, 4, 6, 32), (1, 16, 33, 5, 7, 50)])
+def test_conv3d_winograd_2d_pool_argmax(m3d, B, cin, cout, D, H, W):
+    """F(2x2,3x3) + BN + ReLU + MaxPool3d(2,2) + argmax in one launch == the same kernel's un-pooled output pushed through
+    m3d_maxpool3d_2x_forward (values bit for bit, indices with the first-maximum rule; ReLU zeros make ties common)."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = torch.randn(B, cin, D, H, W, generator=g).cuda()
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5).cuda()
+    sc = (torch.rand(cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(cout, generator=g).cuda()
+    conv = m3d.WinoConv3d(w, two_d=True)
+    y = conv(x, scale=sc, shift=sh, relu=True)                # may come from another tile configuration: equal to a few ulp
+    ref = torch.nn.functional.max_pool3d(y, 2, 2)
+    out, am = conv.pooled(x, scale=sc, shift=sh, relu=True, return_argmax=True)
+    tol = 1e-5 * float(ref.abs().max())
+    assert out.shape == ref.shape and am.shape == ref.shape and am.dtype == torch.uint8 and int(am.max()) <= 7
+    assert (out - ref).abs().max().item() <= tol
+    assert torch.equal(conv.pooled(x, scale=sc, shift=sh, relu=True), out)              # same kernel without the index output
+    # the index points at a child that holds the maximum ...
+    PD, PH, PW = ref.shape[-3:]
+    yc = y[..., :2 * PD, :2 * PH, :2 * PW].reshape(B, cout, PD, 2, PH, 2, PW, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, cout, PD, PH, PW, 8)
+    picked = torch.gather(yc, 5, am.long().unsqueeze(-1)).squeeze(-1)
+    assert (picked - out).abs().max().item() <= tol
+    # ... and at the FIRST one in (dz, dy, dx) order where they tie exactly (all eight children cut to 0 by the ReLU)
+    allzero = (yc == 0).all(-1) & (out == 0)
+    assert int(allzero.sum()) > 0 and int(am[allzero].max()) == 0
+
+
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 128, 256, 16, 16, 16), (1, 256, 256, 8, 25, 23), (2, 20, 40, 3, 13, 12),
                                                 (1, 256, 70, 5, 9, 17), (1, 6, 33, 2, 30, 21)])
 def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
