@@ -268,6 +268,18 @@ size_t m3d_linear_workspace_bytes(int M, int N, int K);
 int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
                        int relu, void* d_ws, size_t ws_bytes, void* stream);
 
+/* The same layer on the bf16 matrix cores at fp32 accuracy ("bf16x3 split"): every fp32 operand is cut EXACTLY into three bf16
+ * numbers (x = xh + xm + xl, 8 significand bits each) and six bf16 MFMAs (the products down to 2^-23 of the full product)
+ * accumulate in fp32 what one fp32 MFMA step does - 16 / 6 of the fp32 matrix rate, error vs fp64 as the fp32 kernel's.
+ * The weight is cut once: m3d_linear_bf16x3_pack writes three bf16 planes in tile order (m3d_linear_bf16x3_packed_bytes =
+ * 6 bytes per weight, N rounded up to 128); x stays fp32 and is cut inside the kernel.  K must be a multiple of 32
+ * (else M3D_EUNSUPPORTED / packed_bytes 0: use m3d_linear_forward).  Same split-K / fixed-order reduction contract. */
+size_t m3d_linear_bf16x3_packed_bytes(int N, int K);
+int m3d_linear_bf16x3_pack(const float* d_weight, int N, int K, void* d_packed, void* stream);
+size_t m3d_linear_bf16x3_workspace_bytes(int M, int N, int K);
+int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
+                              int relu, void* d_ws, size_t ws_bytes, void* stream);
+
 /* norm1 pre-processing of a raw volume on the device: mask = im > 0; out = (im - mean(im[mask])) / std(im[mask])
  * (np.std: population).  Replaces the host NumPy code of lib/utils/blob.py:179-184 (float32; f32_arith = 1) and
  * tools/infer_simple.py:180-183 (float64, crops cast to float32 at :217; f32_arith = 0), so the raw uint16 volume is what

@@ -266,6 +266,217 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix cores, WITHOUT giving up fp32 accuracy ("bf16x3 split", 6 products per fp32 product).
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the FLOP rate of the fp32-input MFMA.  An fp32 number has a 24-bit significand;
+// cut by TRUNCATION into three bf16 numbers (8-bit significands, the same exponent range as fp32)
+//     x = xh + xm + xl          xh = top 8 bits,  xm = top 8 bits of (x - xh),  xl = x - xh - xm   (8 bits are left: exact)
+// the cut is exact, each bf16 x bf16 product is exact in fp32 (16 bits), and
+//     x.w = xh.wh + (xh.wm + xm.wh) + (xm.wm + xh.wl + xl.wh)  +  [xm.wl + xl.wm + xl.wl  <= 2^-23 |x.w|: dropped]
+// so six bf16 MFMAs accumulate in fp32 what one fp32 MFMA step does, to the same accuracy (the dropped terms are below the
+// rounding of the fp32 accumulation itself; tests/test_gpu_ops.py compares both kernels with fp64), at 16 / 6 = 2.7x the rate.
+// The weights are cut once, off line (m3d_linear_bf16x3_pack: three bf16 planes in tile order = 6 bytes per weight instead of 4);
+// x (the RoIAlign output) is cut on the way from global memory to LDS (4 VALU + 1.5 pack ops per element, under the other
+// resident workgroup's MFMAs).  Same tiling as the fp32 kernel: 128 x 128 workgroup tile, 4 waves as 2 x 2, each 64 x 64 = 2 x 2
+// MFMA blocks; per 32-deep K chunk a wave issues 2 k16 steps x 4 blocks x 6 products = 48 MFMAs of 32 cycles (the fp32 kernel:
+// 64 of 64 cycles).  One LDS buffer of [2 operands][3 planes][128 rows][80 B] = 60 KB (row stride 80 B: the 16-byte fragment reads
+// of 8 consecutive rows cover the 32 banks once), two workgroups per CU; the next chunk waits in registers during the MFMAs.
+// Roofline: MFMA (bf16, 2.5 PFLOP/s dense): 6 x 2MNK issued FLOP.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef FCX3_EXP
+#define FCX3_EXP 0        // timing ablations (make fc_variants): 1 no MFMA, 2 no cut arithmetic, 4 no LDS commit, 8 no global fetch in the loop, 16 no x loads, 32 no W loads
+#endif
+
+constexpr int X3_RSW = 20;                        // LDS row stride in dwords (64 B of data + 16 B pad)
+constexpr int X3_PLANE = 128 * X3_RSW;            // dwords of one plane
+constexpr int X3_OPER = 3 * X3_PLANE;             // dwords of one operand (three planes)
+constexpr int X3_CHUNK_U4 = 3 * 128 * 4;          // 16-byte units of one packed (tile, chunk) weight block
+
+// packed[tn][c][s][row][32 k] (bf16) <- W[N][K] fp32; rows beyond N are zero.  One thread = 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void fc_x3_pack_kernel(const float* __restrict__ w, int N, int K, u32x4* __restrict__ packed,
+                                                         int nt, int chunks) {
+  const long long total = (long long)nt * chunks * 128 * 4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int q = (int)(e & 3), row = (int)((e >> 2) & 127);
+    const long long tc = e >> 9;
+    const int c = (int)(tc % chunks), tn = (int)(tc / chunks);
+    const int n = tn * 128 + row;
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = n < N ? w[(size_t)n * K + (size_t)c * 32 + 8 * q + j] : 0.f;
+      const unsigned uh = __float_as_uint(v) & 0xFFFF0000u;
+      const float r1 = v - __uint_as_float(uh);
+      const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+      const float r2 = r1 - __uint_as_float(um);
+      h[j] = uh >> 16; m[j] = um >> 16; l[j] = __float_as_uint(r2) >> 16;
+    }
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ph[j] = h[2 * j] | (h[2 * j + 1] << 16); pm[j] = m[2 * j] | (m[2 * j + 1] << 16); pl[j] = l[2 * j] | (l[2 * j + 1] << 16);
+    }
+    u32x4* dst = packed + (size_t)tc * X3_CHUNK_U4 + row * 4 + q;
+    dst[0] = ph; dst[512] = pm; dst[1024] = pl;
+  }
+}
+
+struct FcX3Args {
+  const float* x; const u32x4* wp; const float* bias; float* out; float* part;
+  int M, N, K, mt, nt, slices, chunks, relu, per_xcd;
+};
+
+__global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
+  extern __shared__ float lds_f[];
+  unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);        // [x planes h, m, l][W planes h, m, l] x [128][20] dwords
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // unit = (slice, tile): the workgroups one XCD runs together share a slice and neighbouring tiles (as in the fp32 kernel)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tiles = a.mt * a.nt, u = xcd * a.per_xcd + idx;
+  if (u >= tiles * a.slices) return;
+  const int slice = u / tiles, tile = u - slice * tiles;
+  const int tm = tile / a.nt, tn = tile - tm * a.nt;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
+
+  // ---- staging: thread -> (row = tid/4 + 64 i, 8 k at 8 (tid % 4)) for x (two float4 per row) and the same (row, 16-byte unit) of
+  // each weight plane
+  const int oct = tid & 3, row0 = tid >> 2;
+  const float* px[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) px[i] = a.x + (size_t)min(m0 + row0 + 64 * i, a.M - 1) * a.K + 8 * oct;   // clamped: masked at the store
+  const u32x4* pw = a.wp + (size_t)tn * a.chunks * X3_CHUNK_U4 + tid;
+  const int ldst = row0 * X3_RSW + 4 * oct;
+  // (a second register stage, loads two chunks ahead, was no faster: the load phase is not latency-bound)
+  struct Stage { f32x4 x[2][2]; u32x4 w[6]; };
+  Stage sa;
+  auto fetch = [&](Stage& g, int c) __attribute__((always_inline)) {
+    if (!(FCX3_EXP & 16)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        g.x[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
+        g.x[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
+      }
+    }
+    if (!(FCX3_EXP & 32)) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) g.w[i] = pw[(size_t)c * X3_CHUNK_U4 + 256 * i];
+    }
+  };
+  auto commit = [&](const Stage& g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 ph, pm, pl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                // elements 2j, 2j+1 of this row's 8
+        const float v0 = g.x[i][j >> 1][2 * (j & 1)], v1 = g.x[i][j >> 1][2 * (j & 1) + 1];
+        if (FCX3_EXP & 2) { ph[j] = __float_as_uint(v0); pm[j] = __float_as_uint(v1); pl[j] = ph[j]; continue; }
+        const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
+        const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+        const unsigned q0 = __float_as_uint(r0) & 0xFFFF0000u, q1 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float t0 = r0 - __uint_as_float(q0), t1 = r1 - __uint_as_float(q1);
+        ph[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+        pm[j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+        pl[j] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+      }
+      unsigned* d = lds + ldst + 64 * i * X3_RSW;
+      *reinterpret_cast<u32x4*>(d) = ph;
+      *reinterpret_cast<u32x4*>(d + X3_PLANE) = pm;
+      *reinterpret_cast<u32x4*>(d + 2 * X3_PLANE) = pl;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      *reinterpret_cast<u32x4*>(lds + X3_OPER + (i >> 1) * X3_PLANE + (64 * (i & 1)) * X3_RSW + ldst) = g.w[i];
+  };
+
+  // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k half h): 8 bf16 at k = 16 t + 8 h
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int offA = (wm * 64 + fr) * X3_RSW + 4 * fh;
+  const int offB = X3_OPER + (wn * 64 + fr) * X3_RSW + 4 * fh;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + offA + s * X3_PLANE + i * 32 * X3_RSW + 8 * t));
+          fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + offB + s * X3_PLANE + i * 32 * X3_RSW + 8 * t));
+        }
+      // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (FCX3_EXP & 1) { asm volatile("" ::"v"(fa[i][PA[p]]), "v"(fb[j][PB[p]])); continue; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][j], 0, 0, 0);
+          }
+    }
+  };
+
+  if (c0 < c1) { fetch(sa, c0); commit(sa); }
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    if (!(FCX3_EXP & 8)) fetch(sa, c + 1 < c1 ? c + 1 : c);       // last chunk: harmless re-fetch instead of a branch around the loads
+    __builtin_amdgcn_sched_barrier(0);                            // the loads stay in front of the MFMAs
+    compute();
+    if (FCX3_EXP & 4) continue;
+    __syncthreads();                                              // everybody has read the buffer
+    commit(sa);
+    __syncthreads();
+  }
+
+  const bool direct = a.slices == 1;
+  float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + fr;
+    const float b = (direct && a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int m = mb + KGmap(g);
+        if (m < a.M && n < a.N) {
+          float v = acc[i][j][g];
+          if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
+          dst[(size_t)m * a.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// split-K factor of the bf16x3 kernel: all row tiles run the full path; fill the 512 resident-workgroup slots
+int x3_slices(int M, int N, int K) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), chunks = K / 32;
+  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) return ts < chunks ? ts : chunks;
+  const int smax = chunks / 8 + 1 < 64 ? chunks / 8 + 1 : 64;
+  double best = 1e30; int bs = 1;
+  for (int s = 1; s <= smax; ++s) {
+    const double rounds = ceil(ceil((double)tiles * s / 8.0) / 64.0);
+    double t = rounds * (2.0 * BM * BN * (double)K / s) / (3.0e14 / 512.0) + rounds * 4e-6;
+    if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;
+    if (t < best) { best = t; bs = s; }
+  }
+  return bs;
+}
+
 struct Plan { int mt, nt, chunks, slices, slices_tail, mt_full, full_per_xcd, tail_per_xcd; };
 
 Plan make_plan(int M, int N, int K) {
@@ -340,4 +551,47 @@ M3D_API int m3d_linear_forward(const float* d_x, const float* d_weight, const fl
                        p.slices_tail, (long long)(p.mt_full < p.mt ? p.mt_full * BM : M) * N, relu);
   }
   return m3d::check_launch("linear_forward");
+}
+
+/* ---- bf16x3 split variant (see the kernel's header comment): weights are cut once into three bf16 planes ---- */
+M3D_API size_t m3d_linear_bf16x3_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return (size_t)((N + BN - 1) / BN) * (K / 32) * X3_CHUNK_U4 * 16;
+}
+
+M3D_API int m3d_linear_bf16x3_pack(const float* d_weight, int N, int K, void* d_packed, void* stream) {
+  if (!d_weight || !d_packed || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (K % 32 != 0) return M3D_EUNSUPPORTED;
+  const int nt = (N + BN - 1) / BN, chunks = K / 32;
+  hipLaunchKernelGGL(fc_x3_pack_kernel, dim3(4096), dim3(256), 0, m3d::as_stream(stream), d_weight, N, K, (u32x4*)d_packed, nt, chunks);
+  return m3d::check_launch("linear_bf16x3_pack");
+}
+
+M3D_API size_t m3d_linear_bf16x3_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  const int s = x3_slices(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 16;
+}
+
+M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
+                                      int relu, void* d_ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (M == 0) return M3D_OK;
+  if (!d_x || !d_packed || !d_out) return M3D_EINVAL;
+  if (K % 32 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
+  const int s = x3_slices(M, N, K);
+  if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
+  FcX3Args a{d_x, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, s, K / 32, relu, 0};
+  a.per_xcd = (a.mt * a.nt * s + 7) / 8;
+  const size_t lds = sizeof(unsigned) * 2 * X3_OPER;
+  hipStream_t st = m3d::as_stream(stream);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fc_x3_gemm_kernel, dim3(8 * a.per_xcd), dim3(256), lds, st, a);
+  if (s > 1) {
+    const long long MN = (long long)M * N;
+    long long blocks = (MN + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
+  }
+  return m3d::check_launch("linear_bf16x3_forward");
 }

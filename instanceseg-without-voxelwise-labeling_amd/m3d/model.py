@@ -106,6 +106,14 @@ class DetectorM3D:
         if self.has_head:
             self.outs_w = torch.cat([params["Box_Outs.cls_score.weight"], params["Box_Outs.bbox_pred.weight"]], 0).contiguous()
             self.outs_b = torch.cat([params["Box_Outs.cls_score.bias"], params["Box_Outs.bbox_pred.bias"]]).contiguous()
+            # fc1 / fc2 on the bf16 matrix cores at fp32 accuracy (exact 3-way bf16 cut, csrc/fc_gemm.hip): weights are cut once
+            # here.  M3D_FC_SPLIT=0 keeps the fp32-input MFMA kernel (A/B tooling).
+            self.fc_split = {}
+            if os.environ.get("M3D_FC_SPLIT", "1") != "0":
+                for name in ("fc1", "fc2"):
+                    w = params["Box_Head.%s.weight" % name]
+                    if ops.SplitLinear.supported(w):
+                        self.fc_split[name] = ops.SplitLinear(w, params["Box_Head.%s.bias" % name])
 
     # ---- lib/modeling/DSN.py:57-68
     def body_layer(self, li, x):
@@ -189,10 +197,12 @@ class DetectorM3D:
         with self.span("roi_align3d"):
             x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
         x = x.view(x.shape[0], -1)
-        with self.span("fc1"):
-            x = ops.linear(x, P["Box_Head.fc1.weight"], P["Box_Head.fc1.bias"], relu=True)          # :114
-        with self.span("fc2"):
-            x = ops.linear(x, P["Box_Head.fc2.weight"], P["Box_Head.fc2.bias"], relu=True)          # :115
+        for name in ("fc1", "fc2"):                                                                 # :114-115
+            with self.span(name):
+                if name in self.fc_split:
+                    x = self.fc_split[name](x, relu=True)
+                else:
+                    x = ops.linear(x, P["Box_Head.%s.weight" % name], P["Box_Head.%s.bias" % name], relu=True)
         o = ops.linear(x, self.outs_w, self.outs_b)              # cls_score and bbox_pred share their input: one GEMM (:42,45)
         nc = c.num_classes
         cls = torch.softmax(o[:, :nc], dim=1)                                                       # :43-44 (eval)

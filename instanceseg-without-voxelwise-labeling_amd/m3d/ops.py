@@ -11,7 +11,7 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear",
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear",
            "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
@@ -345,6 +345,42 @@ def linear(x, weight, bias=None, relu=False, out=None):
     check(lib().m3d_linear_forward(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), M, N, K, int(bool(relu)), _ptr(ws),
                                    C.c_size_t(wsb), _stream()), "linear_forward")
     return out
+
+
+class SplitLinear:
+    """nn.Linear weights cut once into three bf16 planes for m3d_linear_bf16x3_forward (fp32 accuracy at the bf16 matrix rate:
+    x = xh + xm + xl exactly, six bf16 MFMAs per fp32 product).  `supported(weight)`: K a multiple of 32."""
+
+    @staticmethod
+    def supported(weight):
+        return weight.dim() == 2 and weight.shape[1] % 32 == 0 and weight.shape[0] >= 64
+
+    def __init__(self, weight, bias=None):
+        _need_gpu(weight, bias)
+        weight = _f32c(weight)
+        self.N, self.K = int(weight.shape[0]), int(weight.shape[1])
+        nb = lib().m3d_linear_bf16x3_packed_bytes(self.N, self.K)
+        if nb == 0:
+            raise ValueError("SplitLinear: K = %d is not a multiple of 32" % self.K)
+        self.packed = torch.empty((nb,), dtype=torch.uint8, device=weight.device)
+        check(lib().m3d_linear_bf16x3_pack(_ptr(weight), self.N, self.K, _ptr(self.packed), _stream()), "linear_bf16x3_pack")
+        self.bias = None if bias is None else _f32c(bias)
+
+    def __call__(self, x, relu=False, out=None):
+        _need_gpu(x)
+        x = _f32c(x)
+        M, K = x.shape
+        if K != self.K:
+            raise ValueError("SplitLinear: x is [%d,%d] but the weight is [%d,%d]" % (M, K, self.N, self.K))
+        if out is None:
+            out = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
+        if M == 0:
+            return out
+        wsb = lib().m3d_linear_bf16x3_workspace_bytes(M, self.N, K)
+        ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=x.device)
+        check(lib().m3d_linear_bf16x3_forward(_ptr(x), _ptr(self.packed), _ptr(self.bias), _ptr(out), M, self.N, K, int(bool(relu)),
+                                              _ptr(ws), C.c_size_t(wsb), _stream()), "linear_bf16x3_forward")
+        return out
 
 
 def norm1(vol, f32_arith=True, out=None, return_stats=False):

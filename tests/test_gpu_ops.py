@@ -650,6 +650,34 @@ def test_linear_split_k_gemm_vs_fp64(m3d, M, N, K, relu):
     assert m3d.linear(x[:0], w, b).shape == (0, N)
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(1, 64, 32, False), (37, 64, 5504, True), (130, 128, 43904, True), (320, 1024, 87808, True),
+                                         (1283, 1024, 1024, True), (257, 100, 1024, False), (1200, 1024, 87808, True)])
+def test_linear_bf16x3_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K, relu):
+    """Six bf16 MFMAs on the exact 3-way cut of both operands == fp32 accuracy: the error against fp64 stays within the same
+    bound as the fp32 MFMA kernel's and within 2x of its measured error; awkward values (huge / tiny / negative) included."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    x[0, :16] = torch.tensor([1e20, -1e20, 1e-20, -1e-20, 3.0, -3.0, 1.0000001, 0.99999994, 65504.0, 1e-30, 0.0, -0.0, 255.5, 1 / 3, 2 ** -100, 1.0])
+    x = x.cuda()
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    w[0, :16] = torch.tensor([1e-20, 1e-20, 1e20, 1e20, 1 / 3, 1 / 7, 1.0, 1.0, 1e-4, 1e30, 5.0, 5.0, 1e-3, 3.0, 2 ** 100, -1.0]).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    lin = m3d.SplitLinear(w, b)
+    got = lin(x, relu=relu)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    scale = ref.abs().max().item()
+    bound = 2e-6 * scale * max(1.0, np.sqrt(K / 1024.0))
+    err = (got.double() - ref).abs().max().item()
+    err32 = (m3d.linear(x, w, b, relu=relu).double() - ref).abs().max().item()
+    assert got.shape == (M, N) and err <= bound and err <= 2.0 * err32 + 1e-7 * scale, (err, err32, bound)
+    assert torch.equal(got, lin(x, relu=relu))                           # deterministic
+    assert lin(x[:0]).shape == (0, N)
+    with pytest.raises(ValueError):
+        m3d.SplitLinear(w[:, :K - 4].contiguous())                       # K % 32 != 0: the fp32 kernel's job
+
+
 # ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
 def test_fused_proposals_batched_bit_exact_with_oracle_and_golden(m3d, golden):
     """One launch for a batch of tiles == the per-tile reference op, item by item: kept flat indices, probabilities and row

@@ -1,40 +1,39 @@
-#!/usr/bin/env python3
-"""fc1 / fc2 of the box head: the split-K fp32 MFMA GEMM (csrc/fc_gemm.hip) vs the library GEMM torch dispatches to."""
-import os
-import sys
-
+"""A/B of the two box-head GEMM kernels at the fc1 shape: fp32 MFMA (m3d_linear_forward) vs bf16x3 split (m3d_linear_bf16x3_forward).
+usage: python tools/bench_fc.py [M ...]"""
+import sys, os
+import numpy as np
 import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
-import m3d  # noqa: E402
+sys.path[:0] = [ROOT, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd")]
+from m3d import ops as m3d  # noqa: E402
 
 
-def timeit(f, n=10):
-    for _ in range(3):
-        f()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+def timed(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     for _ in range(n):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
 
 
 def main():
-    N = 1024
-    for K in (87808, 43904, 1024):
-        w = torch.randn(N, K, device="cuda") / K ** 0.5
-        b = torch.randn(N, device="cuda")
-        for M in (64, 128, 320, 640, 1000, 1280, 1281, 1313, 2560):
-            x = torch.randn(M, K, device="cuda")
-            t_own = timeit(lambda: m3d.linear(x, w, b, relu=True))
-            t_lib = timeit(lambda: torch.relu(torch.nn.functional.linear(x, w, b)))
-            fl = 2.0 * M * N * K
-            print("K=%6d M=%5d  own %.3f ms %6.1f TF (%.0f%% of 157.3)   library %.3f ms %6.1f TF" %
-                  (K, M, t_own, fl / t_own / 1e9, fl / t_own / 1e9 / 157.3 * 100, t_lib, fl / t_lib / 1e9), flush=True)
+    Ms = [int(v) for v in sys.argv[1:]] or [1200, 1281, 300]
+    N, K = 1024, int(os.environ.get("FC_K", "87808"))
+    w = (torch.randn(N, K) / np.sqrt(K)).cuda()
+    b = torch.randn(N).cuda()
+    lin = m3d.SplitLinear(w, b)
+    for M in Ms:
+        x = torch.randn(M, K).cuda()
+        t32 = timed(lambda: m3d.linear(x, w, b, relu=True))
+        t3 = timed(lambda: lin(x, relu=True))
+        ref = torch.relu(x[:64].double() @ w.double().t() + b.double())
+        e32 = (m3d.linear(x, w, b, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+        e3 = (lin(x, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+        fl = 2.0 * M * N * K
+        print("M=%5d  fp32 MFMA %.3f ms (%.1f TF, err %.2e)   bf16x3 %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
+              % (M, t32, fl / t32 / 1e9, e32, t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
 
 
 if __name__ == "__main__":
