@@ -33,7 +33,8 @@ const char* m3d_error_string(int code);
 const char* m3d_last_hip_error(void);
 /* Tuning options (benchmark / A-B tooling; production callers never set them).  Names: "xcd_map" (1: XCD-aware
  * workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt"
- * (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" / "tune_fc_slices_tail" (split-K factors of m3d_linear_forward).  Unknown name -> M3D_EINVAL. */
+ * (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" / "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of
+ * m3d_linear_bf16x3_forward).  Unknown name -> M3D_EINVAL. */
 int m3d_set_option(const char* name, int value);
 int m3d_get_option(const char* name, int* value);
 

@@ -280,16 +280,14 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 // x (the RoIAlign output) is cut on the way from global memory to LDS (4 VALU + 1.5 pack ops per element, under the other
 // resident workgroup's MFMAs).  Same tiling as the fp32 kernel: 128 x 128 workgroup tile, 4 waves as 2 x 2, each 64 x 64 = 2 x 2
 // MFMA blocks; per 32-deep K chunk a wave issues 2 k16 steps x 4 blocks x 6 products = 48 MFMAs of 32 cycles (the fp32 kernel:
-// 64 of 64 cycles).  One LDS buffer of [2 operands][3 planes][128 rows][80 B] = 60 KB (row stride 80 B: the 16-byte fragment reads
-// of 8 consecutive rows cover the 32 banks once), two workgroups per CU; the next chunk waits in registers during the MFMAs.
+// 64 of 64 cycles).  One LDS buffer of [2 operands][3 planes][128 rows][64 B] = 48 KB (16-byte units XOR-swizzled by the row so the
+// fragment reads of 8 consecutive rows cover the 32 banks once), three workgroups per CU (<= 168 VGPRs): whenever one wave of a
+// SIMD sits in its load-wait / cut / barrier phase two others can issue MFMAs; the next chunk waits in registers during the MFMAs.
 // Roofline: MFMA (bf16, 2.5 PFLOP/s dense): 6 x 2MNK issued FLOP.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#ifndef FCX3_EXP
-#define FCX3_EXP 0        // timing ablations (make fc_variants): 1 no MFMA, 2 no cut arithmetic, 4 no LDS commit, 8 no global fetch in the loop, 16 no x loads, 32 no W loads
-#endif
 
-constexpr int X3_RSW = 20;                        // LDS row stride in dwords (64 B of data + 16 B pad)
+constexpr int X3_RSW = 16;                        // LDS row stride in dwords: 64 B, no pad; the 16-byte unit u of row r sits at u ^ ((r >> 1) & 3)
 constexpr int X3_PLANE = 128 * X3_RSW;            // dwords of one plane
 constexpr int X3_OPER = 3 * X3_PLANE;             // dwords of one operand (three planes)
 constexpr int X3_CHUNK_U4 = 3 * 128 * 4;          // 16-byte units of one packed (tile, chunk) weight block
@@ -328,9 +326,20 @@ struct FcX3Args {
   int M, N, K, mt, nt, slices, chunks, relu, per_xcd;
 };
 
-__global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
+// WR = wave rows of the workgroup: 2 -> 128 x 128 tile, 256 threads, 2 workgroups per CU;  4 -> 256 x 128 tile, 512 threads, one
+// workgroup per CU (x rows are re-used by twice the MFMAs: 28 instead of 40 KB of global loads per 128 x 128 x 32 of work - the
+// loads, not the MFMAs, were what the 128-row kernel waited on: 0.97 ms without them, 1.15 with every load an L2 hit, 1.29 real).
+// Wave schedule of one K chunk (F0 / F1 = the fragments of its two k16 steps, 12 ds_read_b128 each):
+//     read F1 | 24 MFMA(F0) | barrier A (the chunk's LDS image is free) | cut + LDS writes of chunk c+1 under 16 MFMA(F1) |
+//     barrier B | global loads of chunk c+2 -> registers | read F0 of chunk c+1 | 8 MFMA(F1)
+// so every LDS / barrier latency has MFMAs of the same wave to hide under, not only those of the other wave of the SIMD.
+template <int WR>
+__global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(FcX3Args a) {
+  constexpr int TBM = 64 * WR, NT = 128 * WR;                      // tile rows, threads
+  constexpr int XPL = TBM * X3_RSW, XOP = 3 * XPL;                 // dwords of an x plane / of the x operand; W planes: X3_PLANE
+  constexpr int NXI = TBM * 4 / NT, NWI = 3 * 128 * 4 / NT;        // rows of x (two float4 each) / 16-byte units of W per thread and chunk
   extern __shared__ float lds_f[];
-  unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);        // [x planes h, m, l][W planes h, m, l] x [128][20] dwords
+  unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);        // [x planes h, m, l: TBM rows][W planes h, m, l: 128 rows] x 16 dwords
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // unit = (slice, tile): the workgroups one XCD runs together share a slice and neighbouring tiles (as in the fp32 kernel)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -338,41 +347,34 @@ __global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
   if (u >= tiles * a.slices) return;
   const int slice = u / tiles, tile = u - slice * tiles;
   const int tm = tile / a.nt, tn = tile - tm * a.nt;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TBM, n0 = tn * BN;
   const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
 
-  // ---- staging: thread -> (row = tid/4 + 64 i, 8 k at 8 (tid % 4)) for x (two float4 per row) and the same (row, 16-byte unit) of
-  // each weight plane
+  // ---- staging: x: thread -> (row = tid/4 + (NT/4) i, 8 k at 8 (tid % 4)), two float4 per row;  W: 16-byte unit tid + NT i of the
+  // packed (tile, chunk) block = (plane, row, unit tid % 4).  LDS unit u of row r sits at u ^ ((r >> 1) & 3).
   const int oct = tid & 3, row0 = tid >> 2;
-  const float* px[2];
+  const float* px[NXI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) px[i] = a.x + (size_t)min(m0 + row0 + 64 * i, a.M - 1) * a.K + 8 * oct;   // clamped: masked at the store
+  for (int i = 0; i < NXI; ++i) px[i] = a.x + (size_t)min(m0 + row0 + (NT / 4) * i, a.M - 1) * a.K + 8 * oct;   // clamped: masked at the store
   const u32x4* pw = a.wp + (size_t)tn * a.chunks * X3_CHUNK_U4 + tid;
-  const int ldst = row0 * X3_RSW + 4 * oct;
-  // (a second register stage, loads two chunks ahead, was no faster: the load phase is not latency-bound)
-  struct Stage { f32x4 x[2][2]; u32x4 w[6]; };
-  Stage sa;
-  auto fetch = [&](Stage& g, int c) __attribute__((always_inline)) {
-    if (!(FCX3_EXP & 16)) {
+  const int swq = 4 * (oct ^ ((row0 >> 1) & 3));                   // NT/4 is a multiple of 8: every row of this thread swizzles alike
+  f32x4 sx[NXI][2]; u32x4 sw[NWI];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        g.x[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
-        g.x[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
-      }
+    for (int i = 0; i < NXI; ++i) {
+      sx[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
+      sx[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
     }
-    if (!(FCX3_EXP & 32)) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) g.w[i] = pw[(size_t)c * X3_CHUNK_U4 + 256 * i];
-    }
+    for (int i = 0; i < NWI; ++i) sw[i] = pw[(size_t)c * X3_CHUNK_U4 + NT * i];
   };
-  auto commit = [&](const Stage& g) __attribute__((always_inline)) {
+  auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NXI; ++i) {
       u32x4 ph, pm, pl;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {                                // elements 2j, 2j+1 of this row's 8
-        const float v0 = g.x[i][j >> 1][2 * (j & 1)], v1 = g.x[i][j >> 1][2 * (j & 1) + 1];
-        if (FCX3_EXP & 2) { ph[j] = __float_as_uint(v0); pm[j] = __float_as_uint(v1); pl[j] = ph[j]; continue; }
+        const float v0 = sx[i][j >> 1][2 * (j & 1)], v1 = sx[i][j >> 1][2 * (j & 1) + 1];
         const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
         const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
         const unsigned q0 = __float_as_uint(r0) & 0xFFFF0000u, q1 = __float_as_uint(r1) & 0xFFFF0000u;
@@ -381,20 +383,24 @@ __global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
         pm[j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
         pl[j] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
       }
-      unsigned* d = lds + ldst + 64 * i * X3_RSW;
+      unsigned* d = lds + (row0 + (NT / 4) * i) * X3_RSW + swq;
       *reinterpret_cast<u32x4*>(d) = ph;
-      *reinterpret_cast<u32x4*>(d + X3_PLANE) = pm;
-      *reinterpret_cast<u32x4*>(d + 2 * X3_PLANE) = pl;
+      *reinterpret_cast<u32x4*>(d + XPL) = pm;
+      *reinterpret_cast<u32x4*>(d + 2 * XPL) = pl;
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      *reinterpret_cast<u32x4*>(lds + X3_OPER + (i >> 1) * X3_PLANE + (64 * (i & 1)) * X3_RSW + ldst) = g.w[i];
+    for (int i = 0; i < NWI; ++i) {
+      const int un = NT * i;                                       // unit index of thread 0: plane un / 512, row (un % 512) / 4 + row0
+      *reinterpret_cast<u32x4*>(lds + XOP + (un >> 9) * X3_PLANE + (((un & 511) >> 2) + row0) * X3_RSW + swq) = sw[i];
+    }
   };
 
-  // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k half h): 8 bf16 at k = 16 t + 8 h
+  // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k half h): 8 bf16 at k = 16 t + 8 h.
+  // unit of k16 step t = (2t + h) ^ swz = (h ^ swz) ^ 2t: the two steps' addresses differ by XOR 8 dwords
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const int offA = (wm * 64 + fr) * X3_RSW + 4 * fh;
-  const int offB = X3_OPER + (wn * 64 + fr) * X3_RSW + 4 * fh;
+  const int swz = (fr >> 1) & 3;
+  const int offA0 = (wm * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offA1 = offA0 ^ 8;
+  const int offB0 = XOP + (wn * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offB1 = offB0 ^ 8;
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -403,41 +409,51 @@ __global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  auto compute = [&]() __attribute__((always_inline)) {
+  struct Frags { bf16x8 a[2][3], b[2][3]; };
+  Frags f0, f1;
+  auto read_frags = [&](Frags& f, int oa, int ob) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bf16x8 fa[2][3], fb[2][3];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f.a[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + oa + s * XPL + i * 32 * X3_RSW));
+        f.b[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + ob + s * X3_PLANE + i * 32 * X3_RSW));
+      }
+  };
+  // products p0..p1 of one k16 step, small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+  auto mfmas = [&](const Frags& f, int p0, int p1) __attribute__((always_inline)) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      if (p < p0 || p >= p1) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          fa[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + offA + s * X3_PLANE + i * 32 * X3_RSW + 8 * t));
-          fb[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + offB + s * X3_PLANE + i * 32 * X3_RSW + 8 * t));
-        }
-      // small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int p = 0; p < 6; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (FCX3_EXP & 1) { asm volatile("" ::"v"(fa[i][PA[p]]), "v"(fb[j][PB[p]])); continue; }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[p]], f.b[j][PB[p]], acc[i][j], 0, 0, 0);
     }
   };
 
-  if (c0 < c1) { fetch(sa, c0); commit(sa); }
-  __syncthreads();
-  for (int c = c0; c < c1; ++c) {
-    if (!(FCX3_EXP & 8)) fetch(sa, c + 1 < c1 ? c + 1 : c);       // last chunk: harmless re-fetch instead of a branch around the loads
-    __builtin_amdgcn_sched_barrier(0);                            // the loads stay in front of the MFMAs
-    compute();
-    if (FCX3_EXP & 4) continue;
-    __syncthreads();                                              // everybody has read the buffer
-    commit(sa);
+  if (c0 < c1) {
+    fetch(c0); commit();
     __syncthreads();
+    fetch(min(c0 + 1, c1 - 1));
+    read_frags(f0, offA0, offB0);
+  }
+  for (int c = c0; c < c1; ++c) {
+    read_frags(f1, offA1, offB1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f0, 0, 6);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                              // A: everybody holds the chunk's fragments; its LDS image is free
+    commit();                                                     // chunk c + 1 (after the last chunk: a re-write nobody reads) ...
+    mfmas(f1, 0, 4);                                              // ... the compiler interleaves these 16 MFMAs with the cut
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                              // B: the image of chunk c + 1 is complete
+    fetch(min(c + 2, c1 - 1));
+    read_frags(f0, offA0, offB0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(f1, 4, 6);
   }
 
   const bool direct = a.slices == 1;
@@ -462,19 +478,35 @@ __global__ __launch_bounds__(256, 2) void fc_x3_gemm_kernel(FcX3Args a) {
   }
 }
 
-// split-K factor of the bf16x3 kernel: all row tiles run the full path; fill the 512 resident-workgroup slots
-int x3_slices(int M, int N, int K) {
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), chunks = K / 32;
-  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) return ts < chunks ? ts : chunks;
-  const int smax = chunks / 8 + 1 < 64 ? chunks / 8 + 1 : 64;
-  double best = 1e30; int bs = 1;
-  for (int s = 1; s <= smax; ++s) {
-    const double rounds = ceil(ceil((double)tiles * s / 8.0) / 64.0);
-    double t = rounds * (2.0 * BM * BN * (double)K / s) / (3.0e14 / 512.0) + rounds * 4e-6;
-    if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;
-    if (t < best) { best = t; bs = s; }
+// Tile height and split-K factor of the bf16x3 kernel.  256-row tiles (one workgroup per CU: 256 slots) unless the rows they pad
+// cost more than their re-use saves (few RoIs); 128-row tiles: two workgroups per CU (512 slots).
+struct X3Plan { int wr, mt, nt, slices, per_xcd; };
+X3Plan x3_plan(int M, int N, int K) {
+  X3Plan best{2, 0, 0, 1, 0};
+  double best_t = 1e30;
+  const int chunks = K / 32, nt = (N + BN - 1) / BN;
+  const int force = m3d::opt(m3d::OPT_TUNE_FC_SLICES);
+  for (int wr = 2; wr <= 4; wr += 2) {
+    const int tbm = 64 * wr, mt = (M + tbm - 1) / tbm, tiles = mt * nt;
+    const double slots = wr == 2 ? 64.0 : 32.0;                   // per XCD
+    const double rate = (wr == 2 ? 1.65e14 : 2.1e14) / (8.0 * slots) * (wr == 2 ? 1.0 : 1.0);   // fp32-equivalent FLOP/s of one resident workgroup
+    const int smax = chunks / 8 + 1 < 64 ? chunks / 8 + 1 : 64;
+    for (int s = 1; s <= smax; ++s) {
+      if (force > 0 && s != (force < chunks ? force : chunks)) continue;
+      const double rounds = ceil(ceil((double)tiles * s / 8.0) / slots);
+      double t = rounds * (2.0 * tbm * BN * (double)K / s) / rate + rounds * 4e-6;
+      if (s > 1) t += (double)s * M * N * 8.0 / 4e12 + 4e-6;
+      if (t < best_t) { best_t = t; best = X3Plan{wr, mt, nt, s, (tiles * s + 7) / 8}; }
+    }
   }
-  return bs;
+  if (const int w = m3d::opt(m3d::OPT_TUNE_FC_X3_ROWS); w == 128 || w == 256) {      // A/B tooling: force the tile height
+    const int wr = w / 64, tbm = w, mt = (M + tbm - 1) / tbm, tiles = mt * nt;
+    int s = best.slices;
+    if (wr != best.wr) { const double slots = wr == 2 ? 512.0 : 256.0; s = (int)(slots / tiles); s = s < 1 ? 1 : (s > chunks / 8 + 1 ? chunks / 8 + 1 : s); }
+    if (force > 0) s = force < chunks ? force : chunks;
+    best = X3Plan{wr, mt, nt, s, (tiles * s + 7) / 8};
+  }
+  return best;
 }
 
 struct Plan { int mt, nt, chunks, slices, slices_tail, mt_full, full_per_xcd, tail_per_xcd; };
@@ -569,7 +601,7 @@ M3D_API int m3d_linear_bf16x3_pack(const float* d_weight, int N, int K, void* d_
 
 M3D_API size_t m3d_linear_bf16x3_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
-  const int s = x3_slices(M, N, K);
+  const int s = x3_plan(M, N, K).slices;
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 16;
 }
 
@@ -579,14 +611,19 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
   if (M == 0) return M3D_OK;
   if (!d_x || !d_packed || !d_out) return M3D_EINVAL;
   if (K % 32 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
-  const int s = x3_slices(M, N, K);
+  const X3Plan p = x3_plan(M, N, K);
+  const int s = p.slices;
   if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
-  FcX3Args a{d_x, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, (M + BM - 1) / BM, (N + BN - 1) / BN, s, K / 32, relu, 0};
-  a.per_xcd = (a.mt * a.nt * s + 7) / 8;
-  const size_t lds = sizeof(unsigned) * 2 * X3_OPER;
+  FcX3Args a{d_x, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, s, K / 32, relu, p.per_xcd};
   hipStream_t st = m3d::as_stream(stream);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(fc_x3_gemm_kernel, dim3(8 * a.per_xcd), dim3(256), lds, st, a);
+  const size_t lds = sizeof(unsigned) * (3 * (64 * p.wr) * X3_RSW + X3_OPER);
+  if (p.wr == 2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3_gemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fc_x3_gemm_kernel<2>, dim3(8 * a.per_xcd), dim3(256), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3_gemm_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fc_x3_gemm_kernel<4>, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  }
   if (s > 1) {
     const long long MN = (long long)M * N;
     long long blocks = (MN + 255) / 256;

@@ -6,6 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd")]
 from m3d import ops as m3d  # noqa: E402
+from m3d import _lib  # noqa: E402
 
 
 def timed(fn, n=10):
@@ -27,13 +28,16 @@ def main():
     for M in Ms:
         x = torch.randn(M, K).cuda()
         t32 = timed(lambda: m3d.linear(x, w, b, relu=True))
-        t3 = timed(lambda: lin(x, relu=True))
         ref = torch.relu(x[:64].double() @ w.double().t() + b.double())
         e32 = (m3d.linear(x, w, b, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
-        e3 = (lin(x, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
         fl = 2.0 * M * N * K
-        print("M=%5d  fp32 MFMA %.3f ms (%.1f TF, err %.2e)   bf16x3 %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
-              % (M, t32, fl / t32 / 1e9, e32, t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
+        print("M=%5d  fp32 MFMA %.3f ms (%.1f TF, err %.2e)" % (M, t32, fl / t32 / 1e9, e32), flush=True)
+        for rows in (128, 256, -1):
+            _lib.set_option("tune_fc_x3_rows", rows)
+            t3 = timed(lambda: lin(x, relu=True))
+            e3 = (lin(x, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+            print("         bf16x3 rows %4s: %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
+                  % (rows if rows > 0 else "auto", t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
 
 
 if __name__ == "__main__":
