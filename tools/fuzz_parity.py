@@ -228,6 +228,29 @@ def f_conv(rs):
     assert (gw - refw).abs().max().item() / max(terms, 1e-3) < 2e-6, ("conv wgrad", B, cin, cout, D, H, W, k)
 
 
+def f_linear(rs):
+    """Both box-head GEMMs against fp64: the fp32-input MFMA kernel and the bf16x3 split (exact 3-way cut, six MFMAs per product);
+    ragged M / N, many K chunks and slices, operand magnitudes spread over 10^+-12 per row (the cut must stay exact)."""
+    M = int(rs.choice([1, 2, 31, 64, 65, 127, 128, 129, 255, 256, 257, 300, 700]))
+    N = int(rs.choice([64, 65, 100, 128, 192, 1024]))
+    K = 32 * int(rs.choice([1, 2, 3, 7, 33, 172, 500]))
+    x = rs.randn(M, K).astype(np.float32) * np.float32(10.0) ** rs.randint(-12, 13, (M, 1)).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32) * np.float32(10.0) ** rs.randint(-3, 4, (N, 1)).astype(np.float32)
+    b = rs.randn(N).astype(np.float32)
+    relu = bool(rs.randint(2))
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    ref = xd.double() @ wd.double().t() + bd.double()
+    if relu:
+        ref = torch.relu(ref)
+    # per-row scale: rows differ by 24 orders of magnitude
+    rows = (xd.double().abs() @ wd.double().abs().t()).max(dim=1, keepdim=True).values + bd.double().abs().max()
+    tol = 2e-6 * max(1.0, np.sqrt(K / 1024.0))
+    y32 = m3d.linear(xd, wd, bd, relu=relu)
+    y3 = m3d.SplitLinear(wd, bd)(xd, relu=relu)
+    assert ((y32.double() - ref).abs() / rows).max().item() < tol, ("linear fp32", M, N, K)
+    assert ((y3.double() - ref).abs() / rows).max().item() < tol, ("linear bf16x3", M, N, K)
+
+
 _prm_cache = {}
 
 
@@ -289,7 +312,7 @@ def f_quant_segment(rs):
 
 
 ops = [("quantise/segment", f_quant_segment), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
-       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("prm tile", f_prm)]
+       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3", f_linear), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
     ops = [o for o in ops if any(t in o[0] for t in only.split(","))]
