@@ -281,6 +281,19 @@ size_t m3d_linear_bf16x3_workspace_bytes(int M, int N, int K);
 int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
                               int relu, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Paste of the mask branch's soft masks into full-volume uint8 masks: segm_results, lib/core/test.py:886-945.
+ * d_masks [num_dets, channels, M, M, M] (M = resolution, MRCNN.RESOLUTION); d_channel [num_dets]: the channel of each detection
+ * (its class when MRCNN.CLS_SPECIFIC_MASK, else 0); d_boxes [num_dets, 6] = expand_boxes(ref_boxes, (M+2)/M).astype(int32) as
+ * x0, y0, z0, x1, y1, z1 (inclusive; may leave the volume).  The (M+2)^3 zero-padded block of a detection is resized to its box's
+ * (s, h, w) as skimage.transform.resize(order=1, mode='reflect', anti_aliasing=True) does (Gaussian pre-filter + order-1
+ * map_coordinates, 'mirror' boundary; restated on scipy.ndimage's arithmetic, see csrc/mask_paste.hip), thresholded (> thresh) and
+ * written into d_out [num_dets, depth, height, width] (uint8, zeroed here).  The Gaussian taps are the caller's: d_radius
+ * [num_dets, 3] (z, y, x; 0 = axis not filtered) and d_weights [num_dets, 3, weight_stride] doubles, [d] = weight at distance d. */
+size_t m3d_mask_paste3d_workspace_bytes(int num_dets, int resolution);
+int m3d_mask_paste3d(const float* d_masks, int num_dets, int channels, int resolution, const int32_t* d_channel,
+                     const int32_t* d_boxes, const int32_t* d_radius, const double* d_weights, int weight_stride, float thresh,
+                     int depth, int height, int width, unsigned char* d_out, void* d_ws, size_t ws_bytes, void* stream);
+
 /* norm1 pre-processing of a raw volume on the device: mask = im > 0; out = (im - mean(im[mask])) / std(im[mask])
  * (np.std: population).  Replaces the host NumPy code of lib/utils/blob.py:179-184 (float32; f32_arith = 1) and
  * tools/infer_simple.py:180-183 (float64, crops cast to float32 at :217; f32_arith = 0), so the raw uint16 volume is what

@@ -427,7 +427,6 @@ __global__ __launch_bounds__(kWG) void proposals_stage1_kernel(PropFusedArgs a) 
   const PropParams& p = a.p;
   const int A = p.A, SHW = p.S * p.H * p.W, K = a.K;
   const long long total = (long long)A * SHW;
-  const float* scores = a.scores + (size_t)b * total;
   const float* deltas = a.deltas + (size_t)b * total * 6;
   const PropScratch ps = prop_carve(a.ws + (size_t)b * a.ws_item, K);
   const NmsScratch sc = nms_scratch_carve(ps.nms);

@@ -19,7 +19,7 @@ import torch
 from . import ops, tiling
 from .model import DetectorM3D
 from .prm import PRMEngine
-from .mask_head import MaskHeadM3D, im_detect_mask as _im_detect_mask
+from .mask_head import MaskHeadM3D, im_detect_mask as _im_detect_mask, segm_results as _segm_results
 
 
 def _first(x):
@@ -111,6 +111,16 @@ def im_detect_mask(model, im_scale, boxes, blob_conv):
     if net.mask_head is None:
         raise AttributeError("this checkpoint has no Mask_Head / Mask_Outs weights (MODEL.MASK_ON False)")
     return _im_detect_mask(net.mask_head, im_scale, boxes, blob_conv)
+
+
+def segm_results(model, cls_boxes, masks, ref_boxes, im_s, im_h, im_w):
+    """lib/core/test.py:886-945; the reference reads cfg.MODEL.NUM_CLASSES / MRCNN.* globals, here they come from the model's cfg."""
+    net = model.module if hasattr(model, "module") else model
+    if net.mask_head is None:
+        raise AttributeError("this checkpoint has no Mask_Head / Mask_Outs weights (MODEL.MASK_ON False)")
+    mh = net.mask_head
+    return _segm_results(cls_boxes, masks, ref_boxes, im_s, im_h, im_w, num_classes=mh.cfg.num_classes, resolution=mh.M,
+                         cls_specific=mh.cls_specific, thresh=getattr(mh.cfg, "mask_thresh_binarize", 0.5), device=net.device)
 
 
 class PeakResponseMapping_3d(Generalized_RCNN):

@@ -3,8 +3,8 @@ followed by Mask_Outs (Conv3d 1^3 -> sigmoid), and `im_detect_mask` around it.
 
 Reference: lib/modeling/mask_rcnn_heads.py:132-193 (head), :20-68 (outputs), lib/modeling/model_builder.py:327-331 (mask_net),
 lib/core/test.py:439-476 (im_detect_mask).  Both shipped configs run with MODEL.MASK_ON False, so nothing on the headline path
-reaches this; it exists so that a MASK_ON checkpoint has somewhere to go.  The paste of the 14^3 soft masks into the volume
-(core/test.py:886-945) goes through skimage.transform.resize, which is absent here, and is not built.
+reaches this; it exists so that a MASK_ON checkpoint has somewhere to go.  `segm_results` (core/test.py:886-945) pastes the soft
+M^3 masks into the volume on the device (csrc/mask_paste.hip: skimage.transform.resize restated on scipy.ndimage's arithmetic).
 
 Every convolution runs in the HIP library:
   * the dilated 3x3x3 convs through m3d_conv3d_forward_dilated (direct MFMA kernel, halo = dilation);
@@ -90,3 +90,32 @@ def im_detect_mask(mask_head, im_scale, boxes, blob_conv):
     pred = pred.cpu().numpy().squeeze()                                                                       # :469
     K = mask_head.cfg.num_classes if mask_head.cls_specific else 1
     return pred.reshape([-1, K, M, M, M])                                                                     # :471-474
+
+
+def expand_boxes(boxes, scale):
+    """lib/utils/boxes_3d.py:271-292."""
+    boxes = np.asarray(boxes, dtype=np.float64)
+    half = (boxes[:, 3:6] - boxes[:, 0:3]) * .5 * scale
+    ctr = (boxes[:, 3:6] + boxes[:, 0:3]) * .5
+    return np.hstack([ctr - half, ctr + half])
+
+
+def segm_results(cls_boxes, masks, ref_boxes, im_s, im_h, im_w, num_classes=2, resolution=None, cls_specific=True, thresh=0.5,
+                 device="cuda"):
+    """lib/core/test.py:886-945 with the reference's signature (the cfg values are keyword arguments): cls_boxes = per-class lists
+    of [n_j, 7] detections, masks [R, K, M, M, M] from im_detect_mask, ref_boxes [R, 6] (the same class-major order).
+    Returns cls_segms: per class a list of [im_s, im_h, im_w] uint8 arrays (host, as the reference)."""
+    masks_t = masks if torch.is_tensor(masks) else torch.from_numpy(np.ascontiguousarray(masks, dtype=np.float32))
+    masks_t = masks_t.to(device)
+    M = int(masks_t.shape[-1]) if resolution is None else int(resolution)
+    rb = expand_boxes(ref_boxes, (M + 2.0) / M).astype(np.int32)                              # :896-898
+    counts = [0] + [int(cls_boxes[j].shape[0]) for j in range(1, num_classes)]
+    assert sum(counts) == masks_t.shape[0], "segm_results: masks and cls_boxes disagree"        # :944
+    channel = np.concatenate([np.full((counts[j],), j if cls_specific else 0, np.int32) for j in range(num_classes)]) \
+        if masks_t.shape[0] else np.zeros((0,), np.int32)
+    pasted = ops.mask_paste3d(masks_t, channel, rb, (im_s, im_h, im_w), thresh).cpu().numpy()
+    cls_segms, ind = [[] for _ in range(num_classes)], 0
+    for j in range(1, num_classes):
+        cls_segms[j] = [pasted[ind + i] for i in range(counts[j])]
+        ind += counts[j]
+    return cls_segms

@@ -11,7 +11,7 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear",
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
            "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
@@ -381,6 +381,43 @@ class SplitLinear:
         check(lib().m3d_linear_bf16x3_forward(_ptr(x), _ptr(self.packed), _ptr(self.bias), _ptr(out), M, self.N, K, int(bool(relu)),
                                               _ptr(ws), C.c_size_t(wsb), _stream()), "linear_bf16x3_forward")
         return out
+
+
+def mask_paste3d(masks, channel, boxes_int, shape, thresh=0.5):
+    """segm_results' paste (lib/core/test.py:886-945) for all detections at once.  masks [R, C, M, M, M] CUDA fp32; channel [R]
+    ints; boxes_int [R, 6] = expand_boxes(ref_boxes, (M+2)/M).astype(int32) (host); shape = (im_s, im_h, im_w).
+    Returns uint8 [R, im_s, im_h, im_w] on the device.  The Gaussian taps of skimage's anti-aliasing filter are computed here,
+    on the host, exactly as scipy.ndimage does (np.exp, NumPy's pairwise sum), per detection and axis."""
+    _need_gpu(masks)
+    masks = _f32c(masks)
+    R, Cc, M = int(masks.shape[0]), int(masks.shape[1]), int(masks.shape[2])
+    S, H, W = (int(v) for v in shape)
+    out = torch.empty((R, S, H, W), dtype=torch.uint8, device=masks.device)
+    if R == 0:
+        return out
+    rb = np.ascontiguousarray(boxes_int, dtype=np.int32).reshape(R, 6)
+    P = M + 2
+    size = np.maximum(rb[:, [5, 4, 3]] - rb[:, [2, 1, 0]] + 1, 1).astype(np.float64)           # (s, h, w)
+    sigma = np.maximum(0, (float(P) / size - 1) / 2)                                           # skimage: (in/out - 1) / 2
+    radius = np.where(sigma > 1e-15, (4.0 * sigma + 0.5).astype(np.int64), 0).astype(np.int32)  # scipy: int(truncate * sd + 0.5)
+    ws_ = int(radius.max()) + 1
+    weights = np.zeros((R, 3, ws_), dtype=np.float64)
+    for (r, a) in zip(*np.nonzero(radius)):
+        rad, sg = int(radius[r, a]), float(sigma[r, a])
+        x = np.arange(-rad, rad + 1)
+        phi = np.exp(-0.5 / (sg * sg) * x ** 2)
+        phi = phi / phi.sum()
+        weights[r, a, :rad + 1] = phi[rad:]                                                    # symmetric: [d] = distance d
+    dev = masks.device
+    d_ch = torch.from_numpy(np.ascontiguousarray(channel, dtype=np.int32)).to(dev)
+    d_rb = torch.from_numpy(rb).to(dev)
+    d_rad = torch.from_numpy(np.ascontiguousarray(radius)).to(dev)
+    d_w = torch.from_numpy(weights).to(dev)
+    wsb = lib().m3d_mask_paste3d_workspace_bytes(R, M)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    check(lib().m3d_mask_paste3d(_ptr(masks), R, Cc, M, _ptr(d_ch), _ptr(d_rb), _ptr(d_rad), _ptr(d_w), ws_, C.c_float(thresh),
+                                 S, H, W, _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "mask_paste3d")
+    return out
 
 
 def norm1(vol, f32_arith=True, out=None, return_stats=False):

@@ -106,3 +106,53 @@ def test_driver_mask_net_and_im_detect_mask():
     rois = np.hstack([np.zeros((2, 1), np.float32), boxes])
     direct = model.module.mask_net(out["blob_conv"], {"mask_rois": rois}).cpu().numpy()
     assert np.array_equal(direct, masks)
+
+
+def _paste_case(rs, R, M, C, shape):
+    S, H, W = shape
+    masks = rs.rand(R, C, M, M, M).astype(np.float32)
+    masks[:, :, M // 4: 3 * M // 4, M // 4: 3 * M // 4, M // 4: 3 * M // 4] += 0.5       # a blob above the threshold
+    masks = np.clip(masks, 0, 1)
+    ctr = rs.uniform(-4, max(shape) + 4, (R, 3))
+    size = rs.choice([0.4, 2.0, 5.0, 9.0, 14.0, 27.0, 30.0, 31.0, 45.0, 90.0], (R, 3))      # down to 1 voxel, up to 3x the block
+    boxes = np.hstack([ctr - size / 2, ctr + size / 2])
+    lim = np.array([W - 1, H - 1, S - 1] * 2, np.float64)
+    boxes = np.clip(boxes, 0, lim)          # detections are clipped to the image (core/test.py:247); only the expansion leaves it
+    return masks, boxes
+
+
+@pytest.mark.parametrize("M,C,shape,R", [(14, 2, (40, 48, 56), 48), (28, 2, (64, 64, 64), 24), (6, 3, (17, 9, 33), 40)])
+def test_segm_results_paste_equals_the_scipy_restatement(M, C, shape, R):
+    """segm_results (lib/core/test.py:886-945) on the device == the oracle (skimage's n-D resize restated on scipy.ndimage): identical
+    uint8 masks except voxels whose resized value lies within 2e-6 of the threshold; boxes that leave the volume after the (M+2)/M expansion,
+    1-voxel boxes (sigma 14.5, radius 58 > the block), boxes 3x the block (pure interpolation), class-specific channels."""
+    from m3d.mask_head import segm_results
+    rs = np.random.RandomState(M * 100 + R)
+    masks, boxes = _paste_case(rs, R, M, C, shape)
+    n1 = R // 2 if C > 2 else R
+    cls_boxes = [np.zeros((0, 7))] + [np.zeros((n1, 7))] + ([np.zeros((R - n1, 7))] if C > 2 else [])
+    got = segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=True, thresh=0.5)
+    ref = O.segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=True, thresh=0.5)
+    assert len(got) == C and [len(g) for g in got] == [len(r) for r in ref]
+    rb = O.expand_boxes(boxes, (M + 2.0) / M).astype(np.int32)
+    ind, written = 0, 0
+    for j in range(1, C):
+        for g, r in zip(got[j], ref[j]):
+            assert g.shape == tuple(shape) and g.dtype == np.uint8
+            if not np.array_equal(g, r):
+                # only near-threshold voxels may differ: recompute the soft values for this detection
+                b = rb[ind]
+                pad = np.zeros((M + 2,) * 3, np.float32); pad[1:-1, 1:-1, 1:-1] = masks[ind, j]
+                soft = O.skimage_resize_nd(pad, (max(b[5] - b[2] + 1, 1), max(b[4] - b[1] + 1, 1), max(b[3] - b[0] + 1, 1)))
+                zz, yy, xx = np.nonzero(g != r)
+                assert (np.abs(soft[zz - b[2], yy - b[1], xx - b[0]] - 0.5) < 2e-6).all()
+            written += int(r.sum())
+            ind += 1
+    assert ind == R and written > 0
+    # not class specific: channel 0 for every detection
+    got0 = segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=False, thresh=0.5)
+    ref0 = O.segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=False, thresh=0.5)
+    diff = sum(int((a != b).sum()) for j in range(1, C) for a, b in zip(got0[j], ref0[j]))
+    assert diff <= 2
+    empty = segm_results([np.zeros((0, 7))] * C, np.zeros((0, C, M, M, M), np.float32), np.zeros((0, 6)), *shape, num_classes=C, resolution=M)
+    assert [len(e) for e in empty] == [0] * C

@@ -189,3 +189,25 @@ def test_config0_64_cubed_reference_run(golden):
         assert abs(prm.sum() - g["p_prm_sum"][i]) < 1e-4 and int(prm.argmax()) == int(g["p_prm_argmax"][i])
         for ax, key in (((1, 2), "p_prm_z"), ((0, 2), "p_prm_y"), ((0, 1), "p_prm_x")):
             assert np.allclose(prm.sum(ax), g[key][i], rtol=2e-3, atol=2e-6)
+
+
+def test_skimage_resize_restatement_known_answers():
+    """oracle.skimage_resize_nd (parity unpinned: scikit-image is absent) against properties the published algorithm has:
+    identity at equal shape, exact for constant and (away from the border) for linear ramps when up-sampling, mean-preserving
+    Gaussian when down-sampling, and the documented sample positions (i + 0.5) * in/out - 0.5."""
+    rs = np.random.RandomState(3)
+    a = rs.rand(6, 7, 8).astype(np.float32)
+    assert np.array_equal(O.skimage_resize_nd(a, a.shape), a)                         # factor 1: sigma 0, coordinates = indices
+    c = np.full((5, 5, 5), 0.25, np.float32)
+    assert np.allclose(O.skimage_resize_nd(c, (11, 3, 7)), 0.25, atol=1e-7)
+    ramp = np.tile(np.arange(8, dtype=np.float32), (4, 4, 1))
+    up = O.skimage_resize_nd(ramp, (4, 4, 16))                                        # factor 0.5 along x: samples at 0.5 i - 0.25
+    want = 0.5 * (np.arange(16) + 0.5) - 0.5
+    assert np.allclose(up[0, 0, 1:-1], want[1:-1], atol=1e-6)
+    assert np.isclose(up[0, 0, 0], 0.25, atol=1e-6)                                   # c = -0.25 mirrors to +0.25
+    down = O.skimage_resize_nd(a, (3, 7, 4))
+    assert down.shape == (3, 7, 4) and abs(float(down.mean()) - float(a.mean())) < 0.05
+    segs = O.segm_results([np.zeros((0, 7)), np.zeros((1, 7))], np.ones((1, 2, 14, 14, 14), np.float32), np.array([[2., 2, 2, 9, 9, 9]]),
+                          12, 12, 12)
+    m = segs[1][0]
+    assert m.shape == (12, 12, 12) and m[5, 5, 5] == 1 and m[0, 0, 0] == 0 and m.sum() > 0
