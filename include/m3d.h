@@ -280,6 +280,12 @@ int m3d_linear_bf16x3_pack(const float* d_weight, int N, int K, void* d_packed, 
 size_t m3d_linear_bf16x3_workspace_bytes(int M, int N, int K);
 int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
                               int relu, void* d_ws, size_t ws_bytes, void* stream);
+/* The variant for many rows: 256 x 256 tiles, BOTH operands fp32 in HBM (d_weight = the nn.Linear weight itself, [N, K]) and cut on
+ * the way to LDS - 16 KB of loads per 128 x 128 x 32 of work instead of 28-40, which is what bounds the bf16x3 GEMM.  Same accuracy
+ * and contract as above; its own workspace size. */
+size_t m3d_linear_bf16x3_w32_workspace_bytes(int M, int N, int K);
+int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
+                                  int relu, void* d_ws, size_t ws_bytes, void* stream);
 
 /* Paste of the mask branch's soft masks into full-volume uint8 masks: segm_results, lib/core/test.py:886-945.
  * d_masks [num_dets, channels, M, M, M] (M = resolution, MRCNN.RESOLUTION); d_channel [num_dets]: the channel of each detection

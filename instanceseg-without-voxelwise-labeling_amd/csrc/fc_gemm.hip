@@ -478,6 +478,163 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
   }
 }
 
+// 256 x 256 tiles, BOTH operands fp32 in HBM and cut on the way to LDS (no packed weights): 64 KB of global loads per chunk for
+// four 128 x 128 x 32 units of work = 16 KB per unit, against 28 (256 x 128 tile, packed W) and 40 (128 x 128): the bf16x3 GEMM is
+// bound by the bytes it loads per MFMA, so this is the variant for many rows.  8 waves as 4 x 2, each 64 rows x
+// 128 columns = 2 x 4 MFMA blocks (128 accumulator registers), one workgroup per CU; LDS [x: 3 planes x 256 rows][W: 3 x 256]
+// x 64 B = 96 KB, swizzled as above.  The fragments of a k16 step are read in two column halves so that 48 fragment registers
+// suffice beside the accumulators.
+__global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
+  constexpr int TB = 256, NT = 512;
+  constexpr int PL = TB * X3_RSW, OP = 3 * PL;                     // dwords of a plane / of an operand
+  extern __shared__ float lds_f[];
+  unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tiles = a.mt * a.nt, u = xcd * a.per_xcd + idx;
+  if (u >= tiles * a.slices) return;
+  const int slice = u / tiles, tile = u - slice * tiles;
+  const int tm = tile / a.nt, tn = tile - tm * a.nt;
+  const int m0 = tm * TB, n0 = tn * TB;
+  const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
+  const float* wsrc = reinterpret_cast<const float*>(a.wp);       // here: the nn.Linear weight itself, [N, K] fp32
+
+  // ---- staging: thread -> (row = tid/4 + 128 i, 8 k at 8 (tid % 4)), i = 0, 1, for x and for W
+  const int oct = tid & 3, row0 = tid >> 2;
+  const float* px[2]; const float* pq[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    px[i] = a.x + (size_t)min(m0 + row0 + 128 * i, a.M - 1) * a.K + 8 * oct;      // clamped: masked at the store
+    pq[i] = wsrc + (size_t)min(n0 + row0 + 128 * i, a.N - 1) * a.K + 8 * oct;
+  }
+  const int swq = 4 * (oct ^ ((row0 >> 1) & 3));
+  f32x4 sx[2][2], sq[2][2];
+  auto fetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      sx[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
+      sx[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
+      sq[i][0] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32);
+      sq[i][1] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32 + 4);
+    }
+  };
+  auto cut_store = [&](const f32x4 (&v)[2], unsigned* d) __attribute__((always_inline)) {
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = v[j >> 1][2 * (j & 1)], v1 = v[j >> 1][2 * (j & 1) + 1];
+      const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
+      const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+      const unsigned q0 = __float_as_uint(r0) & 0xFFFF0000u, q1 = __float_as_uint(r1) & 0xFFFF0000u;
+      const float t0 = r0 - __uint_as_float(q0), t1 = r1 - __uint_as_float(q1);
+      ph[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+      pm[j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+      pl[j] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+    }
+    *reinterpret_cast<u32x4*>(d) = ph;
+    *reinterpret_cast<u32x4*>(d + PL) = pm;
+    *reinterpret_cast<u32x4*>(d + 2 * PL) = pl;
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      cut_store(sx[i], lds + (row0 + 128 * i) * X3_RSW + swq);
+      cut_store(sq[i], lds + OP + (row0 + 128 * i) * X3_RSW + swq);
+    }
+  };
+
+  // ---- fragments: wave (wm, wn): rows [wm*64, +64), columns [wn*128, +128)
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
+  const int swz = (fr >> 1) & 3;
+  const int offA0 = (wm * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offA1 = offA0 ^ 8;
+  const int offB0 = OP + (wn * 128 + fr) * X3_RSW + 4 * (fh ^ swz), offB1 = offB0 ^ 8;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  bf16x8 fa[2][3], fb[2][3];
+  auto read_a = [&](int oa) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+        fa[i][s3] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + oa + s3 * PL + i * 32 * X3_RSW));
+  };
+  auto read_b = [&](int ob, int jh) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3)
+        fb[j][s3] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + ob + s3 * PL + (2 * jh + j) * 32 * X3_RSW));
+  };
+  auto mfmas = [&](int jh) __attribute__((always_inline)) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
+  };
+
+  if (c0 < c1) {
+    fetch(c0); commit();
+    __syncthreads();
+    fetch(min(c0 + 1, c1 - 1));
+  }
+  for (int c = c0; c < c1; ++c) {
+    read_a(offA0); read_b(offB0, 0);
+    mfmas(0);
+    read_b(offB0, 1);
+    mfmas(1);
+    read_a(offA1); read_b(offB1, 0);
+    mfmas(0);
+    read_b(offB1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                              // A: every wave holds its last fragments; the image is free
+    commit();                                                     // chunk c + 1, under the last 24 MFMAs
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                              // B
+    fetch(min(c + 2, c1 - 1));
+    __builtin_amdgcn_sched_barrier(0);                            // or the scheduler sinks the loads to just before their use
+  }
+
+  const bool direct = a.slices == 1;
+  float* dst = direct ? a.out : a.part + (size_t)slice * a.M * a.N;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 128 + j * 32 + fr;
+    const float b = (direct && a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mb = m0 + wm * 64 + i * 32 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int m = mb + KGmap(g);
+        if (m < a.M && n < a.N) {
+          float v = acc[i][j][g];
+          if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
+          dst[(size_t)m * a.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+int x3b_slices(int M, int N, int K) {
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256), chunks = K / 32;
+  if (const int ts = m3d::opt(m3d::OPT_TUNE_FC_SLICES); ts > 0) return ts < chunks ? ts : chunks;
+  int s = 256 / (tiles > 0 ? tiles : 1);
+  const int smax = chunks / 8 + 1 < 64 ? chunks / 8 + 1 : 64;
+  return s < 1 ? 1 : (s > smax ? smax : s);
+}
+
 // Tile height and split-K factor of the bf16x3 kernel.  256-row tiles (one workgroup per CU: 256 slots) unless the rows they pad
 // cost more than their re-use saves (few RoIs); 128-row tiles: two workgroups per CU (512 slots).
 struct X3Plan { int wr, mt, nt, slices, per_xcd; };
@@ -631,4 +788,34 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
     hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
   }
   return m3d::check_launch("linear_bf16x3_forward");
+}
+
+/* 256 x 256 tiles on the nn.Linear weight itself (fp32, cut in the kernel): the variant for many rows, no packed copy */
+M3D_API size_t m3d_linear_bf16x3_w32_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  const int s = x3b_slices(M, N, K);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 16;
+}
+
+M3D_API int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
+                                          int relu, void* d_ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (M == 0) return M3D_OK;
+  if (!d_x || !d_weight || !d_out) return M3D_EINVAL;
+  if (K % 32 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_weight & 15)) return M3D_EUNSUPPORTED;
+  const int s = x3b_slices(M, N, K);
+  if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
+  FcX3Args a{d_x, (const u32x4*)d_weight, d_bias, d_out, (float*)d_ws, M, N, K, (M + 255) / 256, (N + 255) / 256, s, K / 32, relu, 0};
+  a.per_xcd = (a.mt * a.nt * s + 7) / 8;
+  hipStream_t st = m3d::as_stream(stream);
+  const size_t lds = sizeof(unsigned) * 6 * 256 * X3_RSW;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3b_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fc_x3b_gemm_kernel, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  if (s > 1) {
+    const long long MN = (long long)M * N;
+    long long blocks = (MN + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
+  }
+  return m3d::check_launch("linear_bf16x3_w32_forward");
 }

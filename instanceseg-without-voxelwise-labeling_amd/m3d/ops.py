@@ -365,8 +365,11 @@ class SplitLinear:
         self.packed = torch.empty((nb,), dtype=torch.uint8, device=weight.device)
         check(lib().m3d_linear_bf16x3_pack(_ptr(weight), self.N, self.K, _ptr(self.packed), _stream()), "linear_bf16x3_pack")
         self.bias = None if bias is None else _f32c(bias)
+        self.weight = weight                    # the many-rows kernel (256 x 256 tiles) cuts the fp32 weight itself
+        self.big_rows = 2048                    # from this many rows on (N >= 256): m3d_linear_bf16x3_w32_forward (2560 rows: 2.21 vs 2.35 ms)
 
-    def __call__(self, x, relu=False, out=None):
+    def __call__(self, x, relu=False, out=None, variant=None):
+        """variant: None = by shape, "packed" (128 / 256 x 128 tiles on the packed planes), "w32" (256 x 256 tiles, fp32 weight)."""
         _need_gpu(x)
         x = _f32c(x)
         M, K = x.shape
@@ -375,6 +378,14 @@ class SplitLinear:
         if out is None:
             out = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
         if M == 0:
+            return out
+        if variant is None:
+            variant = "w32" if (M >= self.big_rows and self.N >= 256) else "packed"
+        if variant == "w32":
+            wsb = lib().m3d_linear_bf16x3_w32_workspace_bytes(M, self.N, K)
+            ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=x.device)
+            check(lib().m3d_linear_bf16x3_w32_forward(_ptr(x), _ptr(self.weight), _ptr(self.bias), _ptr(out), M, self.N, K, int(bool(relu)),
+                                                      _ptr(ws), C.c_size_t(wsb), _stream()), "linear_bf16x3_w32_forward")
             return out
         wsb = lib().m3d_linear_bf16x3_workspace_bytes(M, self.N, K)
         ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=x.device)

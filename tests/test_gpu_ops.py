@@ -674,6 +674,9 @@ def test_linear_bf16x3_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K
     assert got.shape == (M, N) and err <= bound and err <= 2.0 * err32 + 1e-7 * scale, (err, err32, bound)
     assert torch.equal(got, lin(x, relu=relu))                           # deterministic
     assert lin(x[:0]).shape == (0, N)
+    for variant in ("packed", "w32"):                                    # 128 / 256 x 128 tiles on packed planes; 256 x 256 tiles, fp32 W cut in the kernel
+        e = (lin(x, relu=relu, variant=variant).double() - ref).abs().max().item()
+        assert e <= bound and e <= 2.0 * err32 + 1e-7 * scale, (variant, e, err32, bound)
     with pytest.raises(ValueError):
         m3d.SplitLinear(w[:, :K - 4].contiguous())                       # K % 32 != 0: the fp32 kernel's job
 

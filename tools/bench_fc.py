@@ -32,10 +32,14 @@ def main():
         e32 = (m3d.linear(x, w, b, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
         fl = 2.0 * M * N * K
         print("M=%5d  fp32 MFMA %.3f ms (%.1f TF, err %.2e)" % (M, t32, fl / t32 / 1e9, e32), flush=True)
-        for rows in (128, 256, -1):
+        t3 = timed(lambda: lin(x, relu=True, variant="w32"))
+        e3 = (lin(x, relu=True, variant="w32")[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+        print("         bf16x3 256 x 256 tiles, fp32 W: %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
+              % (t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
+        for rows in (128, 256):
             _lib.set_option("tune_fc_x3_rows", rows)
-            t3 = timed(lambda: lin(x, relu=True))
-            e3 = (lin(x, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+            t3 = timed(lambda: lin(x, relu=True, variant="packed"))
+            e3 = (lin(x, relu=True, variant="packed")[:64].double() - ref).abs().max().item() / ref.abs().max().item()
             print("         bf16x3 rows %4s: %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
                   % (rows if rows > 0 else "auto", t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
 
