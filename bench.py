@@ -57,10 +57,20 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # wait for all; if one rank dies the others would sit in a collective for ever: stop them (exact PIDs) and report its code
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+        time.sleep(0.2)
     return rc
 
 
@@ -152,6 +162,8 @@ def run_dry(args, rank, world, dist):
         return torch.full(((i % 7) + 1, 7), float(i))
     mine = shard.partition(n_items, rank, world)
     assert len(mine) == nvol
+    if os.environ.get("M3D_BENCH_TEST_KILL_RANK") == str(rank):       # tests/test_host_logic.py: a rank that dies must not hang the rest
+        os._exit(7)
 
     def step():
         got = shard.all_gather_detections([fake(i) for i in mine], cap, n_items, dist)
@@ -482,6 +494,12 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.dry and args.backend == "nccl":
+            import torch                                    # device_count() does not initialise the GPU
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); one rank per GPU over RCCL needs %d "
+                                 "(--backend gloo rehearses more ranks than GPUs)" % (args.gpus, have, args.gpus))
         sys.exit(launch_ranks(args, sys.argv[1:]))          # children are created before anything here touches a GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -120,3 +120,23 @@ def test_bench_launcher_starts_n_ranks_itself_and_does_one_gather():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that exits (here: rank 1, before its first collective) used to leave rank 0 waiting in the all_gather and the
+    launcher waiting for rank 0, for ever.  The launcher now ends the others and returns the failing rank's code."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["M3D_BENCH_TEST_KILL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 7 and time.time() - t0 < 200
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no bench line from a broken run
+    # more ranks than GPUs over RCCL is refused up front, with a message, not discovered by a hang
+    env.pop("M3D_BENCH_TEST_KILL_RANK")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and "GPU(s)" in (r.stderr + r.stdout)
