@@ -18,10 +18,16 @@ from . import ops
 
 
 class MaskHeadM3D:
-    def __init__(self, params, cfg, resolution=14, roi_res=7, sampling_ratio=0, dilation=2, cls_specific=True):
+    def __init__(self, params, cfg, resolution=None, roi_res=None, sampling_ratio=None, dilation=None, cls_specific=None):
         """params: CUDA fp32 tensors under the reference's state-dict keys `Mask_Head.conv_fcn.{0,2,..}.{weight,bias}`,
-        `Mask_Head.upconv.{weight,bias}`, `Mask_Outs.classify.{weight,bias}`.  Defaults = lib/core/config.py:751-780."""
+        `Mask_Head.upconv.{weight,bias}`, `Mask_Outs.classify.{weight,bias}`.  The MRCNN.* settings come from cfg
+        (Cfg.from_yaml reads them; defaults = lib/core/config.py:751-780) unless given here."""
         self.cfg = cfg
+        resolution = getattr(cfg, "mask_resolution", 14) if resolution is None else resolution
+        roi_res = getattr(cfg, "mask_roi_res", 7) if roi_res is None else roi_res
+        sampling_ratio = getattr(cfg, "mask_sampling_ratio", 0) if sampling_ratio is None else sampling_ratio
+        dilation = getattr(cfg, "mask_dilation", 2) if dilation is None else dilation
+        cls_specific = getattr(cfg, "mask_cls_specific", True) if cls_specific is None else cls_specific
         self.M, self.roi_res, self.sampling_ratio, self.dilation = int(resolution), int(roi_res), int(sampling_ratio), int(dilation)
         self.cls_specific = bool(cls_specific)
         self.convs = []

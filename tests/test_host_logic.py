@@ -140,3 +140,74 @@ def test_bench_launcher_stops_the_other_ranks_when_one_dies():
     env.pop("M3D_BENCH_TEST_KILL_RANK")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode != 0 and "GPU(s)" in (r.stderr + r.stdout)
+
+
+_NUCLEI_YAML = """
+PP_METHOD: 'norm1'
+PRM_ON: True
+MODEL:
+  TYPE: generalized_rcnn
+  CONV_BODY: DSN.dsn_body
+  MASK_ON: False
+  NUM_CLASSES: 2
+  BBOX_REG_WEIGHTS: (10., 10., 10., 5., 5., 5.)
+FPN:
+  FPN_ON: False
+RPN:
+  SIZES: (10, 27, 33, 38, 42, 46, 50)
+  STRIDE: 8
+  ASPECT_RATIOS: [[1.0, 0.5], [0.5, 0.5], [2., 0.5], [0.2, 0.5], [3., 2.]]
+FAST_RCNN:
+  ROI_BOX_HEAD: fast_rcnn_heads.roi_2mlp_head
+  ROI_XFORM_METHOD: RoIAlign
+  ROI_XFORM_RESOLUTION: 7
+  ROI_XFORM_SAMPLING_RATIO: 2
+  MLP_HEAD_DIM: 1024
+MRCNN:
+  RESOLUTION: 14
+  DILATION: 1  # default 2
+  CLS_SPECIFIC_MASK: False
+  ROI_XFORM_SAMPLING_RATIO: 2
+TRAIN:
+  IN_SIZE: (64, 256, 256)
+  SOME_KEY_THIS_PATH_DOES_NOT_READ: 3
+TEST:
+  NEED_CROP: True
+  CROP_OVLP: 100
+  NMS: 0.15
+  RPN_NMS_THRESH: 0.15
+  RPN_PRE_NMS_TOP_N: 1000  # Per FPN level
+  RPN_POST_NMS_TOP_N: 1000
+  DETECTIONS_PER_IM: 300
+  IN_SIZE: (64, 200, 200)
+"""
+
+
+def test_cfg_from_yaml_reads_the_reference_keys():
+    """Cfg.from_yaml == cfg_from_file for the keys of this path (lib/core/config.py:1063-1160): tuples as strings are decoded,
+    unknown keys ignored, other model families refused; the two shipped YAMLs (read where the reference lies, when it is there)
+    give exactly Cfg.nuclei() / Cfg.soma()."""
+    from m3d.config import Cfg
+    c = Cfg.from_yaml(_NUCLEI_YAML)
+    ref = Cfg.nuclei()
+    for k in ("stride", "sizes", "aspect_ratios", "pre_nms_topN", "post_nms_topN", "rpn_nms_thresh", "nms", "detections_per_im",
+              "bbox_reg_weights", "num_classes", "roi_res", "sampling_ratio", "mlp_dim", "in_size", "crop_ovlp", "dataset", "score_thresh"):
+        assert getattr(c, k) == getattr(ref, k), k
+    assert np.array_equal(c.anchors, ref.anchors) and c.num_anchors == 35
+    assert (c.mask_on, c.mask_dilation, c.mask_cls_specific, c.mask_sampling_ratio, c.mask_resolution) == (False, 1, False, 2, 14)
+    soma_like = _NUCLEI_YAML.replace("STRIDE: 8", "STRIDE: 4").replace("  CROP_OVLP: 100\n", "").replace("IN_SIZE: (64, 200, 200)", "IN_SIZE: (64, 160, 160)")
+    c4 = Cfg.from_yaml(soma_like)
+    assert c4.dataset == "soma" and Cfg.from_yaml(soma_like, dataset="nuclei").dataset == "nuclei"
+    assert c4.in_size == (64, 160, 160) and c4.crop_ovlp == 32          # a key the file leaves out: lib/core/config.py's default (:250)
+    for bad in ("MODEL:\n  CONV_BODY: ResNet.ResNet50_conv4_body\n", "FPN:\n  FPN_ON: True\n", "FAST_RCNN:\n  ROI_XFORM_METHOD: RoIPoolF\n",
+                "RPN:\n  STRIDE: 8\n"):                                   # the last: 2-D defaults left in place (aspect ratios, 4 box weights)
+        with pytest.raises(NotImplementedError):
+            Cfg.from_yaml(bad)
+    base = "/root/reference/configs"
+    if os.path.isdir(base):
+        n = Cfg.from_yaml(os.path.join(base, "cell_tracking_baseline", "e2e_mask_rcnn_N3DH_SIM_dsn_body.yaml"))
+        s_ = Cfg.from_yaml(os.path.join(base, "soma_starting", "e2e_mask_rcnn_soma_dsn_body.yaml"))
+        for got, want in ((n, Cfg.nuclei()), (s_, Cfg.soma())):
+            for k in ("stride", "sizes", "aspect_ratios", "pre_nms_topN", "post_nms_topN", "rpn_nms_thresh", "nms", "detections_per_im",
+                      "bbox_reg_weights", "num_classes", "roi_res", "sampling_ratio", "mlp_dim", "in_size", "crop_ovlp", "dataset"):
+                assert getattr(got, k) == getattr(want, k), (want.dataset, k, getattr(got, k), getattr(want, k))
