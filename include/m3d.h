@@ -272,6 +272,7 @@ int m3d_linear_forward(const float* d_x, const float* d_weight, const float* d_b
 /* The same layer on the bf16 matrix cores at fp32 accuracy ("bf16x3 split"): every fp32 operand is cut EXACTLY into three bf16
  * numbers (x = xh + xm + xl, 8 significand bits each) and six bf16 MFMAs (the products down to 2^-23 of the full product)
  * accumulate in fp32 what one fp32 MFMA step does - 16 / 6 of the fp32 matrix rate, error vs fp64 as the fp32 kernel's.
+ * Finite operands only: an inf or NaN operand makes its output row / column NaN (fp32 would keep inf * finite = inf).
  * The weight is cut once: m3d_linear_bf16x3_pack writes three bf16 planes in tile order (m3d_linear_bf16x3_packed_bytes =
  * 6 bytes per weight, N rounded up to 128); x stays fp32 and is cut inside the kernel.  K must be a multiple of 32
  * (else M3D_EUNSUPPORTED / packed_bytes 0: use m3d_linear_forward).  Same split-K / fixed-order reduction contract. */

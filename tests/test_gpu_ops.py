@@ -679,6 +679,16 @@ def test_linear_bf16x3_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K
         assert e <= bound and e <= 2.0 * err32 + 1e-7 * scale, (variant, e, err32, bound)
     with pytest.raises(ValueError):
         m3d.SplitLinear(w[:, :K - 4].contiguous())                       # K % 32 != 0: the fp32 kernel's job
+    # non-finite operands: every output fp32 makes non-finite is non-finite here too, and nothing else is (an inf operand comes out
+    # as NaN: its cut is (inf, NaN, NaN) - documented in include/m3d.h; the box head never sees one unless the network diverged)
+    xi = x.clone()
+    xi[0, 20] = float("inf"); xi[min(1, M - 1), 21] = float("nan")
+    if M > 2:
+        xi[2, 22] = float("-inf")
+    ref_i = xi @ w.t()
+    for variant in ("packed", "w32"):
+        got_i = lin(xi, variant=variant)
+        assert torch.equal(torch.isfinite(got_i), torch.isfinite(ref_i)), variant
 
 
 # ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
