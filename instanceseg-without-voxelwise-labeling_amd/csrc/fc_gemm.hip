@@ -280,14 +280,16 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 // x (the RoIAlign output) is cut on the way from global memory to LDS (4 VALU + 1.5 pack ops per element, under the other
 // resident workgroup's MFMAs).  Same tiling as the fp32 kernel: 128 x 128 workgroup tile, 4 waves as 2 x 2, each 64 x 64 = 2 x 2
 // MFMA blocks; per 32-deep K chunk a wave issues 2 k16 steps x 4 blocks x 6 products = 48 MFMAs of 32 cycles (the fp32 kernel:
-// 64 of 64 cycles).  One LDS buffer of [2 operands][3 planes][128 rows][64 B] = 48 KB (16-byte units XOR-swizzled by the row so the
-// fragment reads of 8 consecutive rows cover the 32 banks once), three workgroups per CU (<= 168 VGPRs): whenever one wave of a
+// 64 of 64 cycles).  One LDS buffer of [2 operands][3 planes][128 rows][64 B] = 48 KB; 16-byte units XOR-swizzled by (row >> 2) & 3:
+// ds_read_b128 serves lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} (and the same + 32) per LDS cycle over 64 banks, and in each
+// of those groups the four rows that share row % 4 differ in (row >> 2) & 3, so a fragment read touches every bank once
+// (a swizzle by (row >> 1) & 3, right for 8 consecutive lanes over 32 banks, measured 36 % of the LDS cycles as conflicts), three workgroups per CU (<= 168 VGPRs): whenever one wave of a
 // SIMD sits in its load-wait / cut / barrier phase two others can issue MFMAs; the next chunk waits in registers during the MFMAs.
 // Roofline: MFMA (bf16, 2.5 PFLOP/s dense): 6 x 2MNK issued FLOP.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int X3_RSW = 16;                        // LDS row stride in dwords: 64 B, no pad; the 16-byte unit u of row r sits at u ^ ((r >> 1) & 3)
+constexpr int X3_RSW = 16;                        // LDS row stride in dwords: 64 B, no pad; the 16-byte unit u of row r sits at u ^ ((r >> 2) & 3)
 constexpr int X3_PLANE = 128 * X3_RSW;            // dwords of one plane
 constexpr int X3_OPER = 3 * X3_PLANE;             // dwords of one operand (three planes)
 constexpr int X3_CHUNK_U4 = 3 * 128 * 4;          // 16-byte units of one packed (tile, chunk) weight block
@@ -351,13 +353,13 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
   const int c0 = (int)((long long)slice * a.chunks / a.slices), c1 = (int)((long long)(slice + 1) * a.chunks / a.slices);
 
   // ---- staging: x: thread -> (row = tid/4 + (NT/4) i, 8 k at 8 (tid % 4)), two float4 per row;  W: 16-byte unit tid + NT i of the
-  // packed (tile, chunk) block = (plane, row, unit tid % 4).  LDS unit u of row r sits at u ^ ((r >> 1) & 3).
+  // packed (tile, chunk) block = (plane, row, unit tid % 4).  LDS unit u of row r sits at u ^ ((r >> 2) & 3).
   const int oct = tid & 3, row0 = tid >> 2;
   const float* px[NXI];
 #pragma unroll
   for (int i = 0; i < NXI; ++i) px[i] = a.x + (size_t)min(m0 + row0 + (NT / 4) * i, a.M - 1) * a.K + 8 * oct;   // clamped: masked at the store
   const u32x4* pw = a.wp + (size_t)tn * a.chunks * X3_CHUNK_U4 + tid;
-  const int swq = 4 * (oct ^ ((row0 >> 1) & 3));                   // NT/4 is a multiple of 8: every row of this thread swizzles alike
+  const int swq = 4 * (oct ^ ((row0 >> 2) & 3));                   // NT/4 is a multiple of 16: every row of this thread swizzles alike
   f32x4 sx[NXI][2]; u32x4 sw[NWI];
   auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
   // ---- fragments: wave (wm, wn) owns rows [wm*64, +64) x cols [wn*64, +64); lane = (row r, k half h): 8 bf16 at k = 16 t + 8 h.
   // unit of k16 step t = (2t + h) ^ swz = (h ^ swz) ^ 2t: the two steps' addresses differ by XOR 8 dwords
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const int swz = (fr >> 1) & 3;
+  const int swz = (fr >> 2) & 3;
   const int offA0 = (wm * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offA1 = offA0 ^ 8;
   const int offB0 = XOP + (wn * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offB1 = offB0 ^ 8;
   f32x16 acc[2][2];
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
     px[i] = a.x + (size_t)min(m0 + row0 + 128 * i, a.M - 1) * a.K + 8 * oct;      // clamped: masked at the store
     pq[i] = wsrc + (size_t)min(n0 + row0 + 128 * i, a.N - 1) * a.K + 8 * oct;
   }
-  const int swq = 4 * (oct ^ ((row0 >> 1) & 3));
+  const int swq = 4 * (oct ^ ((row0 >> 2) & 3));
   f32x4 sx[2][2], sq[2][2];
   auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
 
   // ---- fragments: wave (wm, wn): rows [wm*64, +64), columns [wn*128, +128)
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 31, fh = lane >> 5;
-  const int swz = (fr >> 1) & 3;
+  const int swz = (fr >> 2) & 3;
   const int offA0 = (wm * 64 + fr) * X3_RSW + 4 * (fh ^ swz), offA1 = offA0 ^ 8;
   const int offB0 = OP + (wn * 128 + fr) * X3_RSW + 4 * (fh ^ swz), offB1 = offB0 ^ 8;
   f32x16 acc[2][4];
