@@ -251,22 +251,58 @@ class DetectorM3D:
         """data [B,1,S,H,W].  as_dicts=True: list of B per-tile dicts with detect_tile's keys (two host reads in total: the
         proposal counts and the detection counts).  as_dicts=False: one dict of batched device tensors (rois [B,rows,7] +
         num_rois, cls_boxes [B,nc,rows,7] + cls_counts [B,nc], ...) after ONE host read (the proposal counts, which size the
-        box-head GEMM) - what bench.py and the sharded driver consume."""
+        box-head GEMM) - what bench.py and the sharded driver consume.
+        = detect_batch_finish(detect_batch_begin(...)): a driver that has the next batch ready can launch its `begin` (backbone,
+        RPN, proposals: no host read) before it finishes this one, on another stream (bench.py does)."""
+        return self.detect_batch_finish(self.detect_batch_begin(data, im_info), as_dicts)
+
+    def detect_batch_begin(self, data, im_info=None):
+        """Everything up to and including the proposal kernels, launched on the current stream without any host read; the
+        proposal counts travel to pinned host memory behind an event.  Returns the state detect_batch_finish takes."""
         c = self.cfg
-        B = data.shape[0]
         S, H, W = data.shape[-3:]
         if im_info is None:
             im_info = np.array([S, H, W, 1.0], np.float64)
         feat = self.conv_body(data)
         with self.span("rpn"):
             prob, deltas = self.rpn(feat)
-        if not self._fused_ok(prob):
+        st = dict(feat=feat, prob=prob, deltas=deltas, im_info=im_info, fused=self._fused_ok(prob))
+        if st["fused"]:
+            with self.span("proposals"):
+                st["props"] = ops.generate_proposals3d_batched(
+                    prob, deltas, self.anchors, float(c.stride), im_info, c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh,
+                    c.rpn_min_size)
+                num = st["props"][3]
+                st["num_host"] = self._pinned_counts(num)
+                st["num_host"].copy_(num, non_blocking=True)
+                st["ready"] = torch.cuda.Event()
+                st["ready"].record()
+        return st
+
+    def _pinned_counts(self, like):
+        """A small ring of pinned host buffers for the proposal counts (several batches may be in flight)."""
+        ring = self.__dict__.setdefault("_count_ring", {})
+        key = (like.numel(), like.dtype)
+        if key not in ring:                                  # pinning is slow (a driver call): all four at once, the first time
+            ring[key] = ([torch.empty((like.numel(),), dtype=like.dtype).pin_memory() for _ in range(4)], 0)
+        bufs, i = ring[key]
+        ring[key] = (bufs, (i + 1) % 4)
+        return bufs[i]
+
+    def detect_batch_finish(self, st, as_dicts=True):
+        """The rest of detect_batch on the current stream (which may differ from begin's: it waits for begin's event, and the
+        tensors begin produced are marked as used here for the caching allocator)."""
+        c = self.cfg
+        feat, prob, deltas, im_info = st["feat"], st["prob"], st["deltas"], st["im_info"]
+        B = feat.shape[0]
+        if not st["fused"]:
             return self._detect_batch_unfused(feat, prob, deltas, im_info, as_dicts)
-        with self.span("proposals"):
-            rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(
-                prob, deltas, self.anchors, float(c.stride), im_info, c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh,
-                c.rpn_min_size)
-            counts = num.cpu().tolist()                                            # host read 1: sizes the GEMM rows
+        rois_b, probs_b, kidx_b, num = st["props"]
+        st["ready"].synchronize()                                                  # host read 1: sizes the GEMM rows
+        counts = st["num_host"].tolist()
+        cur = torch.cuda.current_stream()
+        for t in (feat, prob, deltas, rois_b, probs_b, kidx_b):
+            t.record_stream(cur)
         rows = rois_b.shape[1]
         raw = dict(feat=feat, rpn_prob=prob, rpn_deltas=deltas, rois=rois_b, roi_probs=probs_b, keep_idx=kidx_b, num_rois=counts)
         total = sum(counts)

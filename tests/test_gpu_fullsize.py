@@ -240,6 +240,45 @@ def test_detect_batch_equals_per_tile_detection():
         assert got["det_scores"].shape == one["det_scores"].shape and torch.allclose(got["det_boxes"], one["det_boxes"], atol=2e-2)
 
 
+def test_detect_batch_begin_finish_with_two_batches_in_flight_on_two_streams():
+    """detect_batch == finish(begin()).  A driver may launch begin(k+1) (backbone, RPN, proposals: no host read) on one stream
+    before finish(k) (RoIAlign, box head, box results) on another (bench.py's `pipelined` loop): the detections of every batch
+    are bit-identical to the serial run's, whatever the interleaving."""
+    from m3d.config import Cfg
+    from m3d.synth import make_params, synth_volume
+    from m3d.model import DetectorM3D
+    from m3d import tiling
+    cfg = Cfg.nuclei(mlp_dim=128, in_size=(32, 64, 64))
+    P = make_params(stride=8, num_anchors=35, mlp_dim=128, seed=2)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    xs = [torch.stack([torch.from_numpy(tiling.norm1(synth_volume(4 * j + i, (32, 64, 64)), np.float32).astype(np.float32)) for i in range(2)])[:, None].cuda()
+          for j in range(4)]
+    serial = [det.detect_batch(x, as_dicts=False) for x in xs]
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    outs, prev = [], None
+    for j in range(len(xs) + 1):
+        st = None
+        if j < len(xs):
+            with torch.cuda.stream(sA):
+                st = det.detect_batch_begin(xs[j])
+        if prev is not None:
+            with torch.cuda.stream(sB):
+                outs.append(det.detect_batch_finish(prev, as_dicts=False))
+        prev = st
+    torch.cuda.synchronize()
+    assert len(outs) == len(serial)
+    for a, b in zip(outs, serial):
+        assert a["num_rois"] == b["num_rois"] and sum(a["num_rois"]) > 0
+        for k in ("cls", "pred_boxes", "cls_counts"):
+            assert torch.equal(a[k], b[k]), k
+        for i, n in enumerate(a["num_rois"]):                                   # padded buffers: the valid rows
+            assert torch.equal(a["rois"][i, :n], b["rois"][i, :n]) and torch.equal(a["keep_idx"][i, :n], b["keep_idx"][i, :n])
+            for j in range(cfg.num_classes):
+                m = int(a["cls_counts"][i, j])
+                assert torch.equal(a["cls_boxes"][i, j, :m], b["cls_boxes"][i, j, :m])
+
+
 def test_config0_64_cubed_equals_the_reference_run(golden):
     """BASELINE.json configs[0]: the reference's own CPU run on one 1x64^3 volume (tests/golden/cfg0_64.npz, gen_cfg0.py) against
     the HIP path: detection mode (scores, decoded boxes, kept detections) and the full PRM tuple (peaks, dets, every map)."""
