@@ -215,6 +215,74 @@ def conv3d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     return _orig_conv3d(input, weight, bias, stride, padding, dilation, groups)
 
 
+# ----------------------------------------------------------------------------- F.linear interception (box head: fast_rcnn_heads.py:84-85,114-117,42-45)
+_orig_linear = None
+_lin_cache = {}           # id(parameter) -> (weakref, _version, data_ptr, bias id / version, SplitLinear)
+
+
+def _split_linear(weight, bias):
+    """bf16x3 pack of an nn.Linear weight, cached like the conv packs: only for live nn.Parameters at the same version / address."""
+    if not isinstance(weight, torch.nn.Parameter):
+        return ops.SplitLinear(weight.detach(), None if bias is None else bias.detach())
+    bkey = None if bias is None else (id(bias), bias._version, bias.data_ptr())
+    ent = _lin_cache.get(id(weight))
+    if ent is not None:
+        ref, ver, ptr, bk, lin = ent
+        if ref() is weight and ver == weight._version and ptr == weight.data_ptr() and bk == bkey:
+            return lin
+    lin = ops.SplitLinear(weight.detach(), None if bias is None else bias.detach())
+    _lin_cache[id(weight)] = (weakref.ref(weight, lambda _r, k=id(weight): _lin_cache.pop(k, None)), weight._version, weight.data_ptr(), bkey, lin)
+    return lin
+
+
+class _LinearFn(torch.autograd.Function):
+    """x [M,K] . W[N,K]^T + b on libm3d's GEMMs: the bf16x3 split kernels (fp32 accuracy) where K % 32 == 0 and N >= 64 (fc1, fc2),
+    else the fp32-input MFMA kernel (cls_score, bbox_pred).  Backward (training; off the inference path): the same kernels on
+    transposed operands."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if ops.SplitLinear.supported(weight):
+            return _split_linear(weight, bias)(x)
+        return ops.linear(x, weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear(gy, weight.detach().t().contiguous()) if gy.shape[1] % 4 == 0 else gy @ weight.detach()
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear(gy.t().contiguous(), x.detach().t().contiguous()) if gy.shape[0] % 4 == 0 else gy.t() @ x.detach()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def linear(input, weight, bias=None):
+    if (input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32 and input.dim() == 2 and weight.dim() == 2
+            and input.shape[1] == weight.shape[1] and input.shape[1] % 4 == 0 and input.shape[0] > 0):
+        return _LinearFn.apply(input.contiguous(), weight, bias)
+    return _orig_linear(input, weight, bias)
+
+
+def install_linear():
+    global _orig_linear
+    if _orig_linear is None:
+        _orig_linear = torch.nn.functional.linear
+        torch.nn.functional.linear = linear
+
+
+def uninstall_linear():
+    global _orig_linear
+    if _orig_linear is not None:
+        torch.nn.functional.linear = _orig_linear
+        _orig_linear = None
+
+
 def install_conv3d():
     global _orig_conv3d
     if _orig_conv3d is None:
@@ -252,7 +320,7 @@ def _pkg(name):
     return sys.modules[name]
 
 
-def install(conv3d=True):
+def install(conv3d=True, linear=True):
     """Register the drop-in modules.  Packages that already exist (the reference's `modeling`, `utils`) are kept;
     only the native-op leaf modules are replaced."""
     for pk in ("modeling", "modeling.roi_xfrom", "modeling.roi_xfrom.roi_align_3d",
@@ -273,3 +341,5 @@ def install(conv3d=True):
         _mod("otsu", otsu_py_2d_fast=otsu_py_2d_fast)
     if conv3d:
         install_conv3d()
+    if linear:
+        install_linear()

@@ -1,4 +1,4 @@
-"""GPU: the drop-in modules (reference dotted names) and the F.conv3d interception."""
+"""GPU: the drop-in modules (reference dotted names) and the F.conv3d / F.linear interceptions."""
 import sys
 
 import numpy as np
@@ -16,6 +16,7 @@ def compat():
     c.install()
     yield c
     c.uninstall_conv3d()
+    c.uninstall_linear()
 
 
 def test_reference_import_names(compat, golden):
@@ -156,3 +157,65 @@ def test_stem_conv_with_input_grad_stays_on_the_hip_path(compat):
     orig(xr, wr, br, 1, 2).backward(g.double().cpu())
     for got, ref in ((x.grad, xr.grad), (conv.weight.grad, wr.grad), (conv.bias.grad, br.grad)):
         assert (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+
+
+def test_linear_interception_runs_the_box_head_modules_unmodified(compat):
+    """The reference's roi_2mlp_head / fast_rcnn_outputs are plain nn.Linear modules (fast_rcnn_heads.py:84-85,114-117,15-19,42-45):
+    with the interception installed their F.linear calls run on libm3d's GEMMs (fc1 / fc2: bf16x3 split; cls / bbox: fp32 MFMA) -
+    forward vs fp64, gradients vs torch's own, pack cache follows in-place weight updates and never crosses layers."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from m3d import ops
+    torch.manual_seed(0)
+    fc1, fc2, cls, box = nn.Linear(3424, 256).cuda(), nn.Linear(256, 256).cuda(), nn.Linear(256, 2).cuda(), nn.Linear(256, 12).cuda()
+    x = torch.randn(77, 3424, device="cuda")
+    calls = {"split": 0, "fp32": 0}
+    orig_split, orig_lin = ops.SplitLinear.__call__, ops.linear
+
+    def count_split(self, *a, **k):
+        calls["split"] += 1
+        return orig_split(self, *a, **k)
+
+    def count_lin(*a, **k):
+        calls["fp32"] += 1
+        return orig_lin(*a, **k)
+    ops.SplitLinear.__call__, ops.linear = count_split, count_lin
+    try:
+        h = F.relu(fc1(x), inplace=True)                      # the module code as the reference writes it (:114-115)
+        h = F.relu(fc2(h), inplace=True)
+        s, b = cls(h), box(h)
+    finally:
+        ops.SplitLinear.__call__, ops.linear = orig_split, orig_lin
+    assert calls == {"split": 2, "fp32": 2}                     # fc1, fc2 on the split kernels; the two narrow heads on the fp32 kernel
+    with torch.no_grad():
+        hd = torch.relu(x.double() @ fc1.weight.double().t() + fc1.bias.double())
+        hd = torch.relu(hd @ fc2.weight.double().t() + fc2.bias.double())
+        sd, bd = hd @ cls.weight.double().t() + cls.bias.double(), hd @ box.weight.double().t() + box.bias.double()
+    assert (s.double() - sd).abs().max().item() <= 1e-5 * sd.abs().max().item() and (b.double() - bd).abs().max().item() <= 1e-5 * bd.abs().max().item()
+    # in-place update of the weight (optimizer step): the cached pack must not be served
+    with torch.no_grad():
+        fc2.weight.mul_(0.5)
+    h1 = F.relu(fc1(x))
+    got = fc2(h1)
+    ref = h1.double() @ fc2.weight.double().t() + fc2.bias.double()
+    assert (got.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # autograd through the interception == torch's own linear
+    lin = nn.Linear(128, 64).cuda()
+    xg = torch.randn(36, 128, device="cuda", requires_grad=True)
+    y = lin(xg)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    compat.uninstall_linear()
+    try:
+        xr = xg.detach().clone().requires_grad_(True)
+        lr = nn.Linear(128, 64).cuda()
+        lr.load_state_dict(lin.state_dict())
+        yr = lr(xr)
+        yr.backward(gy)
+    finally:
+        compat.install_linear()
+    for a, b_ in ((y, yr), (xg.grad, xr.grad), (lin.weight.grad, lr.weight.grad), (lin.bias.grad, lr.bias.grad)):
+        assert torch.allclose(a.detach(), b_.detach(), rtol=1e-4, atol=1e-5 * float(b_.detach().abs().max()))
+    # what does not qualify falls through to torch (3-D input, fp64)
+    assert fc2(torch.randn(2, 3, 256, device="cuda")).shape == (2, 3, 256)
+    assert F.linear(torch.randn(4, 8, device="cuda", dtype=torch.float64), torch.randn(5, 8, device="cuda", dtype=torch.float64)).dtype == torch.float64
