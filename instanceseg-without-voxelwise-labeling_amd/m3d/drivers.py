@@ -187,27 +187,46 @@ def box_results_with_nms_and_limit(model, scores, boxes, scores_keep_idx=None):
 def im_detect_all(model, im, box_proposals=None, timers=None):
     """lib/core/test.py:54-177 with TEST.NEED_CROP: norm1 (blob.py:179-184), slice padding, tiles from TEST.IN_SIZE /
     TEST.CROP_OVLP, per-tile im_detect_bbox + box_results_with_nms_and_limit, tile offsets, cross-tile nms_3d per class.
-    Returns (cls_boxes_total, cls_segms_total, cls_keyps) - the segms list stays empty and keyps None, as in the reference
-    with MASK_ON / KEYPOINTS_ON False."""
+    Returns (cls_boxes_total, cls_segms_total, cls_keyps).  With MODEL.MASK_ON (cfg.mask_on and a checkpoint that carries the
+    mask branch): im_detect_mask on every tile's kept boxes (:123-126), masks and boxes filtered by the cross-tile NMS (:161-163),
+    segm_results over the whole volume (:166) and binary_mask_to_rle per detection (:170-172); otherwise the segms list stays
+    empty, as in the reference.  keyps is None (KEYPOINTS_ON: `pass` in the reference)."""
     c = model.cfg
+    net = model.module if hasattr(model, "module") else model
+    mask_on = bool(getattr(c, "mask_on", False)) and getattr(net, "mask_head", None) is not None
     patch = tuple(c.in_size)
-    vol = tiling.norm1(np.asarray(im), np.float32).astype(np.float32)
+    im = np.asarray(im)
+    vol = tiling.norm1(im, np.float32).astype(np.float32)
     vol, pad_s = tiling.pad_slices(vol, patch[0])                                                          # :79-86
     sidx, hidx, widx = tiling.detect_grid(c, vol.shape)                                                    # :87-90
     cls_total = [np.empty((0, 7), dtype=np.float32) for _ in range(c.num_classes)]
+    boxes_total = np.empty((0, 6), dtype=np.float32)                                                       # :97
+    masks_total = None
     for ss in sidx:
         for hs in hidx:
             for ws in widx:
                 cube = {"data": np.ascontiguousarray(vol[ss:ss + patch[0], hs:hs + patch[1], ws:ws + patch[2]])[None, None],
                         "im_info": np.array(patch + (1.0,), dtype=np.float64)[None, :]}
-                scores, boxes, _, _ = im_detect_bbox(model, cube, 1.0)                                     # :106
-                _, _, cls_boxes, _ = box_results_with_nms_and_limit(model, scores, boxes)                  # :114
+                scores, boxes, im_scale, blob_conv = im_detect_bbox(model, cube, 1.0)                      # :106
+                _, boxes, cls_boxes, _ = box_results_with_nms_and_limit(model, scores, boxes)              # :114
+                if mask_on and boxes.shape[0] > 0:                                                         # :123-126
+                    masks = im_detect_mask(model, [im_scale], boxes, blob_conv)
+                    masks_total = masks if masks_total is None else np.append(masks_total, masks, axis=0)  # :147
                 off = np.array([ws, hs, ss - pad_s, ws, hs, ss - pad_s, 0], dtype=np.float32)              # :117-121,140-141
+                boxes_total = np.append(boxes_total, boxes.reshape(-1, 6) + off[:6], axis=0)               # :143
                 for j in range(1, c.num_classes):
                     cls_total[j] = np.append(cls_total[j], cls_boxes[j] + off, axis=0)                     # :144-145
-    for j in range(1, c.num_classes):                                                                      # :150-160
+    for j in range(1, c.num_classes):                                                                      # :150-163
         d = np.ascontiguousarray(cls_total[j], dtype=np.float32)
         if d.shape[0]:
             keep = ops.nms3d(torch.from_numpy(d).to(model.device), c.nms).cpu().numpy()
             cls_total[j] = d[keep, :]
-    return cls_total, [[] for _ in range(c.num_classes)], None
+            if mask_on and masks_total is not None and masks_total.shape[0] > 0:
+                boxes_total, masks_total = boxes_total[keep, :], masks_total[keep, :]
+    cls_segms = [[] for _ in range(c.num_classes)]
+    if mask_on and masks_total is not None:                                                                # :164-172
+        from .io import binary_mask_to_rle
+        cls_segms = segm_results(model, cls_total, masks_total, boxes_total, im.shape[0], im.shape[1], im.shape[2])
+        for j in range(1, c.num_classes):
+            cls_segms[j] = [binary_mask_to_rle(m) for m in cls_segms[j]]
+    return cls_total, cls_segms, None

@@ -156,3 +156,38 @@ def test_segm_results_paste_equals_the_scipy_restatement(M, C, shape, R):
     assert diff <= 2
     empty = segm_results([np.zeros((0, 7))] * C, np.zeros((0, C, M, M, M), np.float32), np.zeros((0, 6)), *shape, num_classes=C, resolution=M)
     assert [len(e) for e in empty] == [0] * C
+
+
+def test_im_detect_all_with_a_mask_checkpoint_returns_rle_segms():
+    """MODEL.MASK_ON flow of im_detect_all (lib/core/test.py:123-173): masks of every tile's kept boxes, filtered by the cross-tile
+    NMS together with their boxes, pasted over the whole volume and RLE-encoded - one segm per kept detection, each decoding to a
+    mask that lies inside its (M+2)/M-expanded box and equals the paste of its own soft mask."""
+    from m3d.drivers import Generalized_RCNN, im_detect_all
+    from m3d.io import rle_to_binary_mask
+    from m3d.synth import synth_volume
+    cfg = O.Cfg(mlp_dim=64)
+    cfg.in_size, cfg.crop_ovlp, cfg.mask_on, cfg.score_thresh = (32, 64, 64), 16, True, 0.0
+    P = dict(O.make_params(stride=8, num_anchors=cfg.anchors.shape[0], mlp_dim=64, seed=5))
+    P.update(_mask_params(P["Conv_Body.conv4b.weight"].shape[0], 32, cfg.num_classes, 2, seed=9))
+    model = Generalized_RCNN(P, cfg)
+    im = synth_volume(3, (32, 80, 80))
+    cls_boxes, cls_segms, keyps = im_detect_all(model, im)
+    assert keyps is None and len(cls_segms) == cfg.num_classes and cls_segms[0] == []
+    n = cls_boxes[1].shape[0]
+    assert n > 0 and len(cls_segms[1]) == n
+    M = model.mask_head.M
+    rb = O.expand_boxes(cls_boxes[1][:, :6], (M + 2.0) / M).astype(np.int32)
+    some = 0
+    for i, rle in enumerate(cls_segms[1]):
+        assert tuple(rle["size"]) == im.shape
+        m = rle_to_binary_mask(rle)
+        assert m.shape == im.shape and m.dtype == np.uint8
+        zz, yy, xx = np.nonzero(m)
+        if len(zz):
+            some += 1
+            assert xx.min() >= rb[i, 0] and xx.max() <= rb[i, 3] and yy.min() >= rb[i, 1] and yy.max() <= rb[i, 4] and zz.min() >= rb[i, 2] and zz.max() <= rb[i, 5]
+    assert some > 0
+    # the same checkpoint with the branch switched off in the cfg: detections unchanged, no segms (the reference's MASK_ON False path)
+    cfg.mask_on = False
+    cb2, cs2, _ = im_detect_all(Generalized_RCNN(P, cfg), im)
+    assert np.array_equal(cb2[1], cls_boxes[1]) and cs2 == [[] for _ in range(cfg.num_classes)]
