@@ -326,8 +326,7 @@ def bench_detect(args, rank, world, dist):
     # before finish(k) = RoIAlign + box head + box results + cross-tile NMS + exchange, so the latency-bound box kernels of one
     # batch run beside the MFMA kernels of the next (DetectorM3D.detect_batch_begin / _finish).  Reported beside `value`, which
     # stays the serial loop: there every kernel has the chip to itself and the per-kernel event timings mean what they say.
-    piped = None
-    if not backbone_only:
+    def measure_pipelined():
         sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
         xb2 = [xbuf, torch.empty_like(xbuf)]
 
@@ -348,20 +347,23 @@ def bench_detect(args, rank, world, dist):
         torch.cuda.synchronize()
         run_pipelined(2)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
         t0 = time.perf_counter()
         run_pipelined(args.steps)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dtp = sync_max_time(time.perf_counter() - t0, dist, "cpu" if via_host else "cuda")
+        dtp = time.perf_counter() - t0
         same = bool(torch.equal(last["packed_pipelined"].cpu(), last["packed"].cpu())) if "packed" in last else None
-        piped = {"value": n_items * args.steps * VOL ** 3 / dtp, "unit": "voxels/s", "ms_per_step": dtp / args.steps * 1e3,
-                 "what": "the same %d steps with begin(k+1) (norm1, backbone, RPN, proposals) launched on a second stream before "
-                         "finish(k) (RoIAlign, box head, box results, cross-tile NMS, exchange)" % args.steps,
-                 "identical_to_serial": same}
+        return {"value": n_items * args.steps * VOL ** 3 / dtp, "unit": "voxels/s", "ms_per_step": dtp / args.steps * 1e3,
+                "what": "the same %d steps with begin(k+1) (norm1, backbone, RPN, proposals) launched on a second stream before "
+                        "finish(k) (RoIAlign, box head, box results, cross-tile NMS, exchange)" % args.steps,
+                "identical_to_serial": same}
+
+    piped = None
+    if not backbone_only and world == 1:             # N = 1 only: an extra measurement must not be able to stall a multi-rank run
+        try:
+            piped = measure_pipelined()
+        except Exception as e:                       # ... nor lose the main line
+            piped = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
 
     # ---- (2) end to end, host to host: pinned raw volumes -> H2D on a copy stream (double-buffered) -> step -> D2H
     e2e = None
