@@ -21,7 +21,8 @@
 
 #include "m3d_common.h"
 
-// timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU
+// timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU (one-wave kernel),
+// 8 = 4 instead of 16 transform VALU per K step in the eta-split kernel
 #ifndef M3D_EXP
 #define M3D_EXP 0
 #endif
@@ -579,6 +580,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
     r[2][0] = pq[0]; r[2][1] = pq[1]; r[2][2] = pq[C::EP]; r[2][3] = pq[C::EP + 1];
   };
   auto transform = [&](const float (&r)[3][4], float (&bf)[2][4]) __attribute__((always_inline)) {
+#if (M3D_EXP & 8)
+    for (int v = 0; v < 4; ++v) { bf[0][v] = r[0][v]; bf[1][v] = r[2][v] + r[1][v]; }   // timing ablation: 4 instead of 16 VALU
+    return;
+#endif
     float c[2][4];                                     // rows combined (y transform), still raw in x
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
