@@ -74,9 +74,18 @@ def nms3d(dets, thresh, by_volume=False):
         return torch.zeros((0,), dtype=torch.int64, device=dets.device)
     if dets.dim() != 2 or dets.shape[1] != 7:
         raise ValueError("dets must be [N,7]")
-    if n <= fused_max_boxes():                       # one launch (one workgroup) instead of four
-        r = nms3d_batched(dets.unsqueeze(0), None, thresh, by_volume)
-        return r["keep"][0, :int(r["num"].item())]
+    if n <= fused_max_boxes():                       # the fused kernels (three launches instead of seven)
+        # the count lands in pinned host memory, written by the kernel itself: a stream synchronize instead of a D2H copy
+        # (N = 1000: 90 -> 78 us wall; the kernels themselves take 63 us back to back)
+        dev = dets.device
+        keep = torch.empty((1, n), dtype=torch.int64, device=dev)
+        num = _pinned_i32(dev)
+        wsb = lib().m3d_nms3d_batched_workspace_bytes(1)
+        ws = _workspace(wsb, dev, "nmsb")
+        check(lib().m3d_nms3d_batched(_ptr(dets), C.c_size_t(7 * n), None, 0, 1, n, C.c_float(np.float32(thresh)), int(bool(by_volume)),
+                                      0, None, _ptr(keep), _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()), "nms3d_batched")
+        torch.cuda.current_stream().synchronize()
+        return keep[0, :int(num[0])]
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
     num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
     wsb = lib().m3d_nms3d_workspace_bytes(n)
@@ -143,6 +152,17 @@ def fused_max_boxes():
 
 
 _ws_cache = {}
+
+
+_pin_cache = {}
+
+
+def _pinned_i32(device):
+    """One pinned int32 per device: a kernel writes a count there, the caller synchronizes its stream and reads it at once."""
+    t = _pin_cache.get(str(device))
+    if t is None:
+        t = _pin_cache[str(device)] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    return t
 
 
 def _workspace(nbytes, device, tag):
