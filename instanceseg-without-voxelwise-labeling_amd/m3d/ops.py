@@ -386,6 +386,7 @@ class SplitLinear:
         check(lib().m3d_linear_bf16x3_pack(_ptr(weight), self.N, self.K, _ptr(self.packed), _stream()), "linear_bf16x3_pack")
         self.bias = None if bias is None else _f32c(bias)
         self.weight = weight                    # the many-rows kernel (256 x 256 tiles) cuts the fp32 weight itself
+        self.tail_rows = 16                     # <= this many rows past a multiple of 256 go to the fp32 kernel's ragged-tile path
         self.big_rows = 2048                    # from this many rows on (N >= 256): m3d_linear_bf16x3_w32_forward (2560 rows: 2.21 vs 2.35 ms)
 
     def __call__(self, x, relu=False, out=None, variant=None):
@@ -400,7 +401,16 @@ class SplitLinear:
         if M == 0:
             return out
         if variant is None:
+            if M <= 32:                                   # a handful of rows: the fp32-input kernel's ragged-tile path (M = 2: 0.09 vs 0.18 ms)
+                return linear(x, self.weight, self.bias, relu=relu, out=out)
             variant = "w32" if (M >= self.big_rows and self.N >= 256) else "packed"
+            # a few rows past a multiple of the 256-row tile (M = 1281 = 5 x 256 + 1 pads 20 % more rows): those rows go through the
+            # fp32-input kernel's ragged-tile path instead (same accuracy class), the rest through full tiles
+            rem = M % 256
+            if variant == "packed" and M > 512 and 0 < rem <= self.tail_rows:
+                self(x[:M - rem], relu=relu, out=out[:M - rem], variant="packed")
+                linear(x[M - rem:], self.weight, self.bias, relu=relu, out=out[M - rem:])
+                return out
         if variant == "w32":
             wsb = lib().m3d_linear_bf16x3_w32_workspace_bytes(M, self.N, K)
             ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=x.device)

@@ -36,6 +36,12 @@ def main():
         e3 = (lin(x, relu=True, variant="w32")[:64].double() - ref).abs().max().item() / ref.abs().max().item()
         print("         bf16x3 256 x 256 tiles, fp32 W: %.3f ms (%.1f TF fp32-equivalent, %.0f TF bf16 issued, err %.2e)"
               % (t3, fl / t3 / 1e9, 6 * fl / t3 / 1e9, e3), flush=True)
+        _lib.set_option("tune_fc_x3_rows", -1)
+        t3 = timed(lambda: lin(x, relu=True))
+        e3 = (lin(x, relu=True)[:64].double() - ref).abs().max().item() / ref.abs().max().item()
+        eall = (lin(x, relu=True)[-64:].double() - torch.relu(x[-64:].double() @ w.double().t() + b.double())).abs().max().item() / ref.abs().max().item()
+        print("         bf16x3 as the model calls it (variant by shape): %.3f ms (%.1f TF fp32-equivalent, err %.2e / last rows %.2e)"
+              % (t3, fl / t3 / 1e9, e3, eall), flush=True)
         for rows in (128, 256):
             _lib.set_option("tune_fc_x3_rows", rows)
             t3 = timed(lambda: lin(x, relu=True, variant="packed"))
