@@ -451,7 +451,7 @@ def bench_detect(args, rank, world, dist):
             # bf16x3 split: six bf16 MFMAs per fp32 multiply-add (exact 3-way cut of both operands) -> priced against the bf16 peak
             r = {"bound": "mfma", "launch": "one launch over the RoIs of the rank's %d volumes (M = %d rows)" % (nvol, M),
                  "kernel": "fc_x3_gemm_kernel (Box_Head.fc1: [M,87808] x [1024,87808]^T at fp32 accuracy on v_mfma_f32_32x32x16_bf16: "
-                           "exact 3-way bf16 cut of x and W, 6 products per fp32 product, split-K; + fc_reduce_kernel; <= 16 rows past a multiple of the "
+                           "exact 3-way bf16 cut of x and W, 6 products per fp32 product, split-K; + fc_reduce_kernel; <= 64 rows past a multiple of the "
                            "256-row tile go through fc_gemm_kernel's ragged-tile path in the same span)",
                  "achieved": 6.0 * fl / (ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": 6.0 * fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "kernel_ms": ms,

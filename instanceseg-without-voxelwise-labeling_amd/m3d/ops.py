@@ -386,7 +386,7 @@ class SplitLinear:
         check(lib().m3d_linear_bf16x3_pack(_ptr(weight), self.N, self.K, _ptr(self.packed), _stream()), "linear_bf16x3_pack")
         self.bias = None if bias is None else _f32c(bias)
         self.weight = weight                    # the many-rows kernel (256 x 256 tiles) cuts the fp32 weight itself
-        self.tail_rows = 16                     # <= this many rows past a multiple of 256 go to the fp32 kernel's ragged-tile path
+        self.tail_rows = 64                     # <= this many rows past a multiple of 256 go to the fp32 kernel's ragged-tile path
         self.big_rows = 2048                    # from this many rows on (N >= 256): m3d_linear_bf16x3_w32_forward (2560 rows: 2.21 vs 2.35 ms)
 
     def __call__(self, x, relu=False, out=None, variant=None):
