@@ -323,6 +323,7 @@ def bench_detect(args, rank, world, dist):
     dt = sync_max_time(dt, dist, "cpu" if via_host else "cuda")
     torch.cuda.synchronize()
     kern_ms = det.probe.mean_ms()
+    kern_med = det.probe.median_ms()
     det.probe = None
 
     # ---- (1b) the same K steps software-pipelined over two streams: begin(k+1) = norm1 + backbone + RPN + proposals is launched
@@ -491,7 +492,8 @@ def bench_detect(args, rank, world, dist):
                       "dets_per_volume": (float(last["packed"][:, :, cap, 0].mean().item()) if "packed" in last else None),
                       "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9, "backbone_ms_per_volume": body_ms,
                       "backbone_algorithmic_tflops": backbone_flops(VOL) / (body_ms * 1e-3) / 1e12 if body_ms else None,
-                      "kernel_ms_per_launch": kern},
+                      "kernel_ms_per_launch": kern,
+                      "kernel_ms_per_launch_median": {k: round(v, 4) for k, v in sorted(kern_med.items(), key=lambda kv: -kv[1])}},
            "roofline": roof, "rooflines": roofs}
     if piped is not None:
         res["pipelined"] = piped

@@ -55,6 +55,14 @@ class Probe:
         """name -> mean duration in ms (call after a device synchronize)."""
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.spans.items()}
 
+    def median_ms(self):
+        """name -> median duration in ms: one stalled launch (a context switch on a shared box) moves a mean over 10 steps, not this."""
+        out = {}
+        for k, v in self.spans.items():
+            d = sorted(a.elapsed_time(b) for a, b in v)
+            out[k] = d[len(d) // 2] if len(d) % 2 else 0.5 * (d[len(d) // 2 - 1] + d[len(d) // 2])
+        return out
+
 
 class _NoSpan:
     def __enter__(self):
