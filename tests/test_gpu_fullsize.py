@@ -217,6 +217,36 @@ def test_config2_four_volumes_128_cubed_detections_equal_the_oracle():
         assert len(g) <= cfg.detections_per_im
 
 
+def test_config4_rank_shape_eight_volumes_in_one_batch_match_the_per_tile_path_and_pack():
+    """BASELINE.json configs[4], one rank's share: 8 x (1x128^3) in ONE batched pass (what every rank of the 8-GPU run does; the
+    box-head GEMM then has ~2 500 rows and takes the 256 x 256-tile variant) == the per-tile path on the same volumes (which the
+    configs[2] test pins to the oracle), then the exchange block: cross-tile NMS + pack, gathered (world 1), unpacked."""
+    from m3d import ops, shard
+    cfg, P, det = _baseline_model(head=True)
+    vols = torch.cat([_baseline_volume(i) for i in range(8)], 0).cuda()
+    r = det.detect_batch(vols, as_dicts=False)
+    assert len(r["num_rois"]) == 8 and sum(r["num_rois"]) >= 2048                # enough rows for the many-rows GEMM variant
+    offs = r["offsets"]
+    for b in (0, 3, 7):
+        one = det.detect_tile(vols[b:b + 1].contiguous())
+        n = r["num_rois"][b]
+        assert torch.equal(r["keep_idx"][b, :n], one["keep_idx"])
+        assert torch.allclose(r["cls"][offs[b]:offs[b + 1]], one["cls"], atol=2e-4)
+        assert torch.allclose(r["pred_boxes"][offs[b]:offs[b + 1]], one["pred_boxes"], atol=2e-2)
+        m = int(r["cls_counts"][b, 1])
+        assert abs(m - one["cls_boxes"][1].shape[0]) <= max(1, m // 50)
+    cap = cfg.detections_per_im
+    packed = ops.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
+    assert packed.shape == (8, cap + 1, 7)
+    got = shard.gathered_items(shard.all_gather_packed(packed, 8, None), 8)
+    assert len(got) == 8
+    for b in range(8):
+        d = got[b]
+        assert d.shape[1] == 7 and 0 < d.shape[0] <= cap
+        keep = ops.nms3d(r["cls_boxes"][b, 1, :int(r["cls_counts"][b, 1])].contiguous(), cfg.nms)
+        assert d.shape[0] == keep.numel()                                         # the packed block holds exactly the cross-tile NMS survivors
+
+
 def test_detect_batch_equals_per_tile_detection():
     """DetectorM3D.detect_batch (what bench.py and im_detect_all run): 3 tiles in one batched pass == detect_tile per tile
     (same proposals kept, same detections; conv tile choices may differ with the batch size -> fp32 noise only)."""
