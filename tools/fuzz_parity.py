@@ -251,6 +251,37 @@ def f_linear(rs):
     assert ((y3.double() - ref).abs() / rows).max().item() < tol, ("linear bf16x3", M, N, K)
 
 
+def f_mask_paste(rs):
+    """segm_results' paste (csrc/mask_paste.hip) against the oracle's scipy.ndimage restatement of skimage's resize: identical masks
+    except voxels whose soft value is within 2e-6 of the threshold."""
+    from m3d.mask_head import segm_results
+    M = int(rs.choice([4, 7, 14, 28]))
+    C = int(rs.choice([2, 3]))
+    shape = tuple(int(v) for v in rs.randint(6, 48, 3))
+    R = int(rs.randint(1, 12))
+    masks = np.clip(rs.rand(R, C, M, M, M).astype(np.float32) * rs.choice([0.6, 1.0, 1.6]), 0, 1)
+    ctr = rs.uniform(0, max(shape), (R, 3)); size = rs.choice([0.3, 1.0, 3.0, 6.0, 11.0, 20.0, 33.0, 60.0], (R, 3))
+    lim = np.array([shape[2] - 1, shape[1] - 1, shape[0] - 1] * 2, np.float64)
+    boxes = np.clip(np.hstack([ctr - size / 2, ctr + size / 2]), 0, lim)
+    n1 = int(rs.randint(0, R + 1)) if C > 2 else R
+    cls_boxes = [np.zeros((0, 7)), np.zeros((n1, 7))] + ([np.zeros((R - n1, 7))] if C > 2 else [])
+    spec = bool(rs.randint(2))
+    thr = float(rs.choice([0.5, 0.3, 0.7]))
+    got = segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=spec, thresh=thr)
+    ref = O.segm_results(cls_boxes, masks, boxes, *shape, num_classes=C, resolution=M, cls_specific=spec, thresh=thr)
+    rb = O.expand_boxes(boxes, (M + 2.0) / M).astype(np.int32)
+    ind = 0
+    for j in range(1, C):
+        for g, r in zip(got[j], ref[j]):
+            if not np.array_equal(g, r):
+                b = rb[ind]
+                pad = np.zeros((M + 2,) * 3, np.float32); pad[1:-1, 1:-1, 1:-1] = masks[ind, j if spec else 0]
+                soft = O.skimage_resize_nd(pad, (max(b[5] - b[2] + 1, 1), max(b[4] - b[1] + 1, 1), max(b[3] - b[0] + 1, 1)))
+                zz, yy, xx = np.nonzero(g != r)
+                assert (np.abs(soft[zz - b[2], yy - b[1], xx - b[0]] - np.float32(thr)) < 2e-6).all(), ("mask paste", M, shape, ind)
+            ind += 1
+
+
 _prm_cache = {}
 
 
@@ -312,7 +343,7 @@ def f_quant_segment(rs):
 
 
 ops = [("quantise/segment", f_quant_segment), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
-       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3", f_linear), ("prm tile", f_prm)]
+       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3", f_linear), ("mask paste", f_mask_paste), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
     ops = [o for o in ops if any(t in o[0] for t in only.split(","))]
