@@ -495,6 +495,10 @@ def bench_detect(args, rank, world, dist):
                       "kernel_ms_per_launch": kern,
                       "kernel_ms_per_launch_median": {k: round(v, 4) for k, v in sorted(kern_med.items(), key=lambda kv: -kv[1])}},
            "roofline": roof, "rooflines": roofs}
+    if not backbone_only and getattr(det, "fc_split", None):
+        res["dtype_note"] = ("every operand, accumulator and result is fp32; fc1 / fc2 multiply on the bf16 matrix cores after an EXACT 3-way bf16 cut "
+                             "of both fp32 operands (6 MFMAs per product, fp32 accumulation; error vs fp64 = the fp32-input kernel's, "
+                             "tests/test_gpu_ops.py); M3D_FC_SPLIT=0 selects the fp32-input MFMA kernel")
     if piped is not None:
         res["pipelined"] = piped
     if e2e is not None:
