@@ -487,7 +487,7 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
 // x 64 B = 96 KB, swizzled as above.  The fragments of a k16 step are read in two column halves so that 48 fragment registers
 // suffice beside the accumulators.
 __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
-  constexpr int TB = 256, NT = 512;
+  constexpr int TB = 256;                                          // 512 threads
   constexpr int PL = TB * X3_RSW, OP = 3 * PL;                     // dwords of a plane / of an operand
   extern __shared__ float lds_f[];
   unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);
