@@ -17,14 +17,30 @@
 // * the inverse transform is 12 adds per channel on accumulators of the same lane and leaves each lane with a 2x2
 //   output patch: 8-byte stores, and the fused pool needs no cross-lane step in (y, x), only one LDS exchange in z;
 // * coefficients are +-1, 1/2, 1/4: errors stay at the fp32 few-ulp level (tests: < 1e-5 relative against fp64).
+#include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "m3d_common.h"
+#include "conv3d_wino2q.h"
 
 // timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU (one-wave kernel),
-// 8 = 4 instead of 16 transform VALU per K step in the eta-split kernel
+// 8 = 4 instead of 16 transform VALU per K step in the eta-split kernel, 16 = no raw-row LDS reads, 32 = no weight-fragment LDS reads, 64 = no input loads, 128 = input loads without LDS commit,
+// 256 = no weight DMA, 512 = every workgroup stages the same (cache-resident) input tile (eta-split kernel)
 #ifndef M3D_EXP
 #define M3D_EXP 0
+#endif
+
+// diagnostic build only (make w2_stamps; tools/w2_stamps.py): s_memtime stamps of one wave per workgroup around the prologue, the K loop,
+// the eta exchange and the epilogue, written to a buffer of their own (m3d_debug_set_stamp_buffer); no output value depends on them
+#ifdef M3D_W2_STAMPS
+static unsigned long long* g_w2_stamps = nullptr;
+M3D_API void m3d_debug_set_stamp_buffer(void* p) { g_w2_stamps = (unsigned long long*)p; }
+#define W2_STAMP(k) do { if (ep.stamps && tid == 0) ep.stamps[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 8 + (k)] = \
+    (k) == 5 || (k) == 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W2_STAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -32,23 +48,51 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) float lds_cfloat;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;   // LDS-space element type (32-bit addresses, ds_* instructions)
+
+// Pins values at this program point: the empty asm is a use + redefinition, so arithmetic on them cannot be placed earlier (the
+// pre-RA scheduler otherwise hoists the y transform to right behind the LDS reads of the previous step and the wave
+// waits out the full LDS latency four times per K step: tools/asm_trace.py shows "r r r [lgkmcnt(1)] v v").
+template <int N>
+__device__ __forceinline__ void pin_regs(float (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+template <int A, int B>
+__device__ __forceinline__ void pin_regs(float (&r)[A][B]) {
+#pragma unroll
+  for (int a = 0; a < A; ++a) pin_regs(r[a]);
+}
+
+template <int A, int B>
+__device__ __forceinline__ void pin_regs(f32x2 (&r)[A][B]) {      // 64-bit words stay register pairs (pinning their halves costs copies)
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int b = 0; b < B; ++b) asm volatile("" : "+v"(r[a][b]));
+}
 
 constexpr int WT2 = 48;   // weight slots per (cout, cin): 3 dz x 4 eta x 4 xi
 
-// Wp[cin_pair][cout_block32][dz*16 + eta*4 + xi][lane64] = (G g_dz G^T)[eta][xi], co = cb*32 + (lane&31), ci = 2*pair + (lane>>5)
+// Wp[cin_pair][cout_block32][dz*4 + eta][lane64][xi] = (G g_dz G^T)[eta][xi], co = cb*32 + (lane&31), ci = 2*pair + (lane>>5):
+// a lane's four xi fragments of one (dz, eta) are 16 contiguous bytes (one ds_read_b128 in the kernels; round 2 kept [slot][lane],
+// four-byte reads), a (pair, cout block) is 12 KB contiguous (LDS-DMA pieces of 1 KB).
+using m3d_w2q::w2_slot;
 __global__ __launch_bounds__(256) void wino2_pack_kernel(const float* __restrict__ w, int cin, int cout, float* __restrict__ wp,
                                                          int ncb, int npair) {
   const long long total = (long long)npair * ncb * WT2 * 64;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int lane = (int)(e & 63);
-    long long t = e >> 6;
-    const int slot = (int)(t % WT2); t /= WT2;
+    const int xi = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    long long t = e >> 8;
+    const int grp = (int)(t % 12); t /= 12;
     const int cb = (int)(t % ncb); t /= ncb;
     const int cpair = (int)t;
     const int co = cb * 32 + (lane & 31), ci = 2 * cpair + (lane >> 5);
     float v = 0.f;
     if (co < cout && ci < cin) {
-      const int dz = slot >> 4, eta = (slot >> 2) & 3, xi = slot & 3;
+      const int dz = grp >> 2, eta = grp & 3;
       const float* g = w + ((size_t)co * cin + ci) * 27 + dz * 9;      // g[dy*3 + dx]
       float col[3];                                                      // (G g)[eta][dx]
 #pragma unroll
@@ -72,6 +116,9 @@ struct W2Epi {
   int ksplit, cps;
   size_t slice_stride;
   unsigned char* argmax;   // fused-pool kernels instantiated with AM: index 0..7 = (dz, dy, dx) of each pooled value's first maximum
+#ifdef M3D_W2_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 __device__ __forceinline__ int xcd_contiguous2(int bid, int n) {
@@ -251,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   auto load_a = [&](const float* w_k, int s, float (&af)[16]) __attribute__((always_inline)) {
     const int dz = s / C::PP, pp = s % C::PP;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
+    for (int q = 0; q < 16; ++q) af[q] = w_k[pp * C::W_SEG + w2_slot(dz, q >> 2, q & 3, 0)];     // w_k = segment + 4 * lane
   };
 
   // ---- prologue: chunk 0 -> buffer 0, first fragments
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
   float raw[2][4][4], bfq[2][4][4], afq[2][16];
   read_raw(lds + b_base, 0, raw[0]);
   read_raw(lds + b_base, 1, raw[1]);
-  load_a(lds + C::IN_ELEMS + lane, 0, afq[0]);
+  load_a(lds + C::IN_ELEMS + 4 * lane, 0, afq[0]);
   transform(raw[0], bfq[0]);
 
   // ---- K loop, software-pipelined ACROSS chunks.  With one wave per SIMD nothing hides a refill of the fragment
@@ -282,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
     float* nxt_w = nxt_in + C::IN_ELEMS;
     const int nchk = min(chunk + 1, nchunk - 1);
     const float* in_k = cur_in + b_base;
-    const float* w_k = cur_w + lane;
+    const float* w_k = cur_w + 4 * lane;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
@@ -291,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wino2_kernel(const float* __res
       if (s == NS - 1) {                               // next chunk's first fragments (its buffer is complete: barrier below)
         read_raw(nxt_in + b_base, 0, raw[0]);
         read_raw(nxt_in + b_base, 1, raw[1]);
-        load_a(nxt_w + lane, 0, afq[0]);
+        load_a(nxt_w + 4 * lane, 0, afq[0]);
         transform(raw[0], bfq[0]);
       }
 #if !(M3D_EXP & 1)
@@ -428,29 +475,31 @@ struct W2CfgE {
   static constexpr int PP = CC / 2;
   static constexpr int YT = 32 / XT;
   static constexpr int TX = 2 * XT, TY = 2 * YT * WY, TZ = WZ;
-  static constexpr int EP = XT + 2;
-  static constexpr int QR = EP / 2;                            // 16-byte quads per row
-  // row pitch: the YT y-pairs of a block sit 2*HXP floats apart; 2*HXP = XT (mod 32) puts them on disjoint banks
-  static constexpr int HXP = (YT == 1) ? 2 * EP : ((2 * EP - XT / 2 + 15) / 16 * 16 + XT / 2);
+  // halo rows in natural x order: element s <-> x = x0 - 1 + s, s = 0 .. 2*XT + 1; the lane of x pair t reads s = 2t .. 2t + 3 as two
+  // 8-byte words.  Row pitch: the YT y-pairs of a block sit 2*HXP floats apart and must fall on disjoint banks for those reads
+  // (XT * 8 bytes per y-pair out of 256): XT = 32 any pitch, XT = 16 2*HXP = 32 (mod 64), XT = 8 2*HXP = 16 (mod 32)
+  static constexpr int ROW = 2 * XT + 2;
+  static constexpr int HXP = XT == 32 ? 68 : (XT == 16 ? 48 : 24);     // multiples of 4: rows are whole quads
   static constexpr int HY = TY + 2, HZ = TZ + 2;
   static constexpr int CS = HXP * HY * HZ;
-  static constexpr int IN_ELEMS = CC * CS;
+  static constexpr int QR = HXP / 4;                           // 16-byte quads per row
   static constexpr int NQUAD = CC * HZ * HY * QR;
-  static constexpr int W_SEG = WT2 * 64;                       // one cout block
-  static constexpr int W_ELEMS = PP * W_SEG;
   static constexpr int NI = (NQUAD + NT - 1) / NT;
-  static constexpr int NW4 = (W_ELEMS / 4 + NT - 1) / NT;
-  static constexpr int DUMP = IN_ELEMS + W_ELEMS;              // 2 x 8-byte dump slots behind each buffer (branch-free staging)
-  static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS + ((EP + 2 + 3) / 4) * 4;
+  static constexpr int IN_ELEMS = CC * CS + 4;                 // + a 16-byte dump slot (branch-free staging of the ragged last round)
+  static constexpr int DUMP = CC * CS;
+  static constexpr int W_SEG = WT2 * 64;                       // one cout block of one channel pair
+  static constexpr int W_ELEMS = PP * W_SEG;
+  static constexpr int NWD = W_ELEMS / 256 / 8;                // 16-byte LDS-DMA pieces (1 KB) per wave and chunk
+  static constexpr int LDS_FLOATS = IN_ELEMS + W_ELEMS;
   static constexpr int XCH_FLOATS = 4 * 64 * 64;               // eta-half exchange: 4 wave pairs x 64 floats x 64 lanes
   static constexpr int RED_FLOATS = XCH_FLOATS + (POOL ? 4 * 16 * 64 : 0);
   static constexpr int SMEM_FLOATS = 2 * LDS_FLOATS > RED_FLOATS ? 2 * LDS_FLOATS : RED_FLOATS;
   static_assert(WZ * WY == 4, "4 wave pairs per workgroup, one pair per SIMD");
   static_assert(!POOL || WZ == 2, "fused pool: the z pair lives in waves wz = 0, 1");
-  static_assert(HXP % 2 == 0, "8-byte LDS stores");
-  static_assert((W_ELEMS / 4) % NT == 0, "weight staging is branch-free: whole float4 rounds");
+  static_assert(ROW <= HXP && HXP % 4 == 0, "rows are whole 16-byte quads");
+  static_assert(W_ELEMS % (256 * 8) == 0, "weight staging: whole 1 KB pieces per wave");
+  static_assert((3 * HXP + 4) * 4 < 65536, "row reads address one register with 16-bit offsets");
 };
-
 
 template <int CC, int XT, int WZ, int WY, bool POOL, bool AM = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __restrict__ in, const float* __restrict__ wp,
@@ -458,7 +507,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
                                                               int tiles_x, int tiles_y, int tiles_z, int ncb_total, W2Epi ep) {
   using C = W2CfgE<CC, XT, WZ, WY, POOL>;
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  W2_STAMP(0); W2_STAMP(5);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int eh = wave8 >> 2, wave = wave8 & 3;          // eta half (waves w and w + 4 sit on the same SIMD), wave position in the tile
   const int wz = wave / WY, wy = wave % WY;
 
@@ -486,11 +537,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
     }
   }
   const int b = blockIdx.y;
-  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const int x0 = tx * C::TX, y0 = (M3D_EXP & 512) ? 0 : ty * C::TY, z0 = (M3D_EXP & 512) ? 0 : tz * C::TZ;
   const size_t DHW = (size_t)D * H * W;
-  const float* in_b = in + (size_t)b * cin * DHW;
+  const float* in_b = in + (size_t)((M3D_EXP & 512) ? 0 : b) * cin * DHW;
 
-  // ---- input staging descriptors: 16-byte quads, see conv3d_wino.hip
+  // ---- staging.  Weights: LDS-DMA, 1 KB pieces (`buffer_load_dwordx4 ... lds`: no registers, no LDS stores).  Input: 16-byte quads
+  // through registers (global load in step 0, masked `ds_write_b128` in step NS-2): the x borders of the volume (x = -1, x >= W) fall
+  // inside quads, so they need the per-element masks.  (Per-dword LDS-DMA with one lane per LDS element needs no masks at all - the
+  // hardware range check supplies every zero - but costs 13 + 3 vector-memory instructions per wave and chunk instead of 4 + 3, and a
+  // vector-memory instruction is the most expensive thing a wave can issue beside fp32 MFMAs: conv3b 0.461 -> 0.504 ms, measured.)
   int gq[C::NI], mq[C::NI], lq[C::NI];
 #pragma unroll
   for (int i = 0; i < C::NI; ++i) {
@@ -506,49 +561,47 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
       long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
-      if (rok && lin < 0) { lin = 0; m |= 16; }
+      if (rok && lin < 0) { lin = 0; m |= 16; }     // the very first quad of the tensor: loaded one element later and shifted
       mq[i] = m;
       gq[i] = rok ? (int)(lin * 4) : 0;
-      lq[i] = row * C::HXP + 2 * q;
+      lq[i] = row * C::HXP + 4 * q;
     }
   }
-  // weights and input quads are staged one after the other through the SAME registers (weights: loads in step 0,
-  // LDS writes in step 2; input: loads in step 2, writes in step NS-2)
-  constexpr int NSTG = C::NI > C::NW4 ? C::NI : C::NW4;
-  f32x4 stg[NSTG];
+  f32x4 stg[C::NI];
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(in_b), 0, (unsigned)((size_t)cin * DHW * sizeof(float)), 0x00020000);
   const int nchunk_all = (cin + CC - 1) / CC;
   const int c_begin = ep.ksplit > 1 ? (int)blockIdx.z * ep.cps : 0;
   const int nchunk = ep.ksplit > 1 ? min(nchunk_all, c_begin + ep.cps) : nchunk_all;     // one past this slice's last chunk
   if (ep.ksplit > 1) out += (size_t)blockIdx.z * ep.slice_stride;
-  const f32x4* wp4 = reinterpret_cast<const f32x4*>(wp);
-  const size_t w_pair_stride4 = (size_t)ncb_total * WT2 * 64 / 4;
-  const size_t w_tile_off4 = (size_t)cot * WT2 * 64 / 4;
-  auto issue = [&](int idx, int chunk) __attribute__((always_inline)) {
-    if (idx < C::NI) {
-      const int voff = gq[idx] + chunk * (int)(CC * DHW * sizeof(float));
-      stg[idx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, voff, 0, 0));
-    } else {
-      const int i = idx - C::NI;
-      const int e = tid + i * C::NT;
-      const int pr = e / (C::W_SEG / 4), o = e % (C::W_SEG / 4);
-      stg[i] = (wp4 + (size_t)chunk * (CC / 2) * w_pair_stride4 + w_tile_off4)[(size_t)pr * w_pair_stride4 + o];
-    }
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7FFFFFFF, 0x00020000);
+  const unsigned w_pair_bytes = (unsigned)ncb_total * C::W_SEG * 4, w_tile_bytes = (unsigned)cot * C::W_SEG * 4;
+  const int lane16 = lane * 16;
+  const int chunk_bytes = (int)(CC * DHW * sizeof(float));
+  auto issue_in = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i)
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gq[i] + chunk * chunk_bytes, 0, 0));
   };
-  auto commit1 = [&](int idx, float* dst_in, float* dst_w) __attribute__((always_inline)) {
-    if (idx < C::NI) {                                 // branch-free: the K loop must stay one scheduling region
-      const int m = mq[idx];
-      const f32x4 v = stg[idx];
+  auto commit_in = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::NI; ++i) {                    // branch-free: the K loop must stay one scheduling region
+      const int m = mq[i];
+      const f32x4 v = stg[i];
       const bool sh = (m & 16) != 0;
       const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
-      const f32x2 ev = {(m & 2) ? v1 : 0.f, (m & 8) ? v3 : 0.f};
-      const f32x2 ov = {(m & 1) ? v0 : 0.f, (m & 4) ? v2 : 0.f};
-      *reinterpret_cast<f32x2*>(dst_in + lq[idx]) = ev;
-      *reinterpret_cast<f32x2*>(dst_in + lq[idx] + C::EP) = ov;
-    } else {
-      const int i = idx - C::NI;
-      reinterpret_cast<f32x4*>(dst_w)[tid + i * C::NT] = stg[i];
+      const f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
+      *reinterpret_cast<f32x4*>(lds + buf + lq[i]) = o;
+    }
+  };
+  auto stage_w = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < C::NWD; ++i) {
+      const int pc = wave8 * C::NWD + i;                 // 1 KB piece of the chunk's PP x 12 KB
+      const int pr = pc / (C::W_SEG / 256), o = pc % (C::W_SEG / 256);
+      lds_void* dst = reinterpret_cast<lds_void*>((uintptr_t)(lds + buf + C::IN_ELEMS + pc * 256));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, dst, 16, lane16,
+                                               (int)((unsigned)(chunk * C::PP + pr) * w_pair_bytes + w_tile_bytes + (unsigned)o * 1024u), 0, 0);
     }
   };
 
@@ -561,133 +614,174 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
       for (int g = 0; g < 16; ++g) acc[a][x][g] = 0.f;
 
   const int jt = (lane & 31) % XT, ju = (lane & 31) / XT;
-  // B base: channel half, the wave's z plane, halo row 2*(wy*YT + ju) (= output row pair's y-1), E[jt]
-  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HXP) + 2 * (wy * C::YT + ju) * C::HXP + jt;
+  // B base: channel half, the wave's z plane, halo row 2*(wy*YT + ju) (= output row pair's y-1), s = 2*jt
+  const int b_base = (lane >> 5) * C::CS + wz * (C::HY * C::HXP) + 2 * (wy * C::YT + ju) * C::HXP + 2 * jt;
 
   constexpr int NS = 3 * C::PP;                        // K steps per chunk: dz x channel pair
   static_assert(NS % 2 == 0 && NS >= 4, "the fragment rings are indexed statically across the chunk loop");
-  // y transform of this eta half from three of the four halo rows:  cA = U - V,  cB = sgn * P + V
-  //   eh = 0 (eta 0, 1): U = row 0, V = row 2, P = row 1, sgn = +1   (d0 - d2, d1 + d2)
-  //   eh = 1 (eta 2, 3): U = row 2, V = row 1, P = row 3, sgn = -1   (d2 - d1, d1 - d3)
-  const int rowU = (eh ? 2 : 0) * C::HXP, rowV = (eh ? 1 : 2) * C::HXP, rowP = (eh ? 3 : 1) * C::HXP;
-  const float sgnP = eh ? -1.f : 1.f;
-  auto read_raw = [&](const float* in_k, int s, float (&r)[3][4]) __attribute__((always_inline)) {
-    const int dz = s / C::PP, pp = s % C::PP;
-    const float* p = in_k + pp * 2 * C::CS + dz * (C::HY * C::HXP);
-    const float* pu = p + rowU; const float* pv = p + rowV; const float* pq = p + rowP;
-    r[0][0] = pu[0]; r[0][1] = pu[1]; r[0][2] = pu[C::EP]; r[0][3] = pu[C::EP + 1];      // (E[t], E[t+1], O[t], O[t+1])
-    r[1][0] = pv[0]; r[1][1] = pv[1]; r[1][2] = pv[C::EP]; r[1][3] = pv[C::EP + 1];
-    r[2][0] = pq[0]; r[2][1] = pq[1]; r[2][2] = pq[C::EP]; r[2][3] = pq[C::EP + 1];
-  };
-  auto transform = [&](const float (&r)[3][4], float (&bf)[2][4]) __attribute__((always_inline)) {
+  // y transform of this eta half from three of the four halo rows:  cA = U - V,  cB = V +- P
+  //   eh = 0 (eta 0, 1): U = row 0, V = row 2, P = row 1, cB = V + P   (d0 - d2, d1 + d2)
+  //   eh = 1 (eta 2, 3): U = row 2, V = row 1, P = row 3, cB = V - P   (d2 - d1, d1 - d3)
+  // The K loop is instantiated once per eta half (wave-uniform branch below): row offsets and the sign are immediates.
+  f32x2 raw[2][3][2];
+  float bfq[2][2][4], afq[2][8];
+  auto kloop = [&](auto ehc) __attribute__((always_inline)) {
+    constexpr int EH = decltype(ehc)::value;
+    constexpr int rowU = (EH ? 2 : 0) * C::HXP, rowV = (EH ? 1 : 2) * C::HXP, rowP = (EH ? 3 : 1) * C::HXP;
+    auto read_raw = [&](int buf, int s, f32x2 (&r)[3][2]) __attribute__((always_inline)) {
+      const int dz = s / C::PP, pp = s % C::PP;
+#if (M3D_EXP & 16)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(r[i][j]));      // timing ablation: no raw LDS reads (opaque values)
+      return;
+#endif
+      // two address registers per step (pinned): the low and the high 8-byte word of a row are read from DIFFERENT registers, or the
+      // load/store optimiser fuses them into ds_read2_b64 (half the LDS rate of two ds_read_b64)
+      unsigned a0 = (unsigned)(uintptr_t)(lds + buf + b_base + pp * 2 * C::CS + dz * (C::HY * C::HXP));
+      unsigned a1 = a0 + 8;
+      asm volatile("" : "+v"(a0));
+      asm volatile("" : "+v"(a1));
+      const lds_f32x2* p0 = reinterpret_cast<const lds_f32x2*>((uintptr_t)a0);
+      const lds_f32x2* p1 = reinterpret_cast<const lds_f32x2*>((uintptr_t)a1);
+      r[0][0] = p0[rowU / 2]; r[0][1] = p1[rowU / 2];      // r[row][0] = (x 2t-1, x 2t) = (O[t], E[t]),  r[row][1] = (x 2t+1, x 2t+2) = (O[t+1], E[t+1])
+      r[1][0] = p0[rowV / 2]; r[1][1] = p1[rowV / 2];
+      r[2][0] = p0[rowP / 2]; r[2][1] = p1[rowP / 2];
+    };
+    auto transform = [&](const f32x2 (&rw)[3][2], float (&bf)[2][4]) __attribute__((always_inline)) {
+      float r[3][4];                                     // (E[t], E[t+1], O[t], O[t+1]) per row
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { r[i][0] = rw[i][0][1]; r[i][1] = rw[i][1][1]; r[i][2] = rw[i][0][0]; r[i][3] = rw[i][1][0]; }
 #if (M3D_EXP & 8)
-    for (int v = 0; v < 4; ++v) { bf[0][v] = r[0][v]; bf[1][v] = r[2][v] + r[1][v]; }   // timing ablation: 4 instead of 16 VALU
-    return;
+      for (int v = 0; v < 4; ++v) { bf[0][v] = r[0][v]; bf[1][v] = r[2][v] + r[1][v]; }   // timing ablation: 4 instead of 16 VALU
+      return;
 #endif
-    float c[2][4];                                     // rows combined (y transform), still raw in x
+      float c[2][4];                                     // rows combined (y transform), still raw in x
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      c[0][v] = r[0][v] - r[1][v];
-      c[1][v] = sgnP * r[2][v] + r[1][v];
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {                      // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
-      bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
-    }
-  };
-  auto load_a = [&](const float* w_k, int s, float (&af)[8]) __attribute__((always_inline)) {     // w_k points at this half's 8 slots
-    const int dz = s / C::PP, pp = s % C::PP;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) af[q] = w_k[pp * C::W_SEG + (dz * 16 + q) * 64];
-  };
-
-  // ---- prologue: chunk 0 -> buffer 0, first fragments
-#pragma unroll
-  for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, c_begin);
-#pragma unroll
-  for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, lds, lds + C::IN_ELEMS);
-#pragma unroll
-  for (int i = 0; i < C::NI; ++i) issue(i, c_begin);
-#pragma unroll
-  for (int i = 0; i < C::NI; ++i) commit1(i, lds, lds + C::IN_ELEMS);
-  __syncthreads();
-  float raw[2][3][4], bfq[2][2][4], afq[2][8];
-  read_raw(lds + b_base, 0, raw[0]);
-  read_raw(lds + b_base, 1, raw[1]);
-  load_a(lds + C::IN_ELEMS + lane + eh * 8 * 64, 0, afq[0]);
-  transform(raw[0], bfq[0]);
-
-  // ---- K loop, software-pipelined ACROSS chunks.  With one wave per SIMD nothing hides a refill of the fragment
-  // pipeline after the chunk barrier, so the barrier sits at the end of step NS-2 (all staging writes of the next chunk
-  // are done by then and every LDS read of the current chunk has been issued and waited for) and the last step's 16
-  // MFMAs cover the first fragment reads of the next chunk.
-  constexpr int SW = 0, SX = (NS - 2) / 2;             // weights: loads in step SW, writes in step SX; input: loads SX, writes NS-2
-  for (int chunk = c_begin; chunk < nchunk; ++chunk) {
-    const float* cur_in = lds + ((chunk - c_begin) & 1) * C::LDS_FLOATS;
-    const float* cur_w = cur_in + C::IN_ELEMS;
-    float* nxt_in = lds + ((chunk - c_begin + 1) & 1) * C::LDS_FLOATS;
-    float* nxt_w = nxt_in + C::IN_ELEMS;
-    const int nchk = min(chunk + 1, nchunk - 1);
-    const float* in_k = cur_in + b_base;
-    const float* w_k = cur_w + lane + eh * 8 * 64;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
-      if (s + 2 < NS) read_raw(in_k, s + 2, raw[s & 1]);
-      if (s + 1 < NS) load_a(w_k, s + 1, afq[(s + 1) & 1]);
-      if (s == NS - 1) {                               // next chunk's first fragments (its buffer is complete: barrier below)
-        read_raw(nxt_in + b_base, 0, raw[0]);
-        read_raw(nxt_in + b_base, 1, raw[1]);
-        load_a(nxt_w + lane + eh * 8 * 64, 0, afq[0]);
-        transform(raw[0], bfq[0]);
+      for (int v = 0; v < 4; ++v) {
+        c[0][v] = r[0][v] - r[1][v];
+        c[1][v] = EH ? r[1][v] - r[2][v] : r[1][v] + r[2][v];
       }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {                      // x transform: e0 = c[a][0], e1 = c[a][1], o0 = c[a][2], o1 = c[a][3]
+        bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
+      }
+    };
+    auto load_a = [&](int buf, int s, float (&af)[8]) __attribute__((always_inline)) {     // this half's 2 x 4 fragments of the step
+      const int dz = s / C::PP, pp = s % C::PP;
+#if (M3D_EXP & 32)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" : "=v"(af[q]));            // timing ablation: no weight-fragment LDS reads
+      return;
+#endif
+      const float* w = lds + buf + C::IN_ELEMS + pp * C::W_SEG + 4 * lane;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + w2_slot(dz, EH * 2 + a, 0, 0));
+        af[a * 4 + 0] = v[0]; af[a * 4 + 1] = v[1]; af[a * 4 + 2] = v[2]; af[a * 4 + 3] = v[3];
+      }
+    };
+
+    read_raw(0, 0, raw[0]);
+    read_raw(0, 1, raw[1]);
+    load_a(0, 0, afq[0]);
+    transform(raw[0], bfq[0]);
+
+    // ---- K loop, software-pipelined ACROSS chunks: raw rows are read two steps ahead, transformed one step ahead; weight fragments
+    // are read one step ahead.  Every step is two scheduling regions:
+    //   A: the step's LDS reads (raw rows of step s + 2, weight fragments of step s + 1) between MFMAs 0..3; step 0 also issues the
+    //      next chunk's LDS-DMA (its buffer was last read before the previous chunk barrier)
+    //   B: pin + transform of the rows read in the PREVIOUS step between MFMAs 4..7
+    // The pin matters: without it the pre-RA scheduler places the y transform right behind its LDS reads (fewer live registers) and
+    // every step waits out the LDS latency four times (tools/asm_trace.py: "r r r [lgkmcnt(1)] v v").  The chunk barrier sits at the
+    // end of step NS-2, behind the input commit and a wait for the weight DMA issued in step 0; every LDS read of the current chunk has been
+    // issued by then; the last step reads the next chunk's first fragments in its region A and transforms them in B.
+    for (int chunk = c_begin; chunk < nchunk; ++chunk) {
+      const int cur = ((chunk - c_begin) & 1) * C::LDS_FLOATS, nxt = C::LDS_FLOATS - cur;
+      const int nchk = min(chunk + 1, nchunk - 1);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        // ---------------- region A
+        if (s + 2 < NS) read_raw(cur, s + 2, raw[s & 1]);
+        if (s + 1 < NS) load_a(cur, s + 1, afq[(s + 1) & 1]);
+        if (s == NS - 1) {                               // next chunk's first fragments (its buffer is complete: barrier below)
+          read_raw(nxt, 0, raw[0]);
+          read_raw(nxt, 1, raw[1]);
+          load_a(nxt, 0, afq[0]);
+        }
 #if !(M3D_EXP & 1)
-      if (s == SW) {
-#pragma unroll
-        for (int i = 0; i < C::NW4; ++i) issue(C::NI + i, nchk);
-      }
-      if (s == SX) {
-#pragma unroll
-        for (int i = 0; i < C::NW4; ++i) commit1(C::NI + i, nxt_in, nxt_w);
-#pragma unroll
-        for (int i = 0; i < C::NI; ++i) issue(i, nchk);
-      }
+        if (s == 0) {
+#if !(M3D_EXP & 256)
+          stage_w(nchk, nxt);
 #endif
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
+#if !(M3D_EXP & 64)
+          issue_in((M3D_EXP & 512) ? 0 : nchk);
+#endif
+        }
+#endif
 #pragma unroll
         for (int x = 0; x < 4; ++x)
-          acc[a][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][a * 4 + x], bfq[s & 1][a][x], acc[a][x], 0, 0, 0);
-#if !(M3D_EXP & 1)
-      if (s == NS - 2) {
-#pragma unroll
-        for (int i = 0; i < C::NI; ++i) commit1(i, nxt_in, nxt_w);
-      }
-#endif
-      // Two waves per SIMD: the partner's MFMAs fill the pipe while this wave issues its LDS / VALU / VMEM work, which is still
-      // spread between the step's 8 MFMAs so that neither wave presents a long MFMA-free stretch.
-#ifndef M3D_SGE
-#define M3D_SGE 3, 6, 1, 1     /* per MFMA slot: DS reads, VALU, DS writes, VMEM reads */
-#endif
+          acc[0][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][x], bfq[s & 1][0][x], acc[0][x], 0, 0, 0);
 #ifndef M3D_SGE_OFF
-      {
-        constexpr int sg[4] = {M3D_SGE};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, sg[0], 0);     // DS read
-          __builtin_amdgcn_sched_group_barrier(0x002, sg[1], 0);     // VALU
-          __builtin_amdgcn_sched_group_barrier(0x200, sg[2], 0);     // DS write
-          __builtin_amdgcn_sched_group_barrier(0x020, sg[3], 0);     // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);         // VALU (addresses)
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // DS read
+          if (s == 0) {                                              // the next chunk's loads; DMA pieces behind their M0 set-up
+#pragma unroll
+            for (int k = 0; k < (C::NI + C::NWD + 3) / 4; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);     // SALU
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+            }
+          }
         }
-      }
 #endif
-      __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- region B
+#ifndef M3D_NOPIN
+        if (s + 1 < NS) pin_regs(raw[(s + 1) & 1]);
+        if (s == NS - 1) pin_regs(raw[0]);
+#endif
+        if (s + 1 < NS) transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]);
+        if (s == NS - 1) transform(raw[0], bfq[0]);
+#if !(M3D_EXP & 1)
+#if (M3D_EXP & 128)
+        if (s == NS - 2) {                               // timing ablation: wait for the loads, no LDS commit
+#pragma unroll
+          for (int i = 0; i < C::NI; ++i) asm volatile("" :: "v"(stg[i]));
+        }
+#else
+        if (s == NS - 2) commit_in(nxt);
+#endif
+#endif
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          acc[1][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][4 + x], bfq[s & 1][1][x], acc[1][x], 0, 0, 0);
+#ifndef M3D_SGE_OFF
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // MFMA
+          if (s == NS - 2) __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);   // VALU (transform; masks of the input commit)
+          else __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);         // DS write
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
 #if !(M3D_EXP & 2)
-      if (s == NS - 2) __syncthreads();
+        if (s == NS - 2) __syncthreads();                // (waits for this wave's DMA and LDS reads first)
 #endif
+      }
     }
-  }
+  };
+  // ---- prologue: chunk 0 -> buffer 0
+  stage_w(c_begin, 0); issue_in(c_begin);
+  commit_in(0);
+  __syncthreads();
+  W2_STAMP(1);
+  if (eh) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});
+  W2_STAMP(2);
   __syncthreads();                                     // the pool exchange below reuses the staging area
 
   // ---- inverse transform: over xi in the lane, over eta across the two halves:  y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3
@@ -709,6 +803,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
       }
     }
     __syncthreads();
+    W2_STAMP(3);
     if (eh == 1) return;
     yv[0][0] = p0[0] + p0[1]; yv[1][0] = p0[1];
     yv[0][1] = p1[0] + p1[1]; yv[1][1] = p1[1];
@@ -776,6 +871,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
         }
       }
     }
+    W2_STAMP(4); W2_STAMP(6);
     return;
   }
 
@@ -800,6 +896,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
       }
     }
   }
+  W2_STAMP(4); W2_STAMP(6);
 }
 
 // split-K epilogue: out = act(scale * sum_s partial[s] + shift), fixed summation order
@@ -853,6 +950,9 @@ int launch_wino2e(const float* in, const float* wp, float* out, int B, int cin, 
   ep.xcd_map = xcd_map_enabled2();
   const size_t lds = sizeof(float) * C::SMEM_FLOATS;
   if (lds > 160 * 1024) return M3D_EUNSUPPORTED;
+#ifdef M3D_W2_STAMPS
+  ep.stamps = g_w2_stamps;
+#endif
   auto kern = conv3d_wino2e_kernel<CC, XT, WZ, WY, POOL, AM>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -861,11 +961,11 @@ int launch_wino2e(const float* in, const float* wp, float* out, int B, int cin, 
   return m3d::check_launch("conv3d_wino2e");
 }
 
-// tune_wino2 >= 100 selects the one-wave-per-SIMD kernels (A/B measurements); default: the eta-split kernels
+// tune_wino2 / 100 == 1 selects the one-wave-per-SIMD kernels (A/B measurements), else the eta-split kernels
 template <int CC, int XT, int WZ, int WY, bool POOL = false>
 int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep, hipStream_t st,
                  int ksplit = 1) {
-  if (m3d::opt(m3d::OPT_TUNE_WINO2) >= 100)
+  if (m3d::opt(m3d::OPT_TUNE_WINO2) / 100 == 1)
     return launch_wino2_one<CC, XT, WZ, WY, POOL>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
   return launch_wino2e<CC, XT, WZ, WY, POOL>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
 }
@@ -885,15 +985,33 @@ M3D_API int m3d_conv3d_wino2_pack_weights(const float* d_weight, int cin, int co
   return m3d::check_launch("wino2_pack");
 }
 
-// ---- tile choice.  Three output tiles: 64 x 2 x 4 (XT = 32), 32 x 8 x 2 (XT = 16), 16 x 16 x 2 (XT = 8, with split-K over
-// workgroups when the map has too few tiles to give every CU one).  Score = useful fraction of the computed tile volume
-// x how much of the chip the grid fills; ties go to the wider tile (fewer halo columns per output).
+// ---- kernel family and tile choice.
+// Families (option "tune_wino2" / 100): 0 = library default (the quad kernel), 1 = one wave per SIMD (round 1), 2 = eta-split 8-wave
+// workgroups (round 2), 3 = quad kernel (4-wave workgroups, two per CU; conv3d_wino2q.hip).  "tune_wino2" % 100: 99 = library tile
+// choice, 0..5 = one of the fixed tiles of families 1 / 2 (A/B runs).
+// Tiles (x, y, z outputs per workgroup): eta-split / one-wave 64 x 2 x 4, 32 x 8 x 2, 16 x 16 x 2; quad 64 x 2 x 2, 32 x 4 x 2,
+// 16 x 8 x 2; the narrowest with split-K over workgroups when the map has too few tiles to fill the chip.  Score = useful fraction of
+// the computed tile volume x how much of the chip the grid fills; ties go to the wider tile (fewer halo columns per output).
 namespace {
+constexpr int kDefaultFamily = 2;
+inline int family() {
+  const int f = m3d::opt(m3d::OPT_TUNE_WINO2) / 100;
+  return f <= 0 ? kDefaultFamily : f;
+}
+struct Tile { int tx, ty, tz; };
+inline Tile tile_of(int fam, int xt) {
+  if (fam == 3) return xt == 32 ? Tile{64, 2, 2} : xt == 16 ? Tile{32, 4, 2} : Tile{16, 8, 2};
+  return xt == 32 ? Tile{64, 2, 4} : xt == 16 ? Tile{32, 8, 2} : Tile{16, 16, 2};
+}
+inline int chip_slots(int fam) { return fam == 3 ? 512 : 256; }   // resident workgroups: two per CU for the quad kernel
+
 struct SplitPlan { int ksplit, cps; size_t slice; };
-SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int width) {
-  const long long tiles = (long long)((width + 15) / 16) * ((height + 15) / 16) * ((depth + 1) / 2) * ((cout + 31) / 32) * batch;
+SplitPlan plan_splitk(int fam, int batch, int cin, int cout, int depth, int height, int width) {
+  const Tile t = tile_of(fam, 8);
+  const long long tiles = (long long)((width + t.tx - 1) / t.tx) * ((height + t.ty - 1) / t.ty) * ((depth + t.tz - 1) / t.tz) *
+                          ((cout + 31) / 32) * batch;
   const int nchunk = (cin + 3) / 4;
-  int ks = (int)(256 / (tiles > 0 ? tiles : 1));             // one workgroup per CU (256 CUs), never a ragged second round
+  int ks = (int)(chip_slots(fam) / (tiles > 0 ? tiles : 1));   // one resident round, never a ragged second one
   if (ks > 8) ks = 8;
   if (ks > nchunk) ks = nchunk;
   if (ks < 1) ks = 1;
@@ -902,27 +1020,45 @@ SplitPlan plan_splitk(int batch, int cin, int cout, int depth, int height, int w
   return SplitPlan{ks, cps, (size_t)batch * cout * depth * height * width};
 }
 
-int choose_xt(int batch, int cin, int cout, int D, int H, int W, double* best_score = nullptr) {
+int choose_xt(int fam, int batch, int cin, int cout, int D, int H, int W, double* best_score = nullptr) {
   if (best_score) *best_score = 0.0;
   if (const int tv = m3d::opt(m3d::OPT_TUNE_WINO2_XT); tv >= 0) { if (best_score) *best_score = 1.0; return tv; }
   if (W < 12) return 0;
   auto up = [](int v, int t) { return (double)((v + t - 1) / t) * t; };
-  const double vol = (double)D * H * W, cot = (cout + 31) / 32;
+  const double vol = (double)D * H * W, cot = (cout + 31) / 32, slots = chip_slots(fam);
   double best = -1.0; int xt = 0;
-  const int tx[3] = {64, 32, 16}, ty[3] = {2, 8, 16}, tz[3] = {4, 2, 2}, id[3] = {32, 16, 8};
+  const int id[3] = {32, 16, 8};
   for (int i = 0; i < 3; ++i) {
     if (id[i] == 32 && W < 48) continue;
     if (id[i] == 16 && W < 24) continue;
-    const double eff = vol / (up(W, tx[i]) * up(H, ty[i]) * up(D, tz[i]));
-    double wgs = up(W, tx[i]) / tx[i] * up(H, ty[i]) / ty[i] * up(D, tz[i]) / tz[i] * cot * batch;
-    if (id[i] == 8) wgs *= plan_splitk(batch, cin, cout, D, H, W).ksplit;
-    // one workgroup per CU: the grid runs in ceil(wgs / 256) rounds and a ragged last round costs a full one
-    const double rounds = (double)((long long)((wgs + 255.0) / 256.0));
-    const double score = eff * wgs / (256.0 * rounds);
+    const Tile t = tile_of(fam, id[i]);
+    const double eff = vol / (up(W, t.tx) * up(H, t.ty) * up(D, t.tz));
+    double wgs = up(W, t.tx) / t.tx * up(H, t.ty) / t.ty * up(D, t.tz) / t.tz * cot * batch;
+    if (id[i] == 8) wgs *= plan_splitk(fam, batch, cin, cout, D, H, W).ksplit;
+    // the grid runs in ceil(wgs / slots) rounds and a ragged last round costs a full one
+    const double rounds = (double)((long long)((wgs + slots - 1.0) / slots));
+    const double score = eff * wgs / (slots * rounds);
     if (score > best * 1.02) { best = score; xt = id[i]; }
   }
   if (best_score) *best_score = best;
   return xt;
+}
+
+m3d_w2q::Epi quad_epi(const W2Epi& e) {
+  m3d_w2q::Epi q{};
+  q.scale = e.scale; q.shift = e.shift; q.relu = e.relu; q.xcd_map = xcd_map_enabled2();
+  q.ksplit = e.ksplit; q.cps = e.cps; q.slice_stride = e.slice_stride; q.argmax = e.argmax;
+  return q;
+}
+
+// one launch of the chosen family on tile xt (8: the split-K capable tile)
+int launch_family(int fam, int xt, const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep,
+                  hipStream_t st, int ksplit) {
+  if (fam == 3) return m3d_w2q::launch(xt, false, false, in, wp, out, B, cin, cout, D, H, W, quad_epi(ep), st);
+  if (xt == 32) return launch_wino2<4, 32, 4, 1>(in, wp, out, B, cin, cout, D, H, W, ep, st);
+  if (xt == 16) return launch_wino2<4, 16, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st);
+  if (xt == 8) return launch_wino2<4, 8, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
+  return M3D_EUNSUPPORTED;
 }
 }  // namespace
 
@@ -931,14 +1067,15 @@ int choose_xt(int batch, int cin, int cout, int D, int H, int W, double* best_sc
 M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0.0;
   double sc = 0.0;
-  (void)choose_xt(batch, cin, cout, depth, height, width, &sc);
+  (void)choose_xt(family(), batch, cin, cout, depth, height, width, &sc);
   return sc;
 }
 
 M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0;
-  if (choose_xt(batch, cin, cout, depth, height, width) != 8) return 0;
-  const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
+  const int fam = family();
+  if (choose_xt(fam, batch, cin, cout, depth, height, width) != 8) return 0;
+  const SplitPlan p = plan_splitk(fam, batch, cin, cout, depth, height, width);
   return p.ksplit > 1 ? p.ksplit * p.slice * sizeof(float) : 0;
 }
 
@@ -951,25 +1088,27 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  const int variant = m3d::opt(m3d::OPT_TUNE_WINO2) % 100;      // +100: one-wave-per-SIMD kernels (launch_wino2)
+  const int fam = family();
+  const int variant = m3d::opt(m3d::OPT_TUNE_WINO2) % 100;
+  if (fam != 3) {
 #define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
-  M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
-  M3D_W2(1, 4, 32, 4, 1)
-  M3D_W2(2, 4, 32, 1, 4)
-  M3D_W2(3, 4, 16, 2, 2)      // 32 x 8 y x 2 z
-  M3D_W2(4, 4, 16, 4, 1)
-  M3D_W2(5, 4, 16, 1, 4)
+    M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
+    M3D_W2(1, 4, 32, 4, 1)
+    M3D_W2(2, 4, 32, 1, 4)
+    M3D_W2(3, 4, 16, 2, 2)      // 32 x 8 y x 2 z
+    M3D_W2(4, 4, 16, 4, 1)
+    M3D_W2(5, 4, 16, 1, 4)
 #undef M3D_W2
-  if (variant >= 0 && variant != 99) return M3D_EUNSUPPORTED;    // 99 / 199: library tile choice
-  const int xt = choose_xt(batch, cin, cout, depth, height, width);
-  if (xt == 32) return launch_wino2<4, 32, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
-  if (xt == 16) return launch_wino2<4, 16, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  }
+  if (variant >= 0 && variant != 99 && m3d::opt(m3d::OPT_TUNE_WINO2) >= 0) return M3D_EUNSUPPORTED;    // 99: library tile choice
+  const int xt = choose_xt(fam, batch, cin, cout, depth, height, width);
+  if (xt == 32 || xt == 16) return launch_family(fam, xt, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st, 1);
   if (xt != 8) return M3D_EUNSUPPORTED;
-  const SplitPlan p = plan_splitk(batch, cin, cout, depth, height, width);
-  if (p.ksplit <= 1) return launch_wino2<4, 8, 2, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  const SplitPlan p = plan_splitk(fam, batch, cin, cout, depth, height, width);
+  if (p.ksplit <= 1) return launch_family(fam, 8, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st, 1);
   if (!d_ws || ws_bytes < p.ksplit * p.slice * sizeof(float)) return M3D_EWORKSPACE;
   W2Epi eps{nullptr, nullptr, 0, 0, p.ksplit, p.cps, p.slice};
-  const int rc = launch_wino2<4, 8, 2, 2>(d_in, d_packed, (float*)d_ws, batch, cin, cout, depth, height, width, eps, st, p.ksplit);
+  const int rc = launch_family(fam, 8, d_in, d_packed, (float*)d_ws, batch, cin, cout, depth, height, width, eps, st, p.ksplit);
   if (rc != M3D_OK) return rc;
   const size_t total = p.slice;
   size_t blocks = (total + 255) / 256;
@@ -993,9 +1132,12 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 24) return M3D_EUNSUPPORTED;
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  if (width < 48)         // 32-wide tiles (conv3b on 32^3 maps): the pool of the 16^3-class layers is fused as well
-    return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
-  return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, m3d::as_stream(stream));
+  hipStream_t st = m3d::as_stream(stream);
+  // 64-wide tiles from 48 voxels on, else 32-wide (conv3b on 32^3 maps: the pool of the 16^3-class layers is fused as well)
+  if (family() == 3)
+    return m3d_w2q::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
+  if (width < 48) return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+  return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
 }
 
 /* m3d_conv3d_wino2_forward_pool2 that also returns the pool's argmax (uint8 [batch, cout, D/2, H/2, W/2], index = dz*4 + dy*2 + dx
@@ -1009,6 +1151,8 @@ M3D_API int m3d_conv3d_wino2_forward_pool2_argmax(const float* d_in, const float
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || width < 24) return M3D_EUNSUPPORTED;
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0, d_argmax};
   hipStream_t st = m3d::as_stream(stream);
+  if (family() == 3)
+    return m3d_w2q::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
   if (width < 48) return launch_wino2e<4, 16, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   return launch_wino2e<4, 32, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
 }
