@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the 3D detection hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload detect|backbone|prm|prm-nuclei]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload detect|backbone|prm|prm-nuclei] [--stress-rois]
 
 Default workload = BASELINE.json configs[2]: the full detection-mode pipeline of tools/infer_simple.py:249-265 /
-lib/core/test.py:54-177 on a batch of synthetic 1x128x128x128 volumes per rank (4 at N = 1; 8 per rank at N > 1 =
-configs[4]: 64 volumes over 8 GPUs).  One "step" = every volume of the batch through
+lib/core/test.py:54-177 on a batch of 4 synthetic 1x128x128x128 volumes per rank - at every N, so that the driver's 1 -> 8
+scaling ratio compares equal per-GPU work (weak scaling; `--vols-per-rank 8` at N = 8 is configs[4]'s 64 volumes, which the N > 1
+line also carries as `configs4_shape`).  One "step" = every volume of the batch through
     raw uint16 volume -> norm1 (blob.py:179-184, on device) -> dsn_body -> RPN -> proposals (on device) -> RoIAlign3D ->
     2-MLP head -> decode/clip -> per-class NMS + cap -> cross-tile NMS (core/test.py:159)
 followed by the path's ONE exchange: a single all_gather of the padded detections [vols, 301, 7] (m3d.shard; a no-op at N = 1).
-`value` (voxels/s, whole job) is measured with the raw volumes resident in HBM, as the contract asks; the same line also
-carries `e2e_host_to_host`: the same steps with the raw volumes coming from pinned host memory (H2D on a copy stream,
-double-buffered) and the gathered detections copied back to the host (SURVEY 8d's end-to-end definition).
-`roofline` is for the dominant hand-written kernel of the step, timed live with HIP events on its launch stream;
+`value` (voxels/s, whole job) is measured with the raw volumes resident in HBM when the timed region starts (the bench contract);
+`e2e_host_to_host` on the same line is SURVEY 8d's end-to-end definition: the same steps with the raw volumes coming from pinned
+host memory (H2D on a copy stream, double-buffered) and the gathered detections copied back to the host; `sustained` repeats the
+resident loop for at least two seconds.
+`roofline` is the metric's named quantity, the 3D-convolution family (dsn_body + RPN convs): MFMA FLOPs ISSUED by all its launches
+over their summed live duration (HIP events on the launch stream inside the timed region) against the fp32 MFMA peak, with the
+algorithmic (direct-convolution) TFLOP/s beside it and one entry per layer; `rooflines` also holds fc1 (bf16 matrix cores at fp32
+accuracy: 6 MFMAs per product, i.e. a 2500 / 6 = 416.7 TF fp32-equivalent ceiling).
 `cpu_baseline` is the oracle's restatement of the same per-volume pipeline (torch-CPU convs + oracle C ops) on a bounded sample.
 
 N > 1: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in
-their environment, created before this process touches the GPU) unless a launcher (torch.distributed.run) already did.
+their environment, created before this process touches the GPU) unless a launcher (torch.distributed.run) already did.  The N > 1
+line also carries `without_exchange`, `single_gpu_same_batch` (rank 0's batch timed while the other ranks idle) and `exchange`
+(the all_gather alone, microseconds, ranks, backend).
 `--dry --backend gloo` runs the same launcher + exchange with a stub step on CPU (tests/test_host_logic.py).
 Other workloads: backbone (configs[1]: dsn_body forward only), prm (configs[3]: soma PRM tile), prm-nuclei.
+`--stress-rois`: RPN NMS threshold 1.0, so every volume hands the reference's RPN_POST_NMS_TOP_N = 1000 RoIs to the box head.
 """
 import argparse
 import json
@@ -154,7 +162,7 @@ def run_dry(args, rank, world, dist):
     of m3d.shard moves them, every rank checks the global list."""
     import torch
     from m3d import shard
-    nvol = args.vols_per_rank or (4 if world == 1 else 8)
+    nvol = args.vols_per_rank or 4
     n_items = world * nvol
     cap = 300
 
@@ -182,14 +190,18 @@ def run_dry(args, rank, world, dist):
 
 # ------------------------------------------------------------------------------------------------ PRM workloads
 def cone_limited_gflop_per_peak(stride):
-    """Algorithmic FLOPs of one peak's back-propagation when every layer only computes its receptive-field window:
-    window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per voxel."""
+    """(algorithmic, issued) GFLOP of one peak's back-propagation when every layer only computes its receptive-field window (SURVEY
+    8a-12): window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per
+    voxel.  Issued: windows of 16 voxels and more run on the strip Winograd kernel (4/9), the 5^3 stem occupies 32 MFMA rows for its
+    25 (dy, dx) taps, the small windows issue every product."""
     if stride == 8:
         L = [(256, 256, 3, 3), (256, 256, 3, 5), (256, 128, 3, 7), (128, 128, 3, 16), (128, 64, 3, 18), (64, 64, 3, 38), (64, 32, 3, 40),
              (32, 1, 5, 84)]
     else:
         L = [(128, 128, 3, 3), (128, 128, 3, 5), (128, 64, 3, 7), (64, 64, 3, 16), (64, 32, 3, 18), (32, 1, 5, 40)]
-    return sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n in L) / 1e9
+    alg = sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n in L) / 1e9
+    issued = sum(2.0 * a * b * k ** 3 * n ** 3 * (32.0 / 25.0 if k == 5 else (4.0 / 9.0 if n >= 16 else 1.0)) for a, b, k, n in L) / 1e9
+    return alg, issued
 
 
 def bench_prm(args, rank, world, dist):
@@ -228,33 +240,77 @@ def bench_prm(args, rank, world, dist):
     e = [ev() for _ in range(6)]
     e[0].record(); eng.forward(vol); e[1].record()
     out = eng.prm_tile(vol, dense=False); e[2].record()
-    e[3].record()
-    q = m3d.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], (S, H, W))
-    boxes = binarize.det_boxes_int(out["dets"].cpu().numpy(), (S, H, W), mode)
     torch.cuda.synchronize()
-    e[4].record(); r = binarize._tile_instance_masks(raw, q, boxes, mode, 8192); e[5].record(); torch.cuda.synchronize()
-    fwd_ms, prm_ms, otsu_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]), e[4].elapsed_time(e[5])
-    nroi = 0 if r is None else int(r[3].numel())
-    # cone-limited algorithmic work of the back-propagation: receptive-field windows per layer, dgrad with relu(W)
-    cone = cone_limited_gflop_per_peak(cfg.stride)
-    if rank == 0:
-        print(json.dumps({"metric": "voxels/sec end-to-end infer_simple (PRM_ON tile)", "value": world * args.steps * S * H * W / dt,
-                          "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation + per-detection 2D-Otsu -> instance labels%s" %
-                                                 (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
-                                                  "" if nuclei else " [configs[3]]")), "peaks_per_tile": npk[-1],
-                                     "prm_forward_ms": fwd_ms, "prm_tile_ms": prm_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0},
-                          "roofline": {"bound": "mfma", "kernel": "peak back-propagation (all window convs + stem), cone-limited algorithmic FLOPs",
-                                       "achieved": npk[-1] * cone / max(prm_ms - fwd_ms, 1e-6), "peak": 157.3, "unit": "TFLOP/s",
-                                       "frac": npk[-1] * cone / max(prm_ms - fwd_ms, 1e-6) / 157.3,
-                                       "cone_limited_gflop_per_peak": cone, "backward_ms": prm_ms - fwd_ms,
-                                       "note": "backward_ms also holds proposals, RoIAlign and the box head of the tile; Winograd issues 4/9 "
-                                               "of the 3^3 window convs' multiplies, so this is an algorithmic-equivalent figure"},
-                          "otsu": {"rois": nroi, "ms": otsu_ms, "rois_per_s": nroi / otsu_ms * 1e3 if otsu_ms > 0 else None,
-                                   "what": "crop + normalise + 2D-Otsu + largest component%s for the tile's detections" %
-                                           (" + hole fill + 6-closing" if nuclei else "")}}))
+    fwd_ms, prm_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    otsu_ms, nroi, npeaks = None, 0, 0
+    if out is not None:                                   # a tile without a peak above the threshold: nothing to break down
+        npeaks = int(out["peaks"].shape[0])
+        q = m3d.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], (S, H, W))
+        boxes = binarize.det_boxes_int(out["dets"].cpu().numpy(), (S, H, W), mode)
+        torch.cuda.synchronize()
+        e[4].record(); r = binarize._tile_instance_masks(raw, q, boxes, mode, 8192); e[5].record(); torch.cuda.synchronize()
+        otsu_ms = e[4].elapsed_time(e[5])
+        nroi = 0 if r is None else int(r[3].numel())
+    # cone-limited work of the back-propagation: receptive-field windows per layer, dgrad with relu(W); algorithmic =
+    # 2*Cin*Cout*k^3 per window voxel, issued = what the kernels put on the matrix cores (strip Winograd 4/9 for windows >= 16 voxels,
+    # every product for the small-window GEMMs, 32/25 for the stem whose 25 (dy, dx) taps occupy 32 MFMA rows)
+    cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride)
+    back_ms = max(prm_ms - fwd_ms, 1e-6)
+    res = {"metric": "voxels/sec end-to-end infer_simple (PRM_ON tile)", "value": world * args.steps * S * H * W / dt,
+           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation + per-detection 2D-Otsu -> instance labels%s" %
+                                  (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
+                                   "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks,
+                      "prm_forward_ms": fwd_ms, "prm_tile_ms": prm_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0},
+           "roofline": {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks (strip-Winograd / small-window / stem dgrad kernels)" % npeaks,
+                        "achieved": npeaks * cone_issued / back_ms, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": npeaks * cone_issued / back_ms / 157.3,
+                        "algorithmic_tflops": npeaks * cone / back_ms,
+                        "cone_limited_gflop_per_peak": cone, "issued_gflop_per_peak": cone_issued, "backward_ms": back_ms,
+                        "what": "achieved / frac = fp32 MFMA FLOPs issued by the window convolutions of all peaks over backward_ms, which also holds the "
+                                "tile's proposals, RoIAlign, box head and the element-wise prepare kernels; algorithmic_tflops = the cone-limited "
+                                "direct count over the same time", "traffic": None},
+           "otsu": {"rois": nroi, "ms": otsu_ms, "rois_per_s": nroi / otsu_ms * 1e3 if otsu_ms else None,
+                    "what": "crop + normalise + 2D-Otsu + largest component%s for the tile's detections" %
+                            (" + hole fill + 6-closing" if nuclei else "")}}
+    if rank != 0:
+        return
+    if not args.no_cpu_baseline and world == 1 and npeaks > 0:
+        # CPU baseline leg (the only use of oracle/ here): the oracle's restatement of PeakResponseMapping_3d.forward on the SAME tile,
+        # back-propagating a capped number of peaks (a peak costs seconds of dense autograd-equivalent work on the CPU), extrapolated
+        # per peak to the tile's peak count; + the per-detection Otsu loop body on the same capped sample
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        ncpu = host_cores()
+        torch.set_num_threads(ncpu)
+        ocfg = O.Cfg(score_thresh=0.0) if nuclei else O.Cfg.soma()
+        xc = vol.cpu()
+        c0 = time.perf_counter()
+        O.prm_tile(P, ocfg, xc, max_peaks=0)               # forward (2 convs per layer) + proposals + box head + box results
+        t_fwd = time.perf_counter() - c0
+        cap_peaks = min(2, npeaks)
+        c0 = time.perf_counter(); got = O.prm_tile(P, ocfg, xc, max_peaks=cap_peaks); t_peaks = max(time.perf_counter() - c0 - t_fwd, 1e-9)
+        if npeaks > cap_peaks and t_fwd + min(8, npeaks) * t_peaks / cap_peaks < 25.0:     # capped at 8 peaks, ~10-30 s of CPU work
+            cap_peaks = min(8, npeaks)
+            c0 = time.perf_counter(); got = O.prm_tile(P, ocfg, xc, max_peaks=cap_peaks); t_peaks = max(time.perf_counter() - c0 - t_fwd, 1e-9)
+        per_peak = t_peaks / cap_peaks
+        # Otsu stage of the capped sample (quantised maps of the back-propagated peaks)
+        prms = got[2].numpy()
+        qc = np.stack([O.quantize_prm_u8(m_) for m_ in prms])
+        bx = binarize.det_boxes_int(np.asarray(got[3])[:cap_peaks], (S, H, W), mode)
+        c0 = time.perf_counter()
+        O.segment_tile(raw.cpu().numpy(), qc, bx, mode)
+        per_roi = (time.perf_counter() - c0) / cap_peaks
+        t_tile = t_fwd + npeaks * (per_peak + per_roi)
+        res["cpu_baseline"] = {"value": S * H * W / t_tile, "unit": "voxels/s", "cores": ncpu, "kind": "port",
+                               "sample": "the same tile through the oracle's restatement (torch-CPU convs with %d threads, oracle C box ops): forward + box "
+                                         "head %.2f s measured; %d of the tile's %d peaks back-propagated (%.2f s per peak) and binarised (%.3f s per "
+                                         "detection), extrapolated per peak to all %d" % (ncpu, t_fwd, cap_peaks, npeaks, per_peak, per_roi, npeaks),
+                               "seconds_per_tile_extrapolated": t_tile}
+        res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+    print(json.dumps(res))
 
 
 # ------------------------------------------------------------------------------------------------ detect / backbone
@@ -269,34 +325,42 @@ def bench_detect(args, rank, world, dist):
 
     backbone_only = args.workload == "backbone"
     cfg = Cfg.nuclei(in_size=(VOL, VOL, VOL))
+    if args.stress_rois:
+        cfg.rpn_nms_thresh = 1.0                       # nothing overlaps by more than 1: all RPN_POST_NMS_TOP_N = 1000 proposals survive
     P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0, head=not backbone_only)
     det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
-    nvol = args.vols_per_rank or (1 if backbone_only else (4 if world == 1 else 8))
+    # 4 volumes per rank at EVERY N (configs[2] at N = 1): equal per-GPU work, so value(N) / (N * value(1)) is a weak-scaling efficiency
+    nvol = args.vols_per_rank or (1 if backbone_only else 4)
     n_items = world * nvol
-    mine = shard.partition(n_items, rank, world)
-    raw_np = np.stack([synth_volume(i, (VOL, VOL, VOL)) for i in mine])              # uint16 [nvol,128,128,128], what io.imread gives
-    raw_host = torch.from_numpy(raw_np).pin_memory()
-    raw_dev = raw_host.cuda()
     im_info = np.array([VOL, VOL, VOL, 1.0], np.float64)
     cap = cfg.detections_per_im
     last = {}
 
-    xbuf = torch.empty((nvol, 1, VOL, VOL, VOL), dtype=torch.float32, device="cuda")
+    def make_batch(nv):
+        """Per-rank state for nv volumes per step: (batch function raw -> packed detections, raw volumes on host / device, ndarray)."""
+        items = shard.partition(world * nv, rank, world)
+        rnp = np.stack([synth_volume(i, (VOL, VOL, VOL)) for i in items])               # uint16 [nv,128,128,128], what io.imread gives
+        rhost = torch.from_numpy(rnp).pin_memory()
+        rdev = rhost.cuda()
+        xb = torch.empty((nv, 1, VOL, VOL, VOL), dtype=torch.float32, device="cuda")
 
-    def batch(raw):
-        """The rank's batch of volumes -> packed detections [nvol, cap+1, 7] on the device (m3d.shard block: rows = detections,
-        trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
-        launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
-        (the proposal counts that size the GEMM)."""
-        if backbone_only:                                                               # configs[1]: the 3D-conv forward alone (xbuf was
-            return det.conv_body(xbuf)                                                  # normalised once, outside the timed steps)
-        m3d.norm1_batched(raw, f32_arith=True, out=xbuf)                                # blob.py:179-184, per volume statistics
-        r = det.detect_batch(xbuf, im_info, as_dicts=False)                             # core/test.py:106-114 per volume
-        last["num_rois"] = r["num_rois"]
-        if "cls_boxes" not in r:
-            return torch.zeros((nvol, cap + 1, 7), device="cuda")
-        with det.span("cross_tile_nms_pack"):                                           # core/test.py:159 (one tile per volume) + pack
-            return m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
+        def batch(raw):
+            """The rank's batch of volumes -> packed detections [nv, cap+1, 7] on the device (m3d.shard block: rows = detections,
+            trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
+            launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
+            (the proposal counts that size the GEMM)."""
+            if backbone_only:                                                           # configs[1]: the 3D-conv forward alone (xb was
+                return det.conv_body(xb)                                                # normalised once, outside the timed steps)
+            m3d.norm1_batched(raw, f32_arith=True, out=xb)                              # blob.py:179-184, per volume statistics
+            r = det.detect_batch(xb, im_info, as_dicts=False)                           # core/test.py:106-114 per volume
+            last["num_rois"] = r["num_rois"]
+            if "cls_boxes" not in r:
+                return torch.zeros((nv, cap + 1, 7), device="cuda")
+            with det.span("cross_tile_nms_pack"):                                       # core/test.py:159 (one tile per volume) + pack
+                return m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=cap, want_keep=False)["packed"]
+        return batch, rnp, rhost, rdev, xb
+
+    batch, raw_np, raw_host, raw_dev, xbuf = make_batch(nvol)
 
     if backbone_only:
         m3d.norm1_batched(raw_dev, f32_arith=True, out=xbuf)
@@ -305,8 +369,8 @@ def bench_detect(args, rank, world, dist):
     # memory) moves the packed block to the CPU for the collective; nccl (RCCL over xGMI) gathers device to device.
     via_host = dist is not None and args.backend == "gloo"
 
-    def exchange(packed):
-        return shard.all_gather_packed(packed.cpu() if via_host else packed, n_items, dist)            # THE exchange
+    def exchange(packed, items=None):
+        return shard.all_gather_packed(packed.cpu() if via_host else packed, items or n_items, dist)   # THE exchange
 
     def step_resident():
         packed = batch(raw_dev)
@@ -351,18 +415,22 @@ def bench_detect(args, rank, world, dist):
         torch.cuda.synchronize()
         run_pipelined(2)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_pipelined(args.steps)
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t0
+        runs = []
+        for _ in range(3):                               # three repeats: the overlap depends on how the two streams' kernels meet
+            t0 = time.perf_counter()
+            run_pipelined(args.steps)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0) / args.steps * 1e3)
+        ms = sorted(runs)[1]
         same = bool(torch.equal(last["packed_pipelined"].cpu(), last["packed"].cpu())) if "packed" in last else None
-        return {"value": n_items * args.steps * VOL ** 3 / dtp, "unit": "voxels/s", "ms_per_step": dtp / args.steps * 1e3,
+        return {"value": n_items * VOL ** 3 / (ms * 1e-3), "unit": "voxels/s", "ms_per_step": ms, "ms_per_step_runs": [round(r, 4) for r in runs],
                 "what": "the same %d steps with begin(k+1) (norm1, backbone, RPN, proposals) launched on a second stream before "
-                        "finish(k) (RoIAlign, box head, box results, cross-tile NMS, exchange)" % args.steps,
+                        "finish(k) (RoIAlign, box head, box results, cross-tile NMS, exchange); median of three repeats" % args.steps,
                 "identical_to_serial": same}
 
     piped = None
-    if not backbone_only and world == 1:             # N = 1 only: an extra measurement must not be able to stall a multi-rank run
+    if not backbone_only and world == 1 and args.pipelined:   # opt-in (N = 1 only): on some boxes the two streams overlap (0.80 x the serial
+        # step), on others they do not (1.01 x) - see DESIGN.md 5; the default line carries only measurements that reproduce
         try:
             piped = measure_pipelined()
         except Exception as e:                       # ... nor lose the main line
@@ -407,42 +475,84 @@ def bench_detect(args, rank, world, dist):
                "includes": "H2D of the raw uint16 volumes (pinned, copy stream, double-buffered) + D2H of the gathered [%d,%d,7] detections"
                            % (n_items, cap + 1)}
 
-    # ---- (3) N > 1: the same per-rank batches WITHOUT the exchange, so that the collective's cost (and the effect of the larger
-    # per-rank batch of configs[4] on the single-GPU rate) can be read off the line
-    no_xchg = None
+    # ---- (3) sustained: the resident loop again for at least two seconds (the timed region above lasts ~0.1 s)
+    sustained = None
+    if not backbone_only:
+        n_sus = max(args.steps, int(2.0 / max(dt / args.steps, 1e-6)) + 1)            # the same count on every rank (dt is the max over ranks)
+        dts = timed_loop(step_resident, n_sus, 0, dist, torch.cuda.synchronize)
+        dts = sync_max_time(dts, dist, "cpu" if via_host else "cuda")
+        sustained = {"value": n_items * n_sus * VOL ** 3 / dts, "unit": "voxels/s", "ms_per_step": dts / n_sus * 1e3, "steps": n_sus,
+                     "seconds": dts, "clock": "per-kernel clocks under this load: profiles/r03_mfma_busy.txt (GRBM_GUI_ACTIVE, separate PMC pass)"}
+
+    # ---- (4) N > 1: what the scaling ratio is made of.  (a) the same per-rank batches WITHOUT the exchange; (b) rank 0's batch alone
+    # on its GPU while the other ranks wait (a single-GPU run of the same batch inside this job); (c) the all_gather alone;
+    # (d) BASELINE configs[4]'s shape (8 volumes per rank) when this run uses another batch
+    no_xchg = same_batch = xchg = cfg4 = None
     if dist is not None and not backbone_only:
         dt3 = timed_loop(lambda: batch(raw_dev), args.steps, 1, dist, torch.cuda.synchronize)
         dt3 = sync_max_time(dt3, dist, "cpu" if via_host else "cuda")
         no_xchg = {"value": n_items * args.steps * VOL ** 3 / dt3, "unit": "voxels/s", "ms_per_step": dt3 / args.steps * 1e3,
                    "what": "all ranks' batches of %d volumes, no all_gather (max over ranks)" % nvol}
+        dist.barrier()
+        if rank == 0:
+            dt4 = timed_loop(lambda: batch(raw_dev), args.steps, 1, None, torch.cuda.synchronize)
+            same_batch = {"value": nvol * args.steps * VOL ** 3 / dt4, "unit": "voxels/s", "ms_per_step": dt4 / args.steps * 1e3,
+                          "what": "rank 0's batch of %d volumes alone (the other ranks wait at a barrier): the single-GPU rate of the same "
+                                  "per-rank work, measured inside this job" % nvol}
+        dist.barrier()
+        packed0 = batch(raw_dev)
+        torch.cuda.synchronize()
+        nx = 50
+        dt5 = timed_loop(lambda: exchange(packed0), nx, 5, dist, torch.cuda.synchronize)
+        dt5 = sync_max_time(dt5, dist, "cpu" if via_host else "cuda")
+        xchg = {"microseconds_per_all_gather": dt5 / nx * 1e6, "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "bytes_per_rank": int(nvol * (cap + 1) * 7 * 4),
+                "what": "one all_gather_into_tensor of the packed [%d,%d,7] block per rank, issued back to back" % (nvol, cap + 1)}
+        if nvol != 8:
+            b8, _, _, rdev8, _ = make_batch(8)
+            dt6 = timed_loop(lambda: exchange(b8(rdev8), world * 8), args.steps, 2, dist, torch.cuda.synchronize)
+            dt6 = sync_max_time(dt6, dist, "cpu" if via_host else "cuda")
+            cfg4 = {"value": world * 8 * args.steps * VOL ** 3 / dt6, "unit": "voxels/s", "ms_per_step": dt6 / args.steps * 1e3,
+                    "volumes_per_rank": 8, "volumes_per_step": world * 8,
+                    "what": "BASELINE configs[4]'s partition (8 volumes per rank; 64 over 8 GPUs) with the exchange"}
 
     if rank != 0:
         return
     voxels = n_items * args.steps * VOL ** 3
-    # ---- rooflines of the two largest hand-written kernels, from the live HIP-event spans of the timed region; `roofline` is
-    # the one with the longer launch (the dominant kernel of the step)
+    # ---- rooflines from the live HIP-event spans of the timed region.  `roofline` = the 3D-convolution family, the quantity the metric
+    # names: MFMA FLOPs issued by all its launches over their summed duration; `rooflines` = one entry per conv layer + fc1
     wino = det.wino_mode
-    conv2b_alg = nvol * conv_flops(64, 64, 3, (VOL // 2) ** 3)              # 57.98 GFLOP algorithmic per volume, batch in one launch
     kern = {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}
     roofs = {}
-    if "conv2b" in kern_ms:
-        ms = kern_ms["conv2b"]
-        issued = conv2b_alg * WINO_WORK[wino]
-        r = {"bound": "mfma",
-             "launch": "one launch over the rank's batch of %d volumes" % nvol,
-             "kernel": {2: "conv3d_wino2e_kernel<4,32,2,2,true> (conv2b 64->64 3^3 @64^3, Winograd F(2x2,3x3) on (y,x), eta-split 8 waves + fused BN/ReLU/MaxPool)",
-                        1: "conv3d_wino_kernel<4,32,1,2,2,4,1,true> (conv2b, Winograd F(2,3) along x + fused BN/ReLU/MaxPool)",
-                        0: "conv3d_mfma_kernel<3,2,32,4,2,2,2,true,1> (conv2b direct + fused BN/ReLU/MaxPool)"}[wino],
-             "achieved": issued / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": issued / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
-             "issued_gflop_per_launch": issued / 1e9, "algorithmic_gflop_per_launch": conv2b_alg / 1e9,
-             "algorithmic_equivalent_tflops": conv2b_alg / (ms * 1e-3) / 1e12,
-             "note": "achieved/frac count the MFMA FLOPs the kernel ISSUES (Winograd: %s of the algorithmic 2*Cin*Cout*27 per voxel); "
-                     "algorithmic_equivalent_tflops is the direct-convolution FLOP count over the same time" %
-                     {2: "4/9", 1: "2/3", 0: "1"}[wino]}
-        r.update(pmc_traffic({2: "conv3d_wino2e_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
-                              0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
-        roofs["conv2b"] = r
+    work = det.conv_work(nvol, (VOL, VOL, VOL))
+    fam_issued = fam_alg = fam_ms = 0.0
+    for name, wk in work.items():
+        if name not in kern_ms:
+            continue
+        ms = kern_ms[name]
+        fam_issued += wk["issued_flop"]; fam_alg += wk["algorithmic_flop"]; fam_ms += ms
+        roofs[name] = {"bound": "mfma", "kernel": wk["kernel"], "shape": wk["shape"], "launch": "one launch over the rank's batch of %d volumes" % nvol,
+                       "achieved": wk["issued_flop"] / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": wk["issued_flop"] / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
+                       "issued_gflop_per_launch": wk["issued_flop"] / 1e9, "algorithmic_gflop_per_launch": wk["algorithmic_flop"] / 1e9,
+                       "algorithmic_tflops": wk["algorithmic_flop"] / (ms * 1e-3) / 1e12}
+    if "conv2b" in roofs:
+        roofs["conv2b"].update(pmc_traffic({2: "conv3d_wino2e_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
+                                            0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
+    conv_family = None
+    if fam_ms > 0:
+        conv_family = {"bound": "mfma",
+                       "kernel": "3D-convolution family of the step: dsn_body conv1a..conv4b (+BN+ReLU+MaxPool fused) and the RPN convs, %d launches "
+                                 "over the rank's batch of %d volumes" % (len([n for n in work if n in kern_ms]), nvol),
+                       "achieved": fam_issued / (fam_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": fam_issued / (fam_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                       "algorithmic_tflops": fam_alg / (fam_ms * 1e-3) / 1e12, "kernel_ms": fam_ms,
+                       "issued_gflop_per_step": fam_issued / 1e9, "algorithmic_gflop_per_step": fam_alg / 1e9,
+                       "what": "achieved / frac = fp32 MFMA FLOPs ISSUED (Winograd F(2x2,3x3) issues 4/9, the stem's F(2,5) 78/125 of the "
+                               "direct convolution's multiply-adds) over the summed live duration of the launches; algorithmic_tflops = the "
+                               "direct-convolution count 2*Cin*Cout*k^3 per voxel over the same time; per layer: rooflines",
+                       "traffic": (roofs.get("conv2b", {}) or {}).get("traffic"),
+                       "traffic_what": "HBM bytes per launch of the largest member (conv2b), PMC: " + str((roofs.get("conv2b", {}) or {}).get("traffic_source"))}
     if "fc1" in kern_ms and "num_rois" in last:
         ms = kern_ms["fc1"]
         M = int(sum(last["num_rois"]))
@@ -459,6 +569,8 @@ def bench_detect(args, rank, world, dist):
                  "issued_gflop_per_launch": 6.0 * fl / 1e9, "algorithmic_gflop_per_launch": fl / 1e9,
                  "algorithmic_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
                  "fp32_mfma_peak_multiple": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "ceiling_tflops": BF16_MFMA_PEAK_TFLOPS / 6.0,
+                 "frac_of_ceiling": fl / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0),
                  "algorithmic_bytes_per_launch": M * Kf * 4.0 + Nf * Kf * 6.0 + M * Nf * 4.0,
                  "note": "achieved/frac count the bf16 MFMA FLOPs ISSUED (6 x 2MNK) against the dense bf16 peak; "
                          "algorithmic_equivalent_tflops = 2MNK / time, fp32_mfma_peak_multiple = that over the 157.3 TF fp32-input MFMA "
@@ -473,10 +585,7 @@ def bench_detect(args, rank, world, dist):
                  "note": "every multiply-add of the GEMM is issued (no Winograd): achieved = 2*M*N*K / time of the GEMM + its split-K reduction"}
             r.update(pmc_traffic("fc_gemm_kernel"))
         roofs["fc1"] = r
-    roof = None
-    if roofs:
-        dom = max(roofs, key=lambda k: roofs[k]["kernel_ms"])
-        roof = roofs[dom]
+    roof = conv_family
     body_ms = sum(v for k, v in kern_ms.items() if k.startswith("conv")) / nvol      # spans cover the whole batch
     res = {"metric": METRIC, "value": voxels / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -484,8 +593,10 @@ def bench_detect(args, rank, world, dist):
            "config": {"workload": ("dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool; the volume normalised beforehand), 1x1x128x128x128 per rank [configs[1]]"
                                    if backbone_only else
                                    "detection-mode infer_simple: raw u16 volume -> norm1 -> dsn_body -> RPN -> proposals -> RoIAlign3D -> 2-MLP head "
-                                   "-> decode -> NMS -> cross-tile NMS, batch of %d x (1x128^3) per rank, one all_gather of detections per step [%s]"
-                                   % (nvol, "configs[2]" if world == 1 else "configs[4] shape: %d volumes over %d GPUs" % (n_items, world))),
+                                   "-> decode -> NMS -> cross-tile NMS, batch of %d x (1x128^3) per rank, one all_gather of detections per step [%s]%s"
+                                   % (nvol, "configs[2]" if (world == 1 and nvol == 4) else "%d volumes over %d GPUs%s" %
+                                      (n_items, world, " = configs[4]" if n_items == 64 and world == 8 else ""),
+                                      " STRESS: RPN NMS off, %d RoIs per volume (RPN_POST_NMS_TOP_N)" % cfg.post_nms_topN if args.stress_rois else "")),
                       "volumes_per_step": n_items, "volumes_per_rank": nvol, "backend": (args.backend if world > 1 else None), "net": "nuclei stride-8 dsn_body, 35 anchors, MLP 1024",
                       "inputs": "raw uint16 volumes resident in HBM at the start of the timed region",
                       "rois_per_volume": (float(np.mean(last["num_rois"])) if "num_rois" in last else None),
@@ -503,9 +614,14 @@ def bench_detect(args, rank, world, dist):
         res["pipelined"] = piped
     if e2e is not None:
         res["e2e_host_to_host"] = e2e
-    if no_xchg is not None:
-        res["without_exchange"] = no_xchg
-    if not args.no_cpu_baseline and world == 1:      # contract: CPU baseline on rank 0 at N = 1 only
+    if sustained is not None:
+        res["sustained"] = sustained
+    res["value_definition"] = ("voxels of all volumes of the step / wall time of the timed steps, raw uint16 volumes resident in HBM (bench contract); "
+                               "SURVEY 8d's host-to-host definition of the same steps: e2e_host_to_host")
+    for k, v in (("without_exchange", no_xchg), ("single_gpu_same_batch", same_batch), ("exchange", xchg), ("configs4_shape", cfg4)):
+        if v is not None:
+            res[k] = v
+    if not args.no_cpu_baseline and world == 1 and not args.stress_rois:      # contract: CPU baseline on rank 0 at N = 1 only
         # CPU baseline leg: the ONLY place bench.py touches oracle/ (the checker's restatement of the same per-volume pipeline)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
@@ -542,7 +658,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 200 for --workload backbone, whose step is < 1 ms)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 50 for --workload backbone)")
     ap.add_argument("--workload", default="detect", choices=["detect", "backbone", "prm", "prm-nuclei"])
-    ap.add_argument("--vols-per-rank", type=int, default=0, help="volumes per rank per step (default: 4 at N=1, 8 at N>1)")
+    ap.add_argument("--vols-per-rank", type=int, default=0, help="volumes per rank per step (default 4 at every N; 8 = BASELINE configs[4]'s partition)")
+    ap.add_argument("--pipelined", action="store_true", help="also time the two-stream begin(k+1) / finish(k) loop (N = 1)")
+    ap.add_argument("--stress-rois", action="store_true", help="RPN NMS threshold 1.0: every volume gives RPN_POST_NMS_TOP_N = 1000 RoIs to the box head")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

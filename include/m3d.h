@@ -236,6 +236,8 @@ int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_
  *   m3d_box_results3d_batched         box_results_with_nms_and_limit (lib/core/test.py:806-883) per item: rows
  *       [d_offsets[b], d_offsets[b+1]) of d_scores [R,nc] / d_boxes [R,6nc] / d_keep_idx [R] (may be NULL) ->
  *       d_cls_boxes [batch,nc,max_rows,7], d_cls_keep [batch,nc,max_rows] (may be NULL), d_counts [batch,nc].
+ *       Contract: d_offsets is non-decreasing and no item holds more than max_rows_per_item rows (the outputs and the
+ *       scratch are sized for that many); rows of an item beyond max_rows_per_item are ignored.
  *   m3d_nms3d_batched                 nms_3d / nms_3d_volume (lib/utils/cython_nms_3d.pyx:39-159) per item of d_dets
  *       (item b at d_dets + b*item_stride_floats, count d_counts[b*count_stride] or max_boxes if d_counts is NULL):
  *       d_keep [batch,max_boxes] kept indices (ascending), d_num_keep [batch], and/or d_packed [batch,out_cap+1,7] = the

@@ -610,8 +610,8 @@ __global__ __launch_bounds__(kWG) void proposals_stage3_kernel(PropFusedArgs a) 
   int nk;
   if (a.nms_thresh > 0) {                                             // keep = nms_3d(...)[:post_nms_topN] (:167-171)
     nk = wg_nms_resolve(nvalid, a.post, sc, L);
-  } else {
-    nk = (a.post > 0 && nvalid > a.post) ? a.post : nvalid;
+  } else {                                                            // post_nms_topN is applied only inside `if nms_thresh > 0`
+    nk = nvalid;                                                      // (:167-171): without NMS every valid box is kept
     for (int i = tid; i < nk; i += kWG) sc.keep[i] = i;
   }
   __syncthreads();
@@ -650,7 +650,9 @@ __host__ __device__ inline size_t boxres_item_bytes() { return boxres_nms_offset
 __global__ __launch_bounds__(kWG) void box_results_stage1_kernel(BoxResArgs a) {
   __shared__ WgLds L;
   const int tid = threadIdx.x, b = blockIdx.x, j = a.cls;
-  const int r0 = a.offsets[b], R = a.offsets[b + 1] - r0;
+  // an item with more rows than max_rows_per_item breaks the offsets contract (include/m3d.h): its surplus rows are ignored
+  // rather than written past the scratch / the outputs sized for `cap` rows
+  const int r0 = a.offsets[b], R = min(max(a.offsets[b + 1] - r0, 0), a.cap);
   char* w = a.ws + (size_t)b * a.ws_item;
   float* dets = (float*)w;
   int* src = (int*)(w + m3d::align_up(sizeof(float) * 7 * kFusedMax, 256));

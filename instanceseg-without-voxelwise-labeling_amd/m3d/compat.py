@@ -262,11 +262,27 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _aligned16(t):
+    return t.data_ptr() % 16 == 0 and t.is_contiguous()
+
+
 def linear(input, weight, bias=None):
+    # libm3d's GEMMs read 16-byte quads: K % 4 == 0 and 16-byte aligned, contiguous operands (a view into the middle of a
+    # buffer goes to torch's own linear instead of raising M3D_EUNSUPPORTED)
     if (input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32 and input.dim() == 2 and weight.dim() == 2
-            and input.shape[1] == weight.shape[1] and input.shape[1] % 4 == 0 and input.shape[0] > 0):
-        return _LinearFn.apply(input.contiguous(), weight, bias)
+            and input.shape[1] == weight.shape[1] and input.shape[1] % 4 == 0 and input.shape[0] > 0 and _aligned16(weight)):
+        x = input.contiguous()
+        if x.data_ptr() % 16 == 0:
+            return _LinearFn.apply(x, weight, bias)
     return _orig_linear(input, weight, bias)
+
+
+def invalidate_packs():
+    """Drop every cached weight pack (conv and linear).  The caches are keyed on the parameter's `_version`, which in-place
+    updates through `.data` (`p.data.mul_()`, `p.data.copy_()`, old-style optimisers) do NOT bump: call this after such an update,
+    or update through the parameter itself (`with torch.no_grad(): p.mul_()`, `load_state_dict`), which does."""
+    _pack_cache.clear()
+    _lin_cache.clear()
 
 
 def install_linear():

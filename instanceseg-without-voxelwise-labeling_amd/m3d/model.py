@@ -149,6 +149,47 @@ class DetectorM3D:
     def span(self, name):
         return self.probe(name) if self.probe is not None else _NOSPAN
 
+    # MFMA multiply-adds a kernel family ISSUES per algorithmic multiply-add: Winograd F(2x2,3x3) 16/36, F(2,3) along x 4/6,
+    # the stem's F(2,5) along x 78/125 (13 row pairs x 6 xi per output pair against 125 taps per output)
+    ISSUED_FRACTION = {"winograd F(2x2,3x3)": 4.0 / 9.0, "winograd F(2,3)x": 2.0 / 3.0, "winograd F(2,5)x stem": 78.0 / 125.0, "direct": 1.0}
+
+    def conv_work(self, batch, size):
+        """Per probe span of the convolution family (conv1a .. conv4b, rpn): algorithmic FLOPs (2*Cin*Cout*k^3 per output voxel), the
+        FLOPs the chosen kernel issues on the matrix cores (Winograd fraction, output channels padded to blocks of 32) and the
+        kernel kind, for a batch of `batch` volumes of `size` = (S, H, W) - the same decisions as body_layer() / rpn()."""
+        out = {}
+        S, H, W = size
+        names = dsn_layers(self.cfg.stride)
+
+        def pad32(c):
+            return (c + 31) // 32 * 32 / float(c)
+        for li, (cname, _, pool) in enumerate(names):
+            w = self.P["Conv_Body." + cname + ".weight"]
+            cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[-1])
+            small = cin * S * H * W * 4 < 0x7FFFFFFF
+            kind = "direct"
+            if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(W):
+                kind = "winograd F(2,5)x stem"
+            elif small and self.body_wino[li] is not None and self.body_wino[li].supports(W, (batch, S, H, W)):
+                kind = "winograd F(2x2,3x3)" if self.wino_mode == 2 else "winograd F(2,3)x"
+            alg = 2.0 * cin * cout * k ** 3 * S * H * W * batch
+            out[cname] = dict(algorithmic_flop=alg, issued_flop=alg * self.ISSUED_FRACTION[kind] * pad32(cout), kernel=kind,
+                              shape="%d->%d k%d @ %dx%dx%d" % (cin, cout, k, S, H, W))
+            if pool:
+                S, H, W = S // 2, H // 2, W // 2
+        w = self.P["RPN.RPN_conv.weight"]
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        kind = "direct"
+        if self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(W, (batch, S, H, W)) and cin * S * H * W * 4 < 0x7FFFFFFF:
+            kind = "winograd F(2x2,3x3)" if self.wino_mode == 2 else "winograd F(2,3)x"
+        alg = 2.0 * cin * cout * 27 * S * H * W * batch
+        nh = 7 * self.A
+        alg_h = 2.0 * cout * nh * S * H * W * batch
+        out["rpn"] = dict(algorithmic_flop=alg + alg_h, issued_flop=alg * self.ISSUED_FRACTION[kind] * pad32(cout) + alg_h * pad32(nh),
+                          kernel=kind + " (3^3 conv) + direct (the two 1^3 heads as one conv)",
+                          shape="%d->%d k3, %d->%d k1 @ %dx%dx%d" % (cin, cout, cout, nh, S, H, W))
+        return out
+
     def conv_body(self, x, first=0, last=None):
         names = dsn_layers(self.cfg.stride)
         for li in range(first, len(self.body) if last is None else last):
@@ -288,14 +329,18 @@ class DetectorM3D:
         return st
 
     def _pinned_counts(self, like):
-        """A small ring of pinned host buffers for the proposal counts (several batches may be in flight)."""
-        ring = self.__dict__.setdefault("_count_ring", {})
+        """A pinned host buffer for the proposal counts of one batch in flight.  Buffers are pooled: `detect_batch_finish` hands its
+        state's buffer back after reading it; a begin() that finds the pool empty (more batches in flight than ever before) pins a
+        new one, so an earlier batch's counts are never overwritten however many begin() calls are outstanding."""
+        pool = self.__dict__.setdefault("_count_pool", {})
         key = (like.numel(), like.dtype)
-        if key not in ring:                                  # pinning is slow (a driver call): all four at once, the first time
-            ring[key] = ([torch.empty((like.numel(),), dtype=like.dtype).pin_memory() for _ in range(4)], 0)
-        bufs, i = ring[key]
-        ring[key] = (bufs, (i + 1) % 4)
-        return bufs[i]
+        free = pool.setdefault(key, [])
+        if not free:                                         # pinning is slow (a driver call): four at once
+            free.extend(torch.empty((like.numel(),), dtype=like.dtype).pin_memory() for _ in range(4))
+        return free.pop()
+
+    def _release_counts(self, buf):
+        self.__dict__.setdefault("_count_pool", {}).setdefault((buf.numel(), buf.dtype), []).append(buf)
 
     def detect_batch_finish(self, st, as_dicts=True):
         """The rest of detect_batch on the current stream (which may differ from begin's: it waits for begin's event, and the
@@ -308,6 +353,7 @@ class DetectorM3D:
         rois_b, probs_b, kidx_b, num = st["props"]
         st["ready"].synchronize()                                                  # host read 1: sizes the GEMM rows
         counts = st["num_host"].tolist()
+        self._release_counts(st.pop("num_host"))                                   # read: back to the pool
         cur = torch.cuda.current_stream()
         for t in (feat, prob, deltas, rois_b, probs_b, kidx_b):
             t.record_stream(cur)

@@ -185,7 +185,8 @@ def generate_proposals3d_batched(scores, deltas, anchors, feat_stride, im_info, 
     assert deltas.shape == (B, 6 * A, S, H, W)
     total = A * S * H * W
     K = total if (pre_nms_topN <= 0 or pre_nms_topN >= total) else pre_nms_topN
-    rows = K if post_nms_topN <= 0 else min(K, post_nms_topN)
+    # post_nms_topN only cuts the list when NMS runs (generate_proposals_3d.py:167-171)
+    rows = K if (post_nms_topN <= 0 or nms_thresh <= 0) else min(K, post_nms_topN)
     dev = scores.device
     rois = torch.empty((B, rows, 7), dtype=torch.float32, device=dev)
     probs = torch.empty((B, rows), dtype=torch.float32, device=dev)

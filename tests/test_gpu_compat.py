@@ -219,3 +219,27 @@ def test_linear_interception_runs_the_box_head_modules_unmodified(compat):
     # what does not qualify falls through to torch (3-D input, fp64)
     assert fc2(torch.randn(2, 3, 256, device="cuda")).shape == (2, 3, 256)
     assert F.linear(torch.randn(4, 8, device="cuda", dtype=torch.float64), torch.randn(5, 8, device="cuda", dtype=torch.float64)).dtype == torch.float64
+
+
+def test_linear_interception_falls_back_for_unaligned_operands_and_packs_can_be_invalidated(compat):
+    """F.linear interception: operands that libm3d's 16-byte loads cannot take (a view that starts 4 bytes into a buffer) go to
+    torch's own linear instead of raising; after an in-place update through `.data` (which does not bump `_version`)
+    `compat.invalidate_packs()` makes the next call repack."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(256, 128).cuda()
+    x = torch.randn(40, 256, device="cuda")
+    ref = x.double() @ lin.weight.double().t() + lin.bias.double()
+    y = lin(x)
+    assert (y.double() - ref).abs().max().item() < 1e-4
+    buf = torch.randn(40 * 256 + 1, device="cuda")
+    xu = buf[1:].view(40, 256)                                        # 4 bytes past a 16-byte boundary
+    assert xu.data_ptr() % 16 != 0
+    yu = F.linear(xu, lin.weight, lin.bias)
+    refu = xu.double() @ lin.weight.double().t() + lin.bias.double()
+    assert (yu.double() - refu).abs().max().item() < 1e-3             # torch's own GEMM (may use reduced-precision paths)
+    lin.weight.data.mul_(2.0)                                         # `_version` unchanged: the cached pack is stale
+    compat.invalidate_packs()
+    y2 = lin(x)
+    ref2 = x.double() @ lin.weight.double().t() + lin.bias.double()
+    assert (y2.double() - ref2).abs().max().item() < 2e-4

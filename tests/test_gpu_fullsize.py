@@ -309,6 +309,26 @@ def test_detect_batch_begin_finish_with_two_batches_in_flight_on_two_streams():
                 assert torch.equal(a["cls_boxes"][i, j, :m], b["cls_boxes"][i, j, :m])
 
 
+def test_detect_batch_begin_with_six_batches_outstanding_keeps_every_batchs_counts():
+    """More begin() calls outstanding than the detector's first pool of pinned count buffers (4): every state keeps its own
+    buffer until its finish() has read it, so the proposal counts - and everything sized by them - equal the serial run's."""
+    from m3d.config import Cfg
+    from m3d.synth import make_params, synth_volume
+    from m3d.model import DetectorM3D
+    from m3d import tiling
+    cfg = Cfg.nuclei(mlp_dim=128, in_size=(32, 64, 64))
+    P = make_params(stride=8, num_anchors=35, mlp_dim=128, seed=2)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    xs = [torch.from_numpy(tiling.norm1(synth_volume(40 + j, (32, 64, 64)), np.float32).astype(np.float32))[None, None].cuda() for j in range(6)]
+    serial = [det.detect_batch(x, as_dicts=False) for x in xs]
+    assert len({tuple(r["num_rois"]) for r in serial}) > 1              # the batches differ, a mixed-up buffer would show
+    states = [det.detect_batch_begin(x) for x in xs]                     # six in flight
+    outs = [det.detect_batch_finish(st, as_dicts=False) for st in states]
+    for a, b in zip(outs, serial):
+        assert a["num_rois"] == b["num_rois"]
+        assert torch.equal(a["cls"], b["cls"]) and torch.equal(a["cls_counts"], b["cls_counts"])
+
+
 def test_config0_64_cubed_equals_the_reference_run(golden):
     """BASELINE.json configs[0]: the reference's own CPU run on one 1x64^3 volume (tests/golden/cfg0_64.npz, gen_cfg0.py) against
     the HIP path: detection mode (scores, decoded boxes, kept detections) and the full PRM tuple (peaks, dets, every map)."""

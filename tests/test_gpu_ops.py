@@ -692,6 +692,57 @@ def test_linear_bf16x3_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K
 
 
 # ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
+def test_fused_proposals_without_nms_keep_every_valid_box(m3d):
+    """RPN_NMS_THRESH <= 0: the reference applies post_nms_topN only inside `if nms_thresh > 0`
+    (lib/modeling/generate_proposals_3d.py:167-171), so every box that passes the size filter is kept - fused launch, per-tile
+    entry point and oracle agree row for row although post_nms_topN < pre_nms_topN."""
+    rs = np.random.RandomState(21)
+    B, A, S, H, W = 2, 35, 8, 8, 8
+    cfg = O.Cfg()
+    sc = rs.uniform(0, 1, (B, A, S, H, W)).astype(np.float32)
+    dl = (rs.randn(B, 6 * A, S, H, W) * 0.2).astype(np.float32)
+    info = np.array([64., 64., 64., 1.0])
+    pre, post = 600, 100
+    rois, probs, kidx, num = m3d.generate_proposals3d_batched(dev(sc), dev(dl), cfg.anchors, 8., info, pre, post, 0.0)
+    assert rois.shape[1] == pre
+    for b in range(B):
+        r0, p0, k0 = O.generate_proposals_3d(sc[b], dl[b], info, cfg.anchors, 8, pre, post, 0.0, 0)
+        n = int(num[b])
+        assert n == len(k0) and n > post
+        assert np.array_equal(kidx[b, :n].cpu().numpy(), k0)
+        assert np.array_equal(probs[b, :n].cpu().numpy(), p0.ravel())
+        assert np.allclose(rois[b, :n, 1:].cpu().numpy(), r0[:, 1:], rtol=2e-7, atol=1e-5)
+        r1, p1, k1 = m3d.generate_proposals3d(dev(sc[b]), dev(dl[b]), cfg.anchors, 8., info, pre, post, 0.0)
+        assert torch.equal(k1, kidx[b, :n]) and torch.equal(r1[:, 1:], rois[b, :n, 1:])
+
+
+def test_fused_box_results_ignore_rows_beyond_the_declared_maximum(m3d):
+    """Offsets contract of m3d_box_results3d_batched (include/m3d.h): an item with more rows than max_rows_per_item has its
+    surplus rows ignored - nothing is written outside the item's own outputs (the neighbouring item stays exact)."""
+    rs = np.random.RandomState(5)
+    nc, cap = 2, 64
+    rows = [100, 40]                                              # item 0 breaks the contract, item 1 does not
+    R = sum(rows)
+    scores = rs.uniform(0, 1, (R, nc)).astype(np.float32)
+    ctr = rs.uniform(10, 50, (R, 3)); half = rs.uniform(2, 6, (R, 3))
+    one = np.hstack((ctr - half, ctr + half)).astype(np.float32)
+    boxes = np.tile(one, (1, nc))
+    off = torch.tensor([0, rows[0], R], dtype=torch.int32, device="cuda")
+    cb, ck, cnt = m3d.box_results3d_batched(dev(scores), dev(boxes), None, off, nc, 0.05, 0.3, 300, cap)
+    # item 1 alone, within the contract
+    off1 = torch.tensor([0, rows[1]], dtype=torch.int32, device="cuda")
+    cb1, ck1, cnt1 = m3d.box_results3d_batched(dev(scores[rows[0]:]), dev(boxes[rows[0]:]), None, off1, nc, 0.05, 0.3, 300, cap)
+    assert torch.equal(cnt[1], cnt1[0])
+    n1 = int(cnt1[0, 1])
+    assert torch.equal(cb[1, 1, :n1], cb1[0, 1, :n1])
+    # item 0 = its first `cap` rows
+    off0 = torch.tensor([0, cap], dtype=torch.int32, device="cuda")
+    cb0, ck0, cnt0 = m3d.box_results3d_batched(dev(scores[:cap]), dev(boxes[:cap]), None, off0, nc, 0.05, 0.3, 300, cap)
+    assert torch.equal(cnt[0], cnt0[0])
+    n0 = int(cnt0[0, 1])
+    assert torch.equal(cb[0, 1, :n0], cb0[0, 1, :n0])
+
+
 def test_fused_proposals_batched_bit_exact_with_oracle_and_golden(m3d, golden):
     """One launch for a batch of tiles == the per-tile reference op, item by item: kept flat indices, probabilities and row
     order bit for bit (incl. saturated ties), boxes to one fp32 ulp; fixtures of the reference's own GenerateProposalsOp_3d."""

@@ -115,7 +115,7 @@ def test_bench_launcher_starts_n_ranks_itself_and_does_one_gather():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["dry"] is True and d["config"]["volumes_per_step"] == 16 and d["steps"] == 2
+    assert d["n_gpus"] == 2 and d["dry"] is True and d["config"]["volumes_per_step"] == 8 and d["steps"] == 2   # 4 volumes per rank at every N
     # N = 1 path: no process group, same code
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
