@@ -548,7 +548,7 @@ def bench_detect(args, rank, world, dist):
                        "frac": fam_issued / (fam_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                        "algorithmic_tflops": fam_alg / (fam_ms * 1e-3) / 1e12, "kernel_ms": fam_ms,
                        "issued_gflop_per_step": fam_issued / 1e9, "algorithmic_gflop_per_step": fam_alg / 1e9,
-                       "what": "achieved / frac = fp32 MFMA FLOPs ISSUED (Winograd F(2x2,3x3) issues 4/9, the stem's F(2,5) 78/125 of the "
+                       "what": "achieved / frac = fp32 MFMA FLOPs ISSUED (Winograd F(2x4,3x3) issues 1/3 - F(2x2,3x3) 4/9 -, the stem's F(2,5) 78/125 of the "
                                "direct convolution's multiply-adds) over the summed live duration of the launches; algorithmic_tflops = the "
                                "direct-convolution count 2*Cin*Cout*k^3 per voxel over the same time; per layer: rooflines",
                        "traffic": (roofs.get("conv2b", {}) or {}).get("traffic"),

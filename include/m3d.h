@@ -164,9 +164,19 @@ size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth,
 /* useful-work x chip-fill score (0..1) of the tile the library would pick (64x2x4, 32x8x2 or 16x16x2 with split-K);
  * below ~0.5 the direct kernel is the better choice */
 double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width);
+/* the 2-D Winograd kernel family in use: 1-3 = F(2x2,3x3) variants (4/9 of the direct convolution's multiplies), 4 = F(2x4,3x3)
+ * (F(2,3) along y, F(4,3) along x: 1/3; the default); option "tune_wino2" / 100 selects one for A/B runs */
+int m3d_conv3d_wino2_family(void);
 int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                 int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                 void* d_ws, size_t ws_bytes, void* stream);
+/* The same forward through the F(2x2,3x3) family only, whose outputs depend on nothing outside their own 3 x 3 (y, x) support, not
+ * even by rounding (the default family's F(4,3) along x cancels the rest of its 6-wide footprint only to ~1e-7 of those inputs).
+ * Used where unrelated data sits right next to a window (the PRM strip layout, m3d_prm_prepare_ex). */
+size_t m3d_conv3d_wino2_local_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
+int m3d_conv3d_wino2_local_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                      int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                      void* d_ws, size_t ws_bytes, void* stream);
 int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                    int depth, int height, int width, const float* d_scale, const float* d_shift,
                                    int relu, void* stream);

@@ -24,6 +24,7 @@
 
 #include "m3d_common.h"
 #include "conv3d_wino2q.h"
+#include "conv3d_wino24.h"
 
 // timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU (one-wave kernel),
 // 8 = 4 instead of 16 transform VALU per K step in the eta-split kernel, 16 = no raw-row LDS reads, 32 = no weight-fragment LDS reads, 64 = no input loads, 128 = input loads without LDS commit,
@@ -972,28 +973,39 @@ int launch_wino2(const float* in, const float* wp, float* out, int B, int cin, i
 
 }  // namespace
 
+// The packed buffer holds BOTH weight packs: the F(2x2,3x3) pack (48 slots per (cout, cin); families 1-3) followed by the F(2x4,3x3)
+// pack (72 slots; family 4), so the family can be switched between pack and forward (A/B runs) and one buffer serves every kernel.
+namespace {
+inline size_t pack22_floats(int cin, int cout) {
+  const size_t npair = ((cin + 1) / 2 + 15) / 16 * 16, ncb = ((cout + 31) / 32 + 1) / 2 * 2;
+  return npair * ncb * (size_t)WT2 * 64;
+}
+}  // namespace
+
 M3D_API size_t m3d_conv3d_wino2_packed_weight_bytes(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;
-  const size_t npair = ((cin + 1) / 2 + 15) / 16 * 16, ncb = ((cout + 31) / 32 + 1) / 2 * 2;
-  return sizeof(float) * npair * ncb * (size_t)WT2 * 64;
+  return sizeof(float) * (pack22_floats(cin, cout) + m3d_w24::packed_floats(cin, cout));
 }
 
 M3D_API int m3d_conv3d_wino2_pack_weights(const float* d_weight, int cin, int cout, float* d_packed, void* stream) {
   if (!d_weight || !d_packed || cin <= 0 || cout <= 0) return M3D_EINVAL;
   const int npair = ((cin + 1) / 2 + 15) / 16 * 16, ncb = ((cout + 31) / 32 + 1) / 2 * 2;
   hipLaunchKernelGGL(wino2_pack_kernel, dim3(1024), dim3(256), 0, m3d::as_stream(stream), d_weight, cin, cout, d_packed, ncb, npair);
-  return m3d::check_launch("wino2_pack");
+  const int rc = m3d::check_launch("wino2_pack");
+  if (rc != M3D_OK) return rc;
+  return m3d_w24::pack(d_weight, cin, cout, d_packed + pack22_floats(cin, cout), m3d::as_stream(stream));
 }
 
 // ---- kernel family and tile choice.
-// Families (option "tune_wino2" / 100): 0 = library default (the quad kernel), 1 = one wave per SIMD (round 1), 2 = eta-split 8-wave
-// workgroups (round 2), 3 = quad kernel (4-wave workgroups, two per CU; conv3d_wino2q.hip).  "tune_wino2" % 100: 99 = library tile
+// Families (option "tune_wino2" / 100): 0 = library default (family 4), 1 = one wave per SIMD (round 1), 2 = eta-split 8-wave
+// workgroups (round 2 / 3), 3 = quad kernel (4-wave workgroups, two per CU; conv3d_wino2q.hip), 4 = F(2x4,3x3): F(4,3) along x, 3/4 of
+// F(2x2)'s matrix-core work (conv3d_wino24.hip).  "tune_wino2" % 100: 99 = library tile
 // choice, 0..5 = one of the fixed tiles of families 1 / 2 (A/B runs).
 // Tiles (x, y, z outputs per workgroup): eta-split / one-wave 64 x 2 x 4, 32 x 8 x 2, 16 x 16 x 2; quad 64 x 2 x 2, 32 x 4 x 2,
 // 16 x 8 x 2; the narrowest with split-K over workgroups when the map has too few tiles to fill the chip.  Score = useful fraction of
 // the computed tile volume x how much of the chip the grid fills; ties go to the wider tile (fewer halo columns per output).
 namespace {
-constexpr int kDefaultFamily = 2;
+constexpr int kDefaultFamily = 4;
 inline int family() {
   const int f = m3d::opt(m3d::OPT_TUNE_WINO2) / 100;
   return f <= 0 ? kDefaultFamily : f;
@@ -1001,6 +1013,7 @@ inline int family() {
 struct Tile { int tx, ty, tz; };
 inline Tile tile_of(int fam, int xt) {
   if (fam == 3) return xt == 32 ? Tile{64, 2, 2} : xt == 16 ? Tile{32, 4, 2} : Tile{16, 8, 2};
+  if (fam == 4) return xt == 32 ? Tile{64, 4, 2} : xt == 16 ? Tile{32, 8, 2} : Tile{16, 16, 2};
   return xt == 32 ? Tile{64, 2, 4} : xt == 16 ? Tile{32, 8, 2} : Tile{16, 16, 2};
 }
 inline int chip_slots(int fam) { return fam == 3 ? 512 : 256; }   // resident workgroups: two per CU for the quad kernel
@@ -1055,12 +1068,16 @@ m3d_w2q::Epi quad_epi(const W2Epi& e) {
 int launch_family(int fam, int xt, const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, W2Epi ep,
                   hipStream_t st, int ksplit) {
   if (fam == 3) return m3d_w2q::launch(xt, false, false, in, wp, out, B, cin, cout, D, H, W, quad_epi(ep), st);
+  if (fam == 4) return m3d_w24::launch(xt, false, false, in, wp + pack22_floats(cin, cout), out, B, cin, cout, D, H, W, quad_epi(ep), st);
   if (xt == 32) return launch_wino2<4, 32, 4, 1>(in, wp, out, B, cin, cout, D, H, W, ep, st);
   if (xt == 16) return launch_wino2<4, 16, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st);
   if (xt == 8) return launch_wino2<4, 8, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
   return M3D_EUNSUPPORTED;
 }
 }  // namespace
+
+/* the 2-D Winograd family the library currently runs (1, 2, 3: F(2x2,3x3), 16/36 of the direct multiplies; 4: F(2x4,3x3), 24/72) */
+M3D_API int m3d_conv3d_wino2_family(void) { return family(); }
 
 /* useful-work x chip-fill score (0..1) of the best tile for this shape; callers use the direct kernel below ~0.5
  * (measured: 128 -> 128 channels on 16 x 40 x 40: score 0.39, 0.247 ms vs 0.224 ms direct) */
@@ -1071,26 +1088,39 @@ M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, i
   return sc;
 }
 
-M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
+namespace {
+size_t workspace_bytes_for(int fam, int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0;
-  const int fam = family();
   if (choose_xt(fam, batch, cin, cout, depth, height, width) != 8) return 0;
   const SplitPlan p = plan_splitk(fam, batch, cin, cout, depth, height, width);
   return p.ksplit > 1 ? p.ksplit * p.slice * sizeof(float) : 0;
 }
+}  // namespace
 
-M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
-                                        int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
-                                        void* d_ws, size_t ws_bytes, void* stream) {
+M3D_API size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
+  return workspace_bytes_for(family(), batch, cin, cout, depth, height, width);
+}
+
+/* The "_local" pair: the F(2x2,3x3) family, whose outputs depend on NOTHING outside their own 3x3 (y, x) support - not even by
+ * rounding (F(2,3)'s two outputs are sums of products that contain only their own three inputs).  F(4,3) along x is local only in
+ * exact arithmetic: the other inputs of its 6-wide footprint cancel to ~1e-7 of THEIR magnitude.  The PRM back-propagation lays
+ * windows of different peaks side by side with one zero column between them (m3d_prm_prepare_ex) and needs the exact form. */
+M3D_API size_t m3d_conv3d_wino2_local_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
+  return workspace_bytes_for(2, batch, cin, cout, depth, height, width);
+}
+
+namespace {
+int forward_ws_family(int fam, const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                      int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                      void* d_ws, size_t ws_bytes, void* stream) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0)
     return M3D_EINVAL;
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
-  const int fam = family();
   const int variant = m3d::opt(m3d::OPT_TUNE_WINO2) % 100;
-  if (fam != 3) {
+  if (fam != 3 && fam != 4) {
 #define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
     M3D_W2(1, 4, 32, 4, 1)
@@ -1117,6 +1147,20 @@ M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed
                      DHW, total, d_scale, d_shift, relu);
   return m3d::check_launch("wino2_reduce");
 }
+}  // namespace
+
+M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                        int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                        void* d_ws, size_t ws_bytes, void* stream) {
+  return forward_ws_family(family(), d_in, d_packed, d_out, batch, cin, cout, depth, height, width, d_scale, d_shift, relu, d_ws, ws_bytes,
+                           stream);
+}
+
+M3D_API int m3d_conv3d_wino2_local_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
+                                              int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
+                                              void* d_ws, size_t ws_bytes, void* stream) {
+  return forward_ws_family(2, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, d_scale, d_shift, relu, d_ws, ws_bytes, stream);
+}
 
 /* without a workspace: fails with M3D_EWORKSPACE where the split-K tile would be chosen */
 M3D_API int m3d_conv3d_wino2_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
@@ -1136,6 +1180,9 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
   // 64-wide tiles from 48 voxels on, else 32-wide (conv3b on 32^3 maps: the pool of the 16^3-class layers is fused as well)
   if (family() == 3)
     return m3d_w2q::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
+  if (family() == 4)
+    return m3d_w24::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
+                           width, quad_epi(ep), st);
   if (width < 48) return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   return launch_wino2<4, 32, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
 }
@@ -1153,6 +1200,9 @@ M3D_API int m3d_conv3d_wino2_forward_pool2_argmax(const float* d_in, const float
   hipStream_t st = m3d::as_stream(stream);
   if (family() == 3)
     return m3d_w2q::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
+  if (family() == 4)
+    return m3d_w24::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
+                           width, quad_epi(ep), st);
   if (width < 48) return launch_wino2e<4, 16, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
   return launch_wino2e<4, 32, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
 }

@@ -149,9 +149,10 @@ class DetectorM3D:
     def span(self, name):
         return self.probe(name) if self.probe is not None else _NOSPAN
 
-    # MFMA multiply-adds a kernel family ISSUES per algorithmic multiply-add: Winograd F(2x2,3x3) 16/36, F(2,3) along x 4/6,
+    # MFMA multiply-adds a kernel family ISSUES per algorithmic multiply-add: Winograd F(2x2,3x3) 16/36, F(2x4,3x3) 24/72, F(2,3) along x 4/6,
     # the stem's F(2,5) along x 78/125 (13 row pairs x 6 xi per output pair against 125 taps per output)
-    ISSUED_FRACTION = {"winograd F(2x2,3x3)": 4.0 / 9.0, "winograd F(2,3)x": 2.0 / 3.0, "winograd F(2,5)x stem": 78.0 / 125.0, "direct": 1.0}
+    ISSUED_FRACTION = {"winograd F(2x2,3x3)": 4.0 / 9.0, "winograd F(2x4,3x3)": 1.0 / 3.0, "winograd F(2,3)x": 2.0 / 3.0,
+                       "winograd F(2,5)x stem": 78.0 / 125.0, "direct": 1.0}
 
     def conv_work(self, batch, size):
         """Per probe span of the convolution family (conv1a .. conv4b, rpn): algorithmic FLOPs (2*Cin*Cout*k^3 per output voxel), the
@@ -160,6 +161,7 @@ class DetectorM3D:
         out = {}
         S, H, W = size
         names = dsn_layers(self.cfg.stride)
+        two_d = "winograd F(2x4,3x3)" if ops.lib().m3d_conv3d_wino2_family() == 4 else "winograd F(2x2,3x3)"
 
         def pad32(c):
             return (c + 31) // 32 * 32 / float(c)
@@ -171,7 +173,7 @@ class DetectorM3D:
             if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(W):
                 kind = "winograd F(2,5)x stem"
             elif small and self.body_wino[li] is not None and self.body_wino[li].supports(W, (batch, S, H, W)):
-                kind = "winograd F(2x2,3x3)" if self.wino_mode == 2 else "winograd F(2,3)x"
+                kind = two_d if self.wino_mode == 2 else "winograd F(2,3)x"
             alg = 2.0 * cin * cout * k ** 3 * S * H * W * batch
             out[cname] = dict(algorithmic_flop=alg, issued_flop=alg * self.ISSUED_FRACTION[kind] * pad32(cout), kernel=kind,
                               shape="%d->%d k%d @ %dx%dx%d" % (cin, cout, k, S, H, W))
@@ -181,7 +183,7 @@ class DetectorM3D:
         cout, cin = int(w.shape[0]), int(w.shape[1])
         kind = "direct"
         if self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(W, (batch, S, H, W)) and cin * S * H * W * 4 < 0x7FFFFFFF:
-            kind = "winograd F(2x2,3x3)" if self.wino_mode == 2 else "winograd F(2,3)x"
+            kind = two_d if self.wino_mode == 2 else "winograd F(2,3)x"
         alg = 2.0 * cin * cout * 27 * S * H * W * batch
         nh = 7 * self.A
         alg_h = 2.0 * cout * nh * S * H * W * batch

@@ -748,12 +748,15 @@ class WinoConv3d(object):
     two_d=False: F(2,3) along x (2/3 of the MFMA work); two_d=True: F(2x2,3x3) on the (y,x) plane (4/9).
     `supports(width)` says whether the kernel has a tile configuration for the map (else use PackedConv3d)."""
 
-    def __init__(self, weight, two_d=False):
+    def __init__(self, weight, two_d=False, local=False):
+        """local=True (2-D kernels): only the F(2x2,3x3) family, whose outputs depend on nothing outside their own 3 x 3 support even by
+        rounding - for data laid out with unrelated neighbours (the PRM strips); the default family uses F(4,3) along x."""
         _need_gpu(weight)
         w = _f32c(weight)
         assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
         self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
         self.two_d = bool(two_d)
+        self.local = bool(local) and self.two_d
         L = lib()
         self._bytes, self._pack, self._fwd, self._pool = \
             (L.m3d_conv3d_wino2_packed_weight_bytes, L.m3d_conv3d_wino2_pack_weights, L.m3d_conv3d_wino2_forward,
@@ -782,16 +785,18 @@ class WinoConv3d(object):
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
         if self.two_d:                                     # the library picks the tile; small / ragged maps may split K
-            wsb = lib().m3d_conv3d_wino2_workspace_bytes(B, cin, self.cout, D, H, W)
+            wsb_fn, fwd_fn = (lib().m3d_conv3d_wino2_local_workspace_bytes, lib().m3d_conv3d_wino2_local_forward_ws) if self.local else \
+                             (lib().m3d_conv3d_wino2_workspace_bytes, lib().m3d_conv3d_wino2_forward_ws)
+            wsb = wsb_fn(B, cin, self.cout, D, H, W)
             key = (torch.cuda.current_stream().cuda_stream, x.device)           # one scratch buffer per stream: tiles on
             cache = self.__dict__.setdefault("_ws", {})                           # different streams run concurrently
             ws = cache.get(key)
             if ws is None or ws.numel() < wsb:
                 ws = cache[key] = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=x.device)
-            check(lib().m3d_conv3d_wino2_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
-                                                    _ptr(scale) if scale is not None else None,
-                                                    _ptr(shift) if shift is not None else None, int(bool(relu)),
-                                                    _ptr(ws), C.c_size_t(wsb), _stream()), "conv3d_wino2_forward_ws")
+            check(fwd_fn(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                         _ptr(scale) if scale is not None else None,
+                         _ptr(shift) if shift is not None else None, int(bool(relu)),
+                         _ptr(ws), C.c_size_t(wsb), _stream()), "conv3d_wino2_forward_ws")
             return out
         check(self._fwd(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                         _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,

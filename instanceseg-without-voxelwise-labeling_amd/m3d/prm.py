@@ -54,7 +54,7 @@ class PRMEngine:
         """backward-data of a 'same' 3^3 conv with relu(W) (peak_backprop_3d.py:41-42) as a forward conv: taps flipped, channel
         roles swapped; packed for the F(2x2,3x3) kernel."""
         wd = torch.relu(w).flip(2, 3, 4).transpose(0, 1).contiguous()
-        return ops.WinoConv3d(wd, two_d=True)
+        return ops.WinoConv3d(wd, two_d=True, local=True)      # windows of different peaks are neighbours in the strip: exact locality
 
     # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
     def forward(self, data):

@@ -245,15 +245,36 @@ def test_conv3d_winograd_vs_fp64(m3d, B, cin, cout, D, H, W, two_d):
     y = conv(x.cuda()).cpu().double()
     err = (y - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-4, err                                   # north_star tolerance
-    assert err < 5e-6, err                                   # what the fp32 transform actually delivers
+    # what the fp32 transforms actually deliver: F(2,3) along x a few 1e-7; the default 2-D family, F(2x4,3x3) (interpolation points
+    # 0, +-1, +-2, inf along x: coefficients up to 8), about twice F(2x2,3x3)'s error - 5.6e-6 measured at 256 input channels
+    tight = 2e-5 if two_d else 5e-6
+    assert err < tight, err
     ref2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
     y2 = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
-    assert (y2 - ref2).abs().max().item() / ref2.abs().max().item() < 5e-6
+    assert (y2 - ref2).abs().max().item() / ref2.abs().max().item() < tight
     if conv.supports_pool(W) and D >= 2 and H >= 2:           # 2-D kernel: 64- and 32-wide tiles have the fused pool (W >= 24)
         yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
         refp = torch.nn.functional.max_pool3d(ref2, 2, 2)
         assert yp.shape == refp.shape
-        assert (yp - refp).abs().max().item() / refp.abs().max().item() < 5e-6
+        assert (yp - refp).abs().max().item() / refp.abs().max().item() < tight
+
+
+def test_conv3d_winograd_local_family_is_exactly_local(m3d):
+    """WinoConv3d(local=True) = the F(2x2,3x3) family: an output depends on nothing outside its own 3 x 3 (y, x) support, not even by
+    rounding, so a block of zeros next to a block of huge values stays EXACTLY zero (what the PRM strip layout relies on: windows of
+    different peaks are one zero column apart).  The default family's F(4,3) along x is local only up to ~1e-7 of the neighbour."""
+    g = torch.Generator().manual_seed(9)
+    cin, cout, D, H, W = 64, 64, 4, 16, 128
+    x = torch.zeros(1, cin, D, H, W)
+    x[..., 66:] = torch.rand(1, cin, D, H, W - 66, generator=g) * 1e6          # columns 0..64 zero, column 65 the gap, 66.. huge
+    w = torch.rand(cout, cin, 3, 3, 3, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+    local = m3d.WinoConv3d(w.cuda(), two_d=True, local=True)(x.cuda()).cpu()
+    assert float(local[..., :65].abs().max()) == 0.0                            # outputs whose support is all zeros: exactly zero
+    assert (local.double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+    dflt = m3d.WinoConv3d(w.cuda(), two_d=True)(x.cuda()).cpu()
+    assert (dflt.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+    assert float(dflt[..., :62].abs().max()) == 0.0                             # beyond F(4,3)'s 6-wide footprint nothing arrives either
 
 
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 64, 64, 6, 8, 64), (2, 32, 40, 4, 10, 70), (1, 128, 128, 4, 6, 32), (1, 16, 33, 5, 7, 50)])
@@ -298,7 +319,7 @@ def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
     assert conv.supports(W)
     y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
     assert torch.equal(y, conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True))      # deterministic
-    assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 5e-6
+    assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5       # F(2x4,3x3): see test_conv3d_winograd_vs_fp64
 
 
 @pytest.mark.parametrize("B,cout,D,H,W", [(1, 32, 6, 8, 64), (2, 32, 5, 7, 70), (1, 20, 4, 6, 33), (1, 48, 3, 5, 128), (1, 32, 9, 3, 37)])
