@@ -591,8 +591,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
       const f32x4 v = stg[i];
       const bool sh = (m & 16) != 0;
       const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
-      const f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
-      *reinterpret_cast<f32x4*>(lds + buf + lq[i]) = o;
+      f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
+      // pinned as ONE 16-byte register tuple: otherwise the store is split into two ds_write2_b32, whose 16-byte lane stride is a
+      // 4-way bank conflict (PMC: half of the kernel's LDS cycles were conflicts, profiles/r03_mfma_busy.txt)
+      asm volatile("" : "+v"(o));
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + buf + lq[i], 16)) = o;
     }
   };
   auto stage_w = [&](int chunk, int buf) __attribute__((always_inline)) {

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
                                                               float* __restrict__ out, int cin, int cout, int D, int H, int W,
                                                               int tiles_x, int tiles_y, int tiles_z, int ncb_total, m3d_w2q::Epi ep) {
   using C = Cfg24<CC, XQ, WZ, WY, POOL>;
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int eta = wave8 & 3, pos = wave8 >> 2;            // waves w and w + 4 (one SIMD): the same eta row of the two tile positions
@@ -197,8 +197,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
       const f32x4 v = stg[i];
       const bool sh = (m & 16) != 0;
       const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
-      const f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
-      *reinterpret_cast<f32x4*>(lds + buf + lq[i]) = o;
+      f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
+      // pinned as ONE 16-byte register tuple: otherwise the store is split into two ds_write2_b32, whose 16-byte lane stride is a
+      // 4-way bank conflict (PMC: half of the kernel's LDS cycles were conflicts, profiles/r03_mfma_busy.txt)
+      asm volatile("" : "+v"(o));
+      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + buf + lq[i], 16)) = o;
     }
   };
   auto stage_w = [&](int chunk, int buf) __attribute__((always_inline)) {
@@ -236,10 +239,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
       const int dz = s / C::PP, pp = s % C::PP;
       unsigned a = (unsigned)(uintptr_t)(lds + buf + b_base + pp * 2 * C::CS + dz * (C::HY * C::HXP));
       asm volatile("" : "+v"(a));                        // one address register per step; the four reads use immediate offsets
+      // the two 8-byte tails come from their OWN address register each: from one register the load/store optimiser fuses them into
+      // ds_read2_b64, which runs at half the LDS rate of two ds_read_b64
+      unsigned a2 = a + 16 + rowV * 4;
+      asm volatile("" : "+v"(a2));
       const lds_f32x4* p4 = reinterpret_cast<const lds_f32x4*>((uintptr_t)a);
       const lds_f32x2* p2 = reinterpret_cast<const lds_f32x2*>((uintptr_t)(a + 16));
+      const lds_f32x2* p2v = reinterpret_cast<const lds_f32x2*>((uintptr_t)a2);
       const f32x4 u4 = p4[rowU / 4], v4 = p4[rowV / 4];
-      const f32x2 u2 = p2[rowU / 2], v2 = p2[rowV / 2];
+      const f32x2 u2 = p2[rowU / 2], v2 = p2v[0];
       r[0][0] = u4[0]; r[0][1] = u4[1]; r[0][2] = u4[2]; r[0][3] = u4[3]; r[0][4] = u2[0]; r[0][5] = u2[1];
       r[1][0] = v4[0]; r[1][1] = v4[1]; r[1][2] = v4[2]; r[1][3] = v4[3]; r[1][4] = v2[0]; r[1][5] = v2[1];
     };
