@@ -537,7 +537,8 @@ def bench_detect(args, rank, world, dist):
                        "issued_gflop_per_launch": wk["issued_flop"] / 1e9, "algorithmic_gflop_per_launch": wk["algorithmic_flop"] / 1e9,
                        "algorithmic_tflops": wk["algorithmic_flop"] / (ms * 1e-3) / 1e12}
     if "conv2b" in roofs:
-        roofs["conv2b"].update(pmc_traffic({2: "conv3d_wino2e_kernel<4, 32, 2, 2, true>", 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
+        w2 = "conv3d_wino24_kernel<4, 16, 2, 1, true" if "F(2x4" in work["conv2b"]["kernel"] else "conv3d_wino2e_kernel<4, 32, 2, 2, true>"
+        roofs["conv2b"].update(pmc_traffic({2: w2, 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
                                             0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
     conv_family = None
     if fam_ms > 0:
