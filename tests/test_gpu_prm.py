@@ -374,3 +374,37 @@ def test_soma_tile_prm_error_against_fp64_is_the_conditioning_not_the_kernels():
     for p, e_hip, e_t32, l_hip, l_t32 in report:
         assert e_hip <= 2.0 * e_t32 + 1e-6, (p, e_hip, e_t32)
         assert l_hip <= 2.0 * l_t32 + 1e-6, (p, l_hip, l_t32)
+
+
+def test_nuclei_tile_default_engine_equals_the_oracle_at_the_shipped_size():
+    """The nuclei net (stride 8, 35 anchors) on its shipped tile 1x64x200x200: windows grow to 84^3 through three un-pools, the strip
+    Winograd dgrad runs on 16^3 .. 40^3 windows and the fused MFMA stem on 84^3 ones.  Two peaks (a corner whose cone leaves the tile on
+    three sides, an interior one) through the DEFAULT engine against the oracle's per-peak backward on the same tile."""
+    import m3d
+    from m3d.config import Cfg
+    from m3d.synth import synth_volume
+    from m3d import tiling
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    cfg = Cfg.nuclei(mlp_dim=64, score_thresh=0.0)
+    assert tuple(cfg.in_size) == (64, 200, 200)
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=0)
+    vol = torch.from_numpy(tiling.norm1(synth_volume(1, cfg.in_size), np.float32).astype(np.float32)).reshape((1, 1) + tuple(cfg.in_size))
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
+    assert eng.strip_wino and eng.fused_stem
+    data = vol.cuda()
+    feat, prob, deltas, saved, top = eng.forward(data)
+    ocfg = O.Cfg(mlp_dim=64, score_thresh=0.0)
+    with torch.no_grad():
+        f2, p2, d2, osaved = O.prm_forward(P, ocfg, vol)
+    assert np.allclose(prob.cpu().numpy(), p2.numpy(), rtol=1e-4, atol=1e-5)
+    s_, h_, w_ = p2.shape[-3:]
+    peaks = [(0, 0, 0, 0, 0), (0, 17, s_ // 2, h_ // 2, w_ // 2)]
+    pk = torch.tensor([p[1:] for p in peaks], dtype=torch.int32).cuda()
+    win, sums, origins = eng.backward_windows(pk, saved, top, data)
+    dense = m3d.prm_scatter(win, sums, origins, vol.shape[-3:]).cpu()
+    for i, p in enumerate(peaks):
+        with torch.no_grad():
+            ref = O.prm_backward(P, osaved, p, p2.shape)[0]
+        assert float(ref.max()) > 0
+        assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
