@@ -211,14 +211,21 @@ def f_conv(rs):
     two_d = bool(rs.randint(2))
     if k == 3 and W >= (12 if two_d else 24):      # Winograd forward (split-K path below 24 wide; fused pool when it applies)
         sc = torch.from_numpy((rs.rand(cout) + 0.5).astype(np.float32)); sh = torch.from_numpy(rs.randn(cout).astype(np.float32))
-        wc = m3d.WinoConv3d(w.cuda(), two_d=two_d)
+        local = two_d and bool(rs.randint(2))          # the exactly-local F(2x2,3x3) family (PRM strips) or the default F(2x4,3x3)
+        wc = m3d.WinoConv3d(w.cuda(), two_d=two_d, local=local)
+        tol = 2e-5 if (two_d and not local) else 1e-5  # F(4,3) along x: about twice F(2,3)'s error
         r2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
         yw = wc(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
-        assert (yw - r2).abs().max().item() / max(r2.abs().max().item(), 1e-3) < 1e-5, ("conv wino", B, cin, cout, D, H, W)
-        if W >= 48 and D >= 2 and H >= 2:
-            yp = wc.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+        assert (yw - r2).abs().max().item() / max(r2.abs().max().item(), 1e-3) < tol, ("conv wino", two_d, local, B, cin, cout, D, H, W)
+        if wc.supports_pool(W) and D >= 2 and H >= 2:
             rp = torch.nn.functional.max_pool3d(r2, 2, 2)
-            assert (yp - rp).abs().max().item() / max(rp.abs().max().item(), 1e-3) < 1e-5, ("conv wino pool", B, cin, cout, D, H, W)
+            if two_d and rs.rand() < 0.5:              # fused pool + arg-max (PRM forward): the indexed values are the pooled values
+                yp, am = wc.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True, return_argmax=True)
+                yp = yp.cpu().double()
+                assert int(am.max()) <= 7
+            else:
+                yp = wc.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True).cpu().double()
+            assert (yp - rp).abs().max().item() / max(rp.abs().max().item(), 1e-3) < 2e-5, ("conv wino pool", two_d, B, cin, cout, D, H, W)
     gy = torch.from_numpy(rs.randn(B, cout, D, H, W).astype(np.float32))
     refw = torch.nn.grad.conv3d_weight(x.double(), w.shape, gy.double(), 1, k // 2)
     gw = m3d.conv3d_wgrad(x.cuda(), gy.cuda(), k).cpu().double()
