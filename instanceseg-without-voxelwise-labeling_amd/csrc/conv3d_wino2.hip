@@ -1082,8 +1082,8 @@ int launch_family(int fam, int xt, const float* in, const float* wp, float* out,
 /* the 2-D Winograd family the library currently runs (1, 2, 3: F(2x2,3x3), 16/36 of the direct multiplies; 4: F(2x4,3x3), 24/72) */
 M3D_API int m3d_conv3d_wino2_family(void) { return family(); }
 
-/* useful-work x chip-fill score (0..1) of the best tile for this shape; callers use the direct kernel below ~0.5
- * (measured: 128 -> 128 channels on 16 x 40 x 40: score 0.39, 0.247 ms vs 0.224 ms direct) */
+/* useful-work x chip-fill score (0..1) of the best tile for this shape; callers use the direct kernel below ~0.3
+ * (measured with the F(2x4,3x3) family: 128 -> 128 channels on 16 x 40 x 40: score 0.39, 0.194 ms vs 0.253 ms direct) */
 M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0.0;
   double sc = 0.0;

@@ -15,14 +15,24 @@
 // Decomposition (what round 3's ablations of the F(2x2) kernel asked for - fewer non-MFMA instructions per MFMA matter, overlap
 // does not): 8 waves = 4 eta x 2 tile positions; a wave owns ONE eta row = 6 accumulator blocks (96 registers) for 32 output
 // channels x 32 patches.  Per K step (one channel pair, one dz) it reads two halo rows (16 + 8 bytes each), forms its 6 B
-// fragments with 18 VALU operations and issues 6 MFMAs; the eta rows meet in an LDS exchange at the end (waves eta = 1, 2 finish
-// output rows 0, 1).  Staging as in the F(2x2) kernel: input quads through registers, weights by LDS-DMA.
+// fragments with 18 VALU operations and issues 6 MFMAs; the eta rows meet in an LDS exchange at the end, after which every wave
+// finishes one quarter of the channels (both output rows).  Staging as in the F(2x2) kernel: input quads through registers, weights by LDS-DMA.
 #include <stdint.h>
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "conv3d_wino24.h"
+
+// diagnostic build only (make w2_stamps; tools/w2_stamps.py): s_memtime stamps of one wave per workgroup, to a buffer of their own
+#ifdef M3D_W2_STAMPS
+static unsigned long long* g_w24_stamps = nullptr;
+M3D_API void m3d_debug_set_stamp_buffer_24(void* p) { g_w24_stamps = (unsigned long long*)p; }
+#define W24_STAMP(k) do { if (ep.stamps && tid == 0) ep.stamps[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 8 + (k)] = \
+    (k) == 5 || (k) == 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W24_STAMP(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   using C = Cfg24<CC, XQ, WZ, WY, POOL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
+  W24_STAMP(0); W24_STAMP(5);
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int eta = wave8 & 3, pos = wave8 >> 2;            // waves w and w + 4 (one SIMD): the same eta row of the two tile positions
   const int wz = pos / WY, wy = pos % WY;
@@ -334,10 +345,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   stage_w(c_begin, 0); issue_in(c_begin);
   commit_in(0);
   __syncthreads();
+  W24_STAMP(1);
   if (eta == 0) kloop(std::integral_constant<int, 0>{});
   else if (eta == 1) kloop(std::integral_constant<int, 1>{});
   else if (eta == 2) kloop(std::integral_constant<int, 2>{});
   else kloop(std::integral_constant<int, 3>{});
+  W24_STAMP(2);
   __syncthreads();                                     // the exchanges below reuse the staging area
 
   // ---- inverse transform.  Over xi in the lane (4 output columns from 6 xi), over eta across the four waves of a position:
@@ -360,80 +373,65 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
         *reinterpret_cast<f32x4*>(xw + (c * 4 + k) * 256) = f32x4{q[c][4 * k], q[c][4 * k + 1], q[c][4 * k + 2], q[c][4 * k + 3]};
   }
   __syncthreads();
-  if (eta == 0 || eta == 3) return;
-  const int row = eta - 1;                             // eta = 1 finishes output row 0, eta = 2 row 1
-  f32x16 yv[4];
+  W24_STAMP(3);
+  // every wave finishes ONE channel quarter (g = 4*eta .. 4*eta+3 of the lane's 16 channels) of BOTH output rows: the finishing work
+  // (scale / shift / ReLU / pool / stores) runs on all eight waves instead of two, the fused pool has its (y, x) window in the lane
+  f32x4 r0[4], r1[4];                                  // [column][channel of the quarter]
   {
-    const float* xa = lds + ((size_t)(pos * 4 + (row == 0 ? 0 : 1)) * 64) * 64 + 4 * lane;      // row 0: + q0      row 1: + q1
-    const float* xb = lds + ((size_t)(pos * 4 + (row == 0 ? 2 : 3)) * 64) * 64 + 4 * lane;      // row 0: + q2      row 1: - q3
+    const float* xq = lds + ((size_t)(pos * 4) * 64) * 64 + eta * 256 + 4 * lane;       // slot (pos, e, c, k = eta): + e*4096 + c*1024
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xa + (c * 4 + k) * 256);
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(xb + (c * 4 + k) * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          yv[c][4 * k + j] = row == 0 ? (a[j] + q[c][4 * k + j]) + bq[j] : (a[j] - q[c][4 * k + j]) - bq[j];
-      }
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(xq + 0 * 4096 + c * 1024);
+      const f32x4 q1 = *reinterpret_cast<const f32x4*>(xq + 1 * 4096 + c * 1024);
+      const f32x4 q2 = *reinterpret_cast<const f32x4*>(xq + 2 * 4096 + c * 1024);
+      const f32x4 q3 = *reinterpret_cast<const f32x4*>(xq + 3 * 4096 + c * 1024);
+      r0[c] = (q0 + q1) + q2;
+      r1[c] = (q1 - q2) - q3;
+    }
   }
-  const int co0 = cot * 32 + 4 * (lane >> 5);
+  const int co0 = cot * 32 + 4 * (lane >> 5) + 8 * eta;   // channel of element j of the quarter: co0 + j
   const int z = z0 + wz;
   const int x = x0 + 4 * jt;
-  const int y = y0 + 2 * (wy * C::YT + ju) + row;
+  const int y = y0 + 2 * (wy * C::YT + ju);
 
   if constexpr (POOL) {
-    // conv + scale/shift + ReLU + MaxPool3d(2,2): x pairs (0,1), (2,3) in the lane; the y pair is waves eta = 1 / 2 of a position;
-    // the z pair is position 0 / 1.  First maximum in (dz, dy, dx) order (strict >), as maxpool2_fwd_kernel.
-    float pooled[2][16];
-    int pidx[2][16];
+    // conv + scale/shift + ReLU + MaxPool3d(2,2): the (y, x) 2x2 windows (x pairs (0,1), (2,3) of both rows) are in the lane; the z
+    // pair is position 0 / 1.  First maximum in (dz, dy, dx) order (strict >), as maxpool2_fwd_kernel.
+    float pooled[2][4];
+    int pidx[2][4];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int co = min(co0 + (g & 3) + 8 * (g >> 2), cout - 1);
+    for (int j = 0; j < 4; ++j) {
+      const int co = min(co0 + j, cout - 1);
       const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
 #pragma unroll
       for (int hx = 0; hx < 2; ++hx) {
-        float v0 = yv[2 * hx][g] * sc + sh, v1 = yv[2 * hx + 1][g] * sc + sh;
-        if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        if constexpr (AM) { const bool second = v1 > v0; pooled[hx][g] = second ? v1 : v0; pidx[hx][g] = second ? 1 : 0; }
-        else { pooled[hx][g] = fmaxf(v0, v1); pidx[hx][g] = 0; }
+        float m = -INFINITY;
+        int mi = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float v = (r == 0 ? r0[2 * hx + c][j] : r1[2 * hx + c][j]) * sc + sh;
+            if (ep.relu) v = fmaxf(v, 0.f);
+            if constexpr (AM) {
+              if (v > m) { m = v; mi = 2 * r + c; }
+            } else {
+              m = fmaxf(m, v);
+            }
+          }
+        pooled[hx][j] = m;
+        pidx[hx][j] = mi;
       }
     }
-    // y pair: row 1 (eta 2) -> row 0 (eta 1) through LDS (behind the eta exchange area); then z pair: position 1 -> position 0
-    float* red = lds + C::XCH_FLOATS + lane;
-    float* redi = red + 4 * 16 * 64;
-    if (row == 1) {
-#pragma unroll
-      for (int hx = 0; hx < 2; ++hx)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          red[((pos * 2 + hx) * 16 + g) * 64] = pooled[hx][g];
-          if constexpr (AM) redi[((pos * 2 + hx) * 16 + g) * 64] = __int_as_float(pidx[hx][g]);
-        }
-    }
-    __syncthreads();                                   // the four remaining waves (ended waves no longer count)
-    if (row == 1) return;
-#pragma unroll
-    for (int hx = 0; hx < 2; ++hx)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const float lo = red[((pos * 2 + hx) * 16 + g) * 64];
-        if constexpr (AM) {
-          const bool lower = lo > pooled[hx][g];         // the y + 1 row only wins when strictly larger
-          pidx[hx][g] = lower ? 2 + __float_as_int(redi[((pos * 2 + hx) * 16 + g) * 64]) : pidx[hx][g];
-          pooled[hx][g] = lower ? lo : pooled[hx][g];
-        } else {
-          pooled[hx][g] = fmaxf(pooled[hx][g], lo);
-        }
-      }
-    __syncthreads();                                   // the y-pair values have been read: the area is reused for the z pair
+    float* red = lds + C::XCH_FLOATS + (size_t)eta * 8 * 64 + lane;     // behind the eta exchange area: [eta][hx*4 + j][lane]
+    float* redi = red + 4 * 8 * 64;
     if (wz == 1) {
 #pragma unroll
       for (int hx = 0; hx < 2; ++hx)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          red[(hx * 16 + g) * 64] = pooled[hx][g];
-          if constexpr (AM) redi[(hx * 16 + g) * 64] = __int_as_float(pidx[hx][g]);
+        for (int j = 0; j < 4; ++j) {
+          red[(hx * 4 + j) * 64] = pooled[hx][j];
+          if constexpr (AM) redi[(hx * 4 + j) * 64] = __int_as_float(pidx[hx][j]);
         }
     }
     __syncthreads();
@@ -442,20 +440,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
     const int zp = z0 >> 1, yp = y >> 1, xp = x >> 1;
     if (zp >= PD || yp >= PH) return;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int co = co0 + (g & 3) + 8 * (g >> 2);
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + j;
       if (co >= cout) continue;
       const size_t o = ((size_t)b * cout + co) * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp;
       float v[2]; int id[2];
 #pragma unroll
       for (int hx = 0; hx < 2; ++hx) {
-        const float up = red[(hx * 16 + g) * 64];
+        const float up = red[(hx * 4 + j) * 64];
         if constexpr (AM) {
-          const bool upper = up > pooled[hx][g];        // the z + 1 plane only wins when strictly larger
-          v[hx] = upper ? up : pooled[hx][g];
-          id[hx] = upper ? 4 + __float_as_int(redi[(hx * 16 + g) * 64]) : pidx[hx][g];
+          const bool upper = up > pooled[hx][j];        // the z + 1 plane only wins when strictly larger
+          v[hx] = upper ? up : pooled[hx][j];
+          id[hx] = upper ? 4 + __float_as_int(redi[(hx * 4 + j) * 64]) : pidx[hx][j];
         } else {
-          v[hx] = fmaxf(pooled[hx][g], up); id[hx] = 0;
+          v[hx] = fmaxf(pooled[hx][j], up); id[hx] = 0;
         }
       }
       if (xp + 1 < PW && (PW & 1) == 0) {
@@ -466,31 +464,37 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
         if (xp + 1 < PW) { out[o + 1] = v[1]; if constexpr (AM) ep.argmax[o + 1] = (unsigned char)id[1]; }
       }
     }
+    W24_STAMP(4); W24_STAMP(6);
     return;
   }
 
   if (!(z < D && y < H && x < W)) return;
   const bool quad_ok = ((W & 3) == 0);
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int co = co0 + (g & 3) + 8 * (g >> 2);
+  for (int j = 0; j < 4; ++j) {
+    const int co = co0 + j;
     if (co >= cout) continue;
     const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
-    float v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      v[c] = yv[c][g] * sc + sh;
-      if (ep.relu) v[c] = fmaxf(v[c], 0.f);
-    }
-    float* o = out + ((size_t)b * cout + co) * DHW + ((size_t)z * H + y) * W + x;
-    if (quad_ok) {
-      *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
-    } else {
+    for (int r = 0; r < 2; ++r) {
+      if (y + r >= H) continue;
+      float v[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (x + c < W) o[c] = v[c];
+      for (int c = 0; c < 4; ++c) {
+        v[c] = (r == 0 ? r0[c][j] : r1[c][j]) * sc + sh;
+        if (ep.relu) v[c] = fmaxf(v[c], 0.f);
+      }
+      float* o = out + ((size_t)b * cout + co) * DHW + ((size_t)z * H + y + r) * W + x;
+      if (quad_ok) {
+        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (x + c < W) o[c] = v[c];
+      }
     }
   }
+  W24_STAMP(4); W24_STAMP(6);
 }
 
 template <int XQ, int WZ, int WY, bool POOL, bool AM>
@@ -502,6 +506,9 @@ int launch24(const float* in, const float* wp, float* out, int B, int cin, int c
   const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
   if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
   const size_t lds = sizeof(float) * C::SMEM_FLOATS;
+#ifdef M3D_W2_STAMPS
+  ep.stamps = g_w24_stamps;
+#endif
   auto kern = conv3d_wino24_kernel<4, XQ, WZ, WY, POOL, AM>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

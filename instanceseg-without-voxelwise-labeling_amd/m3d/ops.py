@@ -774,7 +774,9 @@ class WinoConv3d(object):
             return False
         if self.two_d and shape is not None:
             B, D, H, W = (int(v) for v in shape)
-            return lib().m3d_conv3d_wino2_score(B, self.cin, self.cout, D, H, W) >= 0.5
+            # below ~0.3 of useful tile volume x chip fill the direct kernel wins (tools/bench_wino_threshold.py; with F(2x4,3x3) the
+            # 0.39-score layers of the soma net run 0.194 vs 0.253 ms, so the round-2 threshold of 0.5 came down)
+            return lib().m3d_conv3d_wino2_score(B, self.cin, self.cout, D, H, W) >= 0.3
         return True
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None):

@@ -31,11 +31,11 @@ for name in (sys.argv[1:] or ["conv2b", "conv2a", "conv3b", "conv4b"]):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q"):       # eta-split (8-wave) and quad kernels
+    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24"):   # every 2-D Winograd family
         getattr(L, f)(ctypes.c_void_p(buf.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
-    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q"):
+    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24"):
         getattr(L, f)(ctypes.c_void_p(0))
     ms = e0.elapsed_time(e1)
     st = buf.view(-1, 8).cpu()
@@ -46,11 +46,12 @@ for name in (sys.argv[1:] or ["conv2b", "conv2a", "conv3b", "conv4b"]):
     tot = t[:, 4] - t[:, 0]
     clk = (tot / (st[:, 6] - st[:, 5]).double().clamp(min=1) * 0.1).median().item()     # GHz: cycles per 10 ns tick
     nchunk = cin // 4
+    IDEAL = 4608 if L.m3d_conv3d_wino2_family() == 4 else 6144      # MFMA cycles per chunk and SIMD: 72 (F(2x4)) or 96 (F(2x2)) x 64
     med = [x_.median().item() for x_ in seg]
     span = (t[:, 4].max() - t[:, 0].min()).item()
     print("%-7s batch %d: %d workgroups, kernel %.3f ms (with stamps), clock %.2f GHz" % (name, BATCH, n, ms, clk))
-    print("   median cycles: prologue %6.0f | K loop %7.0f (%5.0f per chunk, ideal 6144 -> %.1f %%) | exchange %5.0f | epilogue %5.0f | total %7.0f"
-          % (med[0], med[1], med[1] / nchunk, 6144.0 * nchunk / med[1] * 100, med[2], med[3], tot.median().item()))
+    print("   median cycles: prologue %6.0f | K loop %7.0f (%5.0f per chunk, ideal %d -> %.1f %%) | exchange %5.0f | epilogue %5.0f | total %7.0f"
+          % (med[0], med[1], med[1] / nchunk, IDEAL, IDEAL * nchunk / med[1] * 100, med[2], med[3], tot.median().item()))
     print("   shares of a workgroup's time: prologue %.1f %%  loop %.1f %%  exchange %.1f %%  epilogue %.1f %%;  MFMA-ideal share of the total %.1f %%"
-          % tuple([m_ / tot.median().item() * 100 for m_ in med] + [6144.0 * nchunk / tot.median().item() * 100]))
+          % tuple([m_ / tot.median().item() * 100 for m_ in med] + [IDEAL * nchunk / tot.median().item() * 100]))
     print("   sum of workgroup times / (256 CUs x first-to-last span) = %.3f" % (tot.sum().item() / (256.0 * span)))
