@@ -59,7 +59,19 @@ struct SEpi {
   const float* scale;
   const float* shift;
   int relu;
+#ifdef M3D_W2_STAMPS
+  unsigned long long* stamps;
+#endif
 };
+// diagnostic build only (make w2_stamps; tools/stem_stamps.py): s_memtime stamps of wave 0 of every workgroup of the rows kernel
+#ifdef M3D_W2_STAMPS
+static unsigned long long* g_stem_stamps = nullptr;
+M3D_API void m3d_debug_set_stamp_buffer_stem(void* p) { g_stem_stamps = (unsigned long long*)p; }
+#define STEM_STAMP(k) do { if (ep.stamps && threadIdx.x == 0) ep.stamps[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 16 + (k)] = \
+    (k) >= 12 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEM_STAMP(k) do { } while (0)
+#endif
 
 constexpr int TXo = 64, EPs = TXo / 2 + 2;       // 34 entries per plane: E[u] = in[x0+2u-2], O[u] = in[x0+2u-1]
 constexpr int HXs = 2 * EPs;                      // 68 floats per halo row
@@ -236,12 +248,283 @@ __global__ __launch_bounds__(256, POOL ? 4 : 3) void conv3d_stem_wino_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------ round 3: the "rows" kernel
+// The kernel above gives a workgroup ONE pooling row (4 waves x 78 MFMAs) and stages the block's 20 KB of transformed weights for it:
+// 8192 workgroups per 128^3 volume fetch 164 MB of weights for 33 MB of input, every wave reads its six weight fragments from LDS in
+// every K step, and four workgroups per CU leave 128 registers per wave.  Stamps of a first rows kernel (tools/stem_stamps.py) showed
+// where the time of such a workgroup goes: K loops 39 %, epilogues (with the z-pair exchange and its barrier) 31 %, prologue 18 %.  So:
+//   * the wave keeps its 78 weight fragments in REGISTERS (loaded once from global memory, 20 x dwordx4; no weight LDS at all);
+//   * a wave owns one y PAIR of the tile and walks TZ planes with it (tile 64 x 8 y x TZ z, four waves = four y pairs; 256 registers, two
+//     workgroups per CU): per K step 2 LDS reads (the six raw values of a row in natural x order), 12 transform VALU, 6 MFMAs;
+//   * the 2x2x2 pooling window is complete in the wave - x pair in the lane, y pair and z pair in consecutive rows (running maximum
+//     parked in the wave's own LDS slots, 16 more live registers would spill) - so there is NO barrier after the prologue and the
+//     shift / ReLU run once per pooled value (max commutes with them; the scale is applied before the maximum, it may be negative);
+//   * the halo tile is loaded once per 2 TZ rows of a wave: (TZ + 4) / TZ planes per output plane instead of 3.
+constexpr int TY4 = 8, HY4 = TY4 + 4;
+constexpr int HX4 = 68;                             // s = x - (x0 - 2), 0..67
+constexpr int SW4_ELEMS = 20 * 64 * 4;              // register pack of one 32-channel block: [20 groups][lane][4]; slot q = pair*6 + xi
+template <int TZ>
+struct Rows {
+  static constexpr int HZ = TZ + 4;
+  static constexpr int IN = HX4 * HY4 * HZ;         // TZ = 4: 6528 floats, TZ = 8: 9792
+  static constexpr int NQ = HY4 * HZ * (HX4 / 4);
+  static constexpr int NI = (NQ + 255) / 256;
+};
+
+// Wr[cb][g][lane][j] = (G g_row)[xi] for slot q = 4g + j = pair*6 + xi (q >= 78: 0), co = cb*32 + (lane&31), row = 2*pair + (lane>>5)
+__global__ __launch_bounds__(256) void stem_wino_pack4_kernel(const float* __restrict__ w, int cout, float* __restrict__ wp, int ncb) {
+  const int total = ncb * SW4_ELEMS;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int j = e & 3, lane = (e >> 2) & 63, g = (e >> 8) % 20, cb = e / SW4_ELEMS;
+    const int q = 4 * g + j, pair = q / 6, xi = q % 6;
+    const int co = cb * 32 + (lane & 31), row = 2 * pair + (lane >> 5);
+    float v = 0.f;
+    if (q < 78 && co < cout && row < 25) {
+      const float* gw = w + (size_t)co * 125 + row * 5;
+      const double g0 = gw[0], g1 = gw[1], g2 = gw[2], g3 = gw[3], g4 = gw[4];
+      double u;
+      switch (xi) {
+        case 0: u = g0 / 4.0; break;
+        case 1: u = -(g0 + g1 + g2 + g3 + g4) / 6.0; break;
+        case 2: u = -(g0 - g1 + g2 - g3 + g4) / 6.0; break;
+        case 3: u = (g0 + 2.0 * g1 + 4.0 * g2 + 8.0 * g3 + 16.0 * g4) / 24.0; break;
+        case 4: u = (g0 - 2.0 * g1 + 4.0 * g2 - 8.0 * g3 + 16.0 * g4) / 24.0; break;
+        default: u = g4; break;
+      }
+      v = (float)u;
+    }
+    wp[e] = v;
+  }
+}
+
+template <bool POOL, int TZ>
+__global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wr,
+                                                                  float* __restrict__ out, int cout, int D, int H, int W,
+                                                                  int tiles_x, int tiles_y, int tiles_z, SEpi ep) {
+  using C = Rows<TZ>;
+  __shared__ __attribute__((aligned(16))) float lds[C::IN + 8 + 64 + (POOL ? 4 * 16 * 64 : 0)];
+  float* const aff = lds + C::IN + 8;                  // scale[32], shift[32] of the block (1 / 0 where absent or beyond cout)
+  float* const park = aff + 64 + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);      // POOL: running maximum, per wave
+  STEM_STAMP(0); STEM_STAMP(12);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int tz = bid % tiles_z;
+  const int cot = bid / tiles_z;
+  const int b = blockIdx.y;
+  const int x0 = tx * TXo, y0 = ty * TY4, z0 = tz * TZ;
+  const size_t DHW = (size_t)D * H * W;
+  const float* in_b = in + (size_t)b * DHW;
+
+  // ---- the wave's 78 weight fragments -> registers (the block's pack is L2-resident: every workgroup reads the same 20 KB)
+  f32x4 aw[20];
+  {
+    const f32x4* wp4 = reinterpret_cast<const f32x4*>(wr + (size_t)cot * SW4_ELEMS) + lane;
+#pragma unroll
+    for (int g = 0; g < 20; ++g) aw[g] = wp4[g * 64];
+  }
+  // ---- the halo tile -> LDS in natural x order.  A thread owns one 16-byte quad of one halo row (hy, q) and walks the TZ + 4 planes
+  // with it: validity of the row and of its four x is per-thread constant, validity of the plane uniform, the addresses advance by
+  // one plane - about 6 VALU per quad.  (The first version decoded a flat quad index per load, ~70 VALU each: stamps showed a
+  // 29 000-cycle prologue, because a wave whose SIMD neighbour streams fp32 MFMAs gets a VALU slot only every MFMA or so.)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0,
+                                                                         (unsigned)(DHW * sizeof(float)), 0x00020000);
+  {
+    const int hy = tid / (HX4 / 4), q = tid - hy * (HX4 / 4);
+    const bool active = hy < HY4;
+    const int y = y0 + hy - 2, xf = x0 - 2 + 4 * q;
+    const bool yok = active && y >= 0 && y < H;
+    const bool m0 = yok && xf >= 0 && xf < W, m1 = yok && xf + 1 >= 0 && xf + 1 < W, m2 = yok && xf + 2 < W, m3 = yok && xf + 3 < W;
+    const bool head = yok && y == 0 && xf < 0;                        // z = 0 too: the quad starts 2 floats before the tensor
+    const int vrow = (y * W + xf) * 4;                                // byte offset inside a plane (may be negative; clamped per load)
+    const int plane = H * W * 4;
+    float* const ldst = lds + hy * HX4 + 4 * q;
+    f32x4 rin[C::HZ];
+#pragma unroll
+    for (int i = 0; i < C::HZ; ++i)       // every plane is loaded, valid or not: below the tensor the offset clamps to 0, beyond it
+                                          // the buffer's range check returns 0; the masks below zero what is not input
+      rin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, max(vrow + (z0 + i - 2) * plane, 0), 0, 0));
+#pragma unroll
+    for (int i = 0; i < C::HZ; ++i) {
+      const int z = z0 + i - 2;
+      const bool zok = z >= 0 && z < D;
+      f32x4 v = rin[i];
+      if (z == 0 && head) v = f32x4{0.f, 0.f, v[0], v[1]};
+      f32x4 o = {(m0 && zok) ? v[0] : 0.f, (m1 && zok) ? v[1] : 0.f, (m2 && zok) ? v[2] : 0.f, (m3 && zok) ? v[3] : 0.f};
+      asm volatile("" : "+v"(o));                          // one register tuple -> ds_write_b128 (a split store conflicts 4-way)
+      if (active) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(ldst + i * (HY4 * HX4), 16)) = o;
+    }
+  }
+  if (tid < 64) {
+    const int co = cot * 32 + (tid & 31);
+    const float* src = tid < 32 ? ep.scale : ep.shift;
+    aff[tid] = (src && co < cout) ? src[co] : (tid < 32 ? 1.f : 0.f);
+  }
+  __syncthreads();
+  STEM_STAMP(1);
+
+  const int jt = lane & 31, hi = lane >> 5;
+  // Row addressing.  K pair p = rows (2p, 2p+1) of r = dz*5 + dy; lanes 0-31 take row 2p, lanes 32-63 row 2p+1.  The halo row of
+  // (dz, dy) for output row (zz, yl) is (zz + dz)*HY4 + yl + dy.  For ten of the thirteen pairs the second row is the NEXT halo row,
+  // for p = 2, 7 (dy = 4 -> next dz, dy = 0) it lies HY4 - 4 rows on, for p = 12 the second row is the zero pad (read the first row
+  // again): three per-lane base registers, every step an immediate offset.
+  const float* const tile = lds + 2 * jt;
+  const int co0 = cot * 32 + 4 * hi;
+  const int PD = D / 2, PH = H / 2, PW = W / 2;
+#pragma unroll 1
+  for (int rr = 0; rr < 2 * TZ; ++rr) {
+    const int zz = rr >> 1, yl = 2 * wave + (rr & 1);
+    const float* b0 = tile + (size_t)(zz * HY4 + yl) * HX4;      // both halves the same row (pad pair)
+    const float* b1 = b0 + (hi ? HX4 : 0);                       // second row = next halo row
+    const float* b2 = b0 + (hi ? (HY4 - 4) * HX4 : 0);           // second row = first row of the next z plane
+    f32x16 acc[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[x][g] = 0.f;
+    auto read_raw = [&](int p, float (&d)[6]) __attribute__((always_inline)) {
+      const int r0 = 2 * p;
+      const int off = ((r0 / 5) * HY4 + r0 % 5) * HX4;
+      const float* q = (p == 12 ? b0 : (p == 2 || p == 7) ? b2 : b1) + off;
+      const f32x2 u = *reinterpret_cast<const f32x2*>(q), v = *reinterpret_cast<const f32x2*>(q + 2), w2 = *reinterpret_cast<const f32x2*>(q + 4);
+      d[0] = u[0]; d[1] = u[1]; d[2] = v[0]; d[3] = v[1]; d[4] = w2[0]; d[5] = w2[1];      // in[2t-2 .. 2t+3]
+    };
+    auto transform = [&](const float (&d)[6], float (&v)[6]) __attribute__((always_inline)) {
+      const float a = d[4] - 4.f * d[2], bq = d[3] - 4.f * d[1];
+      const float c = d[4] - d[2], e2 = 2.f * (d[3] - d[1]);
+      v[0] = 4.f * d[0] + (d[4] - 5.f * d[2]);
+      v[1] = a + bq; v[2] = a - bq;
+      v[3] = c + e2; v[4] = c - e2;
+      v[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
+    };
+    float raw[2][6], bf[2][6];
+    read_raw(0, raw[0]);
+    read_raw(1, raw[1]);
+    transform(raw[0], bf[0]);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      if (p + 2 < NP) read_raw(p + 2, raw[p & 1]);
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        const int q = p * 6 + x;
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q >> 2][q & 3], bf[p & 1][x], acc[x], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < NP) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(raw[(p + 1) & 1][i]));      // keep the transform out of the read's shadow
+        transform(raw[(p + 1) & 1], bf[(p + 1) & 1]);
+      }
+#pragma unroll
+      for (int x = 3; x < 6; ++x) {
+        const int q = p * 6 + x;
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[q >> 2][q & 3], bf[p & 1][x], acc[x], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STEM_STAMP(rr < 4 ? 2 + 2 * rr : 10);
+    // ---- inverse transform; x pair in the lane
+    const f32x16 y0v = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+    const f32x16 y1v = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]) + acc[5];
+    const int z = z0 + zz, y = y0 + yl, x = x0 + 2 * jt;
+    // scale / shift of the lane's 16 channels (co0 + (g&3) + 8*(g>>2)): four 16-byte LDS reads each.  Read per row - held across the K
+    // loop they would cost 32 registers and spill; fetched per channel from global memory (round-3 first version) the sixteen
+    // dependent load-branch-wait sequences took 12 000 cycles per storing row.
+    int ao = 4 * hi;
+    asm volatile("" : "+v"(ao));                       // (the offset, not the pointer: an opaque pointer becomes a flat load)
+    const float* affl = aff + ao;
+    const bool all8 = (cout & 7) == 0;                 // then a group of four channels is valid or not as a whole (uniform test)
+    if constexpr (POOL) {
+      float cur[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(affl + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[4 * q + j] = fmaxf(y0v[4 * q + j] * sc[j], y1v[4 * q + j] * sc[j]);
+      }
+      if ((rr & 3) != 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) cur[g] = fmaxf(cur[g], park[g * 64]);
+      }
+      if ((rr & 3) != 3) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) park[g * 64] = cur[g];
+      } else {
+        const int py = y >> 1, pz = z >> 1, px = (x0 >> 1) + jt;
+        if (pz < PD && py < PH && px < PW) {
+          const size_t PDHW = (size_t)PD * PH * PW;
+          float* ob = out + ((size_t)b * cout + co0) * PDHW + ((size_t)pz * PH + py) * PW + px;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(affl + 32 + 8 * q);
+            if (cot * 32 + 8 * q >= cout) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = cur[4 * q + j] + sh[j];
+              if (ep.relu) v = fmaxf(v, 0.f);
+              if (all8 || co0 + 8 * q + j < cout) ob[(size_t)(8 * q + j) * PDHW] = v;
+            }
+          }
+        }
+      }
+    } else {
+      if (z < D && y < H && x < W) {
+        const bool pair_ok = ((W & 1) == 0);
+        float* ob = out + ((size_t)b * cout + co0) * DHW + ((size_t)z * H + y) * W + x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(affl + 8 * q), sh = *reinterpret_cast<const f32x4*>(affl + 32 + 8 * q);
+          if (cot * 32 + 8 * q >= cout) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0 = y0v[4 * q + j] * sc[j] + sh[j], v1 = y1v[4 * q + j] * sc[j] + sh[j];
+            if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            if (!(all8 || co0 + 8 * q + j < cout)) continue;
+            float* o = ob + (size_t)(8 * q + j) * DHW;
+            if (pair_ok) {
+              *reinterpret_cast<f32x2*>(o) = f32x2{v0, v1};
+            } else {
+              o[0] = v0;
+              if (x + 1 < W) o[1] = v1;
+            }
+          }
+        }
+      }
+    }
+    STEM_STAMP(rr < 4 ? 3 + 2 * rr : 11);
+  }
+  STEM_STAMP(13);
+}
+
+template <bool POOL, int TZ>
+int launch_stem_rows(const float* in, const float* wr, float* out, int B, int cout, int D, int H, int W, SEpi ep, hipStream_t st) {
+  const int tiles_x = (W + TXo - 1) / TXo, tiles_y = (H + TY4 - 1) / TY4, tiles_z = (D + TZ - 1) / TZ;
+  const long long blocks = (long long)tiles_x * tiles_y * tiles_z * ((cout + 31) / 32);
+  if (blocks > 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
+  hipLaunchKernelGGL((conv3d_stem_wino4_kernel<POOL, TZ>), dim3((unsigned)blocks, B), dim3(256), 0, st, in, wr, out, cout, D, H, W, tiles_x,
+                     tiles_y, tiles_z, ep);
+  return m3d::check_launch("conv3d_stem_wino4");
+}
+
 template <bool POOL>
 int launch_stem_wino(const float* in, const float* wp, float* out, int B, int cout, int D, int H, int W, SEpi ep, hipStream_t st) {
-  const int tiles_x = (W + TXo - 1) / TXo, tiles_y = (H + 1) / 2, tiles_z = (D + 1) / 2;
   const int co_tiles = (cout + 31) / 32;
+  if (B > 65535) return M3D_EUNSUPPORTED;
+  // option "tune_stem": 1 = the one-row kernel of round 2 (A/B measurements), 4 / 8 = rows kernel with that many planes per workgroup
+  const int tune = m3d::opt(m3d::OPT_TUNE_STEM);
+  if (tune != 1) {
+    const float* wr = wp + (size_t)co_tiles * SW_ELEMS;
+    // eight planes per workgroup while that still leaves every CU its two workgroups twice over
+    const long long wg8 = (long long)((W + TXo - 1) / TXo) * ((H + TY4 - 1) / TY4) * ((D + 7) / 8) * co_tiles * B;
+    const bool tz8 = tune == 8 || (tune != 4 && wg8 >= 2 * 512);
+    return tz8 ? launch_stem_rows<POOL, 8>(in, wr, out, B, cout, D, H, W, ep, st)
+               : launch_stem_rows<POOL, 4>(in, wr, out, B, cout, D, H, W, ep, st);
+  }
+  const int tiles_x = (W + TXo - 1) / TXo, tiles_y = (H + 1) / 2, tiles_z = (D + 1) / 2;
   const long long blocks = (long long)tiles_x * tiles_y * tiles_z * co_tiles;
-  if (blocks > 0x7FFFFFFFll || B > 65535) return M3D_EUNSUPPORTED;
+  if (blocks > 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
   hipLaunchKernelGGL(conv3d_stem_wino_kernel<POOL>, dim3((unsigned)blocks, B), dim3(256), 0, st, in, wp, out, cout, D, H, W, tiles_x,
                      tiles_y, tiles_z, ep);
   return m3d::check_launch("conv3d_stem_wino");
@@ -250,12 +533,15 @@ int launch_stem_wino(const float* in, const float* wp, float* out, int B, int co
 }  // namespace
 
 M3D_API size_t m3d_conv3d_stem_wino_packed_weight_bytes(int cout) {
-  return cout <= 0 ? 0 : sizeof(float) * (size_t)((cout + 31) / 32) * SW_ELEMS;
+  return cout <= 0 ? 0 : sizeof(float) * (size_t)((cout + 31) / 32) * (SW_ELEMS + SW4_ELEMS);      // both kernels' packs
 }
 
 M3D_API int m3d_conv3d_stem_wino_pack_weights(const float* d_weight /*[cout,1,5,5,5]*/, int cout, float* d_packed, void* stream) {
   if (!d_weight || !d_packed || cout <= 0) return M3D_EINVAL;
-  hipLaunchKernelGGL(stem_wino_pack_kernel, dim3(64), dim3(256), 0, m3d::as_stream(stream), d_weight, cout, d_packed, (cout + 31) / 32);
+  const int ncb = (cout + 31) / 32;
+  hipLaunchKernelGGL(stem_wino_pack_kernel, dim3(64), dim3(256), 0, m3d::as_stream(stream), d_weight, cout, d_packed, ncb);
+  hipLaunchKernelGGL(stem_wino_pack4_kernel, dim3(64), dim3(256), 0, m3d::as_stream(stream), d_weight, cout,
+                     d_packed + (size_t)ncb * SW_ELEMS, ncb);
   return m3d::check_launch("stem_wino_pack");
 }
 
@@ -267,6 +553,9 @@ M3D_API int m3d_conv3d_stem_wino_forward(const float* d_in, const float* d_packe
   if (width < 32) return M3D_EUNSUPPORTED;           // 64-wide tiles: narrower maps use the direct stem kernel
   if (pool && (depth < 2 || height < 2 || width < 2)) return M3D_EINVAL;
   SEpi ep{d_scale, d_shift, relu};
+#ifdef M3D_W2_STAMPS
+  ep.stamps = g_stem_stamps;
+#endif
   hipStream_t st = m3d::as_stream(stream);
   return pool ? launch_stem_wino<true>(d_in, d_packed, d_out, batch, cout, depth, height, width, ep, st)
               : launch_stem_wino<false>(d_in, d_packed, d_out, batch, cout, depth, height, width, ep, st);

@@ -7,8 +7,8 @@ thread_local char g_last_hip_error[256] = "";
 
 #include <atomic>
 namespace m3d {
-static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
-static const char* const kOptNames[OPT_COUNT] = {"xcd_map", "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt", "tune_fc_slices", "tune_fc_slices_tail", "tune_fc_x3_rows"};
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static const char* const kOptNames[OPT_COUNT] = {"xcd_map", "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt", "tune_fc_slices", "tune_fc_slices_tail", "tune_fc_x3_rows", "tune_stem"};
 int opt(Opt o) { return g_opt[o].load(std::memory_order_relaxed); }
 }  // namespace m3d
 

@@ -57,7 +57,7 @@ def lib():
         # A/B-tooling knobs of tools/*.py once, at load time.
         for env, name in (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
                           ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
-                          ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows")):
+                          ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem")):
             if env in os.environ:
                 set_option(name, int(os.environ[env]))
     return _lib
