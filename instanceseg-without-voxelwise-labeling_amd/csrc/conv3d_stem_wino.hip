@@ -391,13 +391,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* 
       const f32x2 u = *reinterpret_cast<const f32x2*>(q), v = *reinterpret_cast<const f32x2*>(q + 2), w2 = *reinterpret_cast<const f32x2*>(q + 4);
       d[0] = u[0]; d[1] = u[1]; d[2] = v[0]; d[3] = v[1]; d[4] = w2[0]; d[5] = w2[1];      // in[2t-2 .. 2t+3]
     };
+    // B^T d of F(2,5), every product fused explicitly: left to the compiler the contraction differed between the pooled and the
+    // unpooled instantiation (1-ulp different activations) and the uncontracted one carried 40 more instructions per row
     auto transform = [&](const float (&d)[6], float (&v)[6]) __attribute__((always_inline)) {
-      const float a = d[4] - 4.f * d[2], bq = d[3] - 4.f * d[1];
-      const float c = d[4] - d[2], e2 = 2.f * (d[3] - d[1]);
-      v[0] = 4.f * d[0] + (d[4] - 5.f * d[2]);
+      const float a = __builtin_fmaf(-4.f, d[2], d[4]), bq = __builtin_fmaf(-4.f, d[1], d[3]);
+      const float c = d[4] - d[2], e2 = d[3] - d[1];
+      v[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
       v[1] = a + bq; v[2] = a - bq;
-      v[3] = c + e2; v[4] = c - e2;
-      v[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
+      v[3] = __builtin_fmaf(2.f, e2, c); v[4] = __builtin_fmaf(-2.f, e2, c);
+      v[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
     };
     float raw[2][6], bf[2][6];
     read_raw(0, raw[0]);
@@ -479,7 +481,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* 
           if (cot * 32 + 8 * q >= cout) continue;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float v0 = y0v[4 * q + j] * sc[j] + sh[j], v1 = y1v[4 * q + j] * sc[j] + sh[j];
+            // product and sum rounded separately, as the pooled path must (maximum between them): pooled == max_pool3d(unpooled) bit for bit
+            float p0 = y0v[4 * q + j] * sc[j], p1 = y1v[4 * q + j] * sc[j];
+            asm volatile("" : "+v"(p0), "+v"(p1));       // (no contraction into an FMA; __fmul_rn is a plain product to this compiler)
+            float v0 = p0 + sh[j], v1 = p1 + sh[j];
             if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
             if (!(all8 || co0 + 8 * q + j < cout)) continue;
             float* o = ob + (size_t)(8 * q + j) * DHW;

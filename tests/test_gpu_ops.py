@@ -346,6 +346,31 @@ def test_conv3d_stem_winograd_vs_fp64(m3d, B, cout, D, H, W):
         assert yp.shape == refp.shape and (yp - refp).abs().max().item() / refp.abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("tune", [1, 4, 8])
+def test_conv3d_stem_winograd_kernels_agree(m3d, tune):
+    """The three stem kernels (round-2 one-row kernel, rows kernel with 4 / 8 planes per workgroup - the library picks by size) on a
+    ragged volume deeper than one tile, odd D / H, W not a multiple of the tile, 40 channels (a partial block of 8): each against fp64,
+    and the pooled result bit-identical to max_pool3d of the kernel's own unpooled result."""
+    from m3d import _lib
+    g = torch.Generator().manual_seed(tune)
+    x = torch.randn(2, 1, 19, 21, 75, generator=g)
+    w = torch.randn(40, 1, 5, 5, 5, generator=g) * (2.0 / 125) ** 0.5
+    sc = torch.rand(40, generator=g) - 0.3          # some negative scales: the maximum is taken after the scale
+    sh = torch.randn(40, generator=g)
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 2) * sc.double().view(1, -1, 1, 1, 1)
+                     + sh.double().view(1, -1, 1, 1, 1))
+    old = _lib.get_option("tune_stem")
+    _lib.set_option("tune_stem", tune)
+    try:
+        conv = m3d.StemWinoConv3d(w.cuda())
+        y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+        yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    finally:
+        _lib.set_option("tune_stem", old)
+    assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    assert torch.equal(yp, torch.nn.functional.max_pool3d(y, 2, 2))
+
+
 def test_conv3d_winograd_rejects_narrow_maps(m3d):
     conv = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda())
     assert not conv.supports(16) and conv.supports(24) and not conv.supports_pool(32)
