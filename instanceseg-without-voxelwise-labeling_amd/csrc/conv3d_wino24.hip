@@ -343,7 +343,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   };
   // ---- prologue: chunk 0 -> buffer 0
   stage_w(c_begin, 0); issue_in(c_begin);
+  // scale / shift of the four channels this wave finishes in the epilogue (co0e + j): fetched with the first chunk - read where they
+  // are used, the workgroup (alone on its CU) sits out a global-load latency after the eta exchange
+  const int co0e = cot * 32 + 4 * (lane >> 5) + 8 * eta;
+  float scv[4], shv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = min(co0e + j, cout - 1);
+    scv[j] = ep.scale ? ep.scale[co] : 1.f;
+    shv[j] = ep.shift ? ep.shift[co] : 0.f;
+  }
   commit_in(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(scv[j]), "+v"(shv[j]));       // (loaded here, not sunk to the epilogue)
   __syncthreads();
   W24_STAMP(1);
   if (eta == 0) kloop(std::integral_constant<int, 0>{});
@@ -401,8 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
     int pidx[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int co = min(co0 + j, cout - 1);
-      const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+      const float sc = scv[j], sh = shv[j];
 #pragma unroll
       for (int hx = 0; hx < 2; ++hx) {
         float m = -INFINITY;
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   for (int j = 0; j < 4; ++j) {
     const int co = co0 + j;
     if (co >= cout) continue;
-    const float sc = ep.scale ? ep.scale[co] : 1.f, sh = ep.shift ? ep.shift[co] : 0.f;
+    const float sc = scv[j], sh = shv[j];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (y + r >= H) continue;
