@@ -178,8 +178,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
       int m = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
-      long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
-      if (rok && lin < 0) { lin = 0; m |= 16; }     // the very first quad of the tensor: loaded one element later and shifted
+      const long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
+      // The very first quad of the tensor starts one float BEFORE it (x = -1 of row 0, plane 0, channel 0): bit 16.  Only the first
+      // chunk of a slice that starts at channel 0 can meet it, i.e. only the PROLOGUE's load (clamped to offset 0, shifted by one
+      // element at its commit); every later chunk adds chunk_bytes to the same negative offset and is an ordinary load, so the K
+      // loop's commit carries no shift code (it was 4 v_cndmask per quad for one quad of the whole tensor).
+      if (rok && lin < 0) m |= 16;
       mq[i] = m;
       gq[i] = rok ? (int)(lin * 4) : 0;
       lq[i] = row * C::HXP + 4 * q;
@@ -196,26 +200,42 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   const unsigned w_pair_bytes = (unsigned)ncb_total * SEG24 * 4, w_tile_bytes = (unsigned)cot * SEG24 * 4;
   const int lane16 = lane * 16;
   const int chunk_bytes = (int)(CC * DHW * sizeof(float));
-  auto issue_in = [&](int chunk) __attribute__((always_inline)) {
+  auto issue_in = [&](int chunk, auto first) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i)
-      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gq[i] + chunk * chunk_bytes, 0, 0));
+    for (int i = 0; i < C::NI; ++i) {
+      int off = gq[i] + chunk * chunk_bytes;
+      if constexpr (decltype(first)::value) off = max(off, 0);
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
+    }
   };
-  auto commit_in = [&](int buf) __attribute__((always_inline)) {
+  // LDS byte address of every staged quad in buffer 0 / 1 (no address arithmetic in the K loop: its two chunk bodies name their buffer
+  // at compile time, and 75 KB of buffer offset do not fit the 16-bit offset field of a DS instruction)
+  unsigned lqa[2][C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    lqa[0][i] = (unsigned)(uintptr_t)(lds + lq[i]);
+    lqa[1][i] = (unsigned)(uintptr_t)(lds + C::LDS_FLOATS + lq[i]);
+  }
+  auto commit_in = [&](auto kbuf, auto first) __attribute__((always_inline)) {
+    constexpr int KB = decltype(kbuf)::value;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {                    // branch-free: the K loop must stay one scheduling region
       const int m = mq[i];
       const f32x4 v = stg[i];
-      const bool sh = (m & 16) != 0;
-      const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
+      float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+      if constexpr (decltype(first)::value) {
+        const bool sh = (m & 16) != 0 && gq[i] + c_begin * chunk_bytes < 0;
+        v3 = sh ? v2 : v3; v2 = sh ? v1 : v2; v1 = sh ? v0 : v1; v0 = sh ? 0.f : v0;
+      }
       f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
       // pinned as ONE 16-byte register tuple: otherwise the store is split into two ds_write2_b32, whose 16-byte lane stride is a
       // 4-way bank conflict (PMC: half of the kernel's LDS cycles were conflicts, profiles/r03_mfma_busy.txt)
       asm volatile("" : "+v"(o));
-      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + buf + lq[i], 16)) = o;
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)lqa[KB][i]) = o;
     }
   };
-  auto stage_w = [&](int chunk, int buf) __attribute__((always_inline)) {
+  auto stage_w = [&](int chunk, auto kbuf) __attribute__((always_inline)) {
+    constexpr int buf = decltype(kbuf)::value * C::LDS_FLOATS;
 #pragma unroll
     for (int i = 0; i < C::NWD; ++i) {
       const int pc = wave8 + 8 * i;                      // 1 KB piece of the chunk's PP x 18 KB; pieces beyond it go to the dump piece
@@ -246,17 +266,25 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
     // y transform of eta row EH from two of the four halo rows:  c = U -+ V
     //   0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3
     constexpr int rowU = (EH == 0 ? 0 : EH == 2 ? 2 : 1) * C::HXP, rowV = (EH == 0 ? 2 : EH == 1 ? 2 : EH == 2 ? 1 : 3) * C::HXP;
-    auto read_raw = [&](int buf, int s, float (&r)[2][6]) __attribute__((always_inline)) {
+    // Per buffer: the lane's B base, a second B base for the 8-byte tail of row V (from ONE register the load/store optimiser fuses the
+    // two tails into ds_read2_b64, which runs at half the LDS rate of two ds_read_b64), the lane's A bases (16-byte and 8-byte part).
+    // Pinned, so that each stays one register and every read of the K loop is base + immediate offset.
+    unsigned bB[2], bV[2], bA[2], bAh[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      bB[k] = (unsigned)(uintptr_t)(lds + k * C::LDS_FLOATS + b_base);
+      bV[k] = bB[k] + 16 + rowV * 4;
+      bA[k] = (unsigned)(uintptr_t)(lds + k * C::LDS_FLOATS + C::IN_ELEMS + EH * 256 + lane * 4);
+      bAh[k] = (unsigned)(uintptr_t)(lds + k * C::LDS_FLOATS + C::IN_ELEMS + SEG24_HI + EH * 128 + lane * 2);
+      asm volatile("" : "+v"(bB[k]), "+v"(bV[k]), "+v"(bA[k]), "+v"(bAh[k]));
+    }
+    auto read_raw = [&](auto kbuf, int s, float (&r)[2][6]) __attribute__((always_inline)) {
+      constexpr int KB = decltype(kbuf)::value;
       const int dz = s / C::PP, pp = s % C::PP;
-      unsigned a = (unsigned)(uintptr_t)(lds + buf + b_base + pp * 2 * C::CS + dz * (C::HY * C::HXP));
-      asm volatile("" : "+v"(a));                        // one address register per step; the four reads use immediate offsets
-      // the two 8-byte tails come from their OWN address register each: from one register the load/store optimiser fuses them into
-      // ds_read2_b64, which runs at half the LDS rate of two ds_read_b64
-      unsigned a2 = a + 16 + rowV * 4;
-      asm volatile("" : "+v"(a2));
-      const lds_f32x4* p4 = reinterpret_cast<const lds_f32x4*>((uintptr_t)a);
-      const lds_f32x2* p2 = reinterpret_cast<const lds_f32x2*>((uintptr_t)(a + 16));
-      const lds_f32x2* p2v = reinterpret_cast<const lds_f32x2*>((uintptr_t)a2);
+      const unsigned off = (unsigned)(pp * 2 * C::CS + dz * (C::HY * C::HXP)) * 4u;
+      const lds_f32x4* p4 = reinterpret_cast<const lds_f32x4*>((uintptr_t)(bB[KB] + off));
+      const lds_f32x2* p2 = reinterpret_cast<const lds_f32x2*>((uintptr_t)(bB[KB] + off + 16));
+      const lds_f32x2* p2v = reinterpret_cast<const lds_f32x2*>((uintptr_t)(bV[KB] + off));
       const f32x4 u4 = p4[rowU / 4], v4 = p4[rowV / 4];
       const f32x2 u2 = p2[rowU / 2], v2 = p2v[0];
       r[0][0] = u4[0]; r[0][1] = u4[1]; r[0][2] = u4[2]; r[0][3] = u4[3]; r[0][4] = u2[0]; r[0][5] = u2[1];
@@ -275,24 +303,29 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
       bf[4] = fmaf(-2.f, t3, t2);
       bf[5] = fmaf(4.f, c[1], fmaf(-5.f, c[3], c[5]));
     };
-    auto load_a = [&](int buf, int s, float (&af)[6]) __attribute__((always_inline)) {     // this eta row's 6 fragments of the step
+    auto load_a = [&](auto kbuf, int s, float (&af)[6]) __attribute__((always_inline)) {     // this eta row's 6 fragments of the step
+      constexpr int KB = decltype(kbuf)::value;
       const int dz = s / C::PP, pp = s % C::PP;
-      const float* w = lds + buf + C::IN_ELEMS + pp * SEG24;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(w + ((dz * 4 + EH) * 64 + lane) * 4);
-      const f32x2 hi = *reinterpret_cast<const f32x2*>(w + SEG24_HI + ((dz * 4 + EH) * 64 + lane) * 2);
+      const f32x4 lo = *reinterpret_cast<const lds_f32x4*>((uintptr_t)(bA[KB] + (unsigned)(pp * SEG24 + dz * 4 * 256) * 4u));
+      const f32x2 hi = *reinterpret_cast<const lds_f32x2*>((uintptr_t)(bAh[KB] + (unsigned)(pp * SEG24 + dz * 4 * 128) * 4u));
       af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1];
     };
 
-    read_raw(0, 0, raw[0]);
-    read_raw(0, 1, raw[1]);
-    load_a(0, 0, afq[0]);
+    constexpr std::integral_constant<int, 0> B0{};
+    constexpr std::integral_constant<int, 1> B1{};
+    read_raw(B0, 0, raw[0]);
+    read_raw(B0, 1, raw[1]);
+    load_a(B0, 0, afq[0]);
     transform(raw[0], bfq[0]);
 
     // ---- K loop, software-pipelined across chunks as in conv3d_wino2e_kernel: raw rows two steps ahead, transform and weight
     // fragments one step ahead; region A = LDS reads (+ the next chunk's loads in step 0) between MFMAs 0..2, region B = pinned
     // transform (+ the input commit in step NS-2) between MFMAs 3..5; chunk barrier at the end of step NS-2.
-    for (int chunk = c_begin; chunk < nchunk; ++chunk) {
-      const int cur = ((chunk - c_begin) & 1) * C::LDS_FLOATS, nxt = C::LDS_FLOATS - cur;
+    // Two chunk bodies, one per LDS buffer, so that the buffer is a compile-time constant in every address (27 v_add_u32 per chunk
+    // and wave otherwise; beside fp32 MFMAs every VALU instruction costs matrix-pipe time).
+    auto chunk_body = [&](auto curc, int chunk) __attribute__((always_inline)) {
+      constexpr std::integral_constant<int, decltype(curc)::value> cur{};
+      constexpr std::integral_constant<int, 1 - decltype(curc)::value> nxt{};
       const int nchk = min(chunk + 1, nchunk - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
           read_raw(nxt, 1, raw[1]);
           load_a(nxt, 0, afq[0]);
         }
-        if (s == 0) { stage_w(nchk, nxt); issue_in(nchk); }
+        if (s == 0) { stage_w(nchk, nxt); issue_in(nchk, std::false_type{}); }
 #pragma unroll
         for (int x = 0; x < 3; ++x)
           acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][x], bfq[s & 1][x], acc[x], 0, 0, 0);
@@ -325,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
         // ---------------- region B
         if (s + 1 < NS) { pin24(raw[(s + 1) & 1]); transform(raw[(s + 1) & 1], bfq[(s + 1) & 1]); }
         if (s == NS - 1) { pin24(raw[0]); transform(raw[0], bfq[0]); }
-        if (s == NS - 2) commit_in(nxt);
+        if (s == NS - 2) commit_in(nxt, std::false_type{});
 #pragma unroll
         for (int x = 3; x < 6; ++x)
           acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(afq[s & 1][x], bfq[s & 1][x], acc[x], 0, 0, 0);
@@ -339,10 +372,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
         __builtin_amdgcn_sched_barrier(0);
         if (s == NS - 2) __syncthreads();                // (waits for this wave's DMA and LDS operations first)
       }
+    };
+    for (int chunk = c_begin;;) {
+      chunk_body(B0, chunk);
+      if (++chunk >= nchunk) break;
+      chunk_body(B1, chunk);
+      if (++chunk >= nchunk) break;
     }
   };
   // ---- prologue: chunk 0 -> buffer 0
-  stage_w(c_begin, 0); issue_in(c_begin);
+  stage_w(c_begin, std::integral_constant<int, 0>{}); issue_in(c_begin, std::true_type{});
   // scale / shift of the four channels this wave finishes in the epilogue (co0e + j): fetched with the first chunk - read where they
   // are used, the workgroup (alone on its CU) sits out a global-load latency after the eta exchange
   const int co0e = cot * 32 + 4 * (lane >> 5) + 8 * eta;
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
     scv[j] = ep.scale ? ep.scale[co] : 1.f;
     shv[j] = ep.shift ? ep.shift[co] : 0.f;
   }
-  commit_in(0);
+  commit_in(std::integral_constant<int, 0>{}, std::true_type{});
 #pragma unroll
   for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(scv[j]), "+v"(shv[j]));       // (loaded here, not sunk to the epilogue)
   __syncthreads();
