@@ -254,6 +254,11 @@ int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_
  *       kept rows, zero padded, with the count in element [out_cap][0] - the block m3d.shard all-gathers
  *       (lib/core/test.py:150-160). */
 int m3d_fused_max_boxes(void);
+/* Rows [0, min(d_counts[b], max_rows)) of every item b of d_src (item b at d_src + b*item_stride_bytes, rows of row_bytes, a multiple
+ * of 4) packed back to back in item order into d_dst; d_offsets (may be NULL) receives the batch+1 row offsets.  The batched form of
+ * `rois[:num]` per tile (lib/core/test.py:106-114 hands each tile's valid RoIs to the box head): no host round trip. */
+int m3d_compact_rows(const void* d_src, size_t item_stride_bytes, size_t row_bytes, const int32_t* d_counts, int batch, int max_rows,
+                     void* d_dst, int32_t* d_offsets, void* stream);
 size_t m3d_generate_proposals3d_batched_workspace_bytes(int batch, int A, int S, int H, int W, int pre_nms_topN);
 int m3d_generate_proposals3d_batched(const float* d_scores, const float* d_deltas, int batch, int A, int S, int H, int W,
                                      const double* anchors, double feat_stride, const double* im_info, int pre_nms_topN,

@@ -854,6 +854,45 @@ M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float*
   return m3d::check_launch("generate_proposals3d_batched");
 }
 
+// ---- rows [0, counts[b]) of every item, packed in item order (the RoIs of a batch as the box head wants them: lib/core/test.py runs the
+// head per tile on rois[:num]; the batched head takes all tiles' rows at once).  One workgroup per item; the row offset of an item is the
+// sum of the counts before it (batch <= 65535, summed by every workgroup: no second launch, no host round trip).
+namespace {
+__global__ __launch_bounds__(256) void compact_rows_kernel(const unsigned* __restrict__ src, long long item_stride_words, int row_words,
+                                                           const int32_t* __restrict__ counts, int max_rows,
+                                                           unsigned* __restrict__ dst, int32_t* __restrict__ offsets) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ long long s_part[256];
+  long long part = 0;
+  for (int i = tid; i < b; i += 256) part += min(max(counts[i], 0), max_rows);
+  s_part[tid] = part;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) s_part[tid] += s_part[tid + st];
+    __syncthreads();
+  }
+  const long long off = s_part[0];
+  const int n = min(max(counts[b], 0), max_rows);
+  if (offsets && tid == 0) {
+    offsets[b] = (int32_t)off;
+    if (b == (int)gridDim.x - 1) offsets[b + 1] = (int32_t)(off + n);
+  }
+  const unsigned* s = src + (long long)b * item_stride_words;
+  unsigned* d = dst + off * row_words;
+  const long long words = (long long)n * row_words;
+  for (long long e = tid; e < words; e += 256) d[e] = s[e];
+}
+}  // namespace
+
+M3D_API int m3d_compact_rows(const void* d_src, size_t item_stride_bytes, size_t row_bytes, const int32_t* d_counts, int batch,
+                             int max_rows, void* d_dst, int32_t* d_offsets, void* stream) {
+  if (!d_src || !d_counts || !d_dst || batch <= 0 || batch > 65535 || max_rows <= 0 || row_bytes == 0) return M3D_EINVAL;
+  if ((row_bytes & 3) || (item_stride_bytes & 3) || ((size_t)d_src & 3) || ((size_t)d_dst & 3)) return M3D_EINVAL;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(batch), dim3(256), 0, m3d::as_stream(stream), (const unsigned*)d_src,
+                     (long long)(item_stride_bytes / 4), (int)(row_bytes / 4), d_counts, max_rows, (unsigned*)d_dst, d_offsets);
+  return m3d::check_launch("compact_rows");
+}
+
 M3D_API size_t m3d_box_results3d_batched_workspace_bytes(int batch) {
   return (size_t)(batch > 0 ? batch : 1) * boxres_item_bytes() + 256;
 }

@@ -52,6 +52,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) float lds_cfloat;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;   // LDS-space element type (32-bit addresses, ds_* instructions)
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 // Pins values at this program point: the empty asm is a use + redefinition, so arithmetic on them cannot be placed earlier (the
 // pre-RA scheduler otherwise hoists the y transform to right behind the LDS reads of the previous step and the wave
@@ -561,8 +562,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
       int m = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) m |= (rok && xf + j >= 0 && xf + j < W) ? (1 << j) : 0;
-      long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
-      if (rok && lin < 0) { lin = 0; m |= 16; }     // the very first quad of the tensor: loaded one element later and shifted
+      const long long lin = (long long)ci * (long long)DHW + ((long long)z * H + y) * W + xf;
+      // The very first quad of the tensor starts one float BEFORE it: bit 16.  Only the first chunk of a slice that starts at channel 0
+      // meets it, i.e. only the PROLOGUE's load (clamped to offset 0, shifted by one element at its commit); every later chunk adds
+      // chunk_bytes to the same negative offset and is an ordinary load - the K loop's commit carries no shift code.
+      if (rok && lin < 0) m |= 16;
       mq[i] = m;
       gq[i] = rok ? (int)(lin * 4) : 0;
       lq[i] = row * C::HXP + 4 * q;
@@ -579,26 +583,41 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
   const unsigned w_pair_bytes = (unsigned)ncb_total * C::W_SEG * 4, w_tile_bytes = (unsigned)cot * C::W_SEG * 4;
   const int lane16 = lane * 16;
   const int chunk_bytes = (int)(CC * DHW * sizeof(float));
-  auto issue_in = [&](int chunk) __attribute__((always_inline)) {
+  auto issue_in = [&](int chunk, auto first) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < C::NI; ++i)
-      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, gq[i] + chunk * chunk_bytes, 0, 0));
+    for (int i = 0; i < C::NI; ++i) {
+      int off = gq[i] + chunk * chunk_bytes;
+      if constexpr (decltype(first)::value) off = max(off, 0);
+      stg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
+    }
   };
-  auto commit_in = [&](int buf) __attribute__((always_inline)) {
+  // LDS byte address of every staged quad in buffer 0 / 1: the K loop's two chunk bodies name their buffer at compile time
+  unsigned lqa[2][C::NI];
+#pragma unroll
+  for (int i = 0; i < C::NI; ++i) {
+    lqa[0][i] = (unsigned)(uintptr_t)(lds + lq[i]);
+    lqa[1][i] = (unsigned)(uintptr_t)(lds + C::LDS_FLOATS + lq[i]);
+  }
+  auto commit_in = [&](auto kbuf, auto first) __attribute__((always_inline)) {
+    constexpr int KB = decltype(kbuf)::value;
 #pragma unroll
     for (int i = 0; i < C::NI; ++i) {                    // branch-free: the K loop must stay one scheduling region
       const int m = mq[i];
       const f32x4 v = stg[i];
-      const bool sh = (m & 16) != 0;
-      const float v0 = sh ? 0.f : v[0], v1 = sh ? v[0] : v[1], v2 = sh ? v[1] : v[2], v3 = sh ? v[2] : v[3];
+      float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+      if constexpr (decltype(first)::value) {
+        const bool sh = (m & 16) != 0 && gq[i] + c_begin * chunk_bytes < 0;
+        v3 = sh ? v2 : v3; v2 = sh ? v1 : v2; v1 = sh ? v0 : v1; v0 = sh ? 0.f : v0;
+      }
       f32x4 o = {(m & 1) ? v0 : 0.f, (m & 2) ? v1 : 0.f, (m & 4) ? v2 : 0.f, (m & 8) ? v3 : 0.f};
       // pinned as ONE 16-byte register tuple: otherwise the store is split into two ds_write2_b32, whose 16-byte lane stride is a
       // 4-way bank conflict (PMC: half of the kernel's LDS cycles were conflicts, profiles/r03_mfma_busy.txt)
       asm volatile("" : "+v"(o));
-      *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lds + buf + lq[i], 16)) = o;
+      *reinterpret_cast<lds_f32x4*>((uintptr_t)lqa[KB][i]) = o;
     }
   };
-  auto stage_w = [&](int chunk, int buf) __attribute__((always_inline)) {
+  auto stage_w = [&](int chunk, auto kbuf) __attribute__((always_inline)) {
+    constexpr int buf = decltype(kbuf)::value * C::LDS_FLOATS;
 #pragma unroll
     for (int i = 0; i < C::NWD; ++i) {
       const int pc = wave8 * C::NWD + i;                 // 1 KB piece of the chunk's PP x 12 KB
@@ -632,7 +651,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
   auto kloop = [&](auto ehc) __attribute__((always_inline)) {
     constexpr int EH = decltype(ehc)::value;
     constexpr int rowU = (EH ? 2 : 0) * C::HXP, rowV = (EH ? 1 : 2) * C::HXP, rowP = (EH ? 3 : 1) * C::HXP;
-    auto read_raw = [&](int buf, int s, f32x2 (&r)[3][2]) __attribute__((always_inline)) {
+    // Per buffer: two B bases (the low and the high 8-byte word of a row are read from DIFFERENT registers, or the load/store optimiser
+    // fuses them into ds_read2_b64 - half the LDS rate of two ds_read_b64) and the A base; pinned, every read = base + immediate.
+    unsigned bB0[2], bB1[2], bA[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      bB0[k] = (unsigned)(uintptr_t)(lds + k * C::LDS_FLOATS + b_base);
+      bB1[k] = bB0[k] + 8;
+      bA[k] = (unsigned)(uintptr_t)(lds + k * C::LDS_FLOATS + C::IN_ELEMS + 4 * lane);
+      asm volatile("" : "+v"(bB0[k]), "+v"(bB1[k]), "+v"(bA[k]));
+    }
+    auto read_raw = [&](auto kbuf, int s, f32x2 (&r)[3][2]) __attribute__((always_inline)) {
+      constexpr int KB = decltype(kbuf)::value;
       const int dz = s / C::PP, pp = s % C::PP;
 #if (M3D_EXP & 16)
 #pragma unroll
@@ -641,14 +671,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
         for (int j = 0; j < 2; ++j) asm volatile("" : "=v"(r[i][j]));      // timing ablation: no raw LDS reads (opaque values)
       return;
 #endif
-      // two address registers per step (pinned): the low and the high 8-byte word of a row are read from DIFFERENT registers, or the
-      // load/store optimiser fuses them into ds_read2_b64 (half the LDS rate of two ds_read_b64)
-      unsigned a0 = (unsigned)(uintptr_t)(lds + buf + b_base + pp * 2 * C::CS + dz * (C::HY * C::HXP));
-      unsigned a1 = a0 + 8;
-      asm volatile("" : "+v"(a0));
-      asm volatile("" : "+v"(a1));
-      const lds_f32x2* p0 = reinterpret_cast<const lds_f32x2*>((uintptr_t)a0);
-      const lds_f32x2* p1 = reinterpret_cast<const lds_f32x2*>((uintptr_t)a1);
+      const unsigned off = (unsigned)(pp * 2 * C::CS + dz * (C::HY * C::HXP)) * 4u;
+      const lds_f32x2* p0 = reinterpret_cast<const lds_f32x2*>((uintptr_t)(bB0[KB] + off));
+      const lds_f32x2* p1 = reinterpret_cast<const lds_f32x2*>((uintptr_t)(bB1[KB] + off));
       r[0][0] = p0[rowU / 2]; r[0][1] = p1[rowU / 2];      // r[row][0] = (x 2t-1, x 2t) = (O[t], E[t]),  r[row][1] = (x 2t+1, x 2t+2) = (O[t+1], E[t+1])
       r[1][0] = p0[rowV / 2]; r[1][1] = p1[rowV / 2];
       r[2][0] = p0[rowP / 2]; r[2][1] = p1[rowP / 2];
@@ -672,24 +697,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
         bf[a][0] = c[a][2] - c[a][3]; bf[a][1] = c[a][0] + c[a][3]; bf[a][2] = c[a][3] - c[a][0]; bf[a][3] = c[a][0] - c[a][1];
       }
     };
-    auto load_a = [&](int buf, int s, float (&af)[8]) __attribute__((always_inline)) {     // this half's 2 x 4 fragments of the step
+    auto load_a = [&](auto kbuf, int s, float (&af)[8]) __attribute__((always_inline)) {     // this half's 2 x 4 fragments of the step
+      constexpr int KB = decltype(kbuf)::value;
       const int dz = s / C::PP, pp = s % C::PP;
 #if (M3D_EXP & 32)
 #pragma unroll
       for (int q = 0; q < 8; ++q) asm volatile("" : "=v"(af[q]));            // timing ablation: no weight-fragment LDS reads
       return;
 #endif
-      const float* w = lds + buf + C::IN_ELEMS + pp * C::W_SEG + 4 * lane;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(w + w2_slot(dz, EH * 2 + a, 0, 0));
+        const f32x4 v = *reinterpret_cast<const lds_f32x4*>((uintptr_t)(bA[KB] + (unsigned)(pp * C::W_SEG + w2_slot(dz, EH * 2 + a, 0, 0)) * 4u));
         af[a * 4 + 0] = v[0]; af[a * 4 + 1] = v[1]; af[a * 4 + 2] = v[2]; af[a * 4 + 3] = v[3];
       }
     };
 
-    read_raw(0, 0, raw[0]);
-    read_raw(0, 1, raw[1]);
-    load_a(0, 0, afq[0]);
+    constexpr std::integral_constant<int, 0> B0{};
+    constexpr std::integral_constant<int, 1> B1{};
+    read_raw(B0, 0, raw[0]);
+    read_raw(B0, 1, raw[1]);
+    load_a(B0, 0, afq[0]);
     transform(raw[0], bfq[0]);
 
     // ---- K loop, software-pipelined ACROSS chunks: raw rows are read two steps ahead, transformed one step ahead; weight fragments
@@ -701,8 +728,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
     // every step waits out the LDS latency four times (tools/asm_trace.py: "r r r [lgkmcnt(1)] v v").  The chunk barrier sits at the
     // end of step NS-2, behind the input commit and a wait for the weight DMA issued in step 0; every LDS read of the current chunk has been
     // issued by then; the last step reads the next chunk's first fragments in its region A and transforms them in B.
-    for (int chunk = c_begin; chunk < nchunk; ++chunk) {
-      const int cur = ((chunk - c_begin) & 1) * C::LDS_FLOATS, nxt = C::LDS_FLOATS - cur;
+    // (two chunk bodies, one per LDS buffer: the buffer is a compile-time constant in every address - see conv3d_wino24.hip)
+    auto chunk_body = [&](auto curc, int chunk) __attribute__((always_inline)) {
+      constexpr std::integral_constant<int, decltype(curc)::value> cur{};
+      constexpr std::integral_constant<int, 1 - decltype(curc)::value> nxt{};
       const int nchk = min(chunk + 1, nchunk - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -720,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
           stage_w(nchk, nxt);
 #endif
 #if !(M3D_EXP & 64)
-          issue_in((M3D_EXP & 512) ? 0 : nchk);
+          issue_in((M3D_EXP & 512) ? 0 : nchk, std::false_type{});
 #endif
         }
 #endif
@@ -757,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
           for (int i = 0; i < C::NI; ++i) asm volatile("" :: "v"(stg[i]));
         }
 #else
-        if (s == NS - 2) commit_in(nxt);
+        if (s == NS - 2) commit_in(nxt, std::false_type{});
 #endif
 #endif
 #pragma unroll
@@ -777,11 +806,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino2e_kernel(const float* __re
         if (s == NS - 2) __syncthreads();                // (waits for this wave's DMA and LDS reads first)
 #endif
       }
+    };
+    for (int chunk = c_begin;;) {
+      chunk_body(B0, chunk);
+      if (++chunk >= nchunk) break;
+      chunk_body(B1, chunk);
+      if (++chunk >= nchunk) break;
     }
   };
   // ---- prologue: chunk 0 -> buffer 0
-  stage_w(c_begin, 0); issue_in(c_begin);
-  commit_in(0);
+  stage_w(c_begin, std::integral_constant<int, 0>{}); issue_in(c_begin, std::true_type{});
+  commit_in(std::integral_constant<int, 0>{}, std::true_type{});
   __syncthreads();
   W2_STAMP(1);
   if (eh) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});

@@ -10,7 +10,7 @@ from ._lib import lib, check, M3DError
 
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
-__all__ = ["roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
+__all__ = ["compact_rows", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
            "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
@@ -203,6 +203,22 @@ def generate_proposals3d_batched(scores, deltas, anchors, feat_stride, im_info, 
                                                  _ptr(kidx), _ptr(num), _ptr(ws), C.c_size_t(wsb), _stream()),
           "generate_proposals3d_batched")
     return rois, probs, kidx, num
+
+
+def compact_rows(src, counts, offsets=None):
+    """src [B,rows,...] (contiguous, 4-byte elements or int64), counts int32 [B] on the device -> (packed [B*rows,...] whose first
+    sum(counts) rows are item 0's valid rows, item 1's, ..., offsets int32 [B+1] on the device).  No host synchronisation: the caller
+    slices `packed[:total]` once it knows the total."""
+    _need_gpu(src, counts)
+    assert src.is_contiguous() and counts.dtype == torch.int32 and counts.is_contiguous() and src.dim() >= 2
+    B, rows = src.shape[0], src.shape[1]
+    row_bytes = src[0, 0].numel() * src.element_size()
+    out = torch.empty((B * rows,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    if offsets is None:
+        offsets = torch.empty((B + 1,), dtype=torch.int32, device=src.device)
+    check(lib().m3d_compact_rows(_ptr(src), C.c_size_t(rows * row_bytes), C.c_size_t(row_bytes), _ptr(counts), B, rows, _ptr(out),
+                                 _ptr(offsets), _stream()), "compact_rows")
+    return out, offsets
 
 
 def box_results3d_batched(scores, boxes, keep_idx, offsets, num_classes, score_thresh, nms_thresh, detections_per_im, max_rows):

@@ -632,6 +632,23 @@ def test_roi_align_adaptive_grid_large_rois(m3d, res):
     assert np.allclose(ggot, gref, rtol=1e-4, atol=1e-5 * np.abs(gref).max())          # float atomics: order differs
 
 
+def test_compact_rows_packs_the_valid_rows_of_every_item(m3d):
+    """m3d_compact_rows = torch.cat([src[b, :counts[b]] for b]) with the counts read on the device: empty items, a full item, a count
+    beyond the row capacity (clamped), 28-byte (RoI) and 8-byte (int64 index) rows; offsets = the exclusive prefix sums."""
+    g = torch.Generator().manual_seed(5)
+    B, rows = 6, 37
+    counts = torch.tensor([5, 0, 37, 1, 50, 0], dtype=torch.int32)
+    rois = torch.randn(B, rows, 7, generator=g)
+    kidx = torch.randint(0, 1 << 40, (B, rows), generator=g)
+    n = [min(int(c), rows) for c in counts]
+    pr, offs = m3d.compact_rows(rois.cuda(), counts.cuda())
+    pk, offs2 = m3d.compact_rows(kidx.cuda(), counts.cuda())
+    total = sum(n)
+    assert offs.cpu().tolist() == [0] + list(np.cumsum(n)) == offs2.cpu().tolist()
+    assert torch.equal(pr[:total].cpu(), torch.cat([rois[b, :n[b]] for b in range(B)], 0))
+    assert torch.equal(pk[:total].cpu(), torch.cat([kidx[b, :n[b]] for b in range(B)], 0))
+
+
 def test_library_options_are_explicit(m3d):
     """include/m3d.h: no environment reads inside the library; the tuning knobs are explicit options."""
     from m3d import _lib

@@ -14,3 +14,14 @@ print("  ms_per_step %.3f backbone_ms_per_volume %.3f conv-family frac %.3f alg 
 print("  ", d["config"]["kernel_ms_per_launch"])
 PY
 done
+timeout -k 10 300 python bench.py --workload prm --no-cpu-baseline > $O/prm_soma.json 2> $O/prm_soma.err; echo "prm soma rc=$?"
+timeout -k 10 300 python bench.py --workload prm-nuclei --no-cpu-baseline > $O/prm_nuclei.json 2> $O/prm_nuclei.err; echo "prm nuclei rc=$?"
+python - <<'PY'
+import json
+for f in ("prm_soma", "prm_nuclei"):
+    try:
+        d = json.loads(open("gpurun_out/r3_full/%s.json" % f).read().strip().splitlines()[-1])
+        print("==", f, "ms/step %.3f" % d["ms_per_step"], {k: round(v, 3) for k, v in d.get("config", {}).get("stage_ms", {}).items()} if isinstance(d.get("config", {}).get("stage_ms"), dict) else "")
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
