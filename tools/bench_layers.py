@@ -53,9 +53,10 @@ for name, cin, cout, k, s in L:
                 runw()
             e1.record(); torch.cuda.synchronize()
             msw = e0.elapsed_time(e1) / reps
-            frac = 4.0 / 9.0 if two_d else 2.0 / 3.0
-            line += "   %s %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% executed)" % (
-                "F(2x2,3x3)" if two_d else "F(2,3)x", msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * frac)
+            fam4 = two_d and m3d._lib.lib().m3d_conv3d_wino2_family() == 4        # F(2x4,3x3): 1/3 of the multiplies, else F(2x2,3x3): 4/9
+            frac = (1.0 / 3.0 if fam4 else 4.0 / 9.0) if two_d else 2.0 / 3.0
+            line += "   %s %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% issued)" % (
+                ("F(2x4,3x3)" if fam4 else "F(2x2,3x3)") if two_d else "F(2,3)x", msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * frac)
     if k == 5 and mode != 0 and m3d.StemWinoConv3d.supports(s):
         sw = m3d.StemWinoConv3d(w)
         runw = (lambda: sw.pooled(x, scale=sc, shift=sh, relu=True)) if fused else (lambda: sw(x, scale=sc, shift=sh, relu=True, out=out))
@@ -66,7 +67,7 @@ for name, cin, cout, k, s in L:
             runw()
         e1.record(); torch.cuda.synchronize()
         msw = e0.elapsed_time(e1) / reps
-        line += "   F(2,5)x %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% executed)" % (msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 0.624)
+        line += "   F(2,5)x %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% issued)" % (msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 0.624)
     tot_w += msw
     print(line)
 print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (Winograd where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %

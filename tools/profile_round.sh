@@ -12,6 +12,7 @@ python bench.py --stress-rois 2>/dev/null | tail -1 > $P/${R}_bench_detect_stres
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d /tmp/rp_det -o det -- python3 /root/repo/bench.py --no-cpu-baseline > $P/${R}_bench_detect_under_rocprof.json 2>/tmp/rp_det.err
 python3 /root/repo/tools/rocpd_stats.py $(find /tmp/rp_det -name "*_results.db" | head -1) $P/${R}_bench_detect_kernel_stats.csv > $P/det_stats.txt
+python3 /root/repo/tools/step_gaps.py $(find /tmp/rp_det -name "*_results.db" | head -1) 40 > $P/${R}_step_timeline.txt
 rocprofv3 --kernel-trace -d /tmp/rp_soma -o soma -- python3 /root/repo/bench.py --workload prm --no-cpu-baseline > $P/${R}_bench_prm_soma_under_rocprof.json 2>/tmp/rp_soma.err
 python3 /root/repo/tools/rocpd_stats.py $(find /tmp/rp_soma -name "*_results.db" | head -1) $P/${R}_prm_soma_kernel_stats.csv > $P/soma_stats.txt
 rocprofv3 --kernel-trace -d /tmp/rp_nuc -o nuc -- python3 /root/repo/bench.py --workload prm-nuclei --no-cpu-baseline > $P/${R}_bench_prm_nuclei_under_rocprof.json 2>/tmp/rp_nuc.err
@@ -23,4 +24,13 @@ cp $(find /tmp/pmcF -name "*counter_collection.csv" | head -1) $P/${R}_pmc/fetch
 cp $(find /tmp/pmcW -name "*counter_collection.csv" | head -1) $P/${R}_pmc/write_size_counter_collection.csv
 python3 /root/repo/tools/pmc_traffic.py $P/${R}_pmc/fetch_size_counter_collection.csv $P/${R}_pmc/write_size_counter_collection.csv 1342177280 $P/${R}_pmc_traffic.json > /dev/null
 bash /root/repo/tools/pmc_mfma_busy.sh > $P/${R}_mfma_busy.txt 2>&1
+cd /root/repo
+BATCH=4 python tools/bench_layers.py 128 20 2>/dev/null | grep -v amdgpu.ids > $P/${R}_bench_layers_batch4.txt
+if [ -f instanceseg-without-voxelwise-labeling_amd/csrc/libm3d_w2stamps.so ]; then
+  export M3D_LIB_PATH=/root/repo/instanceseg-without-voxelwise-labeling_amd/csrc/libm3d_w2stamps.so
+  python tools/w2_stamps.py conv2b conv2a conv3b conv4b 2>/dev/null | grep -v amdgpu.ids > $P/${R}_w24_stamps.txt
+  python tools/stem_stamps.py 2>/dev/null | grep -v amdgpu.ids > $P/${R}_stem_stamps.txt
+  unset M3D_LIB_PATH
+fi
+python bench.py --interleaved --pipelined --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_detect_interleaved_and_pipelined.json
 ls -la $P | tail -30; head -c 600 $P/${R}_bench_detect.json; echo; head -30 $P/${R}_mfma_busy.txt
