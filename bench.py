@@ -712,8 +712,8 @@ def bench_detect(args, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 200 for --workload backbone, whose step is < 1 ms)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 50 for --workload backbone)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 200 for --workload backbone, whose step is < 1 ms)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5; 50 for --workload backbone)")
     ap.add_argument("--workload", default="detect", choices=["detect", "backbone", "prm", "prm-nuclei"])
     ap.add_argument("--vols-per-rank", type=int, default=0, help="volumes per rank per step (default 4 at every N; 8 = BASELINE configs[4]'s partition)")
     ap.add_argument("--interleaved", action="store_true", help="also time the one-stream begin(k+1) / finish(k) loop (N = 1)")
@@ -724,9 +724,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 200 if args.workload == "backbone" else 10     # a timed region of ~0.2 s either way: the clocks have settled
+        args.steps = 200 if args.workload == "backbone" else 20     # a timed region of ~0.1-0.2 s either way
     if args.warmup is None:
-        args.warmup = 50 if args.workload == "backbone" else 3
+        args.warmup = 50 if args.workload == "backbone" else 5      # (3 left the first timed steps ~5 % slow: clocks / allocator still settling)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if not args.dry and args.backend == "nccl":
