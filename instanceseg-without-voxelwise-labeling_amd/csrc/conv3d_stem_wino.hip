@@ -267,8 +267,7 @@ template <int TZ>
 struct Rows {
   static constexpr int HZ = TZ + 4;
   static constexpr int IN = HX4 * HY4 * HZ;         // TZ = 4: 6528 floats, TZ = 8: 9792
-  static constexpr int NQ = HY4 * HZ * (HX4 / 4);
-  static constexpr int NI = (NQ + 255) / 256;
+  static_assert(HY4 * (HX4 / 4) <= 256, "one staging thread per (halo row, quad)");
 };
 
 // Wr[cb][g][lane][j] = (G g_row)[xi] for slot q = 4g + j = pair*6 + xi (q >= 78: 0), co = cb*32 + (lane&31), row = 2*pair + (lane>>5)
