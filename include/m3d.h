@@ -34,7 +34,8 @@ const char* m3d_last_hip_error(void);
 /* Tuning options (benchmark / A-B tooling; production callers never set them).  Names: "xcd_map" (1: XCD-aware
  * workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt"
  * (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" / "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of
- * m3d_linear_bf16x3_forward).  Unknown name -> M3D_EINVAL. */
+ * m3d_linear_bf16x3_forward), "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per
+ * workgroup; -1: rows kernel, planes by grid size).  Unknown name -> M3D_EINVAL. */
 int m3d_set_option(const char* name, int value);
 int m3d_get_option(const char* name, int* value);
 
