@@ -166,7 +166,8 @@ size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth,
  * below ~0.5 the direct kernel is the better choice */
 double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width);
 /* the 2-D Winograd kernel family in use: 1-3 = F(2x2,3x3) variants (4/9 of the direct convolution's multiplies), 4 = F(2x4,3x3)
- * (F(2,3) along y, F(4,3) along x: 1/3; the default); option "tune_wino2" / 100 selects one for A/B runs */
+ * (F(2,3) along y, F(4,3) along x: 1/3; the default), 5 = F(2x4,3x3) with 64 output channels per 4-wave workgroup (A/B only; layers
+ * whose cout is not a multiple of 64 run family 4); option "tune_wino2" / 100 selects one for A/B runs */
 int m3d_conv3d_wino2_family(void);
 int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                 int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,

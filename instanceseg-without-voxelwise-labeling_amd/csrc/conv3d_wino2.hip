@@ -25,6 +25,7 @@
 #include "m3d_common.h"
 #include "conv3d_wino2q.h"
 #include "conv3d_wino24.h"
+#include "conv3d_wino24w.h"
 
 // timing-only ablation builds (tools/ablate_wino2.sh): 1 = no staging, 2 = no chunk barrier, 4 = no B transform VALU (one-wave kernel),
 // 8 = 4 instead of 16 transform VALU per K step in the eta-split kernel, 16 = no raw-row LDS reads, 32 = no weight-fragment LDS reads, 64 = no input loads, 128 = input loads without LDS commit,
@@ -1037,7 +1038,8 @@ M3D_API int m3d_conv3d_wino2_pack_weights(const float* d_weight, int cin, int co
 // ---- kernel family and tile choice.
 // Families (option "tune_wino2" / 100): 0 = library default (family 4), 1 = one wave per SIMD (round 1), 2 = eta-split 8-wave
 // workgroups (round 2 / 3), 3 = quad kernel (4-wave workgroups, two per CU; conv3d_wino2q.hip), 4 = F(2x4,3x3): F(4,3) along x, 3/4 of
-// F(2x2)'s matrix-core work (conv3d_wino24.hip).  "tune_wino2" % 100: 99 = library tile
+// F(2x2)'s matrix-core work (conv3d_wino24.hip), 5 = the same arithmetic with 4-wave workgroups that feed each B fragment to two
+// output-channel blocks (conv3d_wino24w.hip).  "tune_wino2" % 100: 99 = library tile
 // choice, 0..5 = one of the fixed tiles of families 1 / 2 (A/B runs).
 // Tiles (x, y, z outputs per workgroup): eta-split / one-wave 64 x 2 x 4, 32 x 8 x 2, 16 x 16 x 2; quad 64 x 2 x 2, 32 x 4 x 2,
 // 16 x 8 x 2; the narrowest with split-K over workgroups when the map has too few tiles to fill the chip.  Score = useful fraction of
@@ -1052,15 +1054,19 @@ struct Tile { int tx, ty, tz; };
 inline Tile tile_of(int fam, int xt) {
   if (fam == 3) return xt == 32 ? Tile{64, 2, 2} : xt == 16 ? Tile{32, 4, 2} : Tile{16, 8, 2};
   if (fam == 4) return xt == 32 ? Tile{64, 4, 2} : xt == 16 ? Tile{32, 8, 2} : Tile{16, 16, 2};
+  if (fam == 5) return xt == 32 ? Tile{64, 2, 2} : xt == 16 ? Tile{32, 4, 2} : Tile{16, 8, 2};      // x 64 output channels
   return xt == 32 ? Tile{64, 2, 4} : xt == 16 ? Tile{32, 8, 2} : Tile{16, 16, 2};
 }
 inline int chip_slots(int fam) { return fam == 3 ? 512 : 256; }   // resident workgroups: two per CU for the quad kernel
+inline int cout_tile(int fam) { return fam == 5 ? 64 : 32; }      // output channels per workgroup
+// family 5 (conv3d_wino24w.hip) feeds a B fragment to two 32-channel blocks: layers whose cout is not a multiple of 64 run family 4
+inline int family_for(int fam, int cout) { return (fam == 5 && (cout & 63)) ? 4 : fam; }
 
 struct SplitPlan { int ksplit, cps; size_t slice; };
 SplitPlan plan_splitk(int fam, int batch, int cin, int cout, int depth, int height, int width) {
   const Tile t = tile_of(fam, 8);
   const long long tiles = (long long)((width + t.tx - 1) / t.tx) * ((height + t.ty - 1) / t.ty) * ((depth + t.tz - 1) / t.tz) *
-                          ((cout + 31) / 32) * batch;
+                          ((cout + cout_tile(fam) - 1) / cout_tile(fam)) * batch;
   const int nchunk = (cin + 3) / 4;
   int ks = (int)(chip_slots(fam) / (tiles > 0 ? tiles : 1));   // one resident round, never a ragged second one
   if (ks > 8) ks = 8;
@@ -1076,7 +1082,7 @@ int choose_xt(int fam, int batch, int cin, int cout, int D, int H, int W, double
   if (const int tv = m3d::opt(m3d::OPT_TUNE_WINO2_XT); tv >= 0) { if (best_score) *best_score = 1.0; return tv; }
   if (W < 12) return 0;
   auto up = [](int v, int t) { return (double)((v + t - 1) / t) * t; };
-  const double vol = (double)D * H * W, cot = (cout + 31) / 32, slots = chip_slots(fam);
+  const double vol = (double)D * H * W, cot = (cout + cout_tile(fam) - 1) / cout_tile(fam), slots = chip_slots(fam);
   double best = -1.0; int xt = 0;
   const int id[3] = {32, 16, 8};
   for (int i = 0; i < 3; ++i) {
@@ -1107,6 +1113,7 @@ int launch_family(int fam, int xt, const float* in, const float* wp, float* out,
                   hipStream_t st, int ksplit) {
   if (fam == 3) return m3d_w2q::launch(xt, false, false, in, wp, out, B, cin, cout, D, H, W, quad_epi(ep), st);
   if (fam == 4) return m3d_w24::launch(xt, false, false, in, wp + pack22_floats(cin, cout), out, B, cin, cout, D, H, W, quad_epi(ep), st);
+  if (fam == 5) return m3d_w24w::launch(xt, false, false, in, wp + pack22_floats(cin, cout), out, B, cin, cout, D, H, W, quad_epi(ep), st);
   if (xt == 32) return launch_wino2<4, 32, 4, 1>(in, wp, out, B, cin, cout, D, H, W, ep, st);
   if (xt == 16) return launch_wino2<4, 16, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st);
   if (xt == 8) return launch_wino2<4, 8, 2, 2>(in, wp, out, B, cin, cout, D, H, W, ep, st, ksplit);
@@ -1122,13 +1129,14 @@ M3D_API int m3d_conv3d_wino2_family(void) { return family(); }
 M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0.0;
   double sc = 0.0;
-  (void)choose_xt(family(), batch, cin, cout, depth, height, width, &sc);
+  (void)choose_xt(family_for(family(), cout), batch, cin, cout, depth, height, width, &sc);
   return sc;
 }
 
 namespace {
 size_t workspace_bytes_for(int fam, int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0;
+  fam = family_for(fam, cout);
   if (choose_xt(fam, batch, cin, cout, depth, height, width) != 8) return 0;
   const SplitPlan p = plan_splitk(fam, batch, cin, cout, depth, height, width);
   return p.ksplit > 1 ? p.ksplit * p.slice * sizeof(float) : 0;
@@ -1156,9 +1164,10 @@ int forward_ws_family(int fam, const float* d_in, const float* d_packed, float* 
   const size_t DHW = (size_t)depth * height * width;
   if ((size_t)cin * DHW * sizeof(float) >= 0x7FFFFFFFull || batch > 65535) return M3D_EUNSUPPORTED;
   hipStream_t st = m3d::as_stream(stream);
+  fam = family_for(fam, cout);
   W2Epi ep{d_scale, d_shift, relu, 0, 1, 0, 0};
   const int variant = m3d::opt(m3d::OPT_TUNE_WINO2) % 100;
-  if (fam != 3 && fam != 4) {
+  if (fam != 3 && fam != 4 && fam != 5) {
 #define M3D_W2(i, ...) if (variant == i) return launch_wino2<__VA_ARGS__>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
     M3D_W2(0, 4, 32, 2, 2)      // 64 x 4 y x 2 z outputs x 32 channels
     M3D_W2(1, 4, 32, 4, 1)
@@ -1218,7 +1227,10 @@ M3D_API int m3d_conv3d_wino2_forward_pool2(const float* d_in, const float* d_pac
   // 64-wide tiles from 48 voxels on, else 32-wide (conv3b on 32^3 maps: the pool of the 16^3-class layers is fused as well)
   if (family() == 3)
     return m3d_w2q::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
-  if (family() == 4)
+  if (family_for(family(), cout) == 5)
+    return m3d_w24w::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
+                            width, quad_epi(ep), st);
+  if (family() == 4 || family() == 5)
     return m3d_w24::launch(width < 48 ? 16 : 32, true, false, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
                            width, quad_epi(ep), st);
   if (width < 48) return launch_wino2<4, 16, 2, 2, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
@@ -1238,7 +1250,10 @@ M3D_API int m3d_conv3d_wino2_forward_pool2_argmax(const float* d_in, const float
   hipStream_t st = m3d::as_stream(stream);
   if (family() == 3)
     return m3d_w2q::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed, d_out, batch, cin, cout, depth, height, width, quad_epi(ep), st);
-  if (family() == 4)
+  if (family_for(family(), cout) == 5)
+    return m3d_w24w::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
+                            width, quad_epi(ep), st);
+  if (family() == 4 || family() == 5)
     return m3d_w24::launch(width < 48 ? 16 : 32, true, true, d_in, d_packed + pack22_floats(cin, cout), d_out, batch, cin, cout, depth, height,
                            width, quad_epi(ep), st);
   if (width < 48) return launch_wino2e<4, 16, 2, 2, true, true>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);

@@ -371,6 +371,31 @@ def test_conv3d_stem_winograd_kernels_agree(m3d, tune):
     assert torch.equal(yp, torch.nn.functional.max_pool3d(y, 2, 2))
 
 
+@pytest.mark.parametrize("fam", [2, 3, 5])
+def test_conv3d_winograd_ab_families_agree_with_fp64(m3d, fam):
+    """The A/B kernel families behind option tune_wino2 (2: F(2x2) eta-split, 3: quad, 5: the wide F(2x4) kernel with 64 output channels
+    per workgroup) stay correct: plain and pooled forward of a 64 -> 128 layer on a ragged 9 x 22 x 70 map against fp64."""
+    from m3d import _lib
+    g = torch.Generator().manual_seed(fam)
+    x = torch.randn(2, 64, 9, 22, 70, generator=g)
+    w = torch.randn(128, 64, 3, 3, 3, generator=g) * (2.0 / (64 * 27)) ** 0.5
+    sc = torch.rand(128, generator=g) + 0.5
+    sh = torch.randn(128, generator=g)
+    ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1)
+                     + sh.double().view(1, -1, 1, 1, 1))
+    old = _lib.get_option("tune_wino2")
+    _lib.set_option("tune_wino2", fam * 100 + 99)
+    try:
+        conv = m3d.WinoConv3d(w.cuda(), two_d=True)
+        y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+        yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True) if conv.supports_pool(70) else None
+    finally:
+        _lib.set_option("tune_wino2", old)
+    assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+    if yp is not None:
+        assert torch.equal(yp, torch.nn.functional.max_pool3d(y, 2, 2))
+
+
 def test_conv3d_winograd_rejects_narrow_maps(m3d):
     conv = m3d.WinoConv3d(torch.randn(8, 4, 3, 3, 3).cuda())
     assert not conv.supports(16) and conv.supports(24) and not conv.supports_pool(32)

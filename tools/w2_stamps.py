@@ -31,11 +31,11 @@ for name in (sys.argv[1:] or ["conv2b", "conv2a", "conv3b", "conv4b"]):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24"):   # every 2-D Winograd family
+    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24", "m3d_debug_set_stamp_buffer_24w"):   # every 2-D Winograd family
         getattr(L, f)(ctypes.c_void_p(buf.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
-    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24"):
+    for f in ("m3d_debug_set_stamp_buffer", "m3d_debug_set_stamp_buffer_q", "m3d_debug_set_stamp_buffer_24", "m3d_debug_set_stamp_buffer_24w"):
         getattr(L, f)(ctypes.c_void_p(0))
     ms = e0.elapsed_time(e1)
     st = buf.view(-1, 8).cpu()
@@ -45,8 +45,9 @@ for name in (sys.argv[1:] or ["conv2b", "conv2a", "conv3b", "conv4b"]):
     seg = [(t[:, i + 1] - t[:, i]) for i in range(4)]
     tot = t[:, 4] - t[:, 0]
     clk = (tot / (st[:, 6] - st[:, 5]).double().clamp(min=1) * 0.1).median().item()     # GHz: cycles per 10 ns tick
-    nchunk = cin // 4
-    IDEAL = 4608 if L.m3d_conv3d_wino2_family() == 4 else 6144      # MFMA cycles per chunk and SIMD: 72 (F(2x4)) or 96 (F(2x2)) x 64
+    fam = L.m3d_conv3d_wino2_family()
+    nchunk = cin // 2 if fam == 5 else cin // 4                    # family 5 stages one channel pair per chunk
+    IDEAL = 2304 if fam == 5 else 4608 if fam == 4 else 6144        # MFMA cycles per chunk and SIMD: 36 / 72 (F(2x4)) or 96 (F(2x2)) x 64
     med = [x_.median().item() for x_ in seg]
     span = (t[:, 4].max() - t[:, 0].min()).item()
     print("%-7s batch %d: %d workgroups, kernel %.3f ms (with stamps), clock %.2f GHz" % (name, BATCH, n, ms, clk))
