@@ -256,6 +256,31 @@ __global__ __launch_bounds__(256, 2) void fc_gemm_kernel(FcArgs a) {
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                         float* __restrict__ out, long long MN, int N, int slices, int slices_tail,
                                                         long long full_elems /* m_full * N */, int relu) {
+  // four consecutive outputs per thread (N % 4 == 0: a quad never straddles a row or the full / tail boundary), every slice's quad one
+  // 16-byte load, all issued before the first add; the sum order per element is slice 0, 1, 2, ... as before (bit-identical results)
+  if ((N & 3) == 0 && ((((size_t)part) | ((size_t)out) | ((size_t)bias)) & 15) == 0) {
+    typedef float f32x4r __attribute__((ext_vector_type(4)));
+    const long long Q = MN >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < Q; q += (long long)gridDim.x * 256) {
+      const long long e = q << 2;
+      const int ns = e < full_elems ? slices : slices_tail;
+      if (ns == 1) continue;
+      f32x4r v = *reinterpret_cast<const f32x4r*>(part + e);
+      int s = 1;
+      for (; s + 3 < ns; s += 4) {
+        const f32x4r a = *reinterpret_cast<const f32x4r*>(part + (size_t)s * MN + e);
+        const f32x4r b = *reinterpret_cast<const f32x4r*>(part + (size_t)(s + 1) * MN + e);
+        const f32x4r c = *reinterpret_cast<const f32x4r*>(part + (size_t)(s + 2) * MN + e);
+        const f32x4r d = *reinterpret_cast<const f32x4r*>(part + (size_t)(s + 3) * MN + e);
+        v += a; v += b; v += c; v += d;
+      }
+      for (; s < ns; ++s) v += *reinterpret_cast<const f32x4r*>(part + (size_t)s * MN + e);
+      if (bias) v += *reinterpret_cast<const f32x4r*>(bias + (int)(e % N));
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *reinterpret_cast<f32x4r*>(out + e) = v;
+    }
+    return;
+  }
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < MN; e += (long long)gridDim.x * 256) {
     const int ns = e < full_elems ? slices : slices_tail;
     if (ns == 1) continue;
