@@ -264,7 +264,7 @@ class DetectorM3D:
         c = self.cfg
         R = int(scores.shape[0])
         if 0 < R <= ops.fused_max_boxes():                # one launch, one host read of the per-class counts
-            off = torch.tensor([0, R], dtype=torch.int32, device=scores.device)
+            off = torch.arange(2, dtype=torch.int32, device=scores.device) * R      # [0, R] built on the device (a host list would be a blocking copy)
             kin = None if scores_keep_idx is None else scores_keep_idx.to(torch.int64).contiguous()
             cb, ck, cnt = ops.box_results3d_batched(scores, boxes, kin, off, c.num_classes, c.score_thresh, c.nms, c.detections_per_im, R)
             n = cnt[0].cpu().tolist()

@@ -208,11 +208,13 @@ class PRMEngine:
         a = keep % A                                  # unravel_index(idx, (B,S,H,W,A)) with B = 1 (:136-139)
         pos = keep // A
         peaks = torch.stack([torch.zeros_like(a), a, pos // (h_ * w_), (pos // w_) % h_, pos % w_], 1)
-        valid = sc > peak_threshold                                                                            # :161-162
-        if int(valid.sum()) == 0:
+        # one host read for the peak selection (the index list; its length is then known): a count plus three boolean-mask gathers
+        # were four synchronisations, each an idle gap of 20-70 us on the GPU
+        vidx = torch.nonzero(sc > peak_threshold).squeeze(1)                                                   # :161-162
+        if vidx.numel() == 0:
             return None                                # no score above peak_threshold (:161-162 never true, :189-190)
-        peaks_v = peaks[valid]
-        dets = torch.cat([bx[valid], sc[valid].unsqueeze(1)], 1).double()                                      # :163
+        peaks_v = peaks.index_select(0, vidx)
+        dets = torch.cat([bx.index_select(0, vidx), sc.index_select(0, vidx).unsqueeze(1)], 1).double()        # :163
         win, sums, origins = self.backward_windows(peaks_v[:, 1:].to(torch.int32).contiguous(), saved, top, data)
         out = dict(crm=prob, peaks=peaks_v, dets=dets, windows=win, sums=sums, origins=origins)
         if dense:
