@@ -513,10 +513,13 @@ def bench_detect(args, rank, world, dist):
         def step_host():
             b = state["i"] & 1
             state["i"] += 1
-            upload(b ^ 1)                                        # next step's volumes cross PCIe while this step computes
             torch.cuda.current_stream().wait_event(ready[b])
             packed = batch(bufs[b])
             freed[b].record()
+            # the NEXT step's volumes cross PCIe under this step's box head.  The upload is issued after this step's launches: on this
+            # stack the 16.8 MB pinned hipMemcpyAsync holds the calling thread for ~0.5 ms, and issued first it kept the GPU waiting
+            # for the step's kernels (host-to-host 5.0-5.2 ms against 4.7 resident; now equal)
+            upload(b ^ 1)
             g = exchange(packed)
             if rank == 0:
                 # outputs double-buffered like the inputs: this step's detections start their way to the host, the host waits for the
