@@ -143,20 +143,26 @@ PROBE_STEPS = 3        # timed steps that carry per-kernel HIP-event spans (the 
 
 def timed_loop(step, steps, warmup, dist, sync):
     """The contract's timing: W untimed steps, then exactly K steps between barrier + device synchronize on both sides."""
+    import gc
     for _ in range(warmup):
         step()
     sync()
     if dist is not None:
         dist.barrier()
     sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    sync()
-    return time.perf_counter() - t0
+    gc.collect()
+    gc.disable()                                        # a collection inside a 0.1 s timed region is a millisecond nobody asked for
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+        return time.perf_counter() - t0
+    finally:
+        gc.enable()
 
 
 # ------------------------------------------------------------------------------------------------ dry run (CPU, gloo)
