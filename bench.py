@@ -398,7 +398,7 @@ def bench_detect(args, rank, world, dist):
     # ---- (1) value: raw volumes resident in HBM
     # initialisation, before the W warm-up steps the caller asks for: every kernel's first launch (code-object load), the caching
     # allocator's and the pinned pools' growth, the HIP-event pool of the probe - none of it is the hot path
-    INIT_STEPS = 8
+    INIT_STEPS = int(os.environ.get("M3D_BENCH_INIT_STEPS", "8"))
     det.probe = Probe()
     for _ in range(INIT_STEPS):
         step_resident()
