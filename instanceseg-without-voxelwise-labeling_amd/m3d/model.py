@@ -359,22 +359,24 @@ class DetectorM3D:
         rois_b, probs_b, kidx_b, num = st["props"]
         st["ready"].synchronize()                                                  # host read 1: sizes the GEMM rows
         counts = st["num_host"].tolist()
+        total = sum(counts)
+        # the GPU is idle from here until the first launch below: nothing but that launch's arguments is prepared first, the rest of
+        # the bookkeeping (stream marks, dictionaries, host-side offsets) follows behind the box head's launches
+        head = self.has_head and total > 0
+        if head:
+            rois, kidx = st["rois_packed"][:total], st["kidx_packed"][:total]       # (were two torch.cat launches behind the host read)
+            cls, bbox = self.box_head(feat, rois)                                  # one RoIAlign + one GEMM chain for all tiles
         self._release_counts(st.pop("num_host"))                                   # read: back to the pool
         cur = torch.cuda.current_stream()
-        for t in (feat, prob, deltas, rois_b, probs_b, kidx_b):
+        for t in (feat, prob, deltas, rois_b, probs_b, kidx_b, st["rois_packed"], st["kidx_packed"], st["offs_dev"]):
             t.record_stream(cur)
         rows = rois_b.shape[1]
         raw = dict(feat=feat, rpn_prob=prob, rpn_deltas=deltas, rois=rois_b, roi_probs=probs_b, keep_idx=kidx_b, num_rois=counts)
-        total = sum(counts)
         offs = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
         # the row offsets are on the device already (compact_rows in begin()): a pageable `.to(device)` of `offs` where they are used,
         # behind the box head, made the host wait for the whole box head and left the GPU idle for 44 us per step
         offs_dev = st["offs_dev"]
-        if self.has_head and total > 0:
-            rois, kidx = st["rois_packed"][:total], st["kidx_packed"][:total]       # (were two torch.cat launches behind the host read)
-            for t in (st["rois_packed"], st["kidx_packed"], offs_dev):
-                t.record_stream(cur)
-            cls, bbox = self.box_head(feat, rois)                                  # one RoIAlign + one GEMM chain for all tiles
+        if head:
             pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
             with self.span("box_results"):
                 cb, ck, cnt = ops.box_results3d_batched(cls, pred, kidx, offs_dev,
