@@ -353,6 +353,15 @@ int m3d_norm1_batched(const void* d_in, int in_dtype, int batch, int64_t n, int 
 int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
                  const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
                  float* d_out, void* stream);
+/* Peak selection on the device (lib/prm/peak_response_mapping_3d.py:124-139,161-163): class 1's kept detections d_dets [rows,7]
+ * (x1,y1,z1,x2,y2,z2,score; the first *d_count rows are valid) with their flat score indices d_keep_idx into (S,H,W,A)
+ * (generate_proposals_3d.py:160) -> the detections whose score > peak_threshold, in order: *d_num (<= cap), d_peaks int32 [cap,4] =
+ * (anchor,s,h,w) = unravel_index(idx,(S,H,W,A)) reordered, d_out_dets [cap,7].  h_num / h_peaks / h_out_dets (optional, may be NULL):
+ * device-accessible HOST mirrors (pinned memory) the kernel writes as well, so that the caller learns count, peaks and detections
+ * from one stream event instead of three read-backs.  One workgroup; no host synchronisation. */
+int m3d_prm_select_peaks(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
+                         int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
+                         int32_t* h_peaks, float* h_out_dets, void* stream);
 int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
                     int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height,
                     int up_width, const float* d_scale, const float* d_norm, int depth, int height, int width,

@@ -37,6 +37,63 @@ __global__ __launch_bounds__(256) void prm_seed_kernel(const int* __restrict__ p
   out[e] = (h[c * SHW + pos] - *h_off) * (wv * gn);
 }
 
+// ---- peak selection (peak_response_mapping_3d.py:124-139,161-163) on the device ----
+// The reference takes class 1's kept detections (cls_keep_idx[1], :125), turns each one's flat score index into
+// (b, a, s, h, w) = unravel_index(idx, (B,S,H,W,A)) reordered (:136-139) and keeps those whose score exceeds peak_threshold
+// (:161-162), in detection order.  One workgroup compacts them in that order (ballot + wave prefix) and writes the count, the peaks
+// and the detections to the device (for the back-propagation kernels) and, when given, to a host-mapped mirror (pinned memory: the
+// caller waits for ONE event and has everything it needs - count, peaks, detections - without a further read).
+__global__ __launch_bounds__(256) void prm_select_peaks_kernel(const float* __restrict__ dets /*[rows,7]*/, const long long* __restrict__ keep /*[rows]*/,
+                                                               const int* __restrict__ count, int rows, float thr, int A, int S, int H, int W,
+                                                               int cap, int* __restrict__ num, int* __restrict__ peaks /*[cap,4]*/,
+                                                               float* __restrict__ out /*[cap,7]*/, int* __restrict__ h_num,
+                                                               int* __restrict__ h_peaks, float* __restrict__ h_out) {
+  __shared__ int wave_tot[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(max(*count, 0), rows);
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    float d[7];
+    bool ok = false;
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) d[k] = dets[(size_t)i * 7 + k];
+      ok = d[6] > thr;                                                // :161-162
+    }
+    const unsigned long long m = __ballot(ok);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int pos = base + before;
+    for (int w = 0; w < wave; ++w) pos += wave_tot[w];
+    if (ok && pos < cap) {
+      const long long idx = keep[i];                                  // flat index into (S,H,W,A), generate_proposals_3d.py:160
+      const int a = (int)(idx % A);
+      const long long q = idx / A;
+      const int w_ = (int)(q % W), h_ = (int)((q / W) % H), s_ = (int)(q / ((long long)W * H));
+      peaks[4 * pos] = a; peaks[4 * pos + 1] = s_; peaks[4 * pos + 2] = h_; peaks[4 * pos + 3] = w_;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) out[(size_t)pos * 7 + k] = d[k];
+      if (h_peaks) { h_peaks[4 * pos] = a; h_peaks[4 * pos + 1] = s_; h_peaks[4 * pos + 2] = h_; h_peaks[4 * pos + 3] = w_; }
+      if (h_out) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) h_out[(size_t)pos * 7 + k] = d[k];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int t = min(base, cap);
+    *num = t;
+    if (h_num) *h_num = t;
+  }
+}
+
 // ---- prepare: upper gradient window -> G_N window of this layer ----
 struct PrepParams {
   const float* gup;        // [P, C, U, U, U]
@@ -341,6 +398,16 @@ M3D_API int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_p
 
 // in_strip / out_strip: 0 = batch-major [P,C,n,n,n], 1 = strip [C,n,n,P*(n+1)] (see PrepParams).  d_up_offset non-null: d_gup is the
 // bare backward-data of the layer above (no PreHook multiply in its epilogue) and the multiply by (d_xnext - *d_up_offset) is done here.
+M3D_API int m3d_prm_select_peaks(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
+                                 int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
+                                 int32_t* h_peaks, float* h_out_dets, void* stream) {
+  if (!d_dets || !d_keep_idx || !d_count || !d_num || !d_peaks || !d_out_dets) return M3D_EINVAL;
+  if (rows <= 0 || cap <= 0 || A <= 0 || S <= 0 || H <= 0 || W <= 0) return M3D_EINVAL;
+  hipLaunchKernelGGL(prm_select_peaks_kernel, dim3(1), dim3(256), 0, m3d::as_stream(stream), d_dets, (const long long*)d_keep_idx, d_count, rows,
+                     peak_threshold, A, S, H, W, cap, d_num, d_peaks, d_out_dets, h_num, h_peaks, h_out_dets);
+  return m3d::check_launch("prm_select_peaks");
+}
+
 M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
                                int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
                                const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip,

@@ -44,9 +44,9 @@ struct RoiGeom {
   int grid_w, grid_h, grid_s, batch;
 };
 
-__device__ inline RoiGeom roi_geom(const float* r, float scale, int AS, int AH, int AW, int ratio) {
+__device__ inline RoiGeom roi_geom(const float* r, float scale, int AS, int AH, int AW, int ratio, int B) {
   RoiGeom g;
-  g.batch = (int)r[0];                                                  // :94
+  g.batch = min(max((int)r[0], 0), B - 1);                              // :94 (clamped: a garbage row must not fault the GPU)
   g.start_w = r[1] * scale; g.start_h = r[2] * scale; g.start_s = r[3] * scale;   // :97-102
   float end_w = r[4] * scale, end_h = r[5] * scale, end_s = r[6] * scale;
   float roi_s = fmaxf(end_s - g.start_s, 1.f);                          // :105-107
@@ -168,13 +168,13 @@ __device__ inline void roi_untabled_range(const float* __restrict__ feat_or_top,
 // grid = (num_rois, channel_chunks); block = 256
 template <bool kBackward>
 __global__ __launch_bounds__(256) void roi_align3d_kernel(const float* __restrict__ feat_or_top, const float* __restrict__ rois,
-                                                          float* __restrict__ out_or_grad, int C, int S, int H, int W,
+                                                          float* __restrict__ out_or_grad, int B, int C, int S, int H, int W,
                                                           int AS, int AH, int AW, float scale, int ratio, int ch_per_block,
                                                           int* __restrict__ status) {
   __shared__ AxisSample tz[kMaxTable], ty[kMaxTable], tx[kMaxTable];
   __shared__ RoiGeom sg;
   const int n = blockIdx.x;
-  if (threadIdx.x == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio);
+  if (threadIdx.x == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio, B);
   __syncthreads();
   const RoiGeom g = sg;
   if (AS * g.grid_s > kMaxTable || AH * g.grid_h > kMaxTable || AW * g.grid_w > kMaxTable) {   // adaptive grid beyond the tables
@@ -421,9 +421,9 @@ struct V3Shared {
   int rng[6];
   int s_ok;
 };
-__device__ inline V3Dims v3_setup(const float* __restrict__ rois, int n, float scale, int S, int H, int W, V3Shared& sh) {
+__device__ inline V3Dims v3_setup(const float* __restrict__ rois, int n, float scale, int B, int S, int H, int W, V3Shared& sh) {
   const int tid = threadIdx.x;
-  if (tid == 0) sh.sg = roi_geom(rois + 7 * n, scale, 7, 7, 7, 2);
+  if (tid == 0) sh.sg = roi_geom(rois + 7 * n, scale, 7, 7, 7, 2, B);
   __syncthreads();
   const RoiGeom g = sh.sg;
   if (tid < 14) sh.tz[tid] = make_sample(g.start_s, g.bin_s, tid / 2, tid % 2, 2, S, -1.0);
@@ -470,11 +470,11 @@ __device__ inline int v3_waves(const V3Dims& d) {
 // Every other workgroup of the (RoI, C/8) grid leaves after one load.
 constexpr unsigned int kSmallBits = 0x7FC05A11u, kMedBits = 0x7FC03ED0u;
 
-__global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict__ rois, float* __restrict__ out, int C, int S, int H,
+__global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict__ rois, float* __restrict__ out, int B, int C, int S, int H,
                                                         int W, float scale) {
   __shared__ V3Shared sh;
   const int n = blockIdx.x, tid = threadIdx.x;
-  const V3Dims d = v3_setup(rois, n, scale, S, H, W, sh);
+  const V3Dims d = v3_setup(rois, n, scale, B, S, H, W, sh);
   const unsigned int cls = !sh.s_ok ? kDeclinedBits : (v3_waves(d) == 4 ? kSmallBits : kMedBits);
   for (int k = tid; 8 * k < C; k += 256) out[((size_t)n * C + 8 * k) * 343] = __uint_as_float(cls);
 }
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict_
 // marks = 1: grid (R, C / 8), work split read from the markers.  marks = 0 (C not a multiple of 32): grid (R, ceil(C / ch_per_block)),
 // every workgroup does the set-up and takes its ch_per_block channels if the RoI qualifies.
 __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
-                                                                 float* __restrict__ out, int C, int S, int H, int W, float scale,
+                                                                 float* __restrict__ out, int B, int C, int S, int H, int W, float scale,
                                                                  int ch_per_block, int marks) {
   __shared__ V3Shared sh;
   extern __shared__ float dyn[];
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __
     else if (m == kSmallBits && blockIdx.y == 0) { c0 = 0; c1 = C; }
     else return;
   }
-  const V3Dims d = v3_setup(rois, n, scale, S, H, W, sh);
+  const V3Dims d = v3_setup(rois, n, scale, B, S, H, W, sh);
   if (!sh.s_ok) return;                                     // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI
   const RoiGeom g = sh.sg;
   const int wave = tid >> 6;
@@ -516,7 +516,7 @@ struct AxisTaps { int lo, hi, n; };        // sub-volume range [lo, hi] and numb
 
 template <int kDummy>
 __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
-                                                                  float* __restrict__ out, int C, int S, int H, int W, int AS,
+                                                                  float* __restrict__ out, int B, int C, int S, int H, int W, int AS,
                                                                   int AH, int AW, float scale, int ratio, int ch_per_block,
                                                                   int skip_v3 /* RoIs the v3 kernel handles are skipped */) {
   __shared__ AxisSample tz[kMaxTable], ty[kMaxTable], tx[kMaxTable];
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
   const int tid = threadIdx.x;
   if (skip_v3 == 2 &&                                       // v3 marked the RoIs it declined (see there); everyone else is done
       __float_as_uint(out[((size_t)n * C + (size_t)blockIdx.y * ch_per_block) * (AS * AH * AW)]) != kDeclinedBits) return;
-  if (tid == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio);
+  if (tid == 0) sg = roi_geom(rois + 7 * n, scale, AS, AH, AW, ratio, B);
   __syncthreads();
   const RoiGeom g = sg;
   const int nz = AS * g.grid_s, ny = AH * g.grid_h, nx = AW * g.grid_w;
@@ -775,21 +775,21 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
     // the per-RoI work split travels through markers in the output (every 8th channel); usable when all chunk starts fall there
     const int marks = (C % 32 == 0 && ccpb % 8 == 0) ? 1 : 0;
     if (v3 && marks) {              // work split per RoI through markers in the output (roi_class_kernel)
-      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, C, S, H, W, scale);
-      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, C, S, H, W, scale,
+      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale);
+      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, scale,
                          8, 1);
     } else if (v3) {                // 32 channels per workgroup
       const int cpb3 = 32;
-      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, C, S,
+      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S,
                          H, W, scale, cpb3, 0);
     }
     hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, (C + ccpb - 1) / ccpb) : grid, block, lds, m3d::as_stream(stream), a,
-                       rois, o, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3 ? (marks ? 2 : 1) : 0);
+                       rois, o, B, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3 ? (marks ? 2 : 1) : 0);
   } else if (!backward)
-    hipLaunchKernelGGL(roi_align3d_kernel<false>, grid, block, 0, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
+    hipLaunchKernelGGL(roi_align3d_kernel<false>, grid, block, 0, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, AS, AH, AW,
                        scale, ratio, cpb, (int*)nullptr);
   else
-    hipLaunchKernelGGL(roi_align3d_kernel<true>, grid, block, 0, m3d::as_stream(stream), a, rois, o, C, S, H, W, AS, AH, AW,
+    hipLaunchKernelGGL(roi_align3d_kernel<true>, grid, block, 0, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, AS, AH, AW,
                        scale, ratio, cpb, (int*)nullptr);
   return m3d::check_launch("roi_align3d");
 }

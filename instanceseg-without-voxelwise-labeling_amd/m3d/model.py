@@ -220,9 +220,13 @@ class DetectorM3D:
         rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1], (feat.shape[0],) + tuple(feat.shape[2:]))
                                     and feat[0].numel() * 4 < 0x7FFFFFFF) else self.rpn_conv
         h = rc(feat, shift=self.rpn_conv_bias, relu=True)
+        return self.rpn_outputs(h)
+
+    def rpn_outputs(self, h):
+        """The two 1x1x1 heads as one conv + sigmoid (rpn_heads.py:96-98,116): (prob [B,A,s,h,w], deltas [B,6A,s,h,w])."""
         o = self.rpn_heads(h, shift=self.rpn_heads_bias)
         logits, deltas = o[:, :self.A], o[:, self.A:]
-        return torch.sigmoid(logits), deltas.contiguous()
+        return torch.sigmoid(logits).contiguous(), deltas.contiguous()
 
     def _fused_ok(self, prob):
         """The one-workgroup-per-tile kernels (csrc/box_fused.hip) hold at most 2048 candidates per tile."""
@@ -332,6 +336,10 @@ class DetectorM3D:
                 # head (and their row offsets) by a kernel that reads the counts on the device - finish() only slices
                 st["rois_packed"], st["offs_dev"] = ops.compact_rows(st["props"][0], num)
                 st["kidx_packed"], _ = ops.compact_rows(st["props"][2], num, st["offs_dev"])
+                # finish() may run on another stream: it orders its readers of the packed buffers behind this event with a device-side
+                # wait (the host only ever waits for `ready`, the counts)
+                st["packed_ready"] = torch.cuda.Event()
+                st["packed_ready"].record()
         return st
 
     def _pinned_counts(self, like):
@@ -363,6 +371,7 @@ class DetectorM3D:
         # the GPU is idle from here until the first launch below: nothing but that launch's arguments is prepared first, the rest of
         # the bookkeeping (stream marks, dictionaries, host-side offsets) follows behind the box head's launches
         head = self.has_head and total > 0
+        torch.cuda.current_stream().wait_event(st["packed_ready"])                 # device-side: compact_rows -> RoIAlign / box results
         if head:
             rois, kidx = st["rois_packed"][:total], st["kidx_packed"][:total]       # (were two torch.cat launches behind the host read)
             cls, bbox = self.box_head(feat, rois)                                  # one RoIAlign + one GEMM chain for all tiles

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -583,6 +583,55 @@ def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off):
     check(lib().m3d_prm_seed(_ptr(peaks), P, _ptr(prob), _ptr(norm_cls), _ptr(w_cls), _ptr(h), _ptr(h_off), A, Cc, S, H, W,
                              _ptr(out), _stream()), "prm_seed")
     return out
+
+
+class PinnedPool:
+    """Pinned host buffers of one size, handed out per call and returned after the read: any number of tiles may be in flight
+    (double-buffered volume drivers) without one overwriting another's mirror.  Pinning is a slow driver call, hence the pool."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, nbytes):
+        lst = self.free.setdefault(int(nbytes), [])
+        if not lst:
+            lst.extend(torch.empty((int(nbytes),), dtype=torch.uint8).pin_memory() for _ in range(2))
+        return lst.pop()
+
+    def give(self, buf):
+        self.free.setdefault(int(buf.numel()), []).append(buf)
+
+
+_peak_pool = PinnedPool()
+
+
+def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=None):
+    """Device-side peak selection (peak_response_mapping_3d.py:124-139,161-163): dets [rows,7] (class 1's kept detections), keep_idx
+    int64 [rows], count int32 [1] (all on the device) -> dict(num int32 [1], peaks int32 [cap,4] = (a,s,h,w), dets f32 [cap,7]) on the
+    device plus `host`: a pinned mirror the SAME kernel writes (host["num"] int32 [1], host["peaks"], host["dets"] as NumPy views),
+    valid once the returned `event` has completed; call `release()` after reading it.  No host synchronisation here."""
+    _need_gpu(dets, keep_idx, count)
+    assert dets.dtype == torch.float32 and dets.is_contiguous() and dets.dim() == 2 and dets.shape[1] == 7
+    assert keep_idx.dtype == torch.int64 and keep_idx.is_contiguous() and count.dtype == torch.int32
+    rows = int(dets.shape[0])
+    cap = int(cap or rows)
+    S, H, W = (int(v) for v in fmap_shape)
+    dev = dets.device
+    num = torch.empty((1,), dtype=torch.int32, device=dev)
+    peaks = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    out = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    nb = 64 + cap * 16 + cap * 28
+    buf = _peak_pool.take(nb)
+    base = buf.data_ptr()
+    check(lib().m3d_prm_select_peaks(_ptr(dets), _ptr(keep_idx), _ptr(count), rows, C.c_float(np.float32(peak_threshold)), int(A), S, H, W,
+                                     cap, _ptr(num), _ptr(peaks), _ptr(out), C.c_void_p(base), C.c_void_p(base + 64),
+                                     C.c_void_p(base + 64 + cap * 16), _stream()), "prm_select_peaks")
+    ev = torch.cuda.Event()
+    ev.record()
+    hb = buf.numpy()
+    host = dict(num=hb[:4].view(np.int32), peaks=hb[64:64 + cap * 16].view(np.int32).reshape(cap, 4),
+                dets=hb[64 + cap * 16:64 + cap * 44].view(np.float32).reshape(cap, 7))
+    return dict(num=num, peaks=peaks, dets=out, host=host, event=ev, release=lambda: _peak_pool.give(buf))
 
 
 def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_strip=False, out_strip=False, up_off=None, dims=None):

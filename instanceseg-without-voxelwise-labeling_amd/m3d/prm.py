@@ -57,51 +57,68 @@ class PRMEngine:
         return ops.WinoConv3d(wd, two_d=True, local=True)      # windows of different peaks are neighbours in the strip: exact locality
 
     # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
-    def forward(self, data):
+    # pr_conv3d computes two convolutions per layer: the response Y = conv(X, W, b) that feeds the next layer, and the norm conv
+    # N = conv(X - min X, relu(W)) that only the backward hooks read.  Nothing of the detection path (RPN, proposals, box head, box
+    # results) depends on N, so the forward is split: `forward_response` is the detection-mode forward (+ pool argmax), and
+    # `forward_norms` computes N (and min X) for a set of layers later - prm_tile queues them behind the launches whose results the
+    # host has to wait for (RoI count, peak count), so those waits never leave the GPU idle.
+    def forward_response(self, data):
         det = self.det
         saved = []
         x = data
         for li, L in enumerate(self.layers):
-            off = ops.reduce_min(x)
-            n = L["norm_conv"](x, in_offset=off)
             wnp = det.body_wino[li] if (self.wino_forward and L["pool"] and L["k"] == 3) else None
             if wnp is not None and wnp.two_d and wnp.supports_pool(x.shape[-1]) and x[0].numel() * 4 < 0x7FFFFFFF and \
                     wnp.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
-                xn, am = wnp.pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)     # F(2x2,3x3) + pool + argmax
+                xn, am = wnp.pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)     # F(2x4,3x3) + pool + argmax
             elif L["pool"] and L["conv"].supports_pool(x.shape[-1], x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]):
                 xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
                 wn = det.body_wino[li] if self.wino_forward else None
                 if wn is not None and not L["pool"] and wn.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
-                    y = wn(x, scale=L["scale"], shift=L["shift"], relu=True)        # response conv: F(2x2,3x3) as in detection mode
+                    y = wn(x, scale=L["scale"], shift=L["shift"], relu=True)        # response conv: Winograd as in detection mode
                 else:
                     y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
                 if L["pool"]:
                     xn, am = ops.maxpool3d_2x(y, return_argmax=True)
                 else:
                     xn, am = y, None
-            saved.append(dict(x=x[0], off=off, n=n[0], scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
+            saved.append(dict(x=x[0], off=None, n=None, scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
                               xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_small=L["dgrad_small"],
-                              weight=L["weight"]))
-            if L["k"] == 5 and L["pool"] and self.fused_stem:
-                saved[-1]["den"] = ops.prm_den_pool(am[0], xn[0], n[0])          # peak-independent part of the prepare step
+                              weight=L["weight"], norm_conv=L["norm_conv"]))
             x = xn
         feat = x
-        off = ops.reduce_min(feat)
         wn = det.rpn_conv_wino if self.wino_forward else None
         if wn is not None and wn.supports(feat.shape[-1], (feat.shape[0],) + tuple(feat.shape[2:])):
             h = wn(feat, shift=det.rpn_conv_bias, relu=True)
         else:
             h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
-        n = self.rpn["norm_conv"](feat, in_offset=off)
-        saved.append(dict(x=feat[0], off=off, n=n[0], scale=None, pool=False, argmax=None, xnext=h[0], k=3,
-                          dgrad=self.rpn["dgrad"], dgrad_small=self.rpn["dgrad_small"]))
-        off_h = ops.reduce_min(h)
-        o = det.rpn_heads(h, shift=det.rpn_heads_bias)
-        prob = torch.sigmoid(o[:, :det.A]).contiguous()
-        deltas = o[:, det.A:].contiguous()
-        n_cls = self.cls_norm_conv(h, in_offset=off_h)
-        top = dict(h=h[0], off_h=off_h, n_cls=n_cls[0], prob=prob[0])
+        saved.append(dict(x=feat[0], off=None, n=None, scale=None, pool=False, argmax=None, xnext=h[0], k=3,
+                          dgrad=self.rpn["dgrad"], dgrad_small=self.rpn["dgrad_small"], norm_conv=self.rpn["norm_conv"]))
+        prob, deltas = det.rpn_outputs(h)
+        top = dict(h=h[0], off_h=None, n_cls=None, prob=prob[0])
+        return feat, prob, deltas, saved, top
+
+    def forward_norms(self, saved, top, layers=None, cls=True):
+        """The norm convs (+ input minima, + the stem's denominator map) of saved[i] for i in `layers` (default: all that are still
+        missing) and, with cls, of the RPN_cls_score conv."""
+        for i in (range(len(saved)) if layers is None else layers):
+            rec = saved[i]
+            if rec["n"] is not None:
+                continue
+            x = rec["x"].unsqueeze(0)
+            rec["off"] = ops.reduce_min(x)
+            rec["n"] = rec["norm_conv"](x, in_offset=rec["off"])[0]
+            if rec["k"] == 5 and rec["pool"] and self.fused_stem:
+                rec["den"] = ops.prm_den_pool(rec["argmax"], rec["xnext"], rec["n"])      # peak-independent part of the prepare step
+        if cls and top["n_cls"] is None:
+            h = top["h"].unsqueeze(0)
+            top["off_h"] = ops.reduce_min(h)
+            top["n_cls"] = self.cls_norm_conv(h, in_offset=top["off_h"])[0]
+
+    def forward(self, data):
+        feat, prob, deltas, saved, top = self.forward_response(data)
+        self.forward_norms(saved, top)
         return feat, prob, deltas, saved, top
 
     # ---------------------------------------------------------------- backward for a batch of peaks
@@ -190,33 +207,86 @@ class PRMEngine:
     def prm_tile(self, data, peak_threshold=0.1, dense=True):
         """One tile.  Returns None when the tile yields no RoI or no detection above `peak_threshold` (the reference
         returns (None,)*5 and its driver `continue`s, infer_simple.py:225-226), else a dict: crm [1,A,s,h,w],
-        peaks int64 [P,5] (b,a,s,h,w), dets float64 [P,7], windows/sums/origins (cone-cropped maps) and, with
-        dense=True, prms [P,S,H,W] (each map divided by its sum)."""
+        peaks int64 [P,5] (b,a,s,h,w) and dets float64 [P,7] (host tensors: they arrive with the peak count), peaks_dev int32
+        [P,4] / dets_dev float32 [P,7] (device), windows/sums/origins (cone-cropped maps) and, with dense=True, prms [P,S,H,W]
+        (each map divided by its sum).
+
+        Two host waits per tile - the RoI count that sizes the box head and the peak count that sizes the back-propagation - and both
+        are covered: the norm convs of the forward, which only the backward needs, are queued behind the launches the host waits
+        for."""
         det, c = self.det, self.cfg
         S, H, W = data.shape[-3:]
         im_info = np.array([S, H, W, 1.0], np.float64)
-        feat, prob, deltas, saved, top = self.forward(data)
-        rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
-        if rois.shape[0] == 0:
-            return None                                # nothing survives -> the reference returns five Nones (:190)
+        feat, prob, deltas, saved, top = self.forward_response(data)
+        if not det._fused_ok(prob) or not det.has_head:
+            self.forward_norms(saved, top)
+            return self._prm_tile_unfused(data, feat, prob, deltas, saved, top, peak_threshold, dense)
+        rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(prob, deltas, det.anchors, float(c.stride), im_info, c.pre_nms_topN,
+                                                                        c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
+        num_host = det._pinned_counts(num)
+        num_host.copy_(num, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        _, offs_dev = ops.compact_rows(rois_b, num)                   # [0, R] on the device for box results (no host-side offsets)
+        nl = len(saved)
+        late = [i for i in (0, 1) if i < nl - 1]                      # conv1a / conv2a: the last layers the backward reaches
+        self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
+        ready.synchronize()                                           # host wait 1 (covered by the norm convs above)
+        R = int(num_host[0])
+        det._release_counts(num_host)
+        if R == 0:
+            return None                                               # nothing survives -> the reference returns five Nones (:190)
+        rois, keep_idx = rois_b[0, :R], kidx_b[0, :R]
         cls, bbox = det.box_head(feat, rois)
         pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
-        sc, bx, _, cls_keep = det.box_results_with_nms_and_limit(cls, pred, keep_idx)                          # :124
-        keep = cls_keep[1]                                                                                     # :125
+        cb, ck, cnt = ops.box_results3d_batched(cls, pred, keep_idx, offs_dev, c.num_classes, c.score_thresh, c.nms,
+                                                c.detections_per_im, R)                                          # :124
+        A = prob.shape[1]
+        sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:])          # :125,136-139,161-163
+        self.forward_norms(saved, top, layers=late, cls=False)
+        sel["event"].synchronize()                                    # host wait 2 (covered by the two norm convs above)
+        P = int(sel["host"]["num"][0])
+        if P == 0:
+            sel["release"]()
+            return None                                # no score above peak_threshold (:161-162 never true, :189-190)
+        hp = sel["host"]["peaks"][:P]
+        peaks = torch.from_numpy(np.concatenate((np.zeros((P, 1), np.int64), hp.astype(np.int64)), 1))          # (b,a,s,h,w), b = 0
+        dets = torch.from_numpy(sel["host"]["dets"][:P].astype(np.float64))                                     # :163
+        sel["release"]()
+        win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
+        out = dict(crm=prob, peaks=peaks, dets=dets, peaks_dev=sel["peaks"][:P], dets_dev=sel["dets"][:P], windows=win, sums=sums,
+                   origins=origins)
+        if dense:
+            out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
+        return out
+
+    def _prm_tile_unfused(self, data, feat, prob, deltas, saved, top, peak_threshold, dense):
+        """pre_nms_topN beyond the fused box kernels' capacity (or a model without a box head): the per-stage path with a host read
+        per stage."""
+        det, c = self.det, self.cfg
+        S, H, W = data.shape[-3:]
+        im_info = np.array([S, H, W, 1.0], np.float64)
+        rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
+        if rois.shape[0] == 0:
+            return None
+        cls, bbox = det.box_head(feat, rois)
+        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
+        sc, bx, _, cls_keep = det.box_results_with_nms_and_limit(cls, pred, keep_idx)
+        keep = cls_keep[1]
         A = prob.shape[1]
         s_, h_, w_ = prob.shape[-3:]
-        a = keep % A                                  # unravel_index(idx, (B,S,H,W,A)) with B = 1 (:136-139)
+        a = keep % A
         pos = keep // A
         peaks = torch.stack([torch.zeros_like(a), a, pos // (h_ * w_), (pos // w_) % h_, pos % w_], 1)
-        # one host read for the peak selection (the index list; its length is then known): a count plus three boolean-mask gathers
-        # were four synchronisations, each an idle gap of 20-70 us on the GPU
-        vidx = torch.nonzero(sc > peak_threshold).squeeze(1)                                                   # :161-162
+        vidx = torch.nonzero(sc > peak_threshold).squeeze(1)
         if vidx.numel() == 0:
-            return None                                # no score above peak_threshold (:161-162 never true, :189-190)
+            return None
         peaks_v = peaks.index_select(0, vidx)
-        dets = torch.cat([bx.index_select(0, vidx), sc.index_select(0, vidx).unsqueeze(1)], 1).double()        # :163
-        win, sums, origins = self.backward_windows(peaks_v[:, 1:].to(torch.int32).contiguous(), saved, top, data)
-        out = dict(crm=prob, peaks=peaks_v, dets=dets, windows=win, sums=sums, origins=origins)
+        dets32 = torch.cat([bx.index_select(0, vidx), sc.index_select(0, vidx).unsqueeze(1)], 1)
+        pk32 = peaks_v[:, 1:].to(torch.int32).contiguous()
+        win, sums, origins = self.backward_windows(pk32, saved, top, data)
+        out = dict(crm=prob, peaks=peaks_v.cpu(), dets=dets32.double().cpu(), peaks_dev=pk32, dets_dev=dets32, windows=win, sums=sums,
+                   origins=origins)
         if dense:
             out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
         return out
