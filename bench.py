@@ -232,9 +232,12 @@ def bench_prm(args, rank, world, dist):
     mode = "nuclei" if nuclei else "soma"
     npk, nlab = [], []
 
+    stamps = []
+
     def step():
         """one tile: PRM forward + box head + peak back-propagation -> uint8 quantisation (from the windows; no dense float maps) -> per-detection crop +
         normalisation -> 2D-Otsu -> largest component (+ hole fill / closing) -> instance labels (binarization_*.py loop body)"""
+        stamps.append(time.perf_counter())
         out = eng.prm_tile(vol, dense=False)
         npk.append(0 if out is None else int(out["peaks"].shape[0]))
         if out is not None:
@@ -269,7 +272,8 @@ def bench_prm(args, rank, world, dist):
            "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation + per-detection 2D-Otsu -> instance labels%s" %
                                   (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
                                    "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks,
-                      "prm_forward_ms": fwd_ms, "prm_tile_ms": prm_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0},
+                      "prm_forward_ms": fwd_ms, "prm_tile_ms": prm_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0,
+                      "step_starts_ms_host": [round((b - a) * 1e3, 2) for a, b in zip(stamps[args.warmup:-1], stamps[args.warmup + 1:])][:args.steps]},
            "roofline": {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks (strip-Winograd / small-window / stem dgrad kernels)" % npeaks,
                         "achieved": npeaks * cone_issued / back_ms, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": npeaks * cone_issued / back_ms / 157.3,

@@ -61,8 +61,8 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all
     idx = np.nonzero(okb)[0]
     if len(idx) == 0:
         return None
-    idx_t = torch.from_numpy(idx).to(dev)
-    bsel = torch.from_numpy(boxes[idx]).to(dev)
+    idx_t = ops.upload(idx, dev)
+    bsel = ops.upload(boxes[idx], dev)
     qs = q if len(idx) == q.shape[0] else q[idx_t].contiguous()          # every detection has a valid crop: no 200 MB gather
     oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode, boxes_host=boxes[idx])
     mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)

@@ -151,7 +151,7 @@ class PeakResponseMapping_3d(Generalized_RCNN):
         out = self.engine.prm_tile(x, peak_threshold=float(peak_threshold), dense=True)
         if out is None:
             return None, None, None, None, None                                                           # :189-190
-        return None, out["crm"], out["peaks"].to(torch.int64), out["prms"], out["dets"]                    # :180-185
+        return None, out["crm"], out["peaks"].to(torch.int64).to(out["crm"].device), out["prms"], out["dets"].to(out["crm"].device)                    # :180-185
 
 
 # ------------------------------------------------------------------------------------------- lib/core/test.py drivers

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -585,6 +585,54 @@ def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off):
     return out
 
 
+class _StagingRing:
+    """Small host arrays (index lists, box tables, offsets) on their way to the device: a ring of pinned 64 KB slots, each guarded by
+    the event of its last copy.  `torch.from_numpy(a).to(device)` from pageable memory is a BLOCKING copy that first waits for
+    everything queued on the stream - one idle gap on the GPU per call (tools/prm_timeline.sh showed 20-70 us each)."""
+    SLOT = 1 << 16
+
+    def __init__(self, n=32):
+        self.pool = torch.empty((n * self.SLOT,), dtype=torch.uint8).pin_memory()       # ONE pinning call (each costs milliseconds)
+        self.slots = [self.pool[k * self.SLOT:(k + 1) * self.SLOT] for k in range(n)]
+        self.events, self.i, self.n, self.big = [None] * n, 0, n, []
+
+    def put(self, arr, device):
+        arr = np.ascontiguousarray(arr)
+        nb = arr.nbytes
+        dt = torch.from_numpy(np.empty((0,), arr.dtype)).dtype
+        out = torch.empty(arr.shape, dtype=dt, device=device)
+        if nb == 0:
+            return out
+        if nb > self.SLOT:                                     # big tables: a one-off pinned buffer
+            t = torch.from_numpy(arr).pin_memory()
+            out.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            self.big = [(b, e) for b, e in self.big if not e.query()] + [(t, ev)]
+            return out
+        k = self.i % self.n
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()                       # n copies ago: long done
+        slot = self.slots[k]
+        slot.numpy()[:nb] = arr.reshape(-1).view(np.uint8)
+        out.view(torch.uint8).reshape(-1).copy_(slot[:nb], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        self.events[k] = ev
+        return out
+
+
+_staging = {}
+
+
+def upload(arr, device="cuda"):
+    """Host ndarray -> device tensor of the same dtype/shape through pinned staging, asynchronous on the current stream."""
+    key = str(device)
+    ring = _staging.get(key)
+    if ring is None:
+        ring = _staging[key] = _StagingRing()
+    return ring.put(arr, device)
+
+
 class PinnedPool:
     """Pinned host buffers of one size, handed out per call and returned after the read: any number of tiles may be in flight
     (double-buffered volume drivers) without one overwriting another's mirror.  Pinning is a slow driver call, hence the pool."""
@@ -620,17 +668,17 @@ def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=N
     num = torch.empty((1,), dtype=torch.int32, device=dev)
     peaks = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     out = torch.empty((cap, 7), dtype=torch.float32, device=dev)
-    nb = 64 + cap * 16 + cap * 28
-    buf = _peak_pool.take(nb)
+    capb = max(cap, fused_max_boxes())                      # ONE buffer size for every tile (a new size would pin new memory)
+    buf = _peak_pool.take(64 + capb * 44)
     base = buf.data_ptr()
     check(lib().m3d_prm_select_peaks(_ptr(dets), _ptr(keep_idx), _ptr(count), rows, C.c_float(np.float32(peak_threshold)), int(A), S, H, W,
                                      cap, _ptr(num), _ptr(peaks), _ptr(out), C.c_void_p(base), C.c_void_p(base + 64),
-                                     C.c_void_p(base + 64 + cap * 16), _stream()), "prm_select_peaks")
+                                     C.c_void_p(base + 64 + capb * 16), _stream()), "prm_select_peaks")
     ev = torch.cuda.Event()
     ev.record()
     hb = buf.numpy()
     host = dict(num=hb[:4].view(np.int32), peaks=hb[64:64 + cap * 16].view(np.int32).reshape(cap, 4),
-                dets=hb[64 + cap * 16:64 + cap * 44].view(np.float32).reshape(cap, 7))
+                dets=hb[64 + capb * 16:64 + capb * 16 + cap * 28].view(np.float32).reshape(cap, 7))
     return dict(num=num, peaks=peaks, dets=out, host=host, event=ev, release=lambda: _peak_pool.give(buf))
 
 
@@ -794,7 +842,7 @@ def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None):
     sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
     assert R == 0 or (sizes.min() > 0 and b[:, :3].min() >= 0 and b[:, 3].max() < W and b[:, 4].max() < H and b[:, 5].max() < D)
     offs_h = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
-    offs = torch.from_numpy(offs_h).to(image_u16.device)
+    offs = upload(offs_h, image_u16.device)
     total = int(offs_h[-1]) if R else 0
     oi = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
     op = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)

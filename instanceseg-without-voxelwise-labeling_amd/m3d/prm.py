@@ -200,7 +200,12 @@ class PRMEngine:
         g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
         origin = pk[:, 1:4].contiguous()
         wb = dict(t=g, strip=False, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
-        (win, sums), origins = tail(list(reversed(saved)), wb, origin)
+        try:
+            (win, sums), origins = tail(list(reversed(saved)), wb, origin)
+        finally:
+            # `tail` calls itself, so the function object and its closure cell form a reference cycle that also holds `saved` (every
+            # forward tensor of the tile) until the cyclic collector runs - by then the next tile has allocated its own: break it here
+            tail = run_layer = take = fused = wino = None
         return win, sums, origins
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193

@@ -60,7 +60,7 @@ def test_full_tile_detect_and_prm(name):
         assert w.shape[1] == (84 if s == 8 else 40)
         tot = w.flatten(1).sum(1)
         assert torch.allclose(tot, sums, rtol=1e-3)
-        pk = res["peaks"][:, 2:].to(torch.int32) * s                      # the peak's own voxel lies inside its window
+        pk = res["peaks"][:, 2:].to(torch.int32).cuda() * s                      # the peak's own voxel lies inside its window
         assert ((pk >= org) & (pk < org + w.shape[1])).all()
 
 

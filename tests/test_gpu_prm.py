@@ -408,3 +408,26 @@ def test_nuclei_tile_default_engine_equals_the_oracle_at_the_shipped_size():
             ref = O.prm_backward(P, osaved, p, p2.shape)[0]
         assert float(ref.max()) > 0
         assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
+
+
+@pytest.mark.parametrize("rows,count,cap,thr", [(300, 300, 300, 0.1), (300, 137, 300, 0.5), (1000, 777, 300, 0.05), (64, 0, 64, 0.1), (700, 700, 40, 0.0)])
+def test_select_peaks_kernel_equals_the_host_statements(rows, count, cap, thr):
+    """m3d_prm_select_peaks against the statements it replaces (peak_response_mapping_3d.py:125,136-139,161-163): detections with
+    score > threshold in order, their flat (S,H,W,A) score index unravelled to (a,s,h,w); device outputs and the pinned host mirror."""
+    import m3d
+    rng = np.random.RandomState(rows + count)
+    A, S, H, W = 14, 5, 11, 9
+    dets = rng.rand(rows, 7).astype(np.float32)
+    dets[::7, 6] = np.float32(thr)                                   # ties with the threshold are NOT kept (strict >)
+    keep = rng.randint(0, A * S * H * W, size=rows).astype(np.int64)
+    sel = m3d.ops.prm_select_peaks(torch.from_numpy(dets).cuda(), torch.from_numpy(keep).cuda(),
+                                   torch.tensor([count], dtype=torch.int32).cuda(), thr, A, (S, H, W), cap=cap)
+    sel["event"].synchronize()
+    idx = np.nonzero(dets[:count, 6] > np.float32(thr))[0][:cap]
+    s_, h_, w_, a_ = np.unravel_index(keep[idx], (S, H, W, A))
+    ref_peaks = np.stack([a_, s_, h_, w_], 1).astype(np.int32).reshape(-1, 4)
+    n = int(sel["host"]["num"][0])
+    assert n == len(idx) == int(sel["num"].item())
+    assert np.array_equal(sel["host"]["peaks"][:n], ref_peaks) and np.array_equal(sel["peaks"][:n].cpu().numpy(), ref_peaks)
+    assert np.array_equal(sel["host"]["dets"][:n], dets[idx]) and np.array_equal(sel["dets"][:n].cpu().numpy(), dets[idx])
+    sel["release"]()

@@ -1,7 +1,8 @@
 #!/bin/bash
-O=/root/repo/gpurun_out/prm_tl; mkdir -p $O
+WL=${1:-prm}
+O=/root/repo/gpurun_out/prm_tl_$WL; mkdir -p $O; rm -rf /tmp/rp_prm
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d /tmp/rp_prm -o prm -- python3 /root/repo/bench.py --workload prm --no-cpu-baseline --steps 6 --warmup 2 > $O/bench.json 2> $O/rp.err || { tail -5 $O/rp.err; exit 1; }
+rocprofv3 --kernel-trace -d /tmp/rp_prm -o prm -- python3 /root/repo/bench.py --workload $WL --no-cpu-baseline --steps 6 --warmup 2 > $O/bench.json 2> $O/rp.err || { tail -5 $O/rp.err; exit 1; }
 python3 - $(find /tmp/rp_prm -name "*_results.db" | head -1) > $O/timeline.txt <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
@@ -26,7 +27,7 @@ prev = None
 for n, s, e in seg:
     gap = (s - prev) / 1e3 if prev else 0.0
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    if (e - s) > 60e3 or gap > 12:
+    if (e - s) > 40e3 or gap > 8:
         print("%-80s %9.1f us  gap %7.1f%s" % (n[:80], (e - s) / 1e3, gap, "  <<<" if gap > 8 else ""))
     prev = max(prev or 0, e)
 PY
