@@ -454,6 +454,10 @@ int m3d_roi_normalize(const uint16_t* d_image, const uint8_t* d_prm_u8, const in
  *       d_ws: 24 * num_rois bytes. */
 int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
                                 int depth, int height, int width, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
+/* Round 4: the same uint8 values as WINDOWS [P, win^3] (0 where a window voxel lies outside the tile) - what the whole-volume driver
+ * sends to the host writer (m3d_io.h: m3d_tiff_encode_window_stack_u8) instead of the dense maps.  Same d_ws contract. */
+int m3d_prm_quantize_windows_compact_u8(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
+                                        int depth, int height, int width, uint8_t* d_out_windows, void* d_ws, size_t ws_bytes, void* stream);
 int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,
                          int num_rois, int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
                          uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream);
@@ -503,6 +507,9 @@ int m3d_binary_closing6_batch(const uint8_t* d_mask, const int64_t* d_offsets, c
                               int64_t total_voxels, uint8_t* d_out, void* d_ws, size_t ws_bytes, void* stream);
 int m3d_paint_instances(const uint8_t* d_mask, const int64_t* d_offsets, const int32_t* d_boxes, const int32_t* d_ids,
                         int num_rois, int depth, int height, int width, uint32_t* d_volume, void* stream);
+/* After the last m3d_paint_instances: sentinel 0xFFFFFFFF -> 0 and d_present[id] = 1 (uint8 [max_id + 1], caller zero-fills; may be
+ * NULL) for every id in [1, max_id] that occurs in the volume (`mask_id in np.unique(seg)`, binarization_soma.py:103). */
+int m3d_paint_finish(uint32_t* d_volume, int64_t num_voxels, int max_id, uint8_t* d_present, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,20 @@ extern "C" {
 size_t m3d_tiff_lzw_bound(size_t n);                                                  /* dst capacity that always suffices */
 size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);   /* bytes written; 0 = dst too small */
 size_t m3d_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);   /* bytes produced (<= cap) */
+/* The byte-per-probe textbook encoder that m3d_tiff_lzw_encode (which jumps through runs of zero bytes) must equal byte for byte. */
+size_t m3d_tiff_lzw_encode_plain(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
+/* Whole multi-page files built in memory - little-endian classic TIFF, one LZW strip per page, BlackIsZero, no predictor: what
+ * libtiff's write_image(page, compression='lzw') gives for 2-D pages (tools/infer_simple.py:241-245, binarization_*.py tails).
+ *   m3d_tiff_stack_bound           dst capacity that always suffices
+ *   m3d_tiff_encode_stack          vol [pages,height,width] uint8 (bits 8) / little-endian uint16 (bits 16) -> file bytes (0 = failure)
+ *   m3d_tiff_encode_window_stack_u8  the stack of ONE uint8 peak response map from its non-zero window alone: page q is slice
+ *                                  z_first + q of a [*,height,width] tile that is zero except win[wn,wn,wn] at origin (oz,oy,ox);
+ *                                  equals m3d_tiff_encode_stack of the dense map (infer_simple.py:233-245 per map) */
+size_t m3d_tiff_stack_bound(int pages, int height, int width, int bits);
+size_t m3d_tiff_encode_stack(const void* vol, int pages, int height, int width, int bits, uint8_t* dst, size_t cap);
+size_t m3d_tiff_encode_window_stack_u8(const uint8_t* win, int wn, int oz, int oy, int ox, int z_first, int pages, int height,
+                                       int width, uint8_t* dst, size_t cap);
 
 /* 3D run-length masks ({'counts', 'size'}) of lib/utils/cython_mask_3d.pyx:19-84 / lib/utils/mask_3d.py:15-73:
  * runs over the mask in Fortran order, zeros first.  mask: C-contiguous uint8 [S,H,W].

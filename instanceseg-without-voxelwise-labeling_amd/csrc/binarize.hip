@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void winq_stats_kernel(const float* __restrict
   }
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict__ win, const float* __restrict__ sums,
                                                          const int* __restrict__ origins, int Wn, int D, int H, int W,
                                                          WinQ* __restrict__ st, uint8_t* __restrict__ out) {
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict
   const float mn = covers ? __uint_as_float(s.fmin_bits) : 0.f;      // some voxel of the tile is outside the window: the map holds a 0
   const float mx = __uint_as_float(s.fmax_bits) - mn;                // max(fm - min)
   const float* wp = win + (size_t)p * w3;
-  uint8_t* o = out + (size_t)p * D * H * W;
+  // COMPACT: the uint8 window itself ([P, Wn^3], 0 at window voxels outside the tile) instead of the dense map - all a writer needs
+  // to rebuild the map (zero outside the window unless the window covers the tile, and then the window holds every voxel)
+  uint8_t* o = out + (COMPACT ? (size_t)p * w3 : (size_t)p * D * H * W);
   const float inv_w = 1.0f / (float)Wn;
   int any = 0;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
@@ -170,8 +173,10 @@ __global__ __launch_bounds__(256) void winq_apply_kernel(const float* __restrict
       v = v / mx;
       v = v * 255.f;
       const uint8_t u = (uint8_t)v;
-      o[((size_t)qz * H + qy) * W + qx] = u;
+      if (COMPACT) o[e] = u; else o[((size_t)qz * H + qy) * W + qx] = u;
       any |= u;
+    } else if (COMPACT) {
+      o[e] = 0;
     }
   }
   if (__ballot(any != 0) && (threadIdx.x & 63) == 0) atomicOr(&st[p].pad, 1);      // the map is not all zero (binarization_soma.py:74-76)
@@ -326,9 +331,33 @@ M3D_API int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_s
   chunks = chunks > 64 ? 64 : chunks;
   hipLaunchKernelGGL(winq_stats_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q);
-  hipLaunchKernelGGL(winq_apply_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
+  hipLaunchKernelGGL(winq_apply_kernel<false>, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q, d_out);
   return m3d::check_launch("prm_quantize_windows_u8");
+}
+
+/* Round 4: the same quantisation, written as uint8 WINDOWS [P, win^3] (0 where a window voxel lies outside the tile): the whole-volume
+ * driver moves these to the host (0.59 MB per peak of a nuclei tile instead of 2.56 MB of mostly-zero map) and the file writer rebuilds
+ * each page around them (m3d_tiff_encode_window_stack_u8).  Same d_ws contract as m3d_prm_quantize_windows_u8. */
+M3D_API int m3d_prm_quantize_windows_compact_u8(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,
+                                                int depth, int height, int width, uint8_t* d_out_windows, void* d_ws, size_t ws_bytes,
+                                                void* stream) {
+  if (num_peaks < 0 || win <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_windows || !d_sums || !d_origins || !d_out_windows || !d_ws) return M3D_EINVAL;
+  if (ws_bytes < sizeof(WinQ) * (size_t)num_peaks) return M3D_EWORKSPACE;
+  if (num_peaks > 65535 || win > 100) return M3D_EUNSUPPORTED;
+  hipStream_t st = m3d::as_stream(stream);
+  WinQ* q = (WinQ*)d_ws;
+  hipLaunchKernelGGL(winq_init_kernel, dim3((num_peaks + 255) / 256), dim3(256), 0, st, q, num_peaks);
+  const int w3 = win * win * win;
+  int chunks = (w3 + 255) / 256;
+  chunks = chunks > 64 ? 64 : chunks;
+  hipLaunchKernelGGL(winq_stats_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
+                     width, q);
+  hipLaunchKernelGGL(winq_apply_kernel<true>, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
+                     width, q, d_out_windows);
+  return m3d::check_launch("prm_quantize_windows_compact_u8");
 }
 
 M3D_API int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,

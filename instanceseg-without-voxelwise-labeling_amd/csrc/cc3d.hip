@@ -254,6 +254,17 @@ __global__ __launch_bounds__(256) void paint_kernel(const uint8_t* __restrict__ 
   }
 }
 
+// After all tiles are painted: the 0xFFFFFFFF sentinel back to 0 (the reference's label volume starts at 0) and, for every id in
+// [1, max_id], whether it occurs at all (`mask_id in np.unique(seg)`, binarization_soma.py:103) - one pass, no host read
+// (torch.bincount sizes its result from a device-side max and makes the host wait for the whole tile).
+__global__ __launch_bounds__(256) void paint_finish_kernel(uint32_t* __restrict__ vol, long long n, int max_id, uint8_t* __restrict__ present) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    uint32_t v = vol[i];
+    if (v == 0xFFFFFFFFu) vol[i] = 0u;
+    else if (v >= 1u && v <= (uint32_t)max_id && present) present[v] = 1;
+  }
+}
+
 }  // namespace
 
 constexpr size_t kCcKeyBytes = 65536 * sizeof(unsigned long long);   // one selection key per RoI (grid.y <= 65535)
@@ -315,4 +326,12 @@ M3D_API int m3d_paint_instances(const uint8_t* d_mask, const int64_t* d_offsets,
   hipLaunchKernelGGL(paint_kernel, dim3(64, num_rois), dim3(256), 0, m3d::as_stream(stream), d_mask, d_offsets, d_boxes, d_ids,
                      depth, height, width, d_volume);
   return m3d::check_launch("paint_instances");
+}
+
+M3D_API int m3d_paint_finish(uint32_t* d_volume, int64_t num_voxels, int max_id, uint8_t* d_present, void* stream) {
+  if (!d_volume || num_voxels < 0 || max_id < 0) return M3D_EINVAL;
+  if (num_voxels == 0) return M3D_OK;
+  const int blocks = (int)min((long long)4096, (long long)((num_voxels + 255) / 256));
+  hipLaunchKernelGGL(paint_finish_kernel, dim3(blocks), dim3(256), 0, m3d::as_stream(stream), d_volume, (long long)num_voxels, max_id, d_present);
+  return m3d::check_launch("paint_finish");
 }

@@ -25,4 +25,8 @@ constexpr int kWave = 64;
 // Explicit tuning options (m3d_set_option): the library never reads the environment.  -1 = "not set" for the tile overrides.
 enum Opt { OPT_XCD_MAP = 0, OPT_TUNE_K3, OPT_TUNE_WINO, OPT_TUNE_WINO2, OPT_TUNE_WINO2_XT, OPT_TUNE_FC_SLICES, OPT_TUNE_FC_SLICES_TAIL, OPT_TUNE_FC_X3_ROWS, OPT_TUNE_STEM, OPT_COUNT };
 int opt(Opt o);
+// sums[p] = sum of win[p, 0..w3) in a FIXED order (per-thread strided partial sums, then a fixed tree): the per-peak normaliser of the
+// response maps must not depend on the order in which workgroups finish (float atomics gave maps that differed by one uint8 level from
+// run to run)
+int window_sums(const float* d_win, long long w3, int num_peaks, float* d_sums, hipStream_t st);
 }  // namespace m3d

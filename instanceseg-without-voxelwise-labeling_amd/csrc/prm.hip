@@ -362,7 +362,30 @@ __global__ __launch_bounds__(256) void prm_stem_dgrad_kernel(const float* __rest
   for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
   if ((tid & 63) == 0) red[tid >> 6] = local;
   __syncthreads();
-  if (tid == 0) atomicAdd(&sums[p], red[0] + red[1] + red[2] + red[3]);
+  (void)red; (void)sums;            // the per-peak sums come from m3d::window_sums (fixed order), not from atomics
+}
+
+__global__ __launch_bounds__(1024) void window_sums_kernel(const float* __restrict__ win, long long w3, float* __restrict__ sums) {
+  __shared__ float red[1024];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const float* w = win + (size_t)p * w3;
+  float acc = 0.f;
+  if ((w3 & 3) == 0 && ((uintptr_t)w & 15) == 0) {
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (long long i = tid; i < (w3 >> 2); i += 1024) {
+      const float4 v = w4[i];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long i = tid; i < w3; i += 1024) acc += w[i];
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) sums[p] = red[0];
 }
 
 // ---- normalise + scatter windows into dense [P, D, H, W] maps (zero elsewhere; caller memsets) ----
@@ -384,6 +407,14 @@ __global__ __launch_bounds__(256) void prm_scatter_kernel(const float* __restric
 }
 
 }  // namespace
+
+namespace m3d {
+int window_sums(const float* d_win, long long w3, int num_peaks, float* d_sums, hipStream_t st) {
+  if (num_peaks <= 0) return M3D_OK;
+  hipLaunchKernelGGL(window_sums_kernel, dim3(num_peaks), dim3(1024), 0, st, d_win, w3, d_sums);
+  return check_launch("prm_window_sums");
+}
+}  // namespace m3d
 
 M3D_API int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
                          const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
@@ -499,7 +530,6 @@ M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float
   if (num_peaks < 0 || channels <= 0 || win <= 0) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
   if (!d_gn || !d_wf || !d_data || !d_data_offset || !d_origins || !d_out || !d_sums || num_peaks > 65535) return M3D_EINVAL;
-  (void)hipMemsetAsync(d_sums, 0, sizeof(float) * num_peaks, m3d::as_stream(stream));
   auto launch = [&](auto kern, int TX, int TY, int TILE) {
     const int tx = (win + TX - 1) / TX, ty = (win + TY - 1) / TY, tz = (win + 7) / 8;
     const size_t lds = sizeof(float) * 2 * TILE;
@@ -516,7 +546,8 @@ M3D_API int m3d_prm_stem_dgrad(const float* d_gn, const float* d_wf, const float
     launch(prm_stem_dgrad_kernel<5, 6, false>, 40, 12, SDG<5, 6>::TILE);
   else
     launch(prm_stem_dgrad_kernel<4, 8, false>, 32, 16, SDG<4, 8>::TILE);
-  return m3d::check_launch("prm_stem_dgrad");
+  if (int rc = m3d::check_launch("prm_stem_dgrad")) return rc;
+  return m3d::window_sums(d_out, (long long)win * win * win, num_peaks, d_sums, m3d::as_stream(stream));
 }
 
 M3D_API int m3d_prm_scatter(const float* d_windows, const float* d_sums, const int32_t* d_origins, int num_peaks, int win,

@@ -422,9 +422,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-  if (l == 0) atomicAdd(&q.sums[p], local);
+  (void)local;                       // the per-peak sums come from m3d::window_sums (fixed order), not from atomics
 }
 
 }  // namespace
@@ -478,7 +476,6 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
   if (channels != 32 || !stem_plan(up_size, &pl) || num_peaks > 65535) return M3D_EUNSUPPORTED;
   if (2 * up_depth > depth || 2 * up_height > height || 2 * up_width > width) return M3D_EINVAL;     // MaxPool3d(2,2) floors
   hipStream_t st = m3d::as_stream(stream);
-  (void)hipMemsetAsync(d_sums, 0, sizeof(float) * num_peaks, st);
   StemMArgs q;
   q.gup = d_gup; q.origin_up = d_origin_up; q.den = d_den; q.argmax = d_argmax; q.scale = d_scale; q.wA = d_wa; q.data = d_data;
   q.data_off = d_data_offset; q.out = d_out; q.sums = d_sums; q.origins_out = d_origins_out; q.P = num_peaks; q.U = up_size;
@@ -504,7 +501,9 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
   // a ragged second round)
   if (up_size == 40) launch(prm_stem_dgrad_mfma_kernel<40, 2, 5>);
   else launch(prm_stem_dgrad_mfma_kernel<18, 3, 4>);
-  return m3d::check_launch("prm_stem_dgrad_fused");
+  if (int rc = m3d::check_launch("prm_stem_dgrad_fused")) return rc;
+  const long long wn = 2ll * up_size + 4;
+  return m3d::window_sums(d_out, wn * wn * wn, num_peaks, d_sums, st);
 }
 
 M3D_API int m3d_prm_stem_dgrad_fused(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size,

@@ -28,7 +28,9 @@ static void put(BitW* w, int code, int width) {
 M3D_EXPORT size_t m3d_tiff_lzw_bound(size_t n) { return n + n / 2 + 64; }
 
 /* returns the number of bytes written, or 0 when dst is too small */
-M3D_EXPORT size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+/* The textbook greedy encoder, one hash probe per input byte: kept as the definition the run-accelerated encoder below must
+ * reproduce byte for byte (tests/test_io_formats.py). */
+M3D_EXPORT size_t m3d_tiff_lzw_encode_plain(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
   static const int32_t EMPTY = -1;
   int32_t* hkey = (int32_t*)malloc(sizeof(int32_t) * HSIZE);   /* (prefix << 8) | byte */
   uint16_t* hval = (uint16_t*)malloc(sizeof(uint16_t) * HSIZE);
@@ -68,6 +70,201 @@ M3D_EXPORT size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst
   if (w.nbits > 0) put(&w, 0, 8 - w.nbits);
   free(hkey); free(hval);
   return w.overflow ? 0 : w.n;
+}
+
+/* ---- the production encoder: the same greedy algorithm, the same bytes, but runs of zero bytes cost one step per CODE instead of
+ * one hash probe per BYTE.  The stacks this codec exists for are peak response maps and label volumes: a cone-limited response
+ * window (84^3 of a 64 x 200 x 200 tile) or a few instances in a sea of zeros.  In a zero run the greedy match walks the chain of
+ * dictionary strings 0, 00, 000, ... - zc[k] is the code of 0^k - so the encoder jumps min(run, chain) bytes at once, and extends the
+ * chain by one entry when the run outlasts it (exactly the entry the byte-wise encoder would add).  A prefix can only become a chain
+ * code through the chain itself (after an emit the new prefix is the literal 0 = zc[1]), so chain entries never need the hash. */
+typedef struct { int32_t* hkey; uint16_t* hval; uint16_t* zc; } LzwTables;
+
+static int tables_alloc(LzwTables* t) {
+  t->hkey = (int32_t*)malloc(sizeof(int32_t) * HSIZE);
+  t->hval = (uint16_t*)malloc(sizeof(uint16_t) * HSIZE);
+  t->zc = (uint16_t*)malloc(sizeof(uint16_t) * 4096);
+  return t->hkey && t->hval && t->zc;
+}
+static void tables_free(LzwTables* t) { free(t->hkey); free(t->hval); free(t->zc); }
+
+static size_t zero_run(const uint8_t* p, size_t limit) {      /* number of leading zero bytes of p[0..limit) */
+  size_t k = 0;
+  while (k + 8 <= limit) {
+    uint64_t w;
+    memcpy(&w, p + k, 8);
+    if (w) break;
+    k += 8;
+  }
+  while (k < limit && p[k] == 0) ++k;
+  return k;
+}
+
+static size_t lzw_strip(LzwTables* t, const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  int32_t* hkey = t->hkey;
+  uint16_t* hval = t->hval;
+  uint16_t* zc = t->zc;
+  BitW w = {dst, cap, 0, 0, 0, 0};
+  int width = 9, next = FIRST;
+  memset(hkey, 0xFF, sizeof(int32_t) * HSIZE);                 /* EMPTY = -1 */
+  int zmax = 1;                                                /* zc[1..zmax] defined */
+  zc[1] = 0;
+  put(&w, CLEAR, width);
+  if (n > 0) {
+    int prefix = src[0];
+    int zk = prefix == 0 ? 1 : 0;                              /* prefix == zc[zk] when zk > 0 */
+    size_t i = 1;
+    while (i < n) {
+      const int c = src[i];
+      if (zk > 0 && c == 0) {
+        const size_t room = (size_t)(zmax - zk);               /* chain entries beyond the current prefix */
+        const size_t r = zero_run(src + i, (n - i) < room + 1 ? (n - i) : room + 1);
+        const size_t step = r < room ? r : room;
+        zk += (int)step; i += step; prefix = zc[zk];
+        if (r <= room) continue;                               /* the run (or the input) ended inside the chain */
+        /* (zc[zmax], 0) is not in the dictionary: emit, add it, restart from the literal 0 */
+        put(&w, prefix, width);
+        zc[zmax + 1] = (uint16_t)next; zmax++; next++;
+        if (next == 512 || next == 1024 || next == 2048) width++;
+        if (next == MAXCODE) {
+          put(&w, CLEAR, width);
+          memset(hkey, 0xFF, sizeof(int32_t) * HSIZE);
+          width = 9; next = FIRST; zmax = 1;
+        }
+        prefix = 0; zk = 1; ++i;
+        continue;
+      }
+      const int32_t key = (prefix << 8) | c;
+      uint32_t h = ((uint32_t)key * 2654435761u) >> 18;        /* 14 bits */
+      int found = -1;
+      while (hkey[h] != -1) {
+        if (hkey[h] == key) { found = hval[h]; break; }
+        h = (h + 1) & (HSIZE - 1);
+      }
+      ++i;
+      if (found >= 0) { prefix = found; zk = 0; continue; }
+      put(&w, prefix, width);
+      hkey[h] = key; hval[h] = (uint16_t)next; next++;
+      if (next == 512 || next == 1024 || next == 2048) width++;
+      if (next == MAXCODE) {
+        put(&w, CLEAR, width);
+        memset(hkey, 0xFF, sizeof(int32_t) * HSIZE);
+        width = 9; next = FIRST; zmax = 1;
+      }
+      prefix = c; zk = c == 0 ? 1 : 0;
+    }
+    put(&w, prefix, width);
+    next++;                                                     /* the decoder adds an entry for this code too */
+    if (next == MAXCODE) { put(&w, CLEAR, width); width = 9; }
+    else if (next == 512 || next == 1024 || next == 2048) width++;
+  }
+  put(&w, EOI, width);
+  if (w.nbits > 0) put(&w, 0, 8 - w.nbits);
+  return w.overflow ? 0 : w.n;
+}
+
+/* returns the number of bytes written, or 0 when dst is too small */
+M3D_EXPORT size_t m3d_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  LzwTables t;
+  if (!tables_alloc(&t)) { tables_free(&t); return 0; }
+  const size_t r = lzw_strip(&t, src, n, dst, cap);
+  tables_free(&t);
+  return r;
+}
+
+/* ---- whole multi-page files, built in memory: little-endian classic TIFF, one LZW strip per page, BlackIsZero, no predictor - the
+ * layout of m3d/io.py:write_tiff_stack (libtiff's write_image(page, compression='lzw') for 2-D pages, tools/infer_simple.py:241-245),
+ * byte for byte. */
+typedef struct { uint8_t* p; size_t cap, n; int overflow; } Buf;
+static void bput(Buf* b, const void* src, size_t k) {
+  if (b->n + k <= b->cap) memcpy(b->p + b->n, src, k); else b->overflow = 1;
+  b->n += k;
+}
+static void bput16(Buf* b, unsigned v) { uint8_t t[2] = {(uint8_t)v, (uint8_t)(v >> 8)}; bput(b, t, 2); }
+static void bput32(Buf* b, uint32_t v) { uint8_t t[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; bput(b, t, 4); }
+static void bpatch32(Buf* b, size_t at, uint32_t v) {
+  if (at + 4 <= b->cap) { b->p[at] = (uint8_t)v; b->p[at + 1] = (uint8_t)(v >> 8); b->p[at + 2] = (uint8_t)(v >> 16); b->p[at + 3] = (uint8_t)(v >> 24); }
+}
+static void tag(Buf* b, unsigned id, unsigned type, uint32_t val) {
+  bput16(b, id); bput16(b, type); bput32(b, 1);
+  if (type == 3) { bput16(b, val); bput16(b, 0); } else bput32(b, val);
+}
+
+M3D_EXPORT size_t m3d_tiff_stack_bound(int pages, int height, int width, int bits) {
+  const size_t page = (size_t)height * width * (bits / 8);
+  return 8 + (size_t)pages * (m3d_tiff_lzw_bound(page) + 2 + 11 * 12 + 4 + 4);
+}
+
+static void page_trailer(Buf* b, size_t* prev_next, size_t data_off, size_t data_len, int H, int W, int bits) {
+  if (b->n & 1) { const uint8_t z = 0; bput(b, &z, 1); }
+  const size_t ifd = b->n;
+  bpatch32(b, *prev_next, (uint32_t)ifd);
+  bput16(b, 11);
+  tag(b, 256, 4, (uint32_t)W); tag(b, 257, 4, (uint32_t)H); tag(b, 258, 3, (uint32_t)bits); tag(b, 259, 3, 5); tag(b, 262, 3, 1);
+  tag(b, 273, 4, (uint32_t)data_off); tag(b, 277, 3, 1); tag(b, 278, 4, (uint32_t)H); tag(b, 279, 4, (uint32_t)data_len);
+  tag(b, 284, 3, 1); tag(b, 339, 3, 1);
+  *prev_next = b->n;
+  bput32(b, 0);
+}
+
+/* vol: [pages, height, width] uint8 (bits = 8) or little-endian uint16 (bits = 16), C-contiguous.  Returns the file size, 0 on
+ * failure (dst too small: m3d_tiff_stack_bound always suffices). */
+M3D_EXPORT size_t m3d_tiff_encode_stack(const void* vol, int pages, int height, int width, int bits, uint8_t* dst, size_t cap) {
+  if (!vol || !dst || pages < 0 || height <= 0 || width <= 0 || (bits != 8 && bits != 16) || cap < 8) return 0;
+  LzwTables t;
+  if (!tables_alloc(&t)) { tables_free(&t); return 0; }
+  Buf b = {dst, cap, 0, 0};
+  const uint8_t hdr[8] = {'I', 'I', 42, 0, 0, 0, 0, 0};
+  bput(&b, hdr, 8);
+  size_t prev_next = 4;
+  const size_t page = (size_t)height * width * (bits / 8);
+  for (int p = 0; p < pages && !b.overflow; ++p) {
+    if (b.n & 1) { const uint8_t z = 0; bput(&b, &z, 1); }
+    const size_t off = b.n;
+    const size_t k = off < cap ? lzw_strip(&t, (const uint8_t*)vol + (size_t)p * page, page, dst + off, cap - off) : 0;
+    if (k == 0) { b.overflow = 1; break; }
+    b.n += k;
+    page_trailer(&b, &prev_next, off, k, height, width, bits);
+  }
+  tables_free(&t);
+  return b.overflow ? 0 : b.n;
+}
+
+/* The uint8 stack of ONE peak response map given only its non-zero window: page q (q = 0 .. pages-1) is slice z = z_first + q of a
+ * [*, height, width] tile that is zero everywhere except win[wn,wn,wn] placed at origin (oz, oy, ox) (window voxels outside the tile
+ * are ignored).  The file equals m3d_tiff_encode_stack of the dense map; the dense map itself (2.56 MB per peak of a nuclei tile,
+ * against 0.59 MB of window) never crosses PCIe and never exists on the host: one page buffer is composed at a time. */
+M3D_EXPORT size_t m3d_tiff_encode_window_stack_u8(const uint8_t* win, int wn, int oz, int oy, int ox, int z_first, int pages, int height,
+                                                  int width, uint8_t* dst, size_t cap) {
+  if (!win || !dst || wn <= 0 || pages < 0 || height <= 0 || width <= 0 || cap < 8) return 0;
+  LzwTables t;
+  const size_t page = (size_t)height * width;
+  uint8_t* pg = (uint8_t*)malloc(page);
+  if (!tables_alloc(&t) || !pg) { tables_free(&t); free(pg); return 0; }
+  Buf b = {dst, cap, 0, 0};
+  const uint8_t hdr[8] = {'I', 'I', 42, 0, 0, 0, 0, 0};
+  bput(&b, hdr, 8);
+  size_t prev_next = 4;
+  const int y0 = oy < 0 ? 0 : oy, y1 = oy + wn > height ? height : oy + wn;
+  const int x0 = ox < 0 ? 0 : ox, x1 = ox + wn > width ? width : ox + wn;
+  int dirty = 1;                                               /* the page buffer holds something other than zeros */
+  for (int q = 0; q < pages && !b.overflow; ++q) {
+    const int z = z_first + q, wz = z - oz;
+    if (dirty) { memset(pg, 0, page); dirty = 0; }
+    if (wz >= 0 && wz < wn && y1 > y0 && x1 > x0) {
+      for (int y = y0; y < y1; ++y)
+        memcpy(pg + (size_t)y * width + x0, win + ((size_t)wz * wn + (y - oy)) * wn + (x0 - ox), (size_t)(x1 - x0));
+      dirty = 1;
+    }
+    if (b.n & 1) { const uint8_t zz = 0; bput(&b, &zz, 1); }
+    const size_t off = b.n;
+    const size_t k = off < cap ? lzw_strip(&t, pg, page, dst + off, cap - off) : 0;
+    if (k == 0) { b.overflow = 1; break; }
+    b.n += k;
+    page_trailer(&b, &prev_next, off, k, height, width, 8);
+  }
+  tables_free(&t); free(pg);
+  return b.overflow ? 0 : b.n;
 }
 
 /* returns the number of bytes produced (<= cap); stops at EOI, end of input or a full output buffer */

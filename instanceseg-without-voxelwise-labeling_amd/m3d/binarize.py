@@ -105,8 +105,9 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     cc, offs, bsel, idx_t, ok = r
     ids = (idx_t + first_id).to(torch.int32)
     ids = torch.where(ok, ids, torch.full_like(ids, -1))                                   # skipped: never paints
-    labels = ops.paint_instances(cc, offs, bsel, ids, (S, H, W))
-    present = torch.bincount(labels.reshape(-1), minlength=first_id + P)[first_id:first_id + P] > 0
+    labels = torch.full((S, H, W), -1, dtype=torch.int32, device=dev)                       # 0xFFFFFFFF sentinel
+    ops.paint_instances_into(labels, cc, offs, bsel, ids)
+    present = ops.paint_finish(labels, first_id + P - 1)[first_id:first_id + P]           # (torch.bincount would make the host wait here)
     return labels, present
 
 
@@ -189,8 +190,8 @@ def binarize_volume(img, tiles, dataset, nms_thresh=None, max_gray_range=8192):
         ids = torch.where(ok, ids, torch.full_like(ids, -1))
         gb = (bsel + torch.tensor([ws, hs, ss, ws, hs, ss], dtype=torch.int32, device=bsel.device)).contiguous()
         ops.paint_instances_into(vol, cc, offs, gb, ids)
-    labels = torch.where(vol == -1, torch.zeros_like(vol), vol)
-    present = (torch.bincount(labels.reshape(-1), minlength=n + 1)[1:n + 1] > 0).cpu().numpy()
+    present = ops.paint_finish(vol, n)[1:n + 1].cpu().numpy()
+    labels = vol
     seg = labels.cpu().numpy().astype(np.uint16)
     if dataset == "soma":
         table = np.array([[mask_ids[d], dets[d, -1]] for d in range(n) if present[d]], np.float64).reshape(-1, 2)

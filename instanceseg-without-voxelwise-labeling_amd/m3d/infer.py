@@ -46,29 +46,197 @@ def im_detect_all(det, im, patch=None, overlap=None, dist=None, tile_batch=4):
     return res
 
 
-def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, peak_threshold=0.1):
-    """engine: PRMEngine.  Returns a list of per-tile dicts {num, start, dets (float64 [P,7]), prm_u8 (list of
-    uint8 volumes, slice padding removed)} for tiles that produced detections (infer_simple.py:209-247)."""
+def _device_volume(im, patch_s):
+    """infer_simple.py:180-195 on the device: norm1 in float64 (mask = im > 0; (im - mean) / std, rounded to fp32 once - what
+    `.astype(np.float32)` of the float64 crop gives, :217) and the edge-replicating slice pad.  Integer volumes go up as uint16 (half
+    the bytes of fp32); anything else is normalised on the host in float64 exactly as the reference does.
+    Returns (device fp32 volume [S',H,W], pad_s, original slice count)."""
+    im = np.asarray(im)
+    slices = int(im.shape[0])
+    if im.dtype in (np.uint8, np.uint16):
+        raw = ops.upload(np.ascontiguousarray(im.astype(np.uint16, copy=False)).view(np.uint16), "cuda")
+        vol = ops.norm1(raw, f32_arith=False)
+    elif im.dtype == np.float32:
+        vol = ops.norm1(ops.upload(np.ascontiguousarray(im), "cuda"), f32_arith=False)
+    else:
+        vol = ops.upload(tiling.norm1(im, np.float64).astype(np.float32), "cuda")
+    pad_s = 0
+    if slices < patch_s:                                                      # :188-195
+        pad_s = int((patch_s - slices) / 2)
+        pad_e = patch_s - slices - pad_s
+        vol = torch.cat([vol[:1].expand(pad_s, -1, -1), vol, vol[-1:].expand(pad_e, -1, -1)], 0).contiguous()
+    return vol, pad_s, slices
+
+
+def infer_prm_serial(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, peak_threshold=0.1, device_norm=True):
+    """The straightforward driver: one tile at a time, the dense uint8 maps quantised on the device, copied back and written before the
+    next tile starts.  Kept as the statement `infer_prm` (pipelined) is tested against, file for file and byte for byte.
+    Returns a list of per-tile dicts {num, start, dets (float64 [P,7]), prm_u8 (list of uint8 volumes, slice padding removed), peaks}
+    for tiles that produced detections (infer_simple.py:209-247)."""
     c = engine.cfg
     patch = patch or c.in_size
     overlap = c.crop_ovlp if overlap is None else overlap                     # :197
     dataset = dataset or getattr(c, "dataset", "nuclei")                      # args.dataset (:197,201)
-    vol = tiling.norm1(np.asarray(im), np.float64)                            # :180-183
-    orig_slices = vol.shape[0]
-    vol, pad_s = tiling.pad_slices(vol, patch[0])                             # :188-195
-    sidx, hidx, widx = tiling.tile_grid(vol.shape, patch, overlap, dataset)   # :196-204
+    if device_norm:
+        dvol, pad_s, orig_slices = _device_volume(im, patch[0])
+        shape = tuple(dvol.shape)
+    else:
+        vol = tiling.norm1(np.asarray(im), np.float64)                        # :180-183
+        orig_slices = vol.shape[0]
+        vol, pad_s = tiling.pad_slices(vol, patch[0])                         # :188-195
+        shape = vol.shape
+    sidx, hidx, widx = tiling.tile_grid(shape, patch, overlap, dataset)       # :196-204
     results = []
     for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
-        crop = vol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].copy().astype(np.float32)   # :217
-        out = engine.prm_tile(torch.from_numpy(crop[None, None]).cuda(), peak_threshold=peak_threshold, dense=False)
+        if device_norm:
+            crop_t = dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].contiguous()[None, None]
+        else:
+            crop_t = torch.from_numpy(vol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].copy().astype(np.float32)[None, None]).cuda()   # :217
+        out = engine.prm_tile(crop_t, peak_threshold=peak_threshold, dense=False)
         if out is None:
             continue                                                          # :225-226
         dets = out["dets"].cpu().numpy()
         # :233-238 on device, straight from the cone-cropped windows (no dense float maps), then 1 byte per voxel D2H
-        q = ops.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], crop.shape[-3:]).cpu().numpy()
+        q = ops.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], crop_t.shape[-3:]).cpu().numpy()
         u8 = [q[ch][pad_s:pad_s + orig_slices] if pad_s else q[ch] for ch in range(q.shape[0])]   # :239-240
         rec = dict(num=num, start=(s, h, w), dets=dets, prm_u8=u8, peaks=out["peaks"].cpu().numpy())
         results.append(rec)
         if out_dir is not None:                                               # :213-216,246-247
             mio.save_prm_instances(os.path.join(out_dir, "instances", str(num)), u8, dets)   # {ch}.tif (LZW) + dets.npy
+    return results
+
+
+class _WriterPool:
+    """Host side of the pipelined driver.  `drain` threads wait for a tile's device-to-host copy (an event wait: the GIL is free) and
+    fan its peaks out to `encode` threads, which build each `{ch}.tif` in C (m3d_tiff_encode_window_stack_u8: the GIL is free there
+    too) and write it.  Pinned staging buffers are pooled by size."""
+
+    def __init__(self, workers=None):
+        from concurrent.futures import ThreadPoolExecutor
+        if workers is None:
+            try:
+                workers = len(os.sched_getaffinity(0))
+            except Exception:
+                workers = os.cpu_count() or 1
+            try:
+                q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    workers = min(workers, max(1, int(int(q) / int(p))))
+            except Exception:
+                pass
+        self.workers = max(1, min(32, int(workers)))
+        self.drain = ThreadPoolExecutor(max_workers=2)
+        self.encode = ThreadPoolExecutor(max_workers=self.workers)
+        self.pinned = {}
+        self.pending = []
+        import threading
+        self.lock = threading.Lock()
+
+    def take(self, nbytes):
+        size = 1 << max(20, int(nbytes - 1).bit_length())                    # power-of-two size classes: few pinning calls
+        with self.lock:
+            lst = self.pinned.setdefault(size, [])
+            if lst:
+                return lst.pop()
+        return torch.empty((size,), dtype=torch.uint8).pin_memory()
+
+    def give(self, buf):
+        with self.lock:
+            self.pinned.setdefault(int(buf.numel()), []).append(buf)
+
+    def submit(self, fn, *a):
+        self.pending.append(self.drain.submit(fn, *a))
+
+    def finish(self):
+        for f in self.pending:
+            f.result()
+        self.pending = []
+
+    def close(self):
+        self.finish()
+        self.drain.shutdown()
+        self.encode.shutdown()
+
+
+_pool = None
+
+
+def writer_pool():
+    global _pool
+    if _pool is None:
+        _pool = _WriterPool()
+    return _pool
+
+
+def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, peak_threshold=0.1, keep_maps=True, pool=None):
+    """tools/infer_simple.py:176-247 for one volume, pipelined: the volume goes up once and is normalised (float64) and padded on the
+    device; per tile the back-propagation's windows are quantised to uint8 ON THE DEVICE AS WINDOWS and copied to pinned host memory on
+    a copy stream while the next tile computes; a thread pool rebuilds each peak's pages around its window, LZW-encodes and writes
+    `instances/{num}/{ch}.tif` + `dets.npy` off the critical path.  Files are byte-identical to infer_prm_serial's.
+    keep_maps=False: the returned records carry no dense `prm_u8` maps (files only; nothing dense ever exists on the host)."""
+    c = engine.cfg
+    patch = tuple(patch or c.in_size)
+    overlap = c.crop_ovlp if overlap is None else overlap
+    dataset = dataset or getattr(c, "dataset", "nuclei")
+    pool = pool or writer_pool()
+    dvol, pad_s, orig_slices = _device_volume(im, patch[0])
+    sidx, hidx, widx = tiling.tile_grid(tuple(dvol.shape), patch, overlap, dataset)
+    z_first, pages = (pad_s, orig_slices) if pad_s else (0, patch[0])         # :239-240
+    copy_stream = engine.__dict__.setdefault("_copy_stream", torch.cuda.Stream())
+    results = []
+
+    def finish_tile(rec, ev, hbuf, P, wn, origins_h, tile_dir):
+        ev.synchronize()                                                      # the windows have landed
+        wins = hbuf.numpy()[:P * wn ** 3].reshape(P, wn, wn, wn)
+        org = origins_h.copy()
+
+        def one(ch):
+            data = mio.encode_window_stack_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2])
+            if tile_dir is not None:
+                with open(os.path.join(tile_dir, "%d.tif" % ch), "wb") as f:
+                    f.write(memoryview(data))
+            return None
+        futs = [pool.encode.submit(one, ch) for ch in range(P)] if tile_dir is not None else []
+        if keep_maps:
+            rec["prm_u8"] = [mio.window_to_dense_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2]) for ch in range(P)]
+        if tile_dir is not None:
+            np.save(os.path.join(tile_dir, "dets.npy"), np.asarray(rec["dets"]))
+        for f in futs:
+            f.result()
+        pool.give(hbuf)
+
+    for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):
+        crop = dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]].contiguous()[None, None]      # :217
+        out = engine.prm_tile(crop, peak_threshold=peak_threshold, dense=False)
+        if out is None:
+            continue                                                          # :225-226
+        P, wn = int(out["windows"].shape[0]), int(out["windows"].shape[1])
+        q = ops.prm_quantize_windows_compact_u8(out["windows"], out["sums"], out["origins"], patch)   # :233-238, as windows
+        org_dev = out["origins"]
+        done = torch.cuda.Event()
+        done.record()
+        hbuf = pool.take(P * wn ** 3 + 16 * P)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done)
+            hbuf[:P * wn ** 3].copy_(q.reshape(-1), non_blocking=True)
+            horg = hbuf[P * wn ** 3:P * wn ** 3 + 12 * P].view(torch.int32).view(P, 3) if (P * wn ** 3) % 4 == 0 else None
+            if horg is not None:
+                horg.copy_(org_dev, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record()
+        q.record_stream(copy_stream)
+        org_dev.record_stream(copy_stream)
+        if horg is None:
+            origins_h = org_dev.cpu().numpy()
+        else:
+            origins_h = horg.numpy()
+        rec = dict(num=num, start=(s, h, w), dets=out["dets"].numpy() if out["dets"].device.type == "cpu" else out["dets"].cpu().numpy(),
+                   peaks=out["peaks"].numpy() if out["peaks"].device.type == "cpu" else out["peaks"].cpu().numpy())
+        results.append(rec)
+        tile_dir = None
+        if out_dir is not None:                                               # :213-216
+            tile_dir = os.path.join(out_dir, "instances", str(num))
+            os.makedirs(tile_dir, exist_ok=True)
+        pool.submit(finish_tile, rec, landed, hbuf, P, wn, origins_h, tile_dir)
+    pool.finish()
     return results

@@ -30,6 +30,14 @@ def _lib():
         for f in (lib.m3d_tiff_lzw_encode, lib.m3d_tiff_lzw_decode):
             f.restype = C.c_size_t
             f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.m3d_tiff_lzw_encode_plain.restype = C.c_size_t
+        lib.m3d_tiff_lzw_encode_plain.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.m3d_tiff_stack_bound.restype = C.c_size_t
+        lib.m3d_tiff_stack_bound.argtypes = [C.c_int] * 4
+        lib.m3d_tiff_encode_stack.restype = C.c_size_t
+        lib.m3d_tiff_encode_stack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.m3d_tiff_encode_window_stack_u8.restype = C.c_size_t
+        lib.m3d_tiff_encode_window_stack_u8.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_size_t]
         lib.m3d_rle3d_encode.restype = C.c_size_t
         lib.m3d_rle3d_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.m3d_rle3d_decode.restype = C.c_int
@@ -92,9 +100,67 @@ _W, _H, _BPS, _COMP, _PHOTO, _STRIPOFF, _SPP, _RPS, _STRIPCNT, _PLANAR, _PREDICT
     256, 257, 258, 259, 262, 273, 277, 278, 279, 284, 317, 339
 
 
+def encode_tiff_stack(vol):
+    """uint8 / uint16 [pages, H, W] -> the bytes of the LZW multi-page TIFF (csrc/tiff_lzw.c builds the whole file; the call
+    releases the GIL, so stacks are encoded in parallel on a thread pool)."""
+    vol = np.asarray(vol)
+    if vol.ndim == 2:
+        vol = vol[None]
+    if vol.ndim != 3 or vol.dtype not in (np.uint8, np.uint16):
+        raise ValueError("write_tiff_stack: need a uint8/uint16 [pages,H,W] array, got %s %s" % (vol.dtype, vol.shape))
+    vol = np.ascontiguousarray(vol.astype(vol.dtype.newbyteorder("<"), copy=False))
+    P, H, W = vol.shape
+    bits = vol.dtype.itemsize * 8
+    cap = _lib().m3d_tiff_stack_bound(P, H, W, bits)
+    dst = np.empty((cap,), np.uint8)
+    n = _lib().m3d_tiff_encode_stack(vol.ctypes.data, P, H, W, bits, dst.ctypes.data, cap)
+    if n == 0:
+        raise RuntimeError("tiff_encode_stack failed")
+    return dst[:n]
+
+
+def encode_window_stack_u8(win, origin, z_first, pages, height, width, dst=None):
+    """The LZW TIFF of one uint8 peak response map from its non-zero window alone: win uint8 [n,n,n] at origin (oz,oy,ox) of a
+    [*, height, width] tile; pages = slices z_first .. z_first + pages - 1.  Byte-identical to encode_tiff_stack of the dense map."""
+    win = np.ascontiguousarray(win, dtype=np.uint8)
+    n = int(win.shape[0])
+    assert win.shape == (n, n, n)
+    cap = _lib().m3d_tiff_stack_bound(int(pages), int(height), int(width), 8)
+    if dst is None or dst.size < cap:
+        dst = np.empty((cap,), np.uint8)
+    k = _lib().m3d_tiff_encode_window_stack_u8(win.ctypes.data, n, int(origin[0]), int(origin[1]), int(origin[2]), int(z_first), int(pages),
+                                               int(height), int(width), dst.ctypes.data, dst.size)
+    if k == 0:
+        raise RuntimeError("tiff_encode_window_stack_u8 failed")
+    return dst[:k]
+
+
+def window_to_dense_u8(win, origin, z_first, pages, height, width):
+    """The dense uint8 map [pages, height, width] a window stands for (zero outside it)."""
+    win = np.asarray(win)
+    n = win.shape[0]
+    oz, oy, ox = (int(v) for v in origin)
+    out = np.zeros((pages, height, width), np.uint8)
+    z0, z1 = max(z_first, oz), min(z_first + pages, oz + n)
+    y0, y1, x0, x1 = max(0, oy), min(height, oy + n), max(0, ox), min(width, ox + n)
+    if z1 > z0 and y1 > y0 and x1 > x0:
+        out[z0 - z_first:z1 - z_first, y0:y1, x0:x1] = win[z0 - oz:z1 - oz, y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+    return out
+
+
 def write_tiff_stack(path, vol, compression="lzw"):
     """vol: uint8 / uint16 array [pages, H, W] (a 2-D array is one page).  Little-endian classic TIFF, one strip per
     page, BlackIsZero, no predictor (libtiff's default for write_image)."""
+    if compression != "lzw":
+        return write_tiff_stack_py(path, vol, compression)
+    data = encode_tiff_stack(vol)
+    with open(path, "wb") as f:
+        f.write(memoryview(data))
+
+
+def write_tiff_stack_py(path, vol, compression="lzw"):
+    """The framing of write_tiff_stack in Python, page by page (uncompressed stacks; the independent statement the C file builder
+    is tested against)."""
     vol = np.asarray(vol)
     if vol.ndim == 2:
         vol = vol[None]

@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -830,6 +830,21 @@ def prm_quantize_windows_u8(windows, sums, origins, shape, return_nonempty=False
     return out
 
 
+def prm_quantize_windows_compact_u8(windows, sums, origins, shape, out=None):
+    """The uint8 values of prm_quantize_windows_u8 as windows [P,Wn,Wn,Wn] (0 outside the tile): with `origins`, everything a writer
+    needs to rebuild each uint8 map (m3d.io.encode_window_stack_u8)."""
+    _need_gpu(windows, sums, origins)
+    windows = _f32c(windows)
+    P, Wn = windows.shape[0], windows.shape[1]
+    D, H, W = (int(v) for v in shape)
+    if out is None:
+        out = torch.empty((P, Wn, Wn, Wn), dtype=torch.uint8, device=windows.device)
+    ws = torch.empty((max(16 * P, 16),), dtype=torch.uint8, device=windows.device)
+    check(lib().m3d_prm_quantize_windows_compact_u8(_ptr(windows), _ptr(_f32c(sums)), _ptr(origins.contiguous()), P, Wn, D, H, W, _ptr(out),
+                                                    _ptr(ws), C.c_size_t(ws.numel()), _stream()), "prm_quantize_windows_compact_u8")
+    return out
+
+
 def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None):
     """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
     Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch.
@@ -1074,6 +1089,15 @@ def paint_instances_into(vol, mask, offsets, boxes, ids):
     check(lib().m3d_paint_instances(_ptr(mask), _ptr(offsets), _ptr(boxes.contiguous()), _ptr(ids.contiguous()), boxes.shape[0],
                                     D, H, W, _ptr(vol), _stream()), "paint_instances")
     return vol
+
+
+def paint_finish(vol, max_id):
+    """In place: sentinel -> 0; returns bool [max_id + 1]: id occurs in the volume (index 0 unused).  No host synchronisation."""
+    _need_gpu(vol)
+    assert vol.dtype == torch.int32 and vol.is_contiguous()
+    present = torch.zeros((int(max_id) + 1,), dtype=torch.uint8, device=vol.device)
+    check(lib().m3d_paint_finish(_ptr(vol), C.c_int64(vol.numel()), int(max_id), _ptr(present), _stream()), "paint_finish")
+    return present.view(torch.bool)
 
 
 def paint_instances(mask, offsets, boxes, ids, shape):

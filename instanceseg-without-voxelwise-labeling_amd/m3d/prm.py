@@ -10,13 +10,14 @@ import numpy as np
 import torch
 
 from . import ops
-from .model import DetectorM3D
+from .model import DetectorM3D, _NOSPAN
 
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True):
         self.det = det
         self.cfg = det.cfg
+        self.probe = None                             # optional m3d.model.Probe: HIP-event spans around the phases of prm_tile (bench.py)
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
         # side by side along x): 4/9 of the MFMA work and tiles that fit; strip_wino=False keeps the direct kernel everywhere
         self.strip_wino = bool(strip_wino)
@@ -48,6 +49,9 @@ class PRMEngine:
         self.w_cls = P["RPN.RPN_cls_score.weight"]
         self.cls_norm_conv = ops.PackedConv3d(self.w_cls, ops.W_RELU)
         self.w_cls2d = self.w_cls.reshape(self.w_cls.shape[0], self.w_cls.shape[1]).contiguous()
+
+    def span(self, name):
+        return self.probe(name) if self.probe is not None else _NOSPAN
 
     @staticmethod
     def _dgrad_wino(w):
@@ -222,33 +226,38 @@ class PRMEngine:
         det, c = self.det, self.cfg
         S, H, W = data.shape[-3:]
         im_info = np.array([S, H, W, 1.0], np.float64)
-        feat, prob, deltas, saved, top = self.forward_response(data)
+        with self.span("forward_response"):
+            feat, prob, deltas, saved, top = self.forward_response(data)
         if not det._fused_ok(prob) or not det.has_head:
             self.forward_norms(saved, top)
             return self._prm_tile_unfused(data, feat, prob, deltas, saved, top, peak_threshold, dense)
-        rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(prob, deltas, det.anchors, float(c.stride), im_info, c.pre_nms_topN,
-                                                                        c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
-        num_host = det._pinned_counts(num)
-        num_host.copy_(num, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
-        _, offs_dev = ops.compact_rows(rois_b, num)                   # [0, R] on the device for box results (no host-side offsets)
+        with self.span("proposals"):
+            rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(prob, deltas, det.anchors, float(c.stride), im_info, c.pre_nms_topN,
+                                                                            c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
+            num_host = det._pinned_counts(num)
+            num_host.copy_(num, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            _, offs_dev = ops.compact_rows(rois_b, num)               # [0, R] on the device for box results (no host-side offsets)
         nl = len(saved)
         late = [i for i in (0, 1) if i < nl - 1]                      # conv1a / conv2a: the last layers the backward reaches
-        self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
+        with self.span("norm_convs"):
+            self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
         ready.synchronize()                                           # host wait 1 (covered by the norm convs above)
         R = int(num_host[0])
         det._release_counts(num_host)
         if R == 0:
             return None                                               # nothing survives -> the reference returns five Nones (:190)
         rois, keep_idx = rois_b[0, :R], kidx_b[0, :R]
-        cls, bbox = det.box_head(feat, rois)
-        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
-        cb, ck, cnt = ops.box_results3d_batched(cls, pred, keep_idx, offs_dev, c.num_classes, c.score_thresh, c.nms,
-                                                c.detections_per_im, R)                                          # :124
-        A = prob.shape[1]
-        sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:])          # :125,136-139,161-163
-        self.forward_norms(saved, top, layers=late, cls=False)
+        with self.span("box_head"):
+            cls, bbox = det.box_head(feat, rois)
+            pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
+            cb, ck, cnt = ops.box_results3d_batched(cls, pred, keep_idx, offs_dev, c.num_classes, c.score_thresh, c.nms,
+                                                    c.detections_per_im, R)                                          # :124
+            A = prob.shape[1]
+            sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:])          # :125,136-139,161-163
+        with self.span("norm_convs_late"):
+            self.forward_norms(saved, top, layers=late, cls=False)
         sel["event"].synchronize()                                    # host wait 2 (covered by the two norm convs above)
         P = int(sel["host"]["num"][0])
         if P == 0:
@@ -258,7 +267,8 @@ class PRMEngine:
         peaks = torch.from_numpy(np.concatenate((np.zeros((P, 1), np.int64), hp.astype(np.int64)), 1))          # (b,a,s,h,w), b = 0
         dets = torch.from_numpy(sel["host"]["dets"][:P].astype(np.float64))                                     # :163
         sel["release"]()
-        win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
+        with self.span("backward"):
+            win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
         out = dict(crm=prob, peaks=peaks, dets=dets, peaks_dev=sel["peaks"][:P], dets_dev=sel["dets"][:P], windows=win, sums=sums,
                    origins=origins)
         if dense:

@@ -431,3 +431,34 @@ def test_select_peaks_kernel_equals_the_host_statements(rows, count, cap, thr):
     assert np.array_equal(sel["host"]["peaks"][:n], ref_peaks) and np.array_equal(sel["peaks"][:n].cpu().numpy(), ref_peaks)
     assert np.array_equal(sel["host"]["dets"][:n], dets[idx]) and np.array_equal(sel["dets"][:n].cpu().numpy(), dets[idx])
     sel["release"]()
+
+
+@pytest.mark.parametrize("dataset,shape,patch,overlap", [("nuclei", (12, 40, 40), (16, 24, 24), 8), ("nuclei", (20, 30, 52), (16, 24, 24), 8)])
+def test_pipelined_volume_driver_writes_the_serial_drivers_files_byte_for_byte(tmp_path, dataset, shape, patch, overlap):
+    """infer_prm (device norm1 in float64, uint8 WINDOWS to pinned memory on a copy stream, pages rebuilt and LZW-encoded by a thread
+    pool) against infer_prm_serial (dense uint8 maps copied back and written tile by tile): the same tiles, the same detections, and
+    every file of the instance tree identical byte for byte; and against the host-side float64 norm1 of the reference statements."""
+    import os
+    from m3d.infer import infer_prm, infer_prm_serial
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=2)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0)
+    eng = _engine(P, cfg)
+    rs = np.random.RandomState(7)
+    im = (rs.rand(*shape) * 900 + 50).astype(np.uint16)
+    a = infer_prm_serial(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=str(tmp_path / "serial"))
+    b = infer_prm(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=str(tmp_path / "piped"))
+    h = infer_prm_serial(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=None, device_norm=False)
+    assert len(a) == len(b) == len(h) >= 1
+    for ra, rb, rh in zip(a, b, h):
+        assert ra["num"] == rb["num"] == rh["num"] and ra["start"] == rb["start"]
+        assert np.array_equal(ra["dets"], rb["dets"]) and np.array_equal(ra["peaks"], rb["peaks"])
+        assert len(ra["prm_u8"]) == len(rb["prm_u8"]) and all(np.array_equal(x, y) for x, y in zip(ra["prm_u8"], rb["prm_u8"]))
+        assert np.array_equal(ra["peaks"], rh["peaks"]) and np.allclose(ra["dets"], rh["dets"], rtol=1e-5, atol=1e-4)   # device vs host norm1
+    files = []
+    for root, _, names in os.walk(str(tmp_path / "serial")):
+        files += [os.path.relpath(os.path.join(root, n), str(tmp_path / "serial")) for n in names]
+    assert len(files) >= 2
+    for f in files:
+        assert open(str(tmp_path / "serial" / f), "rb").read() == open(str(tmp_path / "piped" / f), "rb").read(), f
+    n_piped = sum(len(names) for _, _, names in os.walk(str(tmp_path / "piped")))
+    assert n_piped == len(files)

@@ -113,3 +113,50 @@ def test_rle3d_matches_the_reference_module():
         mio.binary_mask_to_rle(np.zeros((3, 4, 5), np.float32))
     with pytest.raises(AssertionError):
         mio.rle_to_binary_mask({"counts": [5], "size": [2, 2, 2]})
+
+
+def test_run_accelerated_lzw_equals_the_textbook_encoder_byte_for_byte():
+    """m3d_tiff_lzw_encode jumps through runs of zero bytes along the dictionary chain 0, 00, 000, ...; it must emit exactly what the
+    byte-per-probe greedy encoder emits - sparse, dense, all-zero, tiny and table-reset-length inputs."""
+    import ctypes as C
+    L = mio._lib()
+    rs = np.random.RandomState(3)
+
+    def enc(fn, a):
+        cap = L.m3d_tiff_lzw_bound(a.size)
+        d = np.empty(cap, np.uint8)
+        return d[:fn(a.ctypes.data, a.size, d.ctypes.data, cap)].tobytes()
+    cases = [np.zeros(n, np.uint8) for n in (0, 1, 2, 5, 40000, 1500000)]
+    for n in (1, 2, 3, 100, 40000, 400000):
+        for dens in (0.0005, 0.01, 0.1, 0.5, 1.0):
+            cases.append(((rs.rand(n) < dens) * rs.randint(0, 256, n)).astype(np.uint8))
+            cases.append(((rs.rand(n) < dens) * rs.randint(0, 3, n)).astype(np.uint8))
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        comp = enc(L.m3d_tiff_lzw_encode, a)
+        assert comp == enc(L.m3d_tiff_lzw_encode_plain, a), a.size
+        assert mio.lzw_decode(comp, a.size) == a.tobytes()
+
+
+def test_c_file_builder_equals_the_python_framing_and_the_window_form_equals_the_dense_map(tmp_path):
+    """m3d_tiff_encode_stack == write_tiff_stack_py (independent framing) for uint8 and uint16 stacks; m3d_tiff_encode_window_stack_u8
+    (a peak response map from its non-zero window: what the volume driver hands the writer pool) == the stack of the dense map,
+    windows sticking out of the tile on every side, slice padding removed (z_first > 0)."""
+    rs = np.random.RandomState(4)
+    for v in volumes():
+        mio.write_tiff_stack_py(str(tmp_path / "a.tif"), v)
+        assert mio.encode_tiff_stack(v).tobytes() == open(str(tmp_path / "a.tif"), "rb").read()
+    S, H, W, n = 12, 40, 52, 20
+    win = (rs.randint(0, 256, (n, n, n)) * (rs.rand(n, n, n) < 0.3)).astype(np.uint8)
+    for oz, oy, ox in ((2, 5, 7), (-9, -11, 40), (0, 0, 0), (8, 35, -15), (30, 0, 0), (-25, 3, 3)):
+        dense = np.zeros((S, H, W), np.uint8)
+        for z in range(n):
+            if 0 <= oz + z < S:
+                y0, y1, x0, x1 = max(0, oy), min(H, oy + n), max(0, ox), min(W, ox + n)
+                if y1 > y0 and x1 > x0:
+                    dense[oz + z, y0:y1, x0:x1] = win[z, y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+        for zf, pages in ((0, S), (2, S - 3)):
+            got = mio.encode_window_stack_u8(win, (oz, oy, ox), zf, pages, H, W).tobytes()
+            assert got == mio.encode_tiff_stack(dense[zf:zf + pages]).tobytes(), (oz, oy, ox, zf)
+            (tmp_path / "w.tif").write_bytes(got)
+            assert np.array_equal(mio.read_tiff_stack(str(tmp_path / "w.tif")), dense[zf:zf + pages])
