@@ -8,8 +8,8 @@
  *   - return value: M3D_OK (0) or a negative M3D_E* code; nothing ever calls exit()
  *     (the reference's launchers print and exit(-1): roi_align_kernel_3d.cu:165-169);
  *   - re-entrant; scratch memory comes from the caller (`d_ws`, sized by the matching *_workspace_bytes());
- *     the library never reads the environment: the only process-wide state is the set of explicit tuning
- *     options below (m3d_set_option), which the CALLER owns and which default to "library decides".
+ *     the library never reads the environment and keeps no mutable process-wide state (the tuning knobs below are compiled out of
+ *     libm3d.so; they live in the separate tuning build libm3d_tune.so).
  * Paths in comments are relative to the reference repository.
  */
 #ifndef M3D_H_
@@ -31,13 +31,17 @@ int m3d_version(void);
 const char* m3d_error_string(int code);
 /* Last HIP runtime error text seen by this thread (for M3D_ELAUNCH). */
 const char* m3d_last_hip_error(void);
-/* Tuning options (benchmark / A-B tooling; production callers never set them).  Names: "xcd_map" (1: XCD-aware
- * workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt"
- * (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" / "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of
- * m3d_linear_bf16x3_forward), "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per
- * workgroup; -1: rows kernel, planes by grid size).  Unknown name -> M3D_EINVAL. */
+/* Tuning options (benchmark / A-B tooling).  The release library libm3d.so keeps NO mutable process-wide state: there
+ * m3d_set_option returns M3D_EUNSUPPORTED for every known name and m3d_get_option reports the built-in defaults.  The knobs are live only
+ * in libm3d_tune.so (same objects, m3d_core built with -DM3D_TUNING; m3d_tuning_build() == 1), which tools/*.py and the kernel-family tests load
+ * beside the release library.  Names: "xcd_map" (1: XCD-aware workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino",
+ * "tune_wino2", "tune_wino2_xt" (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" /
+ * "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of m3d_linear_bf16x3_forward),
+ * "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per workgroup; -1: rows kernel, planes by
+ * grid size).  Unknown name -> M3D_EINVAL. */
 int m3d_set_option(const char* name, int value);
 int m3d_get_option(const char* name, int* value);
+int m3d_tuning_build(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * RoIAlign 3D.  Replaces roi_align_forward_cuda_3d / roi_align_backward_cuda_3d

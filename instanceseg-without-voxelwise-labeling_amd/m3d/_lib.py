@@ -9,7 +9,7 @@ M3D_OK = 0
 _lib = None
 
 SYMBOLS = [
-    "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option",
+    "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option", "m3d_tuning_build",
     "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1", "m3d_norm1_batched",
     "m3d_linear_workspace_bytes", "m3d_linear_forward", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_pack",
     "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward",
@@ -36,35 +36,72 @@ class M3DError(RuntimeError):
     pass
 
 
+_TUNE_ENV = (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
+             ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
+             ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem"))
+TUNE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libm3d_tune.so")
+_tune = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise M3DError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C instanceseg-without-voxelwise-labeling_amd/csrc`. There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    L.m3d_error_string.restype = C.c_char_p
+    L.m3d_last_hip_error.restype = C.c_char_p
+    L.m3d_conv3d_wino2_score.restype = C.c_double
+    for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
+              "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
+              "m3d_box_results3d_batched_workspace_bytes", "m3d_nms3d_batched_workspace_bytes", "m3d_otsu2d_workspace_bytes",
+              "m3d_cc_workspace_bytes", "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_stem_wino_packed_weight_bytes"):
+        getattr(L, n).restype = C.c_size_t
+    return L
+
+
 def lib():
+    """The library every m3d op calls: libm3d.so (release: no mutable process-wide state), or - inside `with tuning():`, or for the
+    whole process when an M3D_TUNE_* / M3D_XCD_MAP knob of the A/B tools is in the environment - the tuning build libm3d_tune.so.
+    The library itself never reads the environment; this loader - the caller - forwards the knobs once."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise M3DError("libm3d.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "or `make -C instanceseg-without-voxelwise-labeling_amd/csrc`. There is no CPU fallback."
-                           % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        L.m3d_error_string.restype = C.c_char_p
-        L.m3d_last_hip_error.restype = C.c_char_p
-        L.m3d_conv3d_wino2_score.restype = C.c_double
-        for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
-                  "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
-                  "m3d_box_results3d_batched_workspace_bytes", "m3d_nms3d_batched_workspace_bytes", "m3d_otsu2d_workspace_bytes",
-                  "m3d_cc_workspace_bytes", "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_stem_wino_packed_weight_bytes"):
-            getattr(L, n).restype = C.c_size_t
-        _lib = L
-        # The library itself never reads the environment (include/m3d.h); this loader - the caller - forwards the
-        # A/B-tooling knobs of tools/*.py once, at load time.
-        for env, name in (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
-                          ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
-                          ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem")):
-            if env in os.environ:
+        knobs = [(env, name) for env, name in _TUNE_ENV if env in os.environ]
+        if knobs and "M3D_LIB_PATH" not in os.environ:
+            _lib = _load(TUNE_LIB_PATH)
+        else:
+            _lib = _load(LIB_PATH)
+        if knobs and _lib.m3d_tuning_build():
+            for env, name in knobs:
                 set_option(name, int(os.environ[env]))
     return _lib
 
 
+class tuning:
+    """`with tuning(): set_option(...)`: m3d ops go to libm3d_tune.so (the build whose option table is mutable) inside the block and
+    back to the release library after it; options are restored to their defaults on exit.  For A/B tools and kernel-family tests."""
+
+    def __enter__(self):
+        global _lib, _tune
+        lib()
+        if _tune is None:
+            _tune = _lib if _lib.m3d_tuning_build() else _load(TUNE_LIB_PATH)
+        self.prev = _lib
+        _lib = _tune
+        return self
+
+    def __exit__(self, *a):
+        global _lib
+        for _, name in _TUNE_ENV:
+            _tune.m3d_set_option(name.encode(), 1 if name == "xcd_map" else -1)
+        _lib = self.prev
+        return False
+
+
 def set_option(name, value):
-    check(lib().m3d_set_option(name.encode(), int(value)), "set_option(%s)" % name)
+    rc = lib().m3d_set_option(name.encode(), int(value))
+    if rc == -4 and not lib().m3d_tuning_build():
+        raise M3DError("set_option(%s): the release library has no mutable options; use `with m3d._lib.tuning():` (libm3d_tune.so)" % name)
+    check(rc, "set_option(%s)" % name)
 
 
 def get_option(name):

@@ -13,11 +13,13 @@ from . import io as mio
 from . import ops, tiling
 
 
-def im_detect_all(det, im, patch=None, overlap=None, dist=None, tile_batch=4):
+def im_detect_all(det, im, patch=None, overlap=None, dist=None, tile_batch=4, device="cuda", nms_fn=None):
     """det: DetectorM3D; im: raw (S,H,W) volume (any dtype).  Returns cls_boxes_total: list (per class) of
     [n,7] float32 arrays (x1,y1,z1,x2,y2,z2,score) in volume coordinates, after the cross-tile nms_3d
     (core/test.py:159).  With `dist` initialised the tiles are sharded round-robin over ranks and their
-    detections exchanged by one all_gather (m3d.shard)."""
+    detections exchanged by ONE all_gather (m3d.shard) - entered by every rank, also by one that holds no tile.
+    `device` / `nms_fn` exist for the multi-process CPU rehearsal of the sharding (tests/test_host_logic.py: gloo, a stub
+    detector): the product path is device="cuda" with the library's NMS."""
     from . import shard
     c = det.cfg
     patch = patch or c.in_size                                                # TEST.IN_SIZE
@@ -28,19 +30,19 @@ def im_detect_all(det, im, patch=None, overlap=None, dist=None, tile_batch=4):
     tiles = tiling.enumerate_tiles(sidx, hidx, widx)
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
-    dvol = torch.from_numpy(vol).cuda()
+    dvol = torch.from_numpy(vol).to(device)
     local = []
     mine = shard.partition(len(tiles), rank, world)
     for j in range(0, len(mine), tile_batch):                                 # tiles are independent: `tile_batch` of them per pass
         grp = [tiles[i] for i in mine[j:j + tile_batch]]
         cubes = torch.stack([dvol[s:s + patch[0], h:h + patch[1], w:w + patch[2]] for _, s, h, w in grp])[:, None].contiguous()
         for (_, s, h, w), out in zip(grp, det.detect_batch(cubes)):
-            d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device="cuda")
+            d = out["cls_boxes"][1] if "cls_boxes" in out else torch.zeros((0, 7), device=device)
             off = torch.tensor([w, h, s - pad_s, w, h, s - pad_s, 0], dtype=torch.float32, device=d.device)   # :117-121,140-141
             local.append(d + off)
-    allt = shard.all_gather_detections(local, c.detections_per_im, len(tiles), dist, device="cuda")   # ONE collective
-    dets = torch.cat(allt, 0) if allt else torch.zeros((0, 7), device="cuda")
-    keep = ops.nms3d(dets.contiguous(), c.nms)                                 # :159
+    allt = shard.all_gather_detections(local, c.detections_per_im, len(tiles), dist, device=device)   # ONE collective
+    dets = torch.cat(allt, 0) if allt else torch.zeros((0, 7), device=device)
+    keep = (nms_fn or ops.nms3d)(dets.contiguous(), c.nms)                     # :159
     res = [np.zeros((0, 7), np.float32) for _ in range(c.num_classes)]
     res[1] = dets[keep].cpu().numpy()
     return res

@@ -202,6 +202,7 @@ def test_config2_four_volumes_128_cubed_detections_equal_the_oracle():
     cfg, P, det = _baseline_model(head=True)
     ocfg = O.Cfg()
     torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    unmatched = []
     for i in range(4):
         vol = _baseline_volume(i)
         got = det.detect_tile(vol.cuda())
@@ -213,8 +214,13 @@ def test_config2_four_volumes_128_cubed_detections_equal_the_oracle():
         r = np.hstack((ref["det_boxes"], ref["det_scores"][:, None]))
         assert abs(len(g) - len(r)) <= max(1, len(r) // 50), (len(g), len(r))              # an NMS decision on the threshold may flip
         matched = sum(np.abs(r - row).max(1).min() < 5e-3 for row in g)
+        unmatched.append((len(g) - matched, len(g), len(r)))
         assert matched >= 0.98 * len(g), (matched, len(g))
         assert len(g) <= cfg.detections_per_im
+    # how many detections actually differ, not only "at least 98 % agree": recorded per volume and bounded in absolute terms - the
+    # saturated synthetic scores tie in thousands, so an order-dependent NMS decision may flip a handful, never more
+    print("configs[2]: (detections without a counterpart within 5e-3, detections, oracle detections) per volume:", unmatched)
+    assert sum(u for u, _, _ in unmatched) <= 4 and max(u for u, _, _ in unmatched) <= 2, unmatched
 
 
 def test_config4_rank_shape_eight_volumes_in_one_batch_match_the_per_tile_path_and_pack():

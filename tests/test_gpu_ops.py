@@ -359,14 +359,11 @@ def test_conv3d_stem_winograd_kernels_agree(m3d, tune):
     sh = torch.randn(40, generator=g)
     ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 2) * sc.double().view(1, -1, 1, 1, 1)
                      + sh.double().view(1, -1, 1, 1, 1))
-    old = _lib.get_option("tune_stem")
-    _lib.set_option("tune_stem", tune)
-    try:
+    with _lib.tuning():                              # the knob lives in libm3d_tune.so only; the release library has no mutable state
+        _lib.set_option("tune_stem", tune)
         conv = m3d.StemWinoConv3d(w.cuda())
         y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
         yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
-    finally:
-        _lib.set_option("tune_stem", old)
     assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
     assert torch.equal(yp, torch.nn.functional.max_pool3d(y, 2, 2))
 
@@ -383,14 +380,11 @@ def test_conv3d_winograd_ab_families_agree_with_fp64(m3d, fam):
     sh = torch.randn(128, generator=g)
     ref = torch.relu(torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1)
                      + sh.double().view(1, -1, 1, 1, 1))
-    old = _lib.get_option("tune_wino2")
-    _lib.set_option("tune_wino2", fam * 100 + 99)
-    try:
+    with _lib.tuning():
+        _lib.set_option("tune_wino2", fam * 100 + 99)
         conv = m3d.WinoConv3d(w.cuda(), two_d=True)
         y = conv(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
         yp = conv.pooled(x.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True) if conv.supports_pool(70) else None
-    finally:
-        _lib.set_option("tune_wino2", old)
     assert (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
     if yp is not None:
         assert torch.equal(yp, torch.nn.functional.max_pool3d(y, 2, 2))
@@ -675,21 +669,31 @@ def test_compact_rows_packs_the_valid_rows_of_every_item(m3d):
 
 
 def test_library_options_are_explicit(m3d):
-    """include/m3d.h: no environment reads inside the library; the tuning knobs are explicit options."""
+    """include/m3d.h: no environment reads and NO mutable process-wide state in the release library - m3d_set_option refuses there; the
+    tuning knobs live in the separate tuning build (libm3d_tune.so), loaded beside it by `with _lib.tuning()` and reset on exit."""
     from m3d import _lib
-    assert _lib.get_option("xcd_map") in (0, 1)
-    old = _lib.get_option("xcd_map")
+    assert _lib.lib().m3d_tuning_build() == 0                                  # the library the product path uses
+    assert _lib.lib().m3d_set_option(b"xcd_map", 0) == -4                      # M3D_EUNSUPPORTED
+    assert _lib.get_option("xcd_map") == 1 and _lib.get_option("tune_wino2") == -1
+    with pytest.raises(m3d.M3DError):
+        _lib.set_option("tune_stem", 4)
     x = torch.randn(1, 32, 8, 16, 64, device="cuda")
     w = torch.randn(64, 32, 3, 3, 3, device="cuda") * 0.05
-    conv = m3d.PackedConv3d(w)
-    _lib.set_option("xcd_map", 0)
-    a = conv(x)
-    _lib.set_option("xcd_map", 1)
-    b = conv(x)
-    _lib.set_option("xcd_map", old)
-    assert torch.equal(a, b)                       # the tile order is a speed option, never a result option
-    with pytest.raises(m3d.M3DError):
-        _lib.set_option("no_such_option", 1)
+    ref = m3d.PackedConv3d(w)(x)
+    with _lib.tuning():
+        assert _lib.lib().m3d_tuning_build() == 1
+        conv = m3d.PackedConv3d(w)
+        _lib.set_option("xcd_map", 0)
+        a = conv(x)
+        _lib.set_option("xcd_map", 1)
+        b = conv(x)
+        _lib.set_option("tune_stem", 4)
+        with pytest.raises(m3d.M3DError):
+            _lib.set_option("no_such_option", 1)
+    assert torch.equal(a, b) and torch.equal(a, ref)  # the tile order is a speed option, never a result option
+    assert _lib.lib().m3d_tuning_build() == 0
+    with _lib.tuning():
+        assert _lib.get_option("tune_stem") == -1 and _lib.get_option("xcd_map") == 1     # reset when the previous block ended
 
 
 @pytest.mark.parametrize("shape", [(5, 6, 7), (64, 64, 64), (128, 128, 128)])

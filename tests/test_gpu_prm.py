@@ -14,6 +14,37 @@ def _engine(P, cfg):
     return PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), peak_chunk=7)
 
 
+def _maps_close(got, ref32, ref64=None, what=""):
+    """PRM maps against the reference arithmetic: 1e-4 relative (+ 2e-6 of the map's maximum) at every voxel OUTSIDE the conditioning
+    band, 2e-3 relative inside it.  The band is measured, not assumed: the voxels where the reference's own fp32 evaluation (torch on the
+    CPU) departs from an fp64 evaluation of the same rule by more than half of the tight tolerance - the rule divides by |N| + 1e-10
+    and cuts at N < 1e-10 layer after layer (peak_backprop_3d.py:30-33), and a voxel beside that cut flips in ANY fp32 evaluation.
+    Without an fp64 run (ref64 None) the band is empty.  Prints the band's size; returns it."""
+    got = np.asarray(got, np.float64); ref32 = np.asarray(ref32, np.float64)
+    mx = float(np.abs(ref32).max())
+    band = np.zeros(ref32.shape, bool)
+    if ref64 is not None:
+        ref64 = np.asarray(ref64, np.float64)
+        band = np.abs(ref32 - ref64) > 5e-5 * np.abs(ref64) + 1e-6 * mx
+    err = np.abs(got - ref32)
+    tight = err <= 1e-4 * np.abs(ref32) + 2e-6 * mx
+    loose = err <= 2e-3 * np.abs(ref32) + 2e-6 * mx
+    print("PRM map check %s: %d voxels, %d in the conditioning band (held to 2e-3), worst error outside the band %.3g of max, inside %.3g"
+          % (what, ref32.size, int(band.sum()), float((err * ~band).max()) / mx, float((err * band).max()) / mx))
+    assert bool(tight[~band].all()), ("outside the band", what, float((err * ~band).max()) / mx, int((~tight & ~band).sum()))
+    assert bool(loose[band].all()), ("inside the band", what, float((err * band).max()) / mx)
+    assert band.mean() < 1e-3, ("the band must stay a handful of voxels", what, int(band.sum()))
+    return int(band.sum())
+
+
+def _oracle_maps(P, cfg, vol, peaks, double):
+    """The oracle's per-peak normalised maps (prm / prm.sum()) for `peaks` [(b,a,s,h,w)], in fp32 or fp64."""
+    Pd = {k: v.double() for k, v in P.items()} if double else P
+    with torch.no_grad():
+        _, p, _, sv = O.prm_forward(Pd, cfg, vol.double() if double else vol)
+        return [O.prm_backward(Pd, sv, tuple(int(v) for v in pk), p.shape)[0].numpy() for pk in peaks]
+
+
 @pytest.mark.parametrize("tag", ["n", "s"])
 def test_prm_golden(golden, tag):
     g = golden("prm_small_" + tag)
@@ -30,14 +61,21 @@ def test_prm_golden(golden, tag):
     win, sums, origins = eng.backward_windows(pk, saved, top, data)
     import m3d
     dense = m3d.prm_scatter(win, torch.ones_like(sums), origins, g["vol"].shape[-3:]).cpu().numpy()
+    vol_t = torch.from_numpy(g["vol"])
+    o32 = _oracle_maps(P, cfg, vol_t, g["peaks"], False)
+    o64 = _oracle_maps(P, cfg, vol_t, g["peaks"], True)
     for i in range(3):
         ref = np.clip(g["grads"][i][0, 0], 0, None)       # kernel stores clamp(min=0) of data.grad
-        assert np.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * ref.max()), i
+        # the band comes from the normalised oracle maps; scale it to this un-normalised gradient
+        _maps_close(dense[i], ref, o64[i] * (ref.sum() / max(o64[i].sum(), 1e-300)) if ref.sum() > 0 else None, "golden data.grad %s peak %d" % (tag, i))
     # (9) the full forward tuple
     out = eng.prm_tile(data)
     assert np.array_equal(out["peaks"].cpu().numpy(), g["o_peaks"])
     assert np.allclose(out["dets"].cpu().numpy(), g["o_dets"], rtol=1e-4, atol=1e-3)
-    assert np.allclose(out["prms"].cpu().numpy(), g["o_prms"], rtol=2e-3, atol=2e-6 * g["o_prms"].max())
+    o64 = _oracle_maps(P, cfg, vol_t, g["o_peaks"], True)
+    got = out["prms"].cpu().numpy()
+    for i in range(got.shape[0]):
+        _maps_close(got[i], g["o_prms"][i], o64[i], "golden forward tuple %s map %d" % (tag, i))
     assert np.allclose(out["prms"].sum((1, 2, 3)).cpu().numpy(), 1.0, atol=1e-4)
 
 
@@ -57,9 +95,10 @@ def test_prm_vs_oracle_border_peaks():
     win, sums, origins = eng.backward_windows(pk, saved, top, data)
     import m3d
     dense = m3d.prm_scatter(win, sums, origins, vol.shape[-3:]).cpu()
+    o64 = _oracle_maps(P, cfg, vol, peaks, True)
     for i, p in enumerate(peaks):
         ref = O.prm_backward(P, osaved, p, p2.shape)[0]
-        assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
+        _maps_close(dense[i].numpy(), ref.numpy(), o64[i], "border peak %d" % i)
 
 
 @pytest.mark.parametrize("stride,shape", [(8, (24, 40, 32)), (4, (16, 24, 40)), (8, (40, 104, 96))])
@@ -184,7 +223,9 @@ def test_driver_boundary_returns_the_reference_tuple(golden, tag):
     assert peaks.dtype == torch.int64 and np.array_equal(peaks.cpu().numpy(), g["o_peaks"])
     assert dets.dtype == torch.float64 and np.allclose(dets.cpu().numpy(), g["o_dets"], rtol=1e-4, atol=1e-3)
     assert prms.shape == g["o_prms"].shape
-    assert np.allclose(prms.cpu().numpy(), g["o_prms"], rtol=2e-3, atol=2e-6 * g["o_prms"].max())
+    o64 = _oracle_maps(P, cfg, torch.from_numpy(g["vol"]), g["o_peaks"], True)
+    for i in range(prms.shape[0]):
+        _maps_close(prms[i].cpu().numpy(), g["o_prms"][i], o64[i], "driver tuple %s map %d" % (tag, i))
 
 
 def test_empty_tiles_are_skipped_like_the_reference(tmp_path):
@@ -332,11 +373,12 @@ def test_soma_tile_default_engine_equals_the_oracle_at_the_shipped_size():
     pk = torch.tensor([p[1:] for p in peaks], dtype=torch.int32).cuda()
     win, sums, origins = eng.backward_windows(pk, saved, top, data)
     dense = m3d.prm_scatter(win, sums, origins, vol.shape[-3:]).cpu()
+    o64 = _oracle_maps(P, ocfg, vol, peaks, True)
     for i, p in enumerate(peaks):
         with torch.no_grad():
             ref = O.prm_backward(P, osaved, p, p2.shape)[0]
         assert float(ref.max()) > 0
-        assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
+        _maps_close(dense[i].numpy(), ref.numpy(), o64[i], "soma tile peak %d" % i)
         assert abs(float(dense[i].sum()) - 1.0) < 1e-4
 
 
@@ -403,11 +445,12 @@ def test_nuclei_tile_default_engine_equals_the_oracle_at_the_shipped_size():
     pk = torch.tensor([p[1:] for p in peaks], dtype=torch.int32).cuda()
     win, sums, origins = eng.backward_windows(pk, saved, top, data)
     dense = m3d.prm_scatter(win, sums, origins, vol.shape[-3:]).cpu()
+    o64 = _oracle_maps(P, ocfg, vol, peaks, True)
     for i, p in enumerate(peaks):
         with torch.no_grad():
             ref = O.prm_backward(P, osaved, p, p2.shape)[0]
         assert float(ref.max()) > 0
-        assert torch.allclose(dense[i], ref, rtol=2e-3, atol=2e-6 * float(ref.max())), i
+        _maps_close(dense[i].numpy(), ref.numpy(), o64[i], "nuclei tile peak %d" % i)
 
 
 @pytest.mark.parametrize("rows,count,cap,thr", [(300, 300, 300, 0.1), (300, 137, 300, 0.5), (1000, 777, 300, 0.05), (64, 0, 64, 0.1), (700, 700, 40, 0.0)])

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd")]
 from m3d import ops as m3d  # noqa: E402
 from m3d import _lib  # noqa: E402
+_lib.tuning().__enter__()      # option sweeps: the tuning build (libm3d_tune.so) for the whole process
 
 
 def timed(fn, n=10):

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
 import m3d
 from m3d import _lib
+_lib.tuning().__enter__()      # option sweeps: the tuning build (libm3d_tune.so) for the whole process
 N, K = 1024, 87808
 w = torch.randn(N, K, device="cuda") / K ** 0.5
 b = torch.randn(N, device="cuda")

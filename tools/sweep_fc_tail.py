@@ -3,6 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
 import m3d
 from m3d import _lib
+_lib.tuning().__enter__()      # option sweeps: the tuning build (libm3d_tune.so) for the whole process
 def timeit(f, n=10):
     for _ in range(3): f()
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
