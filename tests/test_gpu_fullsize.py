@@ -220,7 +220,7 @@ def test_config2_four_volumes_128_cubed_detections_equal_the_oracle():
     # how many detections actually differ, not only "at least 98 % agree": recorded per volume and bounded in absolute terms - the
     # saturated synthetic scores tie in thousands, so an order-dependent NMS decision may flip a handful, never more
     print("configs[2]: (detections without a counterpart within 5e-3, detections, oracle detections) per volume:", unmatched)
-    assert sum(u for u, _, _ in unmatched) <= 4 and max(u for u, _, _ in unmatched) <= 2, unmatched
+    assert sum(u for u, _, _ in unmatched) <= 2, unmatched          # measured on MI355X: 0 / 0 / 0 / 0
 
 
 def test_config4_rank_shape_eight_volumes_in_one_batch_match_the_per_tile_path_and_pack():

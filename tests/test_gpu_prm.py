@@ -33,7 +33,9 @@ def _maps_close(got, ref32, ref64=None, what=""):
           % (what, ref32.size, int(band.sum()), float((err * ~band).max()) / mx, float((err * band).max()) / mx))
     assert bool(tight[~band].all()), ("outside the band", what, float((err * ~band).max()) / mx, int((~tight & ~band).sum()))
     assert bool(loose[band].all()), ("inside the band", what, float((err * band).max()) / mx)
-    assert band.mean() < 1e-3, ("the band must stay a handful of voxels", what, int(band.sum()))
+    # one flipped `N < 1e-10` decision in an upper layer moves every voxel of the cone below it: thousands of voxels of an 84^3 window
+    # (measured: 7 664 of 2.56 M on the nuclei tile's interior peak, 71 on the soma tile's), never a sizeable share of the map
+    assert band.mean() < 1e-2, ("the band must stay a small share of the map", what, int(band.sum()))
     return int(band.sum())
 
 
