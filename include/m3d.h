@@ -33,7 +33,7 @@ const char* m3d_error_string(int code);
 const char* m3d_last_hip_error(void);
 /* Tuning options (benchmark / A-B tooling).  The release library libm3d.so keeps NO mutable process-wide state: there
  * m3d_set_option returns M3D_EUNSUPPORTED for every known name and m3d_get_option reports the built-in defaults.  The knobs are live only
- * in libm3d_tune.so (same objects, m3d_core built with -DM3D_TUNING; m3d_tuning_build() == 1), which tools/*.py and the kernel-family tests load
+ * in libm3d_tune.so (same objects, m3d_core built with -DM3D_TUNING; m3d_tuning_build() == 1), which the scripts under tools/ and the kernel-family tests load
  * beside the release library.  Names: "xcd_map" (1: XCD-aware workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino",
  * "tune_wino2", "tune_wino2_xt" (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" /
  * "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of m3d_linear_bf16x3_forward),
@@ -132,6 +132,11 @@ int m3d_conv3d_pack_weights(const float* d_weight /*[cout,cin,k,k,k]*/, int cin,
 int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                        int depth, int height, int width, int k, const float* d_in_offset /*1 float or NULL*/,
                        const float* d_scale, const float* d_shift, int relu, const float* d_mul, void* stream);
+/* The two 1x1x1 RPN heads as ONE convolution with both epilogues (lib/modeling/rpn_heads.py:96-98 and the sigmoid of :116): output
+ * channels [0, split) -> 1 / (1 + exp(-v)) -> d_out_sigmoid [batch, split, D, H, W]; channels [split, cout) -> d_out_rest
+ * [batch, cout - split, D, H, W].  d_packed = m3d_conv3d_pack_weights of the concatenated weights; d_shift = the concatenated biases. */
+int m3d_conv3d_forward_split_sigmoid(const float* d_in, const float* d_packed, float* d_out_sigmoid, float* d_out_rest, int batch, int cin,
+                                     int cout, int split, int depth, int height, int width, int k, const float* d_shift, void* stream);
 /* 3x3x3 "same" convolution with dilation 2 / padding 2 (dilation 1 = m3d_conv3d_forward): the convolutions of the mask head
  * (lib/modeling/mask_rcnn_heads.py:148-151 with MRCNN.DILATION = 2, lib/core/config.py:767).  d_packed: m3d_conv3d_pack_weights. */
 int m3d_conv3d_forward_dilated(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
@@ -265,6 +270,18 @@ int m3d_fused_max_boxes(void);
  * `rois[:num]` per tile (lib/core/test.py:106-114 hands each tile's valid RoIs to the box head): no host round trip. */
 int m3d_compact_rows(const void* d_src, size_t item_stride_bytes, size_t row_bytes, const int32_t* d_counts, int batch, int max_rows,
                      void* d_dst, int32_t* d_offsets, void* stream);
+/* m3d_compact_rows for TWO row sets that share the counts (the RoIs and their score indices), one launch; h_counts (optional): a
+ * device-accessible HOST mirror (pinned memory) of the clamped counts, written by the kernel - the caller waits for one stream event
+ * instead of issuing a device-to-host copy. */
+int m3d_compact_rows2(const void* d_src_a, size_t item_stride_bytes_a, size_t row_bytes_a, const void* d_src_b, size_t item_stride_bytes_b,
+                      size_t row_bytes_b, const int32_t* d_counts, int batch, int max_rows, void* d_dst_a, void* d_dst_b,
+                      int32_t* d_offsets, int32_t* h_counts, void* stream);
+/* The box head's outputs in one launch (lib/modeling/fast_rcnn_heads.py:42-45, lib/core/test.py:225,250-251): d_outs [num_rois,
+ * nc + 6 nc] = the cls_score and bbox_pred linears computed as ONE GEMM; d_rois [num_rois, 7] (batch, x1, y1, z1, x2, y2, z2) ->
+ * d_cls [num_rois, nc] = softmax of the scores, d_bbox [num_rois, 6 nc] = the raw deltas, d_pred [num_rois, 6 nc] =
+ * bbox_transform_3d(rois[:, 1:7], deltas, weights) clipped to (clip_slices, clip_height, clip_width) when clip_slices > 0. */
+int m3d_box_head_outputs(const float* d_outs, const float* d_rois, int num_rois, int num_classes, const double* weights, double xform_clip,
+                         double clip_slices, double clip_height, double clip_width, float* d_cls, float* d_bbox, float* d_pred, void* stream);
 size_t m3d_generate_proposals3d_batched_workspace_bytes(int batch, int A, int S, int H, int W, int pre_nms_topN);
 int m3d_generate_proposals3d_batched(const float* d_scores, const float* d_deltas, int batch, int A, int S, int H, int W,
                                      const double* anchors, double feat_stride, const double* im_info, int pre_nms_topN,
@@ -366,6 +383,10 @@ int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, con
 int m3d_prm_select_peaks(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
                          int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
                          int32_t* h_peaks, float* h_out_dets, void* stream);
+/* Geometry of the strip layouts [C, n, n, L] of a window batch (all peaks side by side along x; see m3d_prm_prepare_ex): mode 1 =
+ * pitch n + 1 for the exactly-local F(2x2,3x3) kernel, mode 2 = quad-aligned windows for the F(2x4,3x3) kernel (no output quad of one
+ * window reads another window's columns).  Returns L; window p occupies columns lead + p * pitch .. + n - 1, all others are zero. */
+int64_t m3d_prm_strip_geometry(int window, int mode, int num_peaks, int32_t* pitch, int32_t* lead);
 int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
                     int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height,
                     int up_width, const float* d_scale, const float* d_norm, int depth, int height, int width,

@@ -858,10 +858,15 @@ M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float*
 // head per tile on rois[:num]; the batched head takes all tiles' rows at once).  One workgroup per item; the row offset of an item is the
 // sum of the counts before it (batch <= 65535, summed by every workgroup: no second launch, no host round trip).
 namespace {
-__global__ __launch_bounds__(256) void compact_rows_kernel(const unsigned* __restrict__ src, long long item_stride_words, int row_words,
-                                                           const int32_t* __restrict__ counts, int max_rows,
-                                                           unsigned* __restrict__ dst, int32_t* __restrict__ offsets) {
+struct CompactSrc { const unsigned* src; long long item_stride_words; int row_words; unsigned* dst; };
+
+// grid (batch, sources): source blockIdx.y of item blockIdx.x.  The first source's workgroups also publish the offsets and - when the
+// caller gave a host-mapped mirror - the counts themselves (the host then learns them from the stream event behind this launch: no
+// separate device-to-host copy).
+__global__ __launch_bounds__(256) void compact_rows_kernel(CompactSrc a, CompactSrc b2, const int32_t* __restrict__ counts, int max_rows,
+                                                           int32_t* __restrict__ offsets, int32_t* __restrict__ h_counts) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  const CompactSrc c = blockIdx.y == 0 ? a : b2;
   __shared__ long long s_part[256];
   long long part = 0;
   for (int i = tid; i < b; i += 256) part += min(max(counts[i], 0), max_rows);
@@ -873,13 +878,16 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const unsigned* __res
   }
   const long long off = s_part[0];
   const int n = min(max(counts[b], 0), max_rows);
-  if (offsets && tid == 0) {
-    offsets[b] = (int32_t)off;
-    if (b == (int)gridDim.x - 1) offsets[b + 1] = (int32_t)(off + n);
+  if (blockIdx.y == 0 && tid == 0) {
+    if (offsets) {
+      offsets[b] = (int32_t)off;
+      if (b == (int)gridDim.x - 1) offsets[b + 1] = (int32_t)(off + n);
+    }
+    if (h_counts) h_counts[b] = n;
   }
-  const unsigned* s = src + (long long)b * item_stride_words;
-  unsigned* d = dst + off * row_words;
-  const long long words = (long long)n * row_words;
+  const unsigned* s = c.src + (long long)b * c.item_stride_words;
+  unsigned* d = c.dst + off * c.row_words;
+  const long long words = (long long)n * c.row_words;
   for (long long e = tid; e < words; e += 256) d[e] = s[e];
 }
 }  // namespace
@@ -888,9 +896,24 @@ M3D_API int m3d_compact_rows(const void* d_src, size_t item_stride_bytes, size_t
                              int max_rows, void* d_dst, int32_t* d_offsets, void* stream) {
   if (!d_src || !d_counts || !d_dst || batch <= 0 || batch > 65535 || max_rows <= 0 || row_bytes == 0) return M3D_EINVAL;
   if ((row_bytes & 3) || (item_stride_bytes & 3) || ((size_t)d_src & 3) || ((size_t)d_dst & 3)) return M3D_EINVAL;
-  hipLaunchKernelGGL(compact_rows_kernel, dim3(batch), dim3(256), 0, m3d::as_stream(stream), (const unsigned*)d_src,
-                     (long long)(item_stride_bytes / 4), (int)(row_bytes / 4), d_counts, max_rows, (unsigned*)d_dst, d_offsets);
+  const CompactSrc a{(const unsigned*)d_src, (long long)(item_stride_bytes / 4), (int)(row_bytes / 4), (unsigned*)d_dst};
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(batch, 1), dim3(256), 0, m3d::as_stream(stream), a, a, d_counts, max_rows, d_offsets,
+                     (int32_t*)nullptr);
   return m3d::check_launch("compact_rows");
+}
+
+/* Two row sets with the same counts (the RoIs and their score indices) in ONE launch, + an optional host-mapped mirror of the (clamped)
+ * counts (pinned memory the kernel writes: the caller waits for one stream event instead of issuing a device-to-host copy). */
+M3D_API int m3d_compact_rows2(const void* d_src_a, size_t item_stride_bytes_a, size_t row_bytes_a, const void* d_src_b,
+                              size_t item_stride_bytes_b, size_t row_bytes_b, const int32_t* d_counts, int batch, int max_rows, void* d_dst_a,
+                              void* d_dst_b, int32_t* d_offsets, int32_t* h_counts, void* stream) {
+  if (!d_src_a || !d_src_b || !d_counts || !d_dst_a || !d_dst_b || batch <= 0 || batch > 65535 || max_rows <= 0) return M3D_EINVAL;
+  if (row_bytes_a == 0 || row_bytes_b == 0 || ((row_bytes_a | row_bytes_b | item_stride_bytes_a | item_stride_bytes_b) & 3)) return M3D_EINVAL;
+  if (((size_t)d_src_a | (size_t)d_src_b | (size_t)d_dst_a | (size_t)d_dst_b) & 3) return M3D_EINVAL;
+  const CompactSrc a{(const unsigned*)d_src_a, (long long)(item_stride_bytes_a / 4), (int)(row_bytes_a / 4), (unsigned*)d_dst_a};
+  const CompactSrc b{(const unsigned*)d_src_b, (long long)(item_stride_bytes_b / 4), (int)(row_bytes_b / 4), (unsigned*)d_dst_b};
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(batch, 2), dim3(256), 0, m3d::as_stream(stream), a, b, d_counts, max_rows, d_offsets, h_counts);
+  return m3d::check_launch("compact_rows2");
 }
 
 M3D_API size_t m3d_box_results3d_batched_workspace_bytes(int batch) {

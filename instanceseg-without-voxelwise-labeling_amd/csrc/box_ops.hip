@@ -263,6 +263,29 @@ __global__ __launch_bounds__(256) void transform_kernel(const float* __restrict_
   for (int c = 0; c < 6; ++c) out[6 * (size_t)e + c] = o[c];
 }
 
+// The box head's outputs in one launch (fast_rcnn_heads.py:42-45 + core/test.py:225,250-251): `outs` [M, nc + 6 nc] is the ONE GEMM of
+// cls_score and bbox_pred -> cls = softmax over the nc scores (torch's formula: exp(x - max) / sum, the sum in ascending class order),
+// bbox = the raw deltas, pred = decode + clip of every class's deltas around the RoI (rois [M,7] = (batch, x1..z2): columns 1..6).
+// One thread per (row, class).  Replaces a slice copy, torch.softmax, two more copies and the decode launch.
+__global__ __launch_bounds__(256) void head_outputs_kernel(const float* __restrict__ outs, const float* __restrict__ rois, int M, int nc,
+                                                           XformParams p, float* __restrict__ cls, float* __restrict__ bbox,
+                                                           float* __restrict__ pred) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= M * nc) return;
+  const int i = e / nc, j = e - i * nc;
+  const float* o = outs + (size_t)i * (7 * nc);
+  float mx = o[0];
+  for (int k = 1; k < nc; ++k) mx = fmaxf(mx, o[k]);
+  float sum = 0.f;
+  for (int k = 0; k < nc; ++k) sum += expf(o[k] - mx);
+  cls[e] = expf(o[j] - mx) / sum;
+  const float* d = o + nc + 6 * j;
+  float q[6];
+  decode_one(rois + 7 * (size_t)i + 1, d, p, q);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { bbox[6 * (size_t)e + c] = d[c]; pred[6 * (size_t)e + c] = q[c]; }
+}
+
 // ======================================================================================================
 // RPN proposals (generate_proposals_3d.py:19-192)
 // ======================================================================================================
@@ -509,6 +532,20 @@ M3D_API int m3d_bbox_transform3d(const float* d_boxes, const float* d_deltas, in
   hipLaunchKernelGGL(transform_kernel, dim3((n * classes + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_boxes, d_deltas,
                      n, classes, p, d_out);
   return m3d::check_launch("bbox_transform3d");
+}
+
+M3D_API int m3d_box_head_outputs(const float* d_outs, const float* d_rois, int num_rois, int num_classes, const double* weights,
+                                 double xform_clip, double clip_slices, double clip_height, double clip_width, float* d_cls, float* d_bbox,
+                                 float* d_pred, void* stream) {
+  if (num_rois < 0 || num_classes < 1 || !weights) return M3D_EINVAL;
+  if (num_rois == 0) return M3D_OK;
+  if (!d_outs || !d_rois || !d_cls || !d_bbox || !d_pred) return M3D_EINVAL;
+  XformParams p;
+  for (int i = 0; i < 6; ++i) p.w[i] = weights[i];
+  p.clip = xform_clip; p.cs = clip_slices; p.ch = clip_height; p.cw = clip_width;
+  hipLaunchKernelGGL(head_outputs_kernel, dim3((num_rois * num_classes + 255) / 256), dim3(256), 0, m3d::as_stream(stream), d_outs, d_rois,
+                     num_rois, num_classes, p, d_cls, d_bbox, d_pred);
+  return m3d::check_launch("box_head_outputs");
 }
 
 M3D_API size_t m3d_generate_proposals3d_workspace_bytes(int A, int S, int H, int W, int pre_nms_topN) {

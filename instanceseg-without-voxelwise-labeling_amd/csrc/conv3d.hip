@@ -96,6 +96,10 @@ struct Epilogue {
   int FD, FH, FW;
   uint8_t* argmax;      // fused 2x2x2 max-pool variants only: [batch, cout, D/2, H/2, W/2] or null
   int xcd_map;          // 1: XCD-contiguous tile order, cout tile slowest (set by the launcher, see xcd_contiguous)
+  // split output with a sigmoid (the two 1x1x1 RPN heads as ONE conv, rpn_heads.py:96-98,116): channels [0, split_at) go through
+  // 1 / (1 + exp(-v)) into `out` viewed as [batch, split_at, ...], channels [split_at, cout) raw into out2 [batch, cout - split_at, ...]
+  int split_at;         // 0: off
+  float* out2;
 };
 
 __device__ inline float apply_epilogue(const Epilogue& ep, float v, int b, int co, int z, int y, int x, size_t o) {
@@ -134,6 +138,19 @@ __device__ inline void load_affine(const Epilogue& ep, int co0, int cout, ChanAf
 __device__ inline void store_block(const Epilogue& ep, float* __restrict__ out, const f32x16& a, const ChanAffine& A, int b,
                                    int cout, int co0, size_t DHW, int H, int W, int z, int y, int x) {
   const size_t sp = ((size_t)z * H + y) * W + x;
+  if (ep.split_at) {                  // RPN heads: sigmoid scores and raw deltas leave as two contiguous tensors
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int co = co0 + KG(g);
+      if (co < cout) {
+        float v = a[g] * A.sc[g] + A.sh[g];
+        if (ep.relu) v = fmaxf(v, 0.f);
+        if (co < ep.split_at) out[((size_t)b * ep.split_at + co) * DHW + sp] = 1.f / (1.f + expf(-v));      // torch.sigmoid's own formula
+        else ep.out2[((size_t)b * (cout - ep.split_at) + (co - ep.split_at)) * DHW + sp] = v;
+      }
+    }
+    return;
+  }
   if (ep.mul || ep.full) {            // PRM paths: element-wise multiply tensors (rare, keep the general form)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -720,6 +737,17 @@ M3D_API int m3d_conv3d_forward(const float* d_in, const float* d_packed, float* 
 
 /* 3x3x3 "same" convolution with dilation 2 (padding 2): the convs of the mask head, lib/modeling/mask_rcnn_heads.py:148-151 with
  * MRCNN.DILATION = 2 (lib/core/config.py:767).  Same packed weights as m3d_conv3d_forward; small maps (the 7^3 / 14^3 RoI grids). */
+/* The two 1x1x1 RPN heads as ONE convolution with both epilogues (lib/modeling/rpn_heads.py:96-98 + the sigmoid of :116): output
+ * channels [0, split) -> sigmoid -> d_out_sigmoid [batch, split, D, H, W]; channels [split, cout) -> d_out_rest [batch, cout - split, ...].
+ * Replaces a conv + torch.sigmoid + two slice copies (three library launches of the detection step). */
+M3D_API int m3d_conv3d_forward_split_sigmoid(const float* d_in, const float* d_packed, float* d_out_sigmoid, float* d_out_rest, int batch, int cin,
+                                             int cout, int split, int depth, int height, int width, int k, const float* d_shift, void* stream) {
+  if (!d_out_sigmoid || !d_out_rest || split <= 0 || split >= cout) return M3D_EINVAL;
+  Epilogue ep{nullptr, d_shift, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
+  ep.split_at = split; ep.out2 = d_out_rest;
+  return conv_dispatch(d_in, d_packed, d_out_sigmoid, batch, cin, cout, depth, height, width, k, ep, m3d::as_stream(stream));
+}
+
 M3D_API int m3d_conv3d_forward_dilated(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout, int depth,
                                        int height, int width, int k, int dilation, const float* d_scale, const float* d_shift, int relu,
                                        void* stream) {

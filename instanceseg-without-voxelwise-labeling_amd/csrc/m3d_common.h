@@ -28,5 +28,22 @@ int opt(Opt o);
 // sums[p] = sum of win[p, 0..w3) in a FIXED order (per-thread strided partial sums, then a fixed tree): the per-peak normaliser of the
 // response maps must not depend on the order in which workgroups finish (float atomics gave maps that differed by one uint8 level from
 // run to run)
+// Strip layouts of the PRM window batches [C, n, n, L]: the P windows of a layer side by side along x, window p at columns
+// lead + p * pitch .. + n - 1, every other column zero.
+//   mode 1: pitch n + 1, lead 0, L = P (n + 1) - the exactly-local F(2x2,3x3) kernel only needs one zero column between windows;
+//   mode 2: quad-aligned for the F(2x4,3x3) kernel, whose F(4,3) along x is local only in exact arithmetic: an output quad
+//           [4t, 4t+4) reads columns 4t-1 .. 4t+4, so no quad that holds a window's outputs may touch another window's data:
+//           pitch = the smallest multiple of 4 > max(n + r, 4 floor((r + n - 1) / 4) + 4 - r) over the start residue r = lead,
+//           L = P pitch + roundup(lead, 4)  (n = 38: pitch 40, lead 1; n = 40: 44, 0; n = 16: 20, 0; n = 18: 20, 1).
+__host__ __device__ inline void strip_geom(int n, int mode, int num_peaks, int* pitch, int* lead, long long* L) {
+  if (mode != 2) { *pitch = n + 1; *lead = 0; *L = (long long)num_peaks * (n + 1); return; }
+  int bp = 1 << 30, br = 0;
+  for (int r = 0; r < 4; ++r) {
+    const int a = n + r, b = 4 * ((r + n - 1) / 4) + 4 - r;
+    const int pp = ((a > b ? a : b) + 1 + 3) / 4 * 4;
+    if (pp < bp) { bp = pp; br = r; }
+  }
+  *pitch = bp; *lead = br; *L = (long long)num_peaks * bp + (br ? 4 : 0);
+}
 int window_sums(const float* d_win, long long w3, int num_peaks, float* d_sums, hipStream_t st);
 }  // namespace m3d

@@ -112,7 +112,8 @@ struct PrepParams {
   // Winograd kernel convolves as ONE wide volume): ps = n + 1, cs = n^2 L, zs = n L, ys = L with L = P (n + 1).
   long long ips, ics, ops, ocs;
   int izs, iys, ozs, oys;
-  int out_sep;             // strip output: the separator columns are zero-filled here
+  int out_sep;             // strip output: zero columns after each window (pitch - Wn), zero-filled here
+  int out_lead, out_tail;  // strip output: zero columns before window 0 / after the last window's separator
   const float* xoff;       // non-null: gup is a bare backward-data result; the PreHook multiply by (X_{L+1} - *xoff) happens here
 };
 
@@ -150,7 +151,12 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
     }
     float* o = out + (size_t)z * q.ozs + (size_t)y * q.oys + x;
     o[0] = g;
-    if (q.out_sep && x == q.Wn - 1) o[1] = 0.f;
+    if (q.out_sep && x == q.Wn - 1) {
+      const int nz = q.out_sep + (p == q.P - 1 ? q.out_tail : 0);
+      for (int j = 1; j <= nz; ++j) o[j] = 0.f;
+    }
+    if (q.out_lead && p == 0 && x == 0)
+      for (int j = 1; j <= q.out_lead; ++j) o[-j] = 0.f;
   }
 }
 
@@ -202,7 +208,12 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
       if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
         float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
         d[0] = vals[k];
-        if (q.out_sep && wx == q.Wn - 1) d[1] = 0.f;
+        if (q.out_sep && wx == q.Wn - 1) {
+          const int nz = q.out_sep + (p == q.P - 1 ? q.out_tail : 0);
+          for (int j = 1; j <= nz; ++j) d[j] = 0.f;
+        }
+        if (q.out_lead && p == 0 && wx == 0)
+          for (int j = 1; j <= q.out_lead; ++j) d[-j] = 0.f;
       }
     }
   }
@@ -451,19 +462,25 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
   q.norm = d_norm; q.out = d_out; q.origin_out = d_origin_out; q.P = num_peaks; q.C = channels; q.U = up_size;
   q.Wn = (pool ? 2 : 1) * up_size + 2 * border; q.border = border; q.pool = pool ? 1 : 0;
   q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
-  q.xoff = d_up_offset; q.out_sep = out_strip ? 1 : 0;
-  auto strides = [&](int n, int strip, long long* ps, long long* cs, int* zs, int* ys) {
+  q.xoff = d_up_offset; q.out_sep = 0; q.out_lead = 0; q.out_tail = 0;
+  long long ibase = 0, obase = 0;
+  auto strides = [&](int n, int strip, long long* ps, long long* cs, int* zs, int* ys, long long* base, bool is_out) {
     if (strip) {
-      const long long L = (long long)num_peaks * (n + 1);
+      int pitch, lead; long long L;
+      m3d::strip_geom(n, strip, num_peaks, &pitch, &lead, &L);
       if ((long long)n * L >= 0x7FFFFFFFll) return false;
-      *ps = n + 1; *cs = (long long)n * n * L; *zs = (int)(n * L); *ys = (int)L;
+      *ps = pitch; *cs = (long long)n * n * L; *zs = (int)(n * L); *ys = (int)L; *base = lead;
+      if (is_out) { q.out_sep = pitch - n; q.out_lead = lead; q.out_tail = (int)(L - ((long long)num_peaks * pitch + lead)); }
     } else {
-      *ps = (long long)channels * n * n * n; *cs = (long long)n * n * n; *zs = n * n; *ys = n;
+      *ps = (long long)channels * n * n * n; *cs = (long long)n * n * n; *zs = n * n; *ys = n; *base = 0;
     }
     return true;
   };
-  if (!strides(up_size, in_strip, &q.ips, &q.ics, &q.izs, &q.iys) || !strides(q.Wn, out_strip, &q.ops, &q.ocs, &q.ozs, &q.oys))
+  if (in_strip < 0 || in_strip > 2 || out_strip < 0 || out_strip > 2) return M3D_EINVAL;
+  if (!strides(up_size, in_strip, &q.ips, &q.ics, &q.izs, &q.iys, &ibase, false) ||
+      !strides(q.Wn, out_strip, &q.ops, &q.ocs, &q.ozs, &q.oys, &obase, true))
     return M3D_EUNSUPPORTED;
+  q.gup = d_gup + ibase; q.out = d_out + obase;
   if (channels > 65535 || num_peaks > 65535) return M3D_EUNSUPPORTED;
   if (pool) {
     if (border > 2) return M3D_EUNSUPPORTED;      // the one-block shell covers borders of 1 or 2 voxels
@@ -481,6 +498,16 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
     hipLaunchKernelGGL(prm_prepare_kernel, dim3(chunks, channels, num_peaks), dim3(256), 0, m3d::as_stream(stream), q);
   }
   return m3d::check_launch("prm_prepare");
+}
+
+/* The strip layouts' geometry (m3d_common.h strip_geom) for callers that allocate the buffers: mode 1 = pitch n + 1 (F(2x2,3x3), exactly
+ * local), mode 2 = quad-aligned windows for the F(2x4,3x3) kernel.  Returns the row length L; window p starts at column lead + p * pitch. */
+M3D_API int64_t m3d_prm_strip_geometry(int window, int mode, int num_peaks, int32_t* pitch, int32_t* lead) {
+  int pp, ll; long long L;
+  m3d::strip_geom(window, mode, num_peaks, &pp, &ll, &L);
+  if (pitch) *pitch = pp;
+  if (lead) *lead = ll;
+  return (int64_t)L;
 }
 
 M3D_API int m3d_prm_prepare(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,

@@ -483,10 +483,14 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
   if ((d_up_offset != nullptr) != (d_xnext != nullptr)) return M3D_EINVAL;
   q.xnext = d_xnext; q.up_off = d_up_offset;
   {
-    const long long n = up_size, L = (long long)num_peaks * (n + 1);
+    const long long n = up_size;
     if (gup_strip) {
+      if (gup_strip < 0 || gup_strip > 2) return M3D_EINVAL;
+      int pitch, lead; long long L;
+      m3d::strip_geom(up_size, gup_strip, num_peaks, &pitch, &lead, &L);
       if (n * n * L >= 0x7FFFFFFFll / 32) return M3D_EUNSUPPORTED;     // 32-bit offsets inside the gradient tensor
-      q.gps = n + 1; q.gcs = (int)(n * n * L); q.gzs = (int)(n * L); q.gys = (int)L;
+      q.gps = pitch; q.gcs = (int)(n * n * L); q.gzs = (int)(n * L); q.gys = (int)L;
+      q.gup = d_gup + lead;
     } else {
       q.gps = 32 * n * n * n; q.gcs = (int)(n * n * n); q.gzs = (int)(n * n); q.gys = (int)n;
     }

@@ -13,13 +13,13 @@ SYMBOLS = [
     "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1", "m3d_norm1_batched",
     "m3d_linear_workspace_bytes", "m3d_linear_forward", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_pack",
     "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward",
-    "m3d_fused_max_boxes", "m3d_compact_rows", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
+    "m3d_fused_max_boxes", "m3d_compact_rows", "m3d_compact_rows2", "m3d_box_head_outputs", "m3d_conv3d_forward_split_sigmoid", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
     "m3d_box_results3d_batched_workspace_bytes", "m3d_box_results3d_batched", "m3d_nms3d_batched_workspace_bytes", "m3d_nms3d_batched",
     "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward",
     "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
     "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
     "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_pack_weights", "m3d_conv3d_forward", "m3d_conv3d_forward_dilated", "m3d_conv3d_forward_windowed", "m3d_conv3d_forward_pool2",
-    "m3d_prm_seed", "m3d_prm_select_peaks", "m3d_prm_prepare", "m3d_prm_stem_prepare_weights", "m3d_prm_stem_dgrad", "m3d_prm_scatter", "m3d_prm_den_pool", "m3d_prm_stem_mfma_prepare_weights", "m3d_prm_stem_dgrad_fused_supported", "m3d_prm_stem_dgrad_fused", "m3d_prm_stem_dgrad_fused_ex", "m3d_prm_prepare_ex", "m3d_prm_small_dgrad_packed_bytes", "m3d_prm_small_dgrad_pack", "m3d_prm_small_dgrad",
+    "m3d_prm_seed", "m3d_prm_strip_geometry", "m3d_prm_select_peaks", "m3d_prm_prepare", "m3d_prm_stem_prepare_weights", "m3d_prm_stem_dgrad", "m3d_prm_scatter", "m3d_prm_den_pool", "m3d_prm_stem_mfma_prepare_weights", "m3d_prm_stem_dgrad_fused_supported", "m3d_prm_stem_dgrad_fused", "m3d_prm_stem_dgrad_fused_ex", "m3d_prm_prepare_ex", "m3d_prm_small_dgrad_packed_bytes", "m3d_prm_small_dgrad_pack", "m3d_prm_small_dgrad",
     "m3d_maxpool3d_2x_forward", "m3d_maxpool3d_2x_backward",
     "m3d_reduce_min_workspace_bytes", "m3d_reduce_min",
     "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch", "m3d_prm_quantize_u8", "m3d_roi_normalize", "m3d_prm_quantize_windows_u8", "m3d_prm_quantize_windows_compact_u8", "m3d_roi_normalize_ws",
@@ -51,6 +51,7 @@ def _load(path):
     L.m3d_error_string.restype = C.c_char_p
     L.m3d_last_hip_error.restype = C.c_char_p
     L.m3d_conv3d_wino2_score.restype = C.c_double
+    L.m3d_prm_strip_geometry.restype = C.c_int64
     for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
               "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
               "m3d_box_results3d_batched_workspace_bytes", "m3d_nms3d_batched_workspace_bytes", "m3d_otsu2d_workspace_bytes",

@@ -224,9 +224,7 @@ class DetectorM3D:
 
     def rpn_outputs(self, h):
         """The two 1x1x1 heads as one conv + sigmoid (rpn_heads.py:96-98,116): (prob [B,A,s,h,w], deltas [B,6A,s,h,w])."""
-        o = self.rpn_heads(h, shift=self.rpn_heads_bias)
-        logits, deltas = o[:, :self.A], o[:, self.A:]
-        return torch.sigmoid(logits).contiguous(), deltas.contiguous()
+        return self.rpn_heads.split_sigmoid(h, self.A, shift=self.rpn_heads_bias)      # one launch: conv + sigmoid + the split
 
     def _fused_ok(self, prob):
         """The one-workgroup-per-tile kernels (csrc/box_fused.hip) hold at most 2048 candidates per tile."""
@@ -247,7 +245,9 @@ class DetectorM3D:
                                         c.pre_nms_topN, c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size, batch_index=item)
 
     # ---- lib/modeling/fast_rcnn_heads.py:104-117,39-47
-    def box_head(self, feat, rois):
+    def box_head_outputs(self, feat, rois, clip_to=None):
+        """RoIAlign3D -> fc1 -> fc2 -> (cls_score | bbox_pred as one GEMM) -> softmax / deltas / decoded + clipped boxes in one launch:
+        (cls [R,nc], bbox [R,6nc], pred_boxes [R,6nc]).  rois [R,7]."""
         c, P = self.cfg, self.P
         with self.span("roi_align3d"):
             x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
@@ -259,9 +259,11 @@ class DetectorM3D:
                 else:
                     x = ops.linear(x, P["Box_Head.%s.weight" % name], P["Box_Head.%s.bias" % name], relu=True)
         o = ops.linear(x, self.outs_w, self.outs_b)              # cls_score and bbox_pred share their input: one GEMM (:42,45)
-        nc = c.num_classes
-        cls = torch.softmax(o[:, :nc], dim=1)                                                       # :43-44 (eval)
-        return cls, o[:, nc:].contiguous()
+        return ops.box_head_outputs(o, rois, c.num_classes, c.bbox_reg_weights, clip_to=clip_to)   # :43-44 (eval) + core/test.py:250-251
+
+    def box_head(self, feat, rois):
+        cls, bbox, _ = self.box_head_outputs(feat, rois)
+        return cls, bbox
 
     # ---- lib/core/test.py:806-883 (device-side; SOFT_NMS / BBOX_VOTE off)
     def box_results_with_nms_and_limit(self, scores, boxes, scores_keep_idx=None):
@@ -329,17 +331,15 @@ class DetectorM3D:
                     c.rpn_min_size)
                 num = st["props"][3]
                 st["num_host"] = self._pinned_counts(num)
-                st["num_host"].copy_(num, non_blocking=True)
+                # ONE launch packs the valid RoIs of all tiles and their score indices for the box head (+ the row offsets) from the
+                # device-side counts and writes those counts into the pinned host buffer itself: the host waits for the event behind
+                # it - no device-to-host copy, no torch.cat, finish() only slices
+                st["rois_packed"], st["kidx_packed"], st["offs_dev"] = ops.compact_rows2(st["props"][0], st["props"][2], num, st["num_host"])
                 st["ready"] = torch.cuda.Event()
                 st["ready"].record()
-                # behind the event, i.e. while the host is woken and reads the counts: the valid RoIs of all tiles packed for the box
-                # head (and their row offsets) by a kernel that reads the counts on the device - finish() only slices
-                st["rois_packed"], st["offs_dev"] = ops.compact_rows(st["props"][0], num)
-                st["kidx_packed"], _ = ops.compact_rows(st["props"][2], num, st["offs_dev"])
                 # finish() may run on another stream: it orders its readers of the packed buffers behind this event with a device-side
-                # wait (the host only ever waits for `ready`, the counts)
-                st["packed_ready"] = torch.cuda.Event()
-                st["packed_ready"].record()
+                # wait as well (the host wait on it covers the same-thread case)
+                st["packed_ready"] = st["ready"]
         return st
 
     def _pinned_counts(self, like):
@@ -374,7 +374,7 @@ class DetectorM3D:
         torch.cuda.current_stream().wait_event(st["packed_ready"])                 # device-side: compact_rows -> RoIAlign / box results
         if head:
             rois, kidx = st["rois_packed"][:total], st["kidx_packed"][:total]       # (were two torch.cat launches behind the host read)
-            cls, bbox = self.box_head(feat, rois)                                  # one RoIAlign + one GEMM chain for all tiles
+            cls, bbox, pred = self.box_head_outputs(feat, rois, clip_to=im_info[:3])   # one RoIAlign + one GEMM chain for all tiles
         self._release_counts(st.pop("num_host"))                                   # read: back to the pool
         cur = torch.cuda.current_stream()
         for t in (feat, prob, deltas, rois_b, probs_b, kidx_b, st["rois_packed"], st["kidx_packed"], st["offs_dev"]):
@@ -386,7 +386,6 @@ class DetectorM3D:
         # behind the box head, made the host wait for the whole box head and left the GPU idle for 44 us per step
         offs_dev = st["offs_dev"]
         if head:
-            pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
             with self.span("box_results"):
                 cb, ck, cnt = ops.box_results3d_batched(cls, pred, kidx, offs_dev,
                                                         c.num_classes, c.score_thresh, c.nms, c.detections_per_im, rows)
@@ -421,8 +420,7 @@ class DetectorM3D:
         if not self.has_head or sum(counts) == 0:
             return outs
         rois = torch.cat([p[0] for p in props], 0)
-        cls, bbox = self.box_head(feat, rois)
-        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
+        cls, bbox, pred = self.box_head_outputs(feat, rois, clip_to=im_info[:3])
         o = 0
         for b in range(B):
             n = counts[b]

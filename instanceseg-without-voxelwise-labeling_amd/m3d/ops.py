@@ -10,9 +10,9 @@ from ._lib import lib, check, M3DError
 
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
-__all__ = ["compact_rows", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
+__all__ = ["compact_rows", "compact_rows2", "box_head_outputs", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -221,6 +221,43 @@ def compact_rows(src, counts, offsets=None):
     return out, offsets
 
 
+def compact_rows2(src_a, src_b, counts, host_counts=None):
+    """compact_rows of two row sets with the same counts in ONE launch -> (packed_a, packed_b, offsets int32 [B+1]).  host_counts: a
+    PINNED int32 tensor [B] the kernel itself fills with the counts - record an event behind this call and wait for that."""
+    _need_gpu(src_a, src_b, counts)
+    assert src_a.is_contiguous() and src_b.is_contiguous() and counts.dtype == torch.int32 and counts.is_contiguous()
+    B, rows = src_a.shape[0], src_a.shape[1]
+    assert src_b.shape[0] == B and src_b.shape[1] == rows
+    rb_a = src_a[0, 0].numel() * src_a.element_size()
+    rb_b = src_b[0, 0].numel() * src_b.element_size()
+    out_a = torch.empty((B * rows,) + tuple(src_a.shape[2:]), dtype=src_a.dtype, device=src_a.device)
+    out_b = torch.empty((B * rows,) + tuple(src_b.shape[2:]), dtype=src_b.dtype, device=src_b.device)
+    offsets = torch.empty((B + 1,), dtype=torch.int32, device=src_a.device)
+    if host_counts is not None:
+        assert host_counts.is_pinned() and host_counts.dtype == torch.int32 and host_counts.numel() >= B
+    check(lib().m3d_compact_rows2(_ptr(src_a), C.c_size_t(rows * rb_a), C.c_size_t(rb_a), _ptr(src_b), C.c_size_t(rows * rb_b), C.c_size_t(rb_b),
+                                  _ptr(counts), B, rows, _ptr(out_a), _ptr(out_b), _ptr(offsets),
+                                  C.c_void_p(host_counts.data_ptr()) if host_counts is not None else None, _stream()), "compact_rows2")
+    return out_a, out_b, offsets
+
+
+def box_head_outputs(outs, rois, num_classes, weights, clip_to=None, xform_clip=BBOX_XFORM_CLIP):
+    """outs [M, nc + 6 nc] (cls_score and bbox_pred as one GEMM), rois [M,7] -> (cls [M,nc] softmax, bbox [M,6nc] raw deltas,
+    pred [M,6nc] decoded (+ clipped to clip_to = (slices, height, width))); one launch (m3d_box_head_outputs)."""
+    _need_gpu(outs, rois)
+    outs, rois = _f32c(outs), _f32c(rois)
+    M, nc = int(outs.shape[0]), int(num_classes)
+    assert outs.shape[1] == 7 * nc and rois.shape == (M, 7)
+    cls = torch.empty((M, nc), dtype=torch.float32, device=outs.device)
+    bbox = torch.empty((M, 6 * nc), dtype=torch.float32, device=outs.device)
+    pred = torch.empty((M, 6 * nc), dtype=torch.float32, device=outs.device)
+    w = (C.c_double * 6)(*[float(x) for x in weights])
+    cs, ch, cw = (0., 0., 0.) if clip_to is None else [float(v) for v in clip_to]
+    check(lib().m3d_box_head_outputs(_ptr(outs), _ptr(rois), M, nc, w, C.c_double(xform_clip), C.c_double(cs), C.c_double(ch), C.c_double(cw),
+                                     _ptr(cls), _ptr(bbox), _ptr(pred), _stream()), "box_head_outputs")
+    return cls, bbox, pred
+
+
 def box_results3d_batched(scores, boxes, keep_idx, offsets, num_classes, score_thresh, nms_thresh, detections_per_im, max_rows):
     """scores [R,nc], boxes [R,6nc], keep_idx int64 [R] or None, offsets int32 [B+1] (device) ->
     (cls_boxes [B,nc,max_rows,7], cls_keep int64 [B,nc,max_rows], counts int32 [B,nc]); ONE launch, no host sync."""
@@ -305,6 +342,20 @@ class PackedConv3d:
                                              self.k, _ptr(in_offset), _ptr(scale), _ptr(shift), int(bool(relu)), _stream()),
               "conv3d_forward_pool2")
         return (out, am) if return_argmax else out
+
+    def split_sigmoid(self, x, split, shift=None):
+        """One conv, two epilogues (m3d_conv3d_forward_split_sigmoid): (sigmoid(conv)[:, :split], conv[:, split:]) as two contiguous
+        tensors - the RPN's cls_score + sigmoid and bbox_pred heads (rpn_heads.py:96-98,116)."""
+        _need_gpu(x)
+        x = _f32c(x)
+        B, Cin, D, H, W = x.shape
+        if Cin != self.cin:
+            raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
+        a = torch.empty((B, split, D, H, W), dtype=torch.float32, device=x.device)
+        b = torch.empty((B, self.cout - split, D, H, W), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_forward_split_sigmoid(_ptr(x), _ptr(self.packed), _ptr(a), _ptr(b), B, Cin, self.cout, int(split), D, H, W, self.k,
+                                                     _ptr(shift), _stream()), "conv3d_forward_split_sigmoid")
+        return a, b
 
     def __call__(self, x, scale=None, shift=None, relu=False, in_offset=None, mul=None, out=None, dilation=1):
         _need_gpu(x)
@@ -682,6 +733,14 @@ def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=N
     return dict(num=num, peaks=peaks, dets=out, host=host, event=ev, release=lambda: _peak_pool.give(buf))
 
 
+def strip_geometry(n, mode, P):
+    """(pitch, lead, L) of the strip layout of P windows n voxels wide (include/m3d.h: m3d_prm_strip_geometry); mode 1 / True: pitch
+    n + 1 (exactly-local F(2x2,3x3)), mode 2: quad-aligned for F(2x4,3x3)."""
+    pitch, lead = C.c_int32(0), C.c_int32(0)
+    L = lib().m3d_prm_strip_geometry(int(n), int(mode), int(P), C.byref(pitch), C.byref(lead))
+    return pitch.value, lead.value, int(L)
+
+
 def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_strip=False, out_strip=False, up_off=None, dims=None):
     """gup [P,C,U,U,U]; xnext [C,UD,UH,UW]; norm [C,D,H,W] -> (window [P,C,Wn,Wn,Wn], origin int32 [P,3]).
     Strip layout (in_strip / out_strip): the P windows side by side along x with one separator column after each,
@@ -690,13 +749,15 @@ def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_str
     (peak_backprop_3d.py:16-18) is applied here."""
     _need_gpu(gup, origin_up, xnext, norm)
     P, Cc, U = dims if dims is not None else (gup.shape[0], gup.shape[1], gup.shape[2])
-    assert tuple(gup.shape) == ((Cc, U, U, P * (U + 1)) if in_strip else (P, Cc, U, U, U))
+    in_strip, out_strip = int(in_strip), int(out_strip)                       # 0 batch-major, 1 strip (pitch n + 1), 2 quad-aligned strip
+    assert tuple(gup.shape) == ((Cc, U, U, strip_geometry(U, in_strip, P)[2]) if in_strip else (P, Cc, U, U, U))
     Wn = (2 if pool else 1) * U + 2 * border
-    out = torch.empty((Cc, Wn, Wn, P * (Wn + 1)) if out_strip else (P, Cc, Wn, Wn, Wn), dtype=torch.float32, device=gup.device)
+    out = torch.empty((Cc, Wn, Wn, strip_geometry(Wn, out_strip, P)[2]) if out_strip else (P, Cc, Wn, Wn, Wn), dtype=torch.float32,
+                      device=gup.device)
     oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
     check(lib().m3d_prm_prepare_ex(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
                                    xnext.shape[1], xnext.shape[2], xnext.shape[3], _ptr(scale), _ptr(norm), norm.shape[1],
-                                   norm.shape[2], norm.shape[3], int(bool(in_strip)), int(bool(out_strip)), _ptr(up_off), _ptr(out),
+                                   norm.shape[2], norm.shape[3], in_strip, out_strip, _ptr(up_off), _ptr(out),
                                    _ptr(oo), _stream()), "prm_prepare")
     return out, oo
 
@@ -759,13 +820,14 @@ def prm_stem_dgrad_fused(gup, origin_up, den, argmax, scale, wa, data, data_off,
     (windows [P,Wn,Wn,Wn] clamped (Wn = 2U + 4), sums [P], origins int32 [P,3])."""
     _need_gpu(gup, origin_up, den, argmax, wa, data, data_off)
     P, Cc, U = dims if dims is not None else (gup.shape[0], gup.shape[1], gup.shape[2])
-    assert tuple(gup.shape) == ((Cc, U, U, P * (U + 1)) if strip else (P, Cc, U, U, U)) and gup.is_contiguous()
+    strip = int(strip)
+    assert tuple(gup.shape) == ((Cc, U, U, strip_geometry(U, strip, P)[2]) if strip else (P, Cc, U, U, U)) and gup.is_contiguous()
     assert (xnext is None) == (up_off is None)
     Wn = 2 * U + 4
     out = torch.empty((P, Wn, Wn, Wn), dtype=torch.float32, device=gup.device)
     sums = torch.empty((P,), dtype=torch.float32, device=gup.device)
     oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
-    check(lib().m3d_prm_stem_dgrad_fused_ex(_ptr(gup), int(bool(strip)), _ptr(xnext), _ptr(up_off), _ptr(origin_up), P, Cc, U,
+    check(lib().m3d_prm_stem_dgrad_fused_ex(_ptr(gup), strip, _ptr(xnext), _ptr(up_off), _ptr(origin_up), P, Cc, U,
                                             _ptr(den), _ptr(argmax), _ptr(scale), den.shape[1], den.shape[2], den.shape[3],
                                             _ptr(wa), _ptr(data), _ptr(data_off), data.shape[0], data.shape[1], data.shape[2],
                                             _ptr(out), _ptr(sums), _ptr(oo), _stream()), "prm_stem_dgrad_fused")

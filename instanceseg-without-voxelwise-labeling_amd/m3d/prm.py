@@ -14,13 +14,20 @@ from .model import DetectorM3D, _NOSPAN
 
 
 class PRMEngine:
-    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True):
+    def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
+                 strip_f24=True, strip_f24_min=17):
         self.det = det
         self.cfg = det.cfg
         self.probe = None                             # optional m3d.model.Probe: HIP-event spans around the phases of prm_tile (bench.py)
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
         # side by side along x): 4/9 of the MFMA work and tiles that fit; strip_wino=False keeps the direct kernel everywhere
         self.strip_wino = bool(strip_wino)
+        # windows >= strip_f24_min wide take the F(2x4,3x3) family (1/3 instead of 4/9 of the MFMA work) on the QUAD-ALIGNED strip layout
+        # (ops.strip_geometry mode 2: no output quad of one window reads another window's columns, so F(4,3)'s rounding-level footprint
+        # stays inside the peak); the alignment costs columns (38 -> pitch 40 instead of 39, 16 -> 20 instead of 17), which is why the
+        # small windows keep the exactly-local F(2x2) family on the dense layout
+        self.strip_f24 = bool(strip_f24) and self.strip_wino
+        self.strip_f24_min = int(strip_f24_min)
         # forward: the RESPONSE convs of the un-pooled layers may take the detection path's Winograd kernels (values differ from the
         # direct kernel by ~1e-6 relative); the NORM convs never do - their exact zeros (sums of non-negative products) gate the
         # PostHook's `N < 1e-10` test, and a Winograd 1e-8 in place of a 0 would be divided by
@@ -37,6 +44,7 @@ class PRMEngine:
                                     norm_conv=ops.PackedConv3d(w, ops.W_RELU),
                                     dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU),
                                     dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None,
+                                    dgrad_wino24=self._dgrad_wino(w, local=False) if (strip_wino and strip_f24 and w.shape[2] == 3) else None,
                                     dgrad_small=ops.SmallWindowDgrad(w) if (small_gemm and w.shape[2] == 3) else None, weight=w))
         w = P["RPN.RPN_conv.weight"]
         self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU),
@@ -54,11 +62,12 @@ class PRMEngine:
         return self.probe(name) if self.probe is not None else _NOSPAN
 
     @staticmethod
-    def _dgrad_wino(w):
+    def _dgrad_wino(w, local=True):
         """backward-data of a 'same' 3^3 conv with relu(W) (peak_backprop_3d.py:41-42) as a forward conv: taps flipped, channel
-        roles swapped; packed for the F(2x2,3x3) kernel."""
+        roles swapped; packed for the F(2x2,3x3) kernel (local: windows of different peaks are neighbours in the dense strip and need
+        exact locality) or for the library's default family (F(2x4,3x3): the quad-aligned strip)."""
         wd = torch.relu(w).flip(2, 3, 4).transpose(0, 1).contiguous()
-        return ops.WinoConv3d(wd, two_d=True, local=True)      # windows of different peaks are neighbours in the strip: exact locality
+        return ops.WinoConv3d(wd, two_d=True, local=local)
 
     # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
     # pr_conv3d computes two convolutions per layer: the response Y = conv(X, W, b) that feeds the next layer, and the norm conv
@@ -88,7 +97,7 @@ class PRMEngine:
                 else:
                     xn, am = y, None
             saved.append(dict(x=x[0], off=None, n=None, scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
-                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_small=L["dgrad_small"],
+                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_wino24=L["dgrad_wino24"], dgrad_small=L["dgrad_small"],
                               weight=L["weight"], norm_conv=L["norm_conv"]))
             x = xn
         feat = x
@@ -143,7 +152,10 @@ class PRMEngine:
             return self.fused_stem and rec["k"] == 5 and "den" in rec and ops.prm_stem_dgrad_fused_supported(wb["C"], wb["U"])
 
         def wino(rec, Wn):
-            return self.strip_wino and rec["k"] == 3 and rec.get("dgrad_wino") is not None and Wn >= self.strip_min
+            """0: no strip; 1: dense strip + exactly-local F(2x2); 2: quad-aligned strip + F(2x4)"""
+            if not (self.strip_wino and rec["k"] == 3 and rec.get("dgrad_wino") is not None and Wn >= self.strip_min):
+                return 0
+            return 2 if (self.strip_f24 and rec.get("dgrad_wino24") is not None and Wn >= self.strip_f24_min) else 1
 
         def run_layer(rec, wb, origin, border):
             dims = (wb["P"], wb["C"], wb["U"])
@@ -161,21 +173,22 @@ class PRMEngine:
                 w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
                 return (w, s), origin
             cout = rec["x"].shape[0]
-            if strip:                            # F(2x2,3x3) over the whole strip; its PreHook multiply moves to the consumer
-                y = rec["dgrad_wino"](gn.unsqueeze(0))[0]
-                return dict(t=y, strip=True, P=wb["P"], C=cout, U=Wn, up_off=rec["off"]), origin
+            if strip:                            # Winograd over the whole strip; its PreHook multiply moves to the consumer
+                y = (rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"])(gn.unsqueeze(0))[0]
+                return dict(t=y, strip=strip, P=wb["P"], C=cout, U=Wn, up_off=rec["off"]), origin
             small = rec.get("dgrad_small")
             if small is not None and Wn in small.SIZES:      # 3^3 / 5^3 / 7^3: all peaks in one dense GEMM (csrc/prm_small.hip)
                 y = small(gn, rec["x"], rec["off"], origin)
             else:
                 y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
-            return dict(t=y, strip=False, P=wb["P"], C=cout, U=Wn, up_off=None), origin
+            return dict(t=y, strip=0, P=wb["P"], C=cout, U=Wn, up_off=None), origin
 
         def take(wb, c0, c1):
             """peaks [c0, c1) of a window batch"""
             if wb["strip"]:
-                n = wb["U"] + 1
-                t = wb["t"][..., c0 * n:c1 * n].contiguous()
+                pitch, lead, _ = ops.strip_geometry(wb["U"], wb["strip"], wb["P"])
+                L = ops.strip_geometry(wb["U"], wb["strip"], c1 - c0)[2]      # the sub-strip has the same lead; its tail pad may hold the
+                t = wb["t"][..., c0 * pitch:c0 * pitch + L].contiguous()        # next window's first columns (beyond every tile that is read)
             else:
                 t = wb["t"][c0:c1].contiguous()
             return dict(wb, t=t, P=c1 - c0)
@@ -191,8 +204,10 @@ class PRMEngine:
             if fused(rec, wb):
                 per_peak = 4 * Wn ** 3                                    # the un-pooled window is never materialised
             chunk = self.peak_chunk if self.peak_chunk else max(1, min(P, int(budget // per_peak)))
-            if wino(rec, Wn):                                             # 32-bit offsets inside one strip
-                chunk = max(1, min(chunk, (2 ** 31 - 1) // (4 * cmax * Wn * Wn * (Wn + 1))))
+            sm = wino(rec, Wn)
+            if sm:                                                        # 32-bit offsets inside one strip
+                pitch = ops.strip_geometry(Wn, sm, 1)[0]
+                chunk = max(1, min(chunk, (2 ** 31 - 1) // (4 * cmax * Wn * Wn * pitch) - 1))
             if chunk >= P:
                 out, o2 = run_layer(rec, wb, origin, border)
                 return (out, o2) if rec["k"] == 5 else tail(layers[1:], out, o2)
@@ -203,7 +218,7 @@ class PRMEngine:
         pk = peaks_ashw.contiguous()
         g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
         origin = pk[:, 1:4].contiguous()
-        wb = dict(t=g, strip=False, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
+        wb = dict(t=g, strip=0, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
         try:
             (win, sums), origins = tail(list(reversed(saved)), wb, origin)
         finally:
@@ -235,10 +250,10 @@ class PRMEngine:
             rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(prob, deltas, det.anchors, float(c.stride), im_info, c.pre_nms_topN,
                                                                             c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
             num_host = det._pinned_counts(num)
-            num_host.copy_(num, non_blocking=True)
+            # the RoI count reaches the pinned buffer through the kernel that also builds the row offsets box results needs
+            _, _, offs_dev = ops.compact_rows2(rois_b, kidx_b, num, num_host)
             ready = torch.cuda.Event()
             ready.record()
-            _, offs_dev = ops.compact_rows(rois_b, num)               # [0, R] on the device for box results (no host-side offsets)
         nl = len(saved)
         late = [i for i in (0, 1) if i < nl - 1]                      # conv1a / conv2a: the last layers the backward reaches
         with self.span("norm_convs"):
@@ -250,8 +265,7 @@ class PRMEngine:
             return None                                               # nothing survives -> the reference returns five Nones (:190)
         rois, keep_idx = rois_b[0, :R], kidx_b[0, :R]
         with self.span("box_head"):
-            cls, bbox = det.box_head(feat, rois)
-            pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])   # :121-122
+            cls, bbox, pred = det.box_head_outputs(feat, rois, clip_to=im_info[:3])                                # :121-122
             cb, ck, cnt = ops.box_results3d_batched(cls, pred, keep_idx, offs_dev, c.num_classes, c.score_thresh, c.nms,
                                                     c.detections_per_im, R)                                          # :124
             A = prob.shape[1]
@@ -284,8 +298,7 @@ class PRMEngine:
         rois, probs, keep_idx = det.proposals(prob, deltas, im_info)
         if rois.shape[0] == 0:
             return None
-        cls, bbox = det.box_head(feat, rois)
-        pred = ops.bbox_transform3d(rois[:, 1:7].contiguous(), bbox, c.bbox_reg_weights, clip_to=im_info[:3])
+        cls, bbox, pred = det.box_head_outputs(feat, rois, clip_to=im_info[:3])
         sc, bx, _, cls_keep = det.box_results_with_nms_and_limit(cls, pred, keep_idx)
         keep = cls_keep[1]
         A = prob.shape[1]

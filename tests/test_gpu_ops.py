@@ -277,6 +277,35 @@ def test_conv3d_winograd_local_family_is_exactly_local(m3d):
     assert float(dflt[..., :62].abs().max()) == 0.0                             # beyond F(4,3)'s 6-wide footprint nothing arrives either
 
 
+@pytest.mark.parametrize("n", [16, 18, 38, 40])
+def test_quad_aligned_strip_keeps_peaks_apart_under_the_f24_family(m3d, n):
+    """The PRM strip layout for the F(2x4,3x3) family (m3d_prm_strip_geometry mode 2): every window starts on the same residue
+    mod 4 and no output quad that holds a window's columns reads another window's columns.  So a window's outputs must be IDENTICAL BIT
+    FOR BIT whether its neighbours hold zeros or values a million times larger - F(4,3)'s rounding-level 6-wide footprint never leaves
+    the window and its zero gap."""
+    P, cin, cout = 5, 16, 32
+    pitch, lead, L = m3d.strip_geometry(n, 2, P)
+    assert pitch % 4 == 0 and pitch > n and 0 <= lead < 4 and L == P * pitch + (4 if lead else 0)
+    p1, l1, L1 = m3d.strip_geometry(n, 1, P)
+    assert (p1, l1, L1) == (n + 1, 0, P * (n + 1))
+    g = torch.Generator().manual_seed(n)
+    w = torch.rand(cout, cin, 3, 3, 3, generator=g) - 0.3
+    conv = m3d.WinoConv3d(w.cuda(), two_d=True)                          # the library's default family: F(2x4,3x3)
+    wins = [torch.randn(cin, 6, n, n, generator=g) * (1e6 if k % 2 else 1.0) for k in range(P)]
+    full = torch.zeros(1, cin, 6, n, L)
+    for k in range(P):
+        full[0, ..., lead + k * pitch:lead + k * pitch + n] = wins[k]
+    yf = conv(full.cuda()).cpu()
+    for k in range(P):
+        alone = torch.zeros_like(full)
+        alone[0, ..., lead + k * pitch:lead + k * pitch + n] = wins[k]
+        ya = conv(alone.cuda()).cpu()
+        sl = slice(lead + k * pitch, lead + k * pitch + n)
+        assert torch.equal(yf[..., sl], ya[..., sl]), (n, k)
+        ref = torch.nn.functional.conv3d(wins[k][None].double(), w.double(), None, 1, 1)
+        assert (ya[..., sl].double() - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 64, 64, 6, 8, 64), (2, 32, 40, 4, 10, 70), (1, 128, 128, 4, 6, 32), (1, 16, 33, 5, 7, 50)])
 def test_conv3d_winograd_2d_pool_argmax(m3d, B, cin, cout, D, H, W):
     """F(2x2,3x3) + BN + ReLU + MaxPool3d(2,2) + argmax in one launch == the same kernel's un-pooled output pushed through
@@ -932,3 +961,58 @@ def test_fused_box_results_and_batched_nms_vs_oracle(m3d):
             p = r["packed"][b].cpu().numpy()
             m = min(n, 300)
             assert p[300, 0] == m and np.array_equal(p[:m], d[ref[:m]]) and not p[m:300].any() and not p[300, 1:].any()
+
+
+def test_rpn_heads_conv_with_sigmoid_and_split_equals_the_three_launches(m3d):
+    """m3d_conv3d_forward_split_sigmoid (one launch) == the 1x1x1 conv of the concatenated heads + torch.sigmoid of the first A channels +
+    the two slice copies it replaces (rpn_heads.py:96-98,116): bit for bit, on a ragged map and a batch."""
+    for B, Cc, A, shp in ((1, 128, 14, (5, 9, 13)), (3, 256, 35, (4, 8, 24)), (2, 64, 3, (2, 3, 70))):
+        g = torch.Generator().manual_seed(A)
+        x = torch.randn((B, Cc) + shp, generator=g).cuda()
+        w = (torch.randn(7 * A, Cc, 1, 1, 1, generator=g) * 0.2).cuda()
+        b = torch.randn(7 * A, generator=g).cuda()
+        conv = m3d.PackedConv3d(w)
+        o = conv(x, shift=b)
+        prob, deltas = conv.split_sigmoid(x, A, shift=b)
+        assert prob.shape == (B, A) + shp and deltas.shape == (B, 6 * A) + shp and prob.is_contiguous() and deltas.is_contiguous()
+        assert torch.equal(deltas, o[:, A:])
+        assert torch.equal(prob, torch.sigmoid(o[:, :A]))          # the same formula on the same device exp: identical bits
+
+
+def test_box_head_outputs_equals_softmax_and_the_decode_kernel(m3d):
+    """m3d_box_head_outputs (one launch) == torch.softmax of the class scores + the raw deltas + m3d_bbox_transform3d with the clip
+    (fast_rcnn_heads.py:42-45, core/test.py:250-251): bit for bit for nc = 2 (both shipped configs), 1e-7 for nc = 3."""
+    for M, nc in ((1, 2), (333, 2), (1281, 2), (77, 3)):
+        g = torch.Generator().manual_seed(M)
+        outs = (torch.randn(M, 7 * nc, generator=g) * 2).cuda()
+        rois = torch.rand(M, 7, generator=g) * 100
+        rois[:, 4:] = rois[:, 1:4] + 1 + rois[:, 4:] * 0.3
+        rois = rois.cuda()
+        wts = (10., 10., 10., 5., 5., 5.)
+        cls, bbox, pred = m3d.box_head_outputs(outs, rois, nc, wts, clip_to=(64, 200, 200))
+        ref_cls = torch.softmax(outs[:, :nc].contiguous(), dim=1)
+        ref_bbox = outs[:, nc:].contiguous()
+        ref_pred = m3d.bbox_transform3d(rois[:, 1:7].contiguous(), ref_bbox, wts, clip_to=(64, 200, 200))
+        assert torch.equal(bbox, ref_bbox) and torch.equal(pred, ref_pred)
+        if nc == 2:
+            assert torch.equal(cls, ref_cls)
+        else:
+            assert torch.allclose(cls, ref_cls, rtol=0, atol=3e-7)        # three terms: the summation order may differ
+        _, _, unclipped = m3d.box_head_outputs(outs, rois, nc, wts)
+        assert torch.equal(unclipped, m3d.bbox_transform3d(rois[:, 1:7].contiguous(), ref_bbox, wts))
+
+
+def test_compact_rows2_packs_both_sets_and_mirrors_the_counts(m3d):
+    B, rows = 5, 40
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(B, rows, 7, generator=g).cuda()
+    k = torch.randint(0, 1 << 40, (B, rows), generator=g).cuda()
+    counts = torch.tensor([3, 0, 40, 17, 99], dtype=torch.int32).cuda()           # 99 is clamped to the row count
+    host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+    pa, pk, offs = m3d.compact_rows2(a, k, counts, host)
+    torch.cuda.synchronize()
+    n = [3, 0, 40, 17, 40]
+    assert host.tolist() == n and offs.cpu().tolist() == [0, 3, 3, 43, 60, 100]
+    assert torch.equal(pa[:100], torch.cat([a[b, :n[b]] for b in range(B)])) and torch.equal(pk[:100], torch.cat([k[b, :n[b]] for b in range(B)]))
+    p1, o1 = m3d.compact_rows(a, counts)
+    assert torch.equal(p1[:100], pa[:100]) and torch.equal(o1, offs)

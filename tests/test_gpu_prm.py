@@ -116,7 +116,8 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
     plain = PRMEngine(det, fused_stem=False, strip_wino=False, small_gemm=False, wino_forward=False)   # round-1 path: prepare +
     fused = PRMEngine(det, strip_wino=False)                            # direct MFMA dgrad + VALU stem.  fused: + MFMA stem, small GEMM
-    strip = PRMEngine(det)                                              # + F(2x2,3x3) on the strip layout for windows >= 16^3
+    strip = PRMEngine(det)                                              # + Winograd on the strip layouts for windows >= 16^3 (F(2x4) from 30)
+    strip22 = PRMEngine(det, strip_f24=False)                           # round 3: the exactly-local F(2x2,3x3) family on every strip
     mixed = PRMEngine(det, fused_stem=False)                            # strip layers feeding the VALU stem (layout hand-over)
     assert fused.fused_stem and not plain.fused_stem and strip.strip_wino and not fused.strip_wino
     data = torch.randn((1, 1) + shape, generator=torch.Generator().manual_seed(4)).cuda()
@@ -129,7 +130,7 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     b = w0.cpu().numpy()
     assert b.max() > 0
     # Winograd F(2x2,3x3) rounds differently from the direct kernel (~1e-6 per layer, four layers deep)
-    for eng, rtol in ((fused, 1e-4), (strip, 1e-3), (mixed, 1e-3)):
+    for eng, rtol in ((fused, 1e-4), (strip, 1e-3), (strip22, 1e-3), (mixed, 1e-3)):
         w1, s1, o1 = eng.backward_windows(pk, saved, top, data)
         assert w1.shape == w0.shape and torch.equal(o1, o0)
         a = w1.cpu().numpy()
@@ -141,6 +142,9 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     w2, s2, o2 = chunked.backward_windows(pk, saved, top, data)
     w1, s1, o1 = strip.backward_windows(pk, saved, top, data)
     assert torch.equal(o2, o1) and np.allclose(w2.cpu().numpy(), w1.cpu().numpy(), rtol=1e-5, atol=1e-7 * b.max())
+    # ... and with the quad-aligned layout a chunk's windows sit on the same residues as in the full strip: bit-identical maps
+    if shape[0] >= 40:
+        assert torch.equal(w2, w1)
 
 
 @pytest.mark.parametrize("win,cout_f,cin_f,P", [(3, 64, 48, 37), (5, 40, 64, 11), (7, 24, 32, 5), (5, 6, 3, 1)])
