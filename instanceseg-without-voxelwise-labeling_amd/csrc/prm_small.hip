@@ -16,22 +16,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCC = 4;                        // input channels per chunk
-constexpr int kWSeg = (kCC / 2) * 27 * 64;    // floats of one (cout block, chunk) weight segment: [cp][tap][lane]
+constexpr int kTQ = 7;                        // tap quads: 27 taps padded to 28 (the 28th weight is zero and its MFMA is never issued)
+constexpr int kWSeg = (kCC / 2) * kTQ * 64 * 4;   // floats of one (cout block, chunk) weight segment: [cp][tap quad][lane][4]
 
-// wp[cb][chunk][cp][t][lane] = relu(W[ci][co][26 - t]),  co = 32 cb + (lane & 31) (an INPUT channel of the forward conv),
-// ci = 4 chunk + 2 cp + (lane >> 5) (an OUTPUT channel of the forward conv); W: [cout_fwd][cin_fwd][27]
+// wp[cb][chunk][cp][t / 4][lane][t % 4] = relu(W[ci][co][26 - t]),  co = 32 cb + (lane & 31) (an INPUT channel of the forward conv),
+// ci = 4 chunk + 2 cp + (lane >> 5) (an OUTPUT channel of the forward conv); W: [cout_fwd][cin_fwd][27].  Four consecutive taps of a
+// lane are one 16-byte LDS read (round 4; one ds_read_b32 per tap before).
 __global__ __launch_bounds__(256) void small_pack_kernel(const float* __restrict__ w, int cout_fwd, int cin_fwd, float* __restrict__ wp,
                                                          int nchunk, long long total) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int lane = (int)(e & 63);
-    long long r = e >> 6;
-    const int t = (int)(r % 27); r /= 27;
+    const int tj = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    long long r = e >> 8;
+    const int t = 4 * (int)(r % kTQ) + tj; r /= kTQ;
     const int cp = (int)(r % (kCC / 2)); r /= (kCC / 2);
     const int chunk = (int)(r % nchunk);
     const int cb = (int)(r / nchunk);
     const int co = 32 * cb + (lane & 31), ci = kCC * chunk + 2 * cp + (lane >> 5);
     float v = 0.f;
-    if (co < cin_fwd && ci < cout_fwd) {
+    if (co < cin_fwd && ci < cout_fwd && t < 27) {
       v = w[((size_t)ci * cin_fwd + co) * 27 + (26 - t)];
       v = v > 0.f ? v : 0.f;
     }
@@ -49,15 +51,18 @@ struct SmallArgs {
   int P, cin, cout, nchunk, D, H, W;
 };
 
-template <int WN>
+// NCB = output-channel blocks of 32 per workgroup: a wave's B value feeds NCB MFMAs, and with the weights read four taps at a time the
+// K loop issues (NCB + 4) / (4 NCB) LDS reads per MFMA - 1.25 at NCB = 1 - where round 2's kernel issued 2.  The next chunk's global loads (weights and window voxels) are issued into registers BEFORE the chunk's MFMAs and
+// written to LDS after them: round 2 loaded global -> LDS between the two barriers of every chunk, with the latency exposed.
+template <int WN, int NCB>
 __global__ __launch_bounds__(256, 2) void prm_small_dgrad_kernel(SmallArgs q) {
   constexpr int V = WN * WN * WN, PW = WN + 2, CSB = PW * PW * PW;
   constexpr int PK = 127 / V + 2;                          // peaks a 128-column block can touch
   extern __shared__ float sm[];
   float* const lin = sm;                                   // [PK][kCC][CSB]
-  float* const lw = sm + PK * kCC * CSB;                   // [kWSeg]
+  float* const lw = sm + PK * kCC * CSB;                   // [NCB][kWSeg]
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, h = l >> 5, nl = l & 31;
-  const int cb = blockIdx.y;
+  const int cb0 = blockIdx.y * NCB;
   const long long n0 = (long long)blockIdx.x * 128, ntot = (long long)q.P * V;
   const int p_first = (int)(n0 / V);
   // this lane's column
@@ -70,43 +75,93 @@ __global__ __launch_bounds__(256, 2) void prm_small_dgrad_kernel(SmallArgs q) {
 
   for (int e = tid; e < PK * kCC * CSB; e += 256) lin[e] = 0.f;                           // the borders stay zero for the whole kernel
 
-  f32x16 acc;
+  f32x16 acc[NCB];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int k = 0; k < NCB; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-  const f32x4* wsrc = reinterpret_cast<const f32x4*>(q.wp + (size_t)cb * q.nchunk * kWSeg);
-  constexpr int NW4 = (kWSeg / 4 + 255) / 256;                                            // float4 per thread and chunk
+  const int ncb_total = (q.cout + 31) / 32;
+  constexpr int W4 = kWSeg / 4;                                                           // float4 of one segment
+  constexpr int NW4 = (NCB * W4 + 255) / 256;                                             // float4 per thread and chunk
   constexpr int NIN = (PK * kCC * V + 255) / 256;                                         // interior voxels per thread and chunk
-#pragma unroll 1
-  for (int ch = 0; ch < q.nchunk; ++ch) {
-    __syncthreads();                                                                      // previous chunk's reads are done
+  // per-thread staging plan (constant over the chunks): weight quads and window voxels
+  int w_src[NW4];                                                                         // float4 index inside the chunk, -1: none
+#pragma unroll
+  for (int i = 0; i < NW4; ++i) {
+    const int e = tid + 256 * i;
+    const int k = e / W4;
+    w_src[i] = (e < NCB * W4 && cb0 + k < ncb_total) ? e : -1;
+  }
+  int g_src[NIN], g_dst[NIN];                                                             // gn offset of chunk 0 (-1: zero), LDS offset (-1: none)
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int e = tid + 256 * i;
+    g_src[i] = -1; g_dst[i] = -1;
+    if (e < PK * kCC * V) {
+      const int vv = e % V, r = e / V;
+      const int cc = r % kCC, s = r / kCC;
+      const int pp = p_first + s;
+      const int z = vv / (WN * WN), y = (vv / WN) % WN, x = vv % WN;
+      g_dst[i] = (s * kCC + cc) * CSB + ((z + 1) * PW + y + 1) * PW + x + 1;
+      if (pp < q.P) g_src[i] = (int)(((long long)(pp - p_first) * q.cin + cc) * V + vv);
+    }
+  }
+  const float* const gbase = q.gn + (size_t)p_first * q.cin * V;
+  const f32x4* const wbase = reinterpret_cast<const f32x4*>(q.wp);
+  f32x4 sw[NW4];
+  float sg[NIN];
+  auto fetch = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
-      const int e = tid + 256 * i;
-      if (e < kWSeg / 4) reinterpret_cast<f32x4*>(lw)[e] = wsrc[(size_t)ch * (kWSeg / 4) + e];
+      const int e = w_src[i] >= 0 ? w_src[i] : 0;
+      const int k = e / W4, o = e - k * W4;
+      sw[i] = wbase[((size_t)(cb0 + (w_src[i] >= 0 ? k : 0)) * q.nchunk + ch) * W4 + o];
     }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
-      const int e = tid + 256 * i;
-      if (e < PK * kCC * V) {
-        const int vv = e % V, r = e / V;
-        const int cc = r % kCC, s = r / kCC;
-        const int pp = p_first + s, c = kCC * ch + cc;
-        float g = 0.f;
-        if (pp < q.P && c < q.cin) g = q.gn[((size_t)pp * q.cin + c) * V + vv];
-        const int z = vv / (WN * WN), y = (vv / WN) % WN, x = vv % WN;
-        lin[(s * kCC + cc) * CSB + ((z + 1) * PW + y + 1) * PW + x + 1] = g;
-      }
+      const bool ok = g_src[i] >= 0 && kCC * ch + (g_dst[i] / CSB) % kCC < q.cin;
+      sg[i] = gbase[ok ? (size_t)g_src[i] + (size_t)kCC * ch * V : 0];
+      if (!ok) sg[i] = 0.f;
     }
-    __syncthreads();
+  };
+  auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NW4; ++i)
+      if (w_src[i] >= 0) reinterpret_cast<f32x4*>(lw)[w_src[i]] = sw[i];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+      if (g_dst[i] >= 0) lin[g_dst[i]] = sg[i];
+  };
+  // blocks beyond the layer's channels (NCB = 2 with an odd block count): their weights stay zero
+  for (int e = tid; e < NCB * kWSeg; e += 256) lw[e] = 0.f;
+  fetch(0);
+  __syncthreads();
+  commit();
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < q.nchunk; ++ch) {
+    if (ch + 1 < q.nchunk) fetch(ch + 1);                                                 // in flight under this chunk's MFMAs
 #pragma unroll
     for (int cp = 0; cp < kCC / 2; ++cp)
 #pragma unroll
-      for (int t = 0; t < 27; ++t) {
-        const float a = lw[(cp * 27 + t) * 64 + l];
-        const float b = lin[bbase + cp * 2 * CSB + ((t / 9) * PW + (t / 3) % 3) * PW + t % 3];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int tq = 0; tq < kTQ; ++tq) {
+        f32x4 a4[NCB];
+#pragma unroll
+        for (int k = 0; k < NCB; ++k) a4[k] = *reinterpret_cast<const f32x4*>(lw + k * kWSeg + ((cp * kTQ + tq) * 64 + l) * 4);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const int t = 4 * tq + jt;
+          if (t < 27) {
+            const float b = lin[bbase + cp * 2 * CSB + ((t / 9) * PW + (t / 3) % 3) * PW + t % 3];
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k][jt], b, acc[k], 0, 0, 0);
+          }
+        }
       }
+    __syncthreads();                                                                      // this chunk's LDS reads are done
+    if (ch + 1 < q.nchunk) commit();
+    __syncthreads();
   }
   // PreHook multiply (peak_backprop_3d.py:16-18) and store; accumulator register e holds output channel 8*(e/4) + 4*h + e%4
   if (!col_ok) return;
@@ -116,24 +171,35 @@ __global__ __launch_bounds__(256, 2) void prm_small_dgrad_kernel(SmallArgs q) {
   const size_t DHW = (size_t)q.D * q.H * q.W;
   const float off = *q.full_off;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int co = 32 * cb + 8 * (e >> 2) + 4 * h + (e & 3);
-    if (co < q.cout) {
-      const float m = in ? q.full[(size_t)co * DHW + pos] - off : 0.f;
-      q.out[((size_t)p * q.cout + co) * V + v] = in ? m * acc[e] : 0.f;
+  for (int k = 0; k < NCB; ++k)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = 32 * (cb0 + k) + 8 * (e >> 2) + 4 * h + (e & 3);
+      if (co < q.cout) {
+        const float m = in ? q.full[(size_t)co * DHW + pos] - off : 0.f;
+        q.out[((size_t)p * q.cout + co) * V + v] = in ? m * acc[k][e] : 0.f;
+      }
     }
-  }
+}
+
+template <int WN, int NCB>
+int launch_small_n(const SmallArgs& q, hipStream_t st) {
+  constexpr int V = WN * WN * WN, PW = WN + 2, CSB = PW * PW * PW, PK = 127 / V + 2;
+  const size_t lds = sizeof(float) * ((size_t)PK * kCC * CSB + (size_t)NCB * kWSeg);
+  const long long ntot = (long long)q.P * V;
+  auto kern = prm_small_dgrad_kernel<WN, NCB>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int ncb = (q.cout + 31) / 32;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((ntot + 127) / 128), (ncb + NCB - 1) / NCB), dim3(256), lds, st, q);
+  return m3d::check_launch("prm_small_dgrad");
 }
 
 template <int WN>
 int launch_small(const SmallArgs& q, hipStream_t st) {
-  constexpr int V = WN * WN * WN, PW = WN + 2, CSB = PW * PW * PW, PK = 127 / V + 2;
-  const size_t lds = sizeof(float) * ((size_t)PK * kCC * CSB + kWSeg);
-  const long long ntot = (long long)q.P * V;
-  auto kern = prm_small_dgrad_kernel<WN>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)((ntot + 127) / 128), (q.cout + 31) / 32), dim3(256), lds, st, q);
-  return m3d::check_launch("prm_small_dgrad");
+  // NCB = 2 (two output-channel blocks per workgroup: 0.75 instead of 1.25 LDS reads per MFMA) was measured and is NOT used: on the
+  // nuclei tile's 67 peaks the 5^3 / 7^3 launches took 0.450 / 0.472 ms against 0.355 / 0.384 ms with one block per workgroup - these
+  // launches want the occupancy (twice as many, half as heavy waves) more than they want fewer LDS reads
+  return launch_small_n<WN, 1>(q, st);
 }
 
 }  // namespace

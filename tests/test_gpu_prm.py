@@ -142,12 +142,10 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
     w2, s2, o2 = chunked.backward_windows(pk, saved, top, data)
     w1, s1, o1 = strip.backward_windows(pk, saved, top, data)
     assert torch.equal(o2, o1) and np.allclose(w2.cpu().numpy(), w1.cpu().numpy(), rtol=1e-5, atol=1e-7 * b.max())
-    # ... and with the quad-aligned layout a chunk's windows sit on the same residues as in the full strip: bit-identical maps
-    if shape[0] >= 40:
-        assert torch.equal(w2, w1)
 
 
-@pytest.mark.parametrize("win,cout_f,cin_f,P", [(3, 64, 48, 37), (5, 40, 64, 11), (7, 24, 32, 5), (5, 6, 3, 1)])
+@pytest.mark.parametrize("win,cout_f,cin_f,P", [(3, 64, 48, 37), (5, 40, 64, 11), (7, 24, 32, 5), (5, 6, 3, 1), (5, 64, 128, 300), (7, 32, 96, 150),
+                                                 (3, 256, 256, 67)])
 def test_small_window_gemm_equals_the_direct_windowed_kernel(win, cout_f, cin_f, P):
     """csrc/prm_small.hip against m3d_conv3d_forward_windowed on dgrad-packed relu(W): same sums in another order."""
     import m3d
