@@ -15,6 +15,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef M3D_SMALL_OCC
+#define M3D_SMALL_OCC 2
+#endif
 constexpr int kCC = 4;                        // input channels per chunk
 constexpr int kTQ = 7;                        // tap quads: 27 taps padded to 28 (the 28th weight is zero and its MFMA is never issued)
 constexpr int kWSeg = (kCC / 2) * kTQ * 64 * 4;   // floats of one (cout block, chunk) weight segment: [cp][tap quad][lane][4]
@@ -55,7 +58,7 @@ struct SmallArgs {
 // K loop issues (NCB + 4) / (4 NCB) LDS reads per MFMA - 1.25 at NCB = 1 - where round 2's kernel issued 2.  The next chunk's global loads (weights and window voxels) are issued into registers BEFORE the chunk's MFMAs and
 // written to LDS after them: round 2 loaded global -> LDS between the two barriers of every chunk, with the latency exposed.
 template <int WN, int NCB>
-__global__ __launch_bounds__(256, 2) void prm_small_dgrad_kernel(SmallArgs q) {
+__global__ __launch_bounds__(256, M3D_SMALL_OCC) void prm_small_dgrad_kernel(SmallArgs q) {
   constexpr int V = WN * WN * WN, PW = WN + 2, CSB = PW * PW * PW;
   constexpr int PK = 127 / V + 2;                          // peaks a 128-column block can touch
   extern __shared__ float sm[];

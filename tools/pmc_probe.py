@@ -30,4 +30,24 @@ for _ in range(3):
     r = det.detect_batch(x, as_dicts=False)
     m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=300, want_keep=False)
 torch.cuda.synchronize()
+# configs[1]: the backbone alone on ONE volume (the sub-record `configs1_backbone`; same kernels, a quarter of the grid)
+for _ in range(3):
+    det.conv_body(x[:1].contiguous())
+torch.cuda.synchronize()
+del det, x
+# PRM tiles (configs[3] soma 64x160x160 and the nuclei net's 64x200x200): three tiles each
+from m3d.prm import PRMEngine
+import numpy as np
+from m3d import tiling
+for cfgp in (Cfg.soma(), Cfg.nuclei(score_thresh=0.0)):
+    Pp = make_params(stride=cfgp.stride, num_anchors=cfgp.num_anchors, mlp_dim=cfgp.mlp_dim, seed=0)
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in Pp.items()}, cfgp))
+    S, H, W = cfgp.in_size
+    vol = torch.from_numpy(tiling.norm1(synth_volume(0, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
+    for _ in range(3):
+        out = eng.prm_tile(vol, dense=False)
+    torch.cuda.synchronize()
+    print("prm tile", cfgp.in_size, "peaks", None if out is None else int(out["peaks"].shape[0]))
+    del eng, Pp
+    torch.cuda.empty_cache()
 print("pmc_probe done; calibration bytes", N_CAL * 4, "rois", r["num_rois"])

@@ -1,22 +1,28 @@
 #!/bin/bash
 # Round profiles: bench lines, rocprofv3 kernel statistics of the same commands, PMC traffic and MFMA-busy passes.
 #   usage (on the GPU box): bash tools/profile_round.sh r03      -> gpurun_out/prof/ ; copy what should be judged into profiles/
-R=${1:-r03}
+R=${1:-r04}
+PHASE=${2:-AB}          # A: bench lines + kernel traces;  B: PMC passes, layer benches, stamps (two gpurun calls fit the 20-minute limit)
 cd /root/repo
 P=/root/repo/gpurun_out/prof; mkdir -p $P
-python bench.py > $P/${R}_bench_detect.json 2> $P/bench_detect.err
+if [[ $PHASE == *A* ]]; then
+python bench.py > $P/${R}_bench_default_line.json 2> $P/bench_detect.err          # the driver's command: headline + every sub-record
 python bench.py --workload prm 2>/dev/null | tail -1 > $P/${R}_bench_prm_soma.json
-python bench.py --workload prm-nuclei --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei.json
-python bench.py --workload backbone --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_backbone.json
-python bench.py --stress-rois 2>/dev/null | tail -1 > $P/${R}_bench_detect_stress_1000_rois.json
+python bench.py --workload prm-nuclei 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei.json
+python bench.py --workload volume 2>/dev/null | tail -1 > $P/${R}_bench_volume.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d /tmp/rp_det -o det -- python3 /root/repo/bench.py --no-cpu-baseline > $P/${R}_bench_detect_under_rocprof.json 2>/tmp/rp_det.err
+rocprofv3 --kernel-trace -d /tmp/rp_det -o det -- python3 /root/repo/bench.py --no-cpu-baseline --no-subrecords > $P/${R}_bench_detect_under_rocprof.json 2>/tmp/rp_det.err
 python3 /root/repo/tools/rocpd_stats.py $(find /tmp/rp_det -name "*_results.db" | head -1) $P/${R}_bench_detect_kernel_stats.csv > $P/det_stats.txt
 python3 /root/repo/tools/step_gaps.py $(find /tmp/rp_det -name "*_results.db" | head -1) 40 > $P/${R}_step_timeline.txt
 rocprofv3 --kernel-trace -d /tmp/rp_soma -o soma -- python3 /root/repo/bench.py --workload prm --no-cpu-baseline > $P/${R}_bench_prm_soma_under_rocprof.json 2>/tmp/rp_soma.err
 python3 /root/repo/tools/rocpd_stats.py $(find /tmp/rp_soma -name "*_results.db" | head -1) $P/${R}_prm_soma_kernel_stats.csv > $P/soma_stats.txt
 rocprofv3 --kernel-trace -d /tmp/rp_nuc -o nuc -- python3 /root/repo/bench.py --workload prm-nuclei --no-cpu-baseline > $P/${R}_bench_prm_nuclei_under_rocprof.json 2>/tmp/rp_nuc.err
 python3 /root/repo/tools/rocpd_stats.py $(find /tmp/rp_nuc -name "*_results.db" | head -1) $P/${R}_prm_nuclei_kernel_stats.csv > $P/nuc_stats.txt
+rocprofv3 --kernel-trace -d /tmp/rp_vol -o vol -- python3 /root/repo/bench.py --workload volume --no-cpu-baseline > $P/${R}_bench_volume_under_rocprof.json 2>/tmp/rp_vol.err
+python3 /root/repo/tools/volume_gaps.py $(find /tmp/rp_vol -name "*_results.db" | head -1) > $P/${R}_volume_gaps.txt
+fi
+if [[ $PHASE == *B* ]]; then
+cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -- python3 /root/repo/tools/pmc_probe.py > /tmp/pF.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -- python3 /root/repo/tools/pmc_probe.py > /tmp/pW.log 2>&1
 mkdir -p $P/${R}_pmc
@@ -32,5 +38,6 @@ if [ -f instanceseg-without-voxelwise-labeling_amd/csrc/libm3d_w2stamps.so ]; th
   python tools/stem_stamps.py 2>/dev/null | grep -v amdgpu.ids > $P/${R}_stem_stamps.txt
   unset M3D_LIB_PATH
 fi
-python bench.py --interleaved --pipelined --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_detect_interleaved_and_pipelined.json
+python bench.py --interleaved --pipelined --no-cpu-baseline --no-subrecords 2>/dev/null | tail -1 > $P/${R}_bench_detect_interleaved_and_pipelined.json
+fi
 ls -la $P | tail -30; head -c 600 $P/${R}_bench_detect.json; echo; head -30 $P/${R}_mfma_busy.txt
