@@ -37,7 +37,8 @@ const char* m3d_last_hip_error(void);
  * beside the release library.  Names: "xcd_map" (1: XCD-aware workgroup->tile order, default; 0: plain order), "tune_k3", "tune_wino",
  * "tune_wino2", "tune_wino2_xt" (tile-variant overrides of the conv dispatchers, -1 = library chooses), "tune_fc_slices" /
  * "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of m3d_linear_bf16x3_forward),
- * "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per workgroup; -1: rows kernel, planes by
+ * "tune_fc_x_alias" (> 0: m3d_linear_bf16x3_forward reads row m of x from row m % value - a cache-resident operand, WRONG results:
+ * the GEMM's cost with a free operand, tools/f1_ab.py), "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per workgroup; -1: rows kernel, planes by
  * grid size).  Unknown name -> M3D_EINVAL. */
 int m3d_set_option(const char* name, int value);
 int m3d_get_option(const char* name, int* value);
@@ -327,6 +328,19 @@ int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, const floa
 size_t m3d_linear_bf16x3_w32_workspace_bytes(int M, int N, int K);
 int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
                                   int relu, void* d_ws, size_t ws_bytes, void* stream);
+
+/* f-1 A/B: the fc1 GEMM with the RoIAlign gather in its A-operand loader - the [M, C * 343] RoIAlign output is never
+ * written.  m3d_roi_align3d_tap_tables: the RoIs' per-axis sample tables (7^3 bins, sampling grid 2 - the shipped geometry) -> d_tab
+ * (16 bytes x 3 axes x 14 samples per RoI) and d_roi_batch [num_rois]; m3d_linear_bf16x3_roi_forward: out[M, N] = act(RoIAlign3D(features,
+ * rois) W^T + b) with d_packed = m3d_linear_bf16x3_pack(W) and K = channels * 343.  Same samples and weights as m3d_roi_align3d_forward
+ * (another summation order).  Measured against the two-launch path (RoIAlign, then m3d_linear_bf16x3_forward) in profiles/r04_f1_ab.json:
+ * the two-launch path is the product path. */
+int m3d_roi_align3d_tap_tables(const float* d_rois, int num_rois, float spatial_scale, int batch, int slices, int height, int width,
+                               void* d_tab, int32_t* d_batch, void* stream);
+size_t m3d_linear_bf16x3_roi_workspace_bytes(int M, int N, int K);
+int m3d_linear_bf16x3_roi_forward(const float* d_features, int batch, int channels, int slices, int height, int width, const void* d_tab,
+                                  const int32_t* d_roi_batch, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int relu,
+                                  void* d_ws, size_t ws_bytes, void* stream);
 
 /* Paste of the mask branch's soft masks into full-volume uint8 masks: segm_results, lib/core/test.py:886-945.
  * d_masks [num_dets, channels, M, M, M] (M = resolution, MRCNN.RESOLUTION); d_channel [num_dets]: the channel of each detection

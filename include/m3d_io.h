@@ -27,6 +27,11 @@ size_t m3d_tiff_stack_bound(int pages, int height, int width, int bits);
 size_t m3d_tiff_encode_stack(const void* vol, int pages, int height, int width, int bits, uint8_t* dst, size_t cap);
 size_t m3d_tiff_encode_window_stack_u8(const uint8_t* win, int wn, int oz, int oy, int ox, int z_first, int pages, int height,
                                        int width, uint8_t* dst, size_t cap);
+/* A tile's whole instance tree in one call: `{dir}/{ch}.tif` = m3d_tiff_encode_window_stack_u8 of wins[ch] ([num_peaks, wn^3] uint8) at
+ * origins[ch] (int32 [num_peaks, 3] = (oz, oy, ox)), encoded and written by `threads` worker threads (tools/infer_simple.py:239-245 for
+ * all peaks of a tile).  Returns the number of files that could not be written. */
+int m3d_tiff_write_window_stacks_u8(const char* dir, const uint8_t* wins, const int32_t* origins, int num_peaks, int wn, int z_first,
+                                    int pages, int height, int width, int threads);
 
 /* 3D run-length masks ({'counts', 'size'}) of lib/utils/cython_mask_3d.pyx:19-84 / lib/utils/mask_3d.py:15-73:
  * runs over the mask in Fortran order, zeros first.  mask: C-contiguous uint8 [S,H,W].

@@ -351,7 +351,42 @@ __global__ __launch_bounds__(256) void fc_x3_pack_kernel(const float* __restrict
 struct FcX3Args {
   const float* x; const u32x4* wp; const float* bias; float* out; float* part;
   int M, N, K, mt, nt, slices, chunks, relu, per_xcd;
+  int x_alias;             // > 0 (tuning build only, option tune_fc_x_alias): row m of x is read from row m % x_alias - a cache-resident A
+                           // operand: what the GEMM costs when its operand is free (WRONG results; the f-1 lower bound, tools/f1_ab.py)
+  // XM = 1 (f-1 A/B): x[m][k] is not read but computed - the RoIAlign gather in the operand loader (taps: roi_tap_table_kernel)
+  const float* feat; const int4* taps; const int* roi_batch; int fC, fS, fH, fW;
 };
+
+// one element of the RoIAlign output of RoI row `tp` (its 42 tap entries): k = channel * 343 + (ph * 7 + pw) * 7 + ps, the memory order
+// of the reference's output tensor (roi_align_kernel_3d.cu:87-91); 2 x 2 x 2 samples x 8 corners, mean over the samples
+__device__ inline float roi_gather_element(const float* __restrict__ fb /* feature map of the RoI's batch item */, const int4* __restrict__ tp,
+                                           int k, int S, int H, int W) {
+  const int ch = k / 343, bin = k - ch * 343;
+  const int ph = bin / 49, rem = bin - ph * 49, pw = rem / 7, ps = rem - pw * 7;
+  const float* f = fb + (size_t)ch * S * H * W;
+  int zi[4], yi[4], xi[4];
+  float zw[4], yw[4], xw[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int4 ez = tp[2 * ps + a], ey = tp[14 + 2 * ph + a], ex = tp[28 + 2 * pw + a];
+    zi[2 * a] = ez.x * H * W; zi[2 * a + 1] = ez.y * H * W; zw[2 * a] = __int_as_float(ez.z); zw[2 * a + 1] = __int_as_float(ez.w);
+    yi[2 * a] = ey.x * W; yi[2 * a + 1] = ey.y * W; yw[2 * a] = __int_as_float(ey.z); yw[2 * a + 1] = __int_as_float(ey.w);
+    xi[2 * a] = ex.x; xi[2 * a + 1] = ex.y; xw[2 * a] = __int_as_float(ex.z); xw[2 * a + 1] = __int_as_float(ex.w);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float az = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* row = f + zi[i] + yi[j];
+      const float ax = (xw[0] * row[xi[0]] + xw[1] * row[xi[1]]) + (xw[2] * row[xi[2]] + xw[3] * row[xi[3]]);
+      az += yw[j] * ax;
+    }
+    acc += zw[i] * az;
+  }
+  return 0.125f * acc;
+}
 
 // WR = wave rows of the workgroup: 2 -> 128 x 128 tile, 256 threads, 2 workgroups per CU;  4 -> 256 x 128 tile, 512 threads, one
 // workgroup per CU (x rows are re-used by twice the MFMAs: 28 instead of 40 KB of global loads per 128 x 128 x 32 of work - the
@@ -360,7 +395,7 @@ struct FcX3Args {
 //     read F1 | 24 MFMA(F0) | barrier A (the chunk's LDS image is free) | cut + LDS writes of chunk c+1 under 16 MFMA(F1) |
 //     barrier B | global loads of chunk c+2 -> registers | read F0 of chunk c+1 | 8 MFMA(F1)
 // so every LDS / barrier latency has MFMAs of the same wave to hide under, not only those of the other wave of the SIMD.
-template <int WR>
+template <int WR, int XM = 0>
 __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(FcX3Args a) {
   constexpr int TBM = 64 * WR, NT = 128 * WR;                      // tile rows, threads
   constexpr int XPL = TBM * X3_RSW, XOP = 3 * XPL;                 // dwords of an x plane / of the x operand; W planes: X3_PLANE
@@ -381,16 +416,33 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
   // packed (tile, chunk) block = (plane, row, unit tid % 4).  LDS unit u of row r sits at u ^ ((r >> 2) & 3).
   const int oct = tid & 3, row0 = tid >> 2;
   const float* px[NXI];
+  const int4* ptap[NXI];                                           // XM = 1: the row's tap table
+  const float* pfeat[NXI];
 #pragma unroll
-  for (int i = 0; i < NXI; ++i) px[i] = a.x + (size_t)min(m0 + row0 + (NT / 4) * i, a.M - 1) * a.K + 8 * oct;   // clamped: masked at the store
+  for (int i = 0; i < NXI; ++i) {
+    const int mrow = min(m0 + row0 + (NT / 4) * i, a.M - 1);       // clamped: masked at the store
+    if constexpr (XM == 1) {
+      ptap[i] = a.taps + (size_t)mrow * 42;
+      pfeat[i] = a.feat + (size_t)a.roi_batch[mrow] * a.fC * a.fS * a.fH * a.fW;
+      px[i] = nullptr;
+    } else {
+      px[i] = a.x + (size_t)(a.x_alias > 0 ? mrow % a.x_alias : mrow) * a.K + 8 * oct;
+    }
+  }
   const u32x4* pw = a.wp + (size_t)tn * a.chunks * X3_CHUNK_U4 + tid;
   const int swq = 4 * (oct ^ ((row0 >> 2) & 3));                   // NT/4 is a multiple of 16: every row of this thread swizzles alike
   f32x4 sx[NXI][2]; u32x4 sw[NWI];
   auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      sx[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
-      sx[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
+      if constexpr (XM == 1) {
+        const int k0 = c * 32 + 8 * oct;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sx[i][e >> 2][e & 3] = roi_gather_element(pfeat[i], ptap[i], k0 + e, a.fS, a.fH, a.fW);
+      } else {
+        sx[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
+        sx[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) sw[i] = pw[(size_t)c * X3_CHUNK_U4 + NT * i];
@@ -799,6 +851,8 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
   const int s = p.slices;
   if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
   FcX3Args a{d_x, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, s, K / 32, relu, p.per_xcd};
+  a.x_alias = m3d::opt(m3d::OPT_TUNE_FC_X_ALIAS) > 0 ? m3d::opt(m3d::OPT_TUNE_FC_X_ALIAS) : 0;     // tuning build only (timing, wrong results)
+  a.feat = nullptr; a.taps = nullptr; a.roi_batch = nullptr; a.fC = a.fS = a.fH = a.fW = 0;
   hipStream_t st = m3d::as_stream(stream);
   const size_t lds = sizeof(unsigned) * (3 * (64 * p.wr) * X3_RSW + X3_OPER);
   if (p.wr == 2) {
@@ -815,6 +869,45 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
     hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
   }
   return m3d::check_launch("linear_bf16x3_forward");
+}
+
+/* f-1 A/B ("hand-written MFMA GEMM whose A-operand loader performs the RoIAlign gather"): out[M, N] = act(x W^T + b) where
+ * x[m, :] = RoIAlign3D(features, roi m) (7^3 bins, sampling grid 2, the reference's memory order) is COMPUTED by the loader from the
+ * feature maps and the tap tables of m3d_roi_align3d_tap_tables - the [M, C*343] intermediate never exists.  Same tiles, cut, MFMA loop
+ * and split-K as m3d_linear_bf16x3_forward (256 x 128 tiles).  Measured against the two-launch path in profiles/r04_f1_ab.json. */
+M3D_API size_t m3d_linear_bf16x3_roi_workspace_bytes(int M, int N, int K) { return m3d_linear_bf16x3_workspace_bytes(M, N, K); }
+
+M3D_API int m3d_linear_bf16x3_roi_forward(const float* d_features, int batch, int channels, int slices, int height, int width, const void* d_tab,
+                                          const int32_t* d_roi_batch, const void* d_packed, const float* d_bias, float* d_out, int M, int N,
+                                          int relu, void* d_ws, size_t ws_bytes, void* stream) {
+  const int K = channels * 343;
+  if (M < 0 || N <= 0 || channels <= 0 || batch <= 0) return M3D_EINVAL;
+  if (M == 0) return M3D_OK;
+  if (!d_features || !d_tab || !d_roi_batch || !d_packed || !d_out) return M3D_EINVAL;
+  if (K % 32 != 0 || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
+  X3Plan p = x3_plan(M, N, K);
+  if (p.wr != 4) {                                                 // the fused loader is instantiated for the 256-row tile
+    const int mt = (M + 255) / 256, nt = (N + BN - 1) / BN, tiles = mt * nt;
+    int s = 256 / tiles; s = s < 1 ? 1 : (s > K / 256 + 1 ? K / 256 + 1 : s);
+    p = X3Plan{4, mt, nt, s, (tiles * s + 7) / 8};
+  }
+  const int s = p.slices;
+  if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
+  FcX3Args a{nullptr, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, s, K / 32, relu, p.per_xcd};
+  a.x_alias = 0; a.feat = d_features; a.taps = (const int4*)d_tab; a.roi_batch = d_roi_batch;
+  a.fC = channels; a.fS = slices; a.fH = height; a.fW = width;
+  hipStream_t st = m3d::as_stream(stream);
+  const size_t lds = sizeof(unsigned) * (3 * 256 * X3_RSW + X3_OPER);
+  auto kern = fc_x3_gemm_kernel<4, 1>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  if (s > 1) {
+    const long long MN = (long long)M * N;
+    long long blocks = (MN + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
+  }
+  return m3d::check_launch("linear_bf16x3_roi_forward");
 }
 
 /* 256 x 256 tiles on the nn.Linear weight itself (fp32, cut in the kernel): the variant for many rows, no packed copy */
@@ -834,6 +927,7 @@ M3D_API int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weigh
   if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
   FcX3Args a{d_x, (const u32x4*)d_weight, d_bias, d_out, (float*)d_ws, M, N, K, (M + 255) / 256, (N + 255) / 256, s, K / 32, relu, 0};
   a.per_xcd = (a.mt * a.nt * s + 7) / 8;
+  a.x_alias = 0; a.feat = nullptr; a.taps = nullptr; a.roi_batch = nullptr; a.fC = a.fS = a.fH = a.fW = 0;
   hipStream_t st = m3d::as_stream(stream);
   const size_t lds = sizeof(unsigned) * 6 * 256 * X3_RSW;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3b_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

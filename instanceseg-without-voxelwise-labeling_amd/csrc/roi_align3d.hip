@@ -747,6 +747,24 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_sep_kernel(const float* _
   }
 }
 
+// ---- f-1: per-RoI tap tables for a GEMM whose A-operand loader performs the RoIAlign gather (fc_gemm.hip).
+// For the shipped geometry (7^3 bins, sampling grid 2) a RoI has 14 samples per axis; sample s contributes to bin s / 2 through its
+// two corners (lo, hi) with weights (h, l) - zero when the coordinate is out of range (roi_align_kernel_3d.cu:19-22).  Entry
+// tab[r][axis][s] = (lo, hi, bits(h * valid), bits(l * valid)), axis 0 = z (bin ps), 1 = y (ph), 2 = x (pw).
+__global__ __launch_bounds__(64) void roi_tap_table_kernel(const float* __restrict__ rois, int R, float scale, int B, int S, int H, int W,
+                                                           int4* __restrict__ tab, int* __restrict__ batch) {
+  const int r = blockIdx.x, t = threadIdx.x;
+  if (r >= R || t >= 42) return;
+  const RoiGeom g = roi_geom(rois + 7 * r, scale, 7, 7, 7, 2, B);
+  const int ax = t / 14, s = t % 14;
+  const float start = ax == 0 ? g.start_s : (ax == 1 ? g.start_h : g.start_w);
+  const float bin = ax == 0 ? g.bin_s : (ax == 1 ? g.bin_h : g.bin_w);
+  const int dim = ax == 0 ? S : (ax == 1 ? H : W);
+  const AxisSample a = make_sample(start, bin, s / 2, s % 2, 2, dim, -1.0);
+  tab[(size_t)r * 42 + t] = make_int4(a.lo, a.hi, __float_as_int(a.valid ? a.h : 0.f), __float_as_int(a.valid ? a.l : 0.f));
+  if (t == 0) batch[r] = g.batch;
+}
+
 int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int AW, float scale, int ratio, const float* a, const float* rois, float* o, int B,
            int C, int S, int H, int W, int R, int roi_cols, void* stream) {
   if (roi_cols != 7) return M3D_EINVAL;   // roi_align_cuda_3d.c:19-22
@@ -815,4 +833,16 @@ M3D_API int m3d_roi_align3d_forward_exact(int AS, int AH, int AW, float spatial_
                                           const float* d_rois, int num_rois, int roi_cols, float* d_output, void* stream) {
   return launch(1, AS, AH, AW, spatial_scale, sampling_ratio, d_features, d_rois, d_output, batch, channels, slices, height,
                 width, num_rois, roi_cols, stream);
+}
+
+/* f-1 A/B: tap tables of the RoIs for m3d_linear_bf16x3_roi_forward, the fc1 GEMM whose operand loader performs the
+ * RoIAlign gather (7^3 bins, sampling grid 2 only).  d_tab: int4 [num_rois, 3, 14]; d_batch: int32 [num_rois]. */
+M3D_API int m3d_roi_align3d_tap_tables(const float* d_rois, int num_rois, float spatial_scale, int batch, int slices, int height, int width,
+                                       void* d_tab, int32_t* d_batch, void* stream) {
+  if (num_rois < 0 || batch <= 0 || slices <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (num_rois == 0) return M3D_OK;
+  if (!d_rois || !d_tab || !d_batch) return M3D_EINVAL;
+  hipLaunchKernelGGL(roi_tap_table_kernel, dim3(num_rois), dim3(64), 0, m3d::as_stream(stream), d_rois, num_rois, spatial_scale, batch, slices,
+                     height, width, (int4*)d_tab, d_batch);
+  return m3d::check_launch("roi_align3d_tap_tables");
 }

@@ -315,3 +315,61 @@ M3D_EXPORT size_t m3d_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst
   free(prefix); free(suffix); free(length);
   return op;
 }
+
+/* ---- a whole tile's instance tree in ONE call: `{dir}/{ch}.tif` for ch = 0 .. num_peaks-1, each the uint8 stack of window ch
+ * (m3d_tiff_encode_window_stack_u8), encoded and written by `threads` worker threads of this call.  The Python driver hands a tile
+ * over with one foreign call (the interpreter lock is free for its whole duration: per-peak Python calls - a future, a buffer, a
+ * file object each - cost the launching thread more than the encoding cost the workers, tools/volume_gaps.py).
+ * Returns the number of files that could not be written (0 = success). */
+#include <pthread.h>
+#include <stdio.h>
+
+typedef struct {
+  const char* dir; const uint8_t* wins; const int32_t* origins;
+  int num_peaks, wn, z_first, pages, height, width, threads, tid;
+  int failed;
+} TileJob;
+
+static void* tile_worker(void* arg) {
+  TileJob* j = (TileJob*)arg;
+  const size_t cap = m3d_tiff_stack_bound(j->pages, j->height, j->width, 8);
+  uint8_t* buf = (uint8_t*)malloc(cap);
+  char path[4096];
+  if (!buf) { j->failed = j->num_peaks; return NULL; }
+  const size_t w3 = (size_t)j->wn * j->wn * j->wn;
+  for (int ch = j->tid; ch < j->num_peaks; ch += j->threads) {
+    const size_t n = m3d_tiff_encode_window_stack_u8(j->wins + (size_t)ch * w3, j->wn, j->origins[3 * ch], j->origins[3 * ch + 1],
+                                                     j->origins[3 * ch + 2], j->z_first, j->pages, j->height, j->width, buf, cap);
+    int ok = n > 0 && snprintf(path, sizeof(path), "%s/%d.tif", j->dir, ch) < (int)sizeof(path);
+    if (ok) {
+      FILE* f = fopen(path, "wb");
+      ok = f != NULL;
+      if (f) { ok = fwrite(buf, 1, n, f) == n; ok = (fclose(f) == 0) && ok; }
+    }
+    if (!ok) j->failed++;
+  }
+  free(buf);
+  return NULL;
+}
+
+M3D_EXPORT int m3d_tiff_write_window_stacks_u8(const char* dir, const uint8_t* wins, const int32_t* origins, int num_peaks, int wn, int z_first,
+                                               int pages, int height, int width, int threads) {
+  if (!dir || !wins || !origins || num_peaks < 0 || wn <= 0 || pages < 0 || height <= 0 || width <= 0) return num_peaks > 0 ? num_peaks : 1;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  if (threads > num_peaks) threads = num_peaks > 0 ? num_peaks : 1;
+  TileJob jobs[64];
+  pthread_t th[64];
+  int started[64];
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = (TileJob){dir, wins, origins, num_peaks, wn, z_first, pages, height, width, threads, t, 0};
+    started[t] = (t > 0 && pthread_create(&th[t], NULL, tile_worker, &jobs[t]) == 0);
+  }
+  tile_worker(&jobs[0]);                                       /* the calling thread is worker 0 */
+  int failed = jobs[0].failed;
+  for (int t = 1; t < threads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL); else tile_worker(&jobs[t]);   /* a thread that could not start: do its share here */
+    failed += jobs[t].failed;
+  }
+  return failed;
+}

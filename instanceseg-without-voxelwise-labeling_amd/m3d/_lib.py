@@ -12,7 +12,7 @@ SYMBOLS = [
     "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option", "m3d_tuning_build",
     "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1", "m3d_norm1_batched",
     "m3d_linear_workspace_bytes", "m3d_linear_forward", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_pack",
-    "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward",
+    "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward", "m3d_roi_align3d_tap_tables", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_linear_bf16x3_roi_forward",
     "m3d_fused_max_boxes", "m3d_compact_rows", "m3d_compact_rows2", "m3d_box_head_outputs", "m3d_conv3d_forward_split_sigmoid", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
     "m3d_box_results3d_batched_workspace_bytes", "m3d_box_results3d_batched", "m3d_nms3d_batched_workspace_bytes", "m3d_nms3d_batched",
     "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward",
@@ -38,7 +38,7 @@ class M3DError(RuntimeError):
 
 _TUNE_ENV = (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
              ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
-             ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem"))
+             ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem"), ("M3D_TUNE_FC_X_ALIAS", "tune_fc_x_alias"))
 TUNE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libm3d_tune.so")
 _tune = None
 
@@ -53,7 +53,7 @@ def _load(path):
     L.m3d_conv3d_wino2_score.restype = C.c_double
     L.m3d_prm_strip_geometry.restype = C.c_int64
     for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
-              "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
+              "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
               "m3d_box_results3d_batched_workspace_bytes", "m3d_nms3d_batched_workspace_bytes", "m3d_otsu2d_workspace_bytes",
               "m3d_cc_workspace_bytes", "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_stem_wino_packed_weight_bytes"):
         getattr(L, n).restype = C.c_size_t

@@ -109,9 +109,10 @@ def infer_prm_serial(engine, im, dataset=None, patch=None, overlap=None, out_dir
 
 
 class _WriterPool:
-    """Host side of the pipelined driver.  `drain` threads wait for a tile's device-to-host copy (an event wait: the GIL is free) and
-    fan its peaks out to `encode` threads, which build each `{ch}.tif` in C (m3d_tiff_encode_window_stack_u8: the GIL is free there
-    too) and write it.  Pinned staging buffers are pooled by size."""
+    """Host side of the pipelined driver.  Two `drain` threads wait for a tile's device-to-host copy (an event wait: the GIL is free)
+    and hand the tile to ONE foreign call that encodes and writes every `{ch}.tif` on `workers` C threads (m3d_tiff_write_window_stacks_u8;
+    the GIL is free there too: a Python-level task per peak - future, buffer, file object - cost the launching thread more than the
+    encoding cost the workers).  Pinned staging buffers are pooled by size."""
 
     def __init__(self, workers=None):
         from concurrent.futures import ThreadPoolExecutor
@@ -128,7 +129,6 @@ class _WriterPool:
                 pass
         self.workers = max(1, min(32, int(workers)))
         self.drain = ThreadPoolExecutor(max_workers=2)
-        self.encode = ThreadPoolExecutor(max_workers=self.workers)
         self.pinned = {}
         self.pending = []
         import threading
@@ -157,7 +157,6 @@ class _WriterPool:
     def close(self):
         self.finish()
         self.drain.shutdown()
-        self.encode.shutdown()
 
 
 _pool = None
@@ -192,19 +191,11 @@ def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, 
         wins = hbuf.numpy()[:P * wn ** 3].reshape(P, wn, wn, wn)
         org = origins_h.copy()
 
-        def one(ch):
-            data = mio.encode_window_stack_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2])
-            if tile_dir is not None:
-                with open(os.path.join(tile_dir, "%d.tif" % ch), "wb") as f:
-                    f.write(memoryview(data))
-            return None
-        futs = [pool.encode.submit(one, ch) for ch in range(P)] if tile_dir is not None else []
+        if tile_dir is not None:                                              # every `{ch}.tif` of the tile in one foreign call (C worker threads)
+            mio.write_window_stacks_u8(tile_dir, wins, org, z_first, pages, patch[1], patch[2], threads=pool.workers)
+            np.save(os.path.join(tile_dir, "dets.npy"), np.asarray(rec["dets"]))
         if keep_maps:
             rec["prm_u8"] = [mio.window_to_dense_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2]) for ch in range(P)]
-        if tile_dir is not None:
-            np.save(os.path.join(tile_dir, "dets.npy"), np.asarray(rec["dets"]))
-        for f in futs:
-            f.result()
         pool.give(hbuf)
 
     for num, s, h, w in tiling.enumerate_tiles(sidx, hidx, widx):

@@ -38,6 +38,8 @@ def _lib():
         lib.m3d_tiff_encode_stack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.m3d_tiff_encode_window_stack_u8.restype = C.c_size_t
         lib.m3d_tiff_encode_window_stack_u8.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_size_t]
+        lib.m3d_tiff_write_window_stacks_u8.restype = C.c_int
+        lib.m3d_tiff_write_window_stacks_u8.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7
         lib.m3d_rle3d_encode.restype = C.c_size_t
         lib.m3d_rle3d_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         lib.m3d_rle3d_decode.restype = C.c_int
@@ -133,6 +135,19 @@ def encode_window_stack_u8(win, origin, z_first, pages, height, width, dst=None)
     if k == 0:
         raise RuntimeError("tiff_encode_window_stack_u8 failed")
     return dst[:k]
+
+
+def write_window_stacks_u8(save_path, wins, origins, z_first, pages, height, width, threads=8):
+    """`{save_path}/{ch}.tif` for every window of a tile in ONE foreign call (csrc/tiff_lzw.c: `threads` worker threads encode and write;
+    the GIL is free meanwhile).  wins uint8 [P,n,n,n] (C-contiguous), origins int32 [P,3]."""
+    wins = np.ascontiguousarray(wins, dtype=np.uint8)
+    origins = np.ascontiguousarray(origins, dtype=np.int32)
+    P, n = int(wins.shape[0]), int(wins.shape[1])
+    assert wins.shape == (P, n, n, n) and origins.shape == (P, 3)
+    bad = _lib().m3d_tiff_write_window_stacks_u8(os.fsencode(save_path), wins.ctypes.data, origins.ctypes.data, P, n, int(z_first), int(pages),
+                                                 int(height), int(width), int(threads))
+    if bad:
+        raise IOError("write_window_stacks_u8: %d of %d files could not be written under %s" % (bad, P, save_path))
 
 
 def window_to_dense_u8(win, origin, z_first, pages, height, width):

@@ -11,7 +11,7 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "compact_rows2", "box_head_outputs", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "mask_paste3d",
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "linear_roi_fused", "mask_paste3d",
            "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
@@ -490,6 +490,28 @@ class SplitLinear:
         check(lib().m3d_linear_bf16x3_forward(_ptr(x), _ptr(self.packed), _ptr(self.bias), _ptr(out), M, self.N, K, int(bool(relu)),
                                               _ptr(ws), C.c_size_t(wsb), _stream()), "linear_bf16x3_forward")
         return out
+
+
+def linear_roi_fused(split, features, rois, spatial_scale, relu=False):
+    """f-1 A/B: act(RoIAlign3D(features, rois).view(R, -1) @ W.T + b) with the gather inside the GEMM's operand loader
+    (m3d_linear_bf16x3_roi_forward; 7^3 bins, sampling grid 2): the [R, C*343] intermediate is never written.  split: SplitLinear of the
+    layer.  The product path stays RoIAlign + SplitLinear (two launches): see profiles/r04_f1_ab.json."""
+    _need_gpu(features, rois)
+    features, rois = _f32c(features), _f32c(rois)
+    B, Cc, S, H, W = features.shape
+    R = int(rois.shape[0])
+    assert split.K == Cc * 343 and rois.shape[1] == 7
+    out = torch.empty((R, split.N), dtype=torch.float32, device=features.device)
+    if R == 0:
+        return out
+    tab = torch.empty((R, 42, 4), dtype=torch.int32, device=features.device)
+    rb = torch.empty((R,), dtype=torch.int32, device=features.device)
+    check(lib().m3d_roi_align3d_tap_tables(_ptr(rois), R, C.c_float(spatial_scale), B, S, H, W, _ptr(tab), _ptr(rb), _stream()), "roi_align3d_tap_tables")
+    wsb = lib().m3d_linear_bf16x3_roi_workspace_bytes(R, split.N, split.K)
+    ws = torch.empty((max(wsb, 16) // 4,), dtype=torch.float32, device=features.device)
+    check(lib().m3d_linear_bf16x3_roi_forward(_ptr(features), B, Cc, S, H, W, _ptr(tab), _ptr(rb), _ptr(split.packed), _ptr(split.bias), _ptr(out),
+                                              R, split.N, int(bool(relu)), _ptr(ws), C.c_size_t(wsb), _stream()), "linear_bf16x3_roi_forward")
+    return out
 
 
 def mask_paste3d(masks, channel, boxes_int, shape, thresh=0.5):

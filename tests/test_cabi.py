@@ -38,7 +38,7 @@ def test_io_library_exports_its_header(built):
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "m3d_io.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", src)))
     assert syms == ["m3d_rle3d_decode", "m3d_rle3d_encode", "m3d_tiff_encode_stack", "m3d_tiff_encode_window_stack_u8", "m3d_tiff_lzw_bound",
-                    "m3d_tiff_lzw_decode", "m3d_tiff_lzw_encode", "m3d_tiff_lzw_encode_plain", "m3d_tiff_stack_bound"]
+                    "m3d_tiff_lzw_decode", "m3d_tiff_lzw_encode", "m3d_tiff_lzw_encode_plain", "m3d_tiff_stack_bound", "m3d_tiff_write_window_stacks_u8"]
     L = ctypes.CDLL(os.path.join(os.path.dirname(built), "libm3dio.so"))
     for s in syms:
         assert hasattr(L, s), s

@@ -1016,3 +1016,28 @@ def test_compact_rows2_packs_both_sets_and_mirrors_the_counts(m3d):
     assert torch.equal(pa[:100], torch.cat([a[b, :n[b]] for b in range(B)])) and torch.equal(pk[:100], torch.cat([k[b, :n[b]] for b in range(B)]))
     p1, o1 = m3d.compact_rows(a, counts)
     assert torch.equal(p1[:100], pa[:100]) and torch.equal(o1, offs)
+
+
+@pytest.mark.parametrize("R,C,shape", [(37, 32, (6, 9, 11)), (300, 64, (8, 12, 12)), (70, 256, (4, 5, 6))])
+def test_fc1_with_the_roialign_gather_in_its_operand_loader_equals_the_two_launch_path(m3d, R, C, shape):
+    """SURVEY 8f-1's fused variant (m3d_linear_bf16x3_roi_forward: the GEMM computes its A operand from the feature maps) against the
+    product path it was measured against (RoIAlign3D, then the bf16x3 GEMM): the same samples and weights in another summation order -
+    the GEMM inputs agree to 1e-6 of max|x|, the outputs to 1e-5 of max|out|.  RoIs sticking out of the map, batch indices, zero-size."""
+    g = torch.Generator().manual_seed(R)
+    B = 2
+    S, H, W = shape
+    feat = torch.randn((B, C) + shape, generator=g).cuda()
+    lo = torch.rand(R, 3, generator=g) * torch.tensor([W * 8.0, H * 8.0, S * 8.0]) - 6.0
+    sz = torch.rand(R, 3, generator=g) * 30.0 + 1.0
+    rois = torch.cat([torch.randint(0, B, (R, 1), generator=g).float(), lo, lo + sz], 1)
+    rois[0, 4:] = rois[0, 1:4]                                      # a zero-size RoI (clamped to one voxel by the reference rule)
+    rois[1, 1:4] = -100.0; rois[1, 4:] = -90.0                      # a RoI wholly outside: every sample invalid -> zeros
+    rois = rois.cuda()
+    w = (torch.randn(128, C * 343, generator=g) / (C * 343) ** 0.5).cuda()
+    b = torch.randn(128, generator=g).cuda()
+    lin = m3d.SplitLinear(w, b)
+    x = m3d.roi_align3d_forward(feat, rois, 7, 7, 7, 0.125, 2).view(R, -1)
+    ref = lin(x, relu=True, variant="packed")
+    got = m3d.linear_roi_fused(lin, feat, rois, 0.125, relu=True)
+    assert float(x[1].abs().max()) == 0.0
+    assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
