@@ -175,6 +175,8 @@ size_t m3d_conv3d_wino2_workspace_bytes(int batch, int cin, int cout, int depth,
 /* useful-work x chip-fill score (0..1) of the tile the library would pick (64x2x4, 32x8x2 or 16x16x2 with split-K);
  * below ~0.5 the direct kernel is the better choice */
 double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, int height, int width);
+/* ... and for the exactly-local F(2x2,3x3) family of m3d_conv3d_wino2_local_forward_ws (other tiles, hence its own score) */
+double m3d_conv3d_wino2_local_score(int batch, int cin, int cout, int depth, int height, int width);
 /* the 2-D Winograd kernel family in use: 1-3 = F(2x2,3x3) variants (4/9 of the direct convolution's multiplies), 4 = F(2x4,3x3)
  * (F(2,3) along y, F(4,3) along x: 1/3; the default), 5 = F(2x4,3x3) with 64 output channels per 4-wave workgroup (A/B only; layers
  * whose cout is not a multiple of 64 run family 4); option "tune_wino2" / 100 selects one for A/B runs */
@@ -284,6 +286,9 @@ int m3d_compact_rows2(const void* d_src_a, size_t item_stride_bytes_a, size_t ro
 int m3d_box_head_outputs(const float* d_outs, const float* d_rois, int num_rois, int num_classes, const double* weights, double xform_clip,
                          double clip_slices, double clip_height, double clip_width, float* d_cls, float* d_bbox, float* d_pred, void* stream);
 size_t m3d_generate_proposals3d_batched_workspace_bytes(int batch, int A, int S, int H, int W, int pre_nms_topN);
+/* m3d_generate_proposals3d_batched: out_rows = rows of the per-item output blocks, >= min(K, post_nms_topN) with NMS; with nms_thresh <= 0
+ * every valid box of the K pre-NMS candidates is a proposal (generate_proposals_3d.py:167-171), so out_rows must be >= K - M3D_EINVAL
+ * otherwise, never a silently truncated list. */
 int m3d_generate_proposals3d_batched(const float* d_scores, const float* d_deltas, int batch, int A, int S, int H, int W,
                                      const double* anchors, double feat_stride, const double* im_info, int pre_nms_topN,
                                      int post_nms_topN, float nms_thresh, double min_size, double xform_clip,

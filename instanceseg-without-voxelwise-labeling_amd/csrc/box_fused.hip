@@ -827,6 +827,9 @@ M3D_API int m3d_generate_proposals3d_batched(const float* d_scores, const float*
   const long long Kll = (pre_nms_topN <= 0 || pre_nms_topN >= total) ? total : pre_nms_topN;   // :135
   if (Kll > kFusedMax) return M3D_EUNSUPPORTED;        // larger pre-NMS sets: the multi-launch m3d_generate_proposals3d
   const int K = (int)Kll;
+  // without NMS every valid box of the pre-NMS set is a proposal (generate_proposals_3d.py:167-171: post_nms_topN only cuts behind the
+  // NMS): a caller that sized its outputs by post_nms_topN would get a silently truncated list - refuse instead
+  if (nms_thresh <= 0 && out_rows < K) return M3D_EINVAL;
   if (ws_bytes < (size_t)batch * prop_item_bytes(K, (long long)A * S * H * W) + 256) return M3D_EWORKSPACE;
   PropFusedArgs a;
   a.scores = d_scores; a.deltas = d_deltas; a.rois = d_rois; a.probs = d_probs; a.keep_idx = d_keep_idx; a.num = d_num;

@@ -1133,6 +1133,15 @@ M3D_API double m3d_conv3d_wino2_score(int batch, int cin, int cout, int depth, i
   return sc;
 }
 
+/* the same score for the exactly-local F(2x2,3x3) family (m3d_conv3d_wino2_local_forward_ws): its tiles differ from the default
+ * family's (64 x 2 x 4 against 64 x 4 x 2), so a go / no-go decision for the local path must ask about ITS tiles */
+M3D_API double m3d_conv3d_wino2_local_score(int batch, int cin, int cout, int depth, int height, int width) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0.0;
+  double sc = 0.0;
+  (void)choose_xt(family_for(2, cout), batch, cin, cout, depth, height, width, &sc);
+  return sc;
+}
+
 namespace {
 size_t workspace_bytes_for(int fam, int batch, int cin, int cout, int depth, int height, int width) {
   if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return 0;

@@ -25,7 +25,7 @@ SYMBOLS = [
     "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch", "m3d_prm_quantize_u8", "m3d_roi_normalize", "m3d_prm_quantize_windows_u8", "m3d_prm_quantize_windows_compact_u8", "m3d_roi_normalize_ws",
     "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wgrad", "m3d_conv3d_bias_grad",
     "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino_pack_weights", "m3d_conv3d_wino_forward", "m3d_conv3d_wino_forward_pool2",
-    "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_pack_weights", "m3d_conv3d_wino2_forward", "m3d_conv3d_wino2_forward_pool2", "m3d_conv3d_wino2_forward_pool2_argmax", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_forward_ws", "m3d_conv3d_wino2_score", "m3d_conv3d_wino2_family", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_wino2_local_forward_ws",
+    "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_pack_weights", "m3d_conv3d_wino2_forward", "m3d_conv3d_wino2_forward_pool2", "m3d_conv3d_wino2_forward_pool2_argmax", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_forward_ws", "m3d_conv3d_wino2_score", "m3d_conv3d_wino2_local_score", "m3d_conv3d_wino2_family", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_wino2_local_forward_ws",
     "m3d_conv3d_stem_wino_packed_weight_bytes", "m3d_conv3d_stem_wino_pack_weights", "m3d_conv3d_stem_wino_forward",
     "m3d_gaussian_filter_u16", "m3d_median_filter3_u16",
     "m3d_cc_workspace_bytes", "m3d_cc_largest_batch", "m3d_binary_closing6_batch", "m3d_paint_instances", "m3d_paint_finish",
@@ -51,6 +51,7 @@ def _load(path):
     L.m3d_error_string.restype = C.c_char_p
     L.m3d_last_hip_error.restype = C.c_char_p
     L.m3d_conv3d_wino2_score.restype = C.c_double
+    L.m3d_conv3d_wino2_local_score.restype = C.c_double
     L.m3d_prm_strip_geometry.restype = C.c_int64
     for n in ("m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
               "m3d_conv3d_packed_weight_bytes", "m3d_reduce_min_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",

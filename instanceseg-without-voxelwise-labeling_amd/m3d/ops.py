@@ -988,7 +988,8 @@ class WinoConv3d(object):
             B, D, H, W = (int(v) for v in shape)
             # below ~0.3 of useful tile volume x chip fill the direct kernel wins (tools/bench_wino_threshold.py; with F(2x4,3x3) the
             # 0.39-score layers of the soma net run 0.194 vs 0.253 ms, so the round-2 threshold of 0.5 came down)
-            return lib().m3d_conv3d_wino2_score(B, self.cin, self.cout, D, H, W) >= 0.3
+            score = lib().m3d_conv3d_wino2_local_score if self.local else lib().m3d_conv3d_wino2_score     # each family asks about its own tiles
+            return score(B, self.cin, self.cout, D, H, W) >= 0.3
         return True
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None):

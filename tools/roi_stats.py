@@ -11,6 +11,8 @@ from m3d.synth import make_params, synth_volume
 
 B = 4
 cfg = Cfg.nuclei(in_size=(128, 128, 128))
+if "--stress" in sys.argv:                      # RPN NMS off: RPN_POST_NMS_TOP_N = 1000 proposals per volume (bench.py's stress_rois sub-record)
+    cfg.rpn_nms_thresh = 1.0
 P = make_params(stride=8, num_anchors=35, mlp_dim=cfg.mlp_dim, seed=0)
 det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
 x = torch.stack([m3d.norm1(torch.from_numpy(synth_volume(i, (128, 128, 128))).cuda()) for i in range(B)])[:, None]

@@ -36,21 +36,27 @@ def main(db, gap_ms=12.0):
         # busy = union of the kernel intervals (a copy stream may overlap the compute stream)
         busy, end = 0.0, None
         gaps = []
-        for _, a, b in r:
+        prev_name = ""
+        for nm, a, b in r:
             if end is None or a >= end:
                 if end is not None:
-                    gaps.append((a - end) / 1e3)
+                    gaps.append(((a - end) / 1e3, prev_name, nm))
                 busy += b - a
                 end = b
             elif b > end:
                 busy += b - end
                 end = b
+            prev_name = nm
         tiles = sum(1 for n, _, _ in r if "prm_select_peaks_kernel" in n)
         gaps.sort(reverse=True)
         print("%4d %10.2f %10.2f %8.1f %9d %9d  %s" % (k, wall, busy / 1e6, 100.0 * (1 - busy / 1e6 / wall), len(r), tiles,
-                                                       " ".join("%.0f" % g for g in gaps[:6])))
+                                                       " ".join("%.0f" % g[0] for g in gaps[:6])))
+        if "-v" in sys.argv:
+            short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48]     # noqa: E731
+            for g, a_, b_ in gaps[:8]:
+                print("          gap %7.0f us between %-48s and %s" % (g, short(a_), short(b_)))
         k += 1
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 12.0)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-v" else 12.0)
