@@ -276,7 +276,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     # 2*Cin*Cout*k^3 per window voxel, issued = what the kernels put on the matrix cores (strip Winograd 4/9 for windows >= 16 voxels,
     # every product for the small-window GEMMs, 32/25 for the stem whose 25 (dy, dx) taps occupy 32 MFMA rows)
     cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride)
-    dom = "conv3d_wino2e_kernel<4, 32, 4, 1, false, false>"
+    dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if nuclei else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"     # the largest backward launch
     roof = None
     if back_ms and npeaks:
         roof = {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks: prm_seed, prm_prepare*, the strip-Winograd / small-window / "
@@ -640,9 +640,20 @@ def bench_detect(args, rank, world, dist):
     # ---- the same steps with the raw volumes resident in HBM (the `value` of rounds 1-3)
     resident = None
     if not backbone_only:
-        dtr = timed_loop(step_resident, args.steps, 2, dist, torch.cuda.synchronize)
+        for _ in range(2):
+            step_resident()
+        rprobe = Probe()
+        arm(rprobe, PROBE_STEPS)
+        dtr = timed_loop(step_resident, args.steps, 0, dist, torch.cuda.synchronize)
         dtr = sync_max_time(dtr, dist, "cpu" if via_host else "cuda")
+        torch.cuda.synchronize()
+        det.probe = None
+        arm(None, 0)
+        rfam, _ = conv_family_roofline(det, det.conv_work(nvol, (VOL, VOL, VOL)), rprobe.mean_ms(), nvol, "the rank's batch of %d volumes" % nvol)
         resident = {"value": n_items * args.steps * VOL ** 3 / dtr, "unit": "voxels/s", "ms_per_step": dtr / args.steps * 1e3,
+                    "roofline": None if rfam is None else {k: rfam[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "kernel_ms")},
+                    "roofline_note": "the conv family's spans in THIS loop: no upload runs beside the kernels (in the host-to-host loop the next "
+                                     "batch's 16.8 MB H2D copy shares HBM and power with them)",
                     "what": "the same %d steps over the same rotating batches with the raw uint16 volumes already in HBM and the "
                             "detections left on the device (the definition of `value` in rounds 1-3)" % args.steps}
 

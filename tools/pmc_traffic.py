@@ -21,13 +21,15 @@ def main():
     fetch, write, cal_bytes, out = load(sys.argv[1]), load(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
     def find(d, frag):
         ks = [k for k in d if frag in k[0]]
-        return max(ks, key=lambda k: sum(d[k]) / len(d[k])) if ks else None
+        return max(ks, key=lambda k: max(d[k])) if ks else None
     k_min = find(fetch, "min_partial_kernel")
     others = [k for k in fetch if "copyBuffer" in k[0] or "direct_copy" in k[0]]
-    k_cpy = max(others, key=lambda k: sum(fetch[k]) / len(fetch[k])) if others else None      # the 1.25 GiB torch copy
-    f_dword = cal_bytes / (sum(fetch[k_min]) / len(fetch[k_min]))
-    f_vec = cal_bytes / (sum(fetch[k_cpy]) / len(fetch[k_cpy])) if k_cpy else None
-    w_chk = (sum(write[k_cpy]) / len(write[k_cpy])) / cal_bytes if k_cpy and k_cpy in write else None
+    k_cpy = max(others, key=lambda k: max(fetch[k])) if others else None      # the 1.25 GiB torch copy
+    # the calibration launches are the LARGEST of their kernel (the PRM engine's reduce_min runs the same kernel, same grid, on small
+    # tensors later in the probe): calibrate on the maximum, not on the mean of the group
+    f_dword = cal_bytes / max(fetch[k_min])
+    f_vec = cal_bytes / max(fetch[k_cpy]) if k_cpy else None
+    w_chk = max(write[k_cpy]) / cal_bytes if k_cpy and k_cpy in write else None
     res = {"units": "bytes per launch", "calibration": {"known_bytes": cal_bytes, "fetch_factor_dword_loads": f_dword,
            "fetch_factor_16B_loads": f_vec, "write_size_over_known": w_chk,
            "kernels": {"dword": k_min[0][:80], "vec": k_cpy[0][:80] if k_cpy else None}}, "kernels": []}

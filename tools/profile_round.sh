@@ -40,4 +40,4 @@ if [ -f instanceseg-without-voxelwise-labeling_amd/csrc/libm3d_w2stamps.so ]; th
 fi
 python bench.py --interleaved --pipelined --no-cpu-baseline --no-subrecords 2>/dev/null | tail -1 > $P/${R}_bench_detect_interleaved_and_pipelined.json
 fi
-ls -la $P | tail -30; head -c 600 $P/${R}_bench_detect.json; echo; head -30 $P/${R}_mfma_busy.txt
+ls -la $P | tail -40
