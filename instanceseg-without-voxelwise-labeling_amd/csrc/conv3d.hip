@@ -708,7 +708,10 @@ static int conv_dispatch(const float* d_in, const float* d_packed, float* d_out,
     }
     if (xb == 16) {
       const long long wg = (vox / 256) * ((ncb_total + 1) / 2);
-      if (wg >= 512) return launch_cfg<3, 4, 16, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      if (wg >= 1024) return launch_cfg<3, 4, 16, 2, 2, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
+      // one to two rounds of the big tile (the soma tile's 32 x 80 x 80 maps: 800 workgroups on 512 slots) leave a ragged second round:
+      // the quarter-size tile (tools/tune_k3_prm.py, round 4: conv2a 0.256 -> 0.202 ms, conv2b 0.438 -> 0.382 ms; equal from 1250 up)
+      if (wg >= 512) return launch_cfg<3, 4, 16, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       // 16^3-class maps: exactly one 32x32 output block per SIMD -> split K in the workgroup for 2 waves/SIMD
       if (cin >= 16) return launch_cfg<3, 8, 16, 1, 1, 4, 1, false, 2>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
       return launch_cfg<3, 4, 16, 1, 1, 4, 1>(d_in, d_packed, d_out, batch, cin, cout, depth, height, width, ep, st);
