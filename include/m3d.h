@@ -505,6 +505,13 @@ int m3d_prm_quantize_windows_compact_u8(const float* d_windows, const float* d_s
 int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,
                          int num_rois, int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
                          uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream);
+/* ... with an indirection and an optional compact source: RoI r reads map d_map_index[r] (int32 [num_rois]; NULL = map r) of d_prm_u8 =
+ * the dense stack (win = 0) or the uint8 windows [*, win^3] of m3d_prm_quantize_windows_compact_u8 with d_win_origins int32 [*, 3] (a
+ * map is zero outside its window): neither a gathered copy of the valid detections' maps nor the dense maps are needed. */
+int m3d_roi_normalize_idx(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_map_index, int win,
+                          const int32_t* d_win_origins, const int32_t* d_boxes, const int64_t* d_offsets, int num_rois,
+                          int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image, uint16_t* d_out_prm,
+                          void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Per-RoI 2D-Otsu binarisation.  Replaces otsu.otsu_py_2d_fast (tools/otsu.py:199-284) for uint16 inputs

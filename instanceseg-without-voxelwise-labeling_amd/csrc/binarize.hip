@@ -139,10 +139,18 @@ __global__ __launch_bounds__(256) void winq_stats_kernel(const float* __restrict
   for (int o = 32; o > 0; o >>= 1) {
     mn = fminf(mn, __shfl_down(mn, o, 64)); mx = fmaxf(mx, __shfl_down(mx, o, 64)); cnt += __shfl_down(cnt, o, 64);
   }
-  if ((threadIdx.x & 63) == 0 && cnt) {
-    atomicMin(&st[p].fmin_bits, __float_as_uint(mn));
-    atomicMax(&st[p].fmax_bits, __float_as_uint(mx));
-    atomicAdd(&st[p].inside, cnt);
+  // one atomic triple per WORKGROUP (round 4): per wave they were 100 k atomics on 128 addresses - the kernel spent its time queueing
+  __shared__ float s_mn[4], s_mx[4];
+  __shared__ int s_cnt[4];
+  if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c4 = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (c4) {
+      atomicMin(&st[p].fmin_bits, __float_as_uint(fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]))));
+      atomicMax(&st[p].fmax_bits, __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+      atomicAdd(&st[p].inside, c4);
+    }
   }
 }
 
@@ -192,20 +200,38 @@ __device__ inline bool roi_box(const int* boxes, const int64_t* offsets, int r, 
   return V > 0 && offsets[r + 1] - offsets[r] == V;
 }
 
-__global__ __launch_bounds__(256) void roi_stats_kernel(const uint16_t* __restrict__ image, const uint8_t* __restrict__ prm,
+// Where a RoI's uint8 peak response map comes from: a dense stack [*, D, H, W] (win == 0) or the compact windows [*, win^3] of
+// m3d_prm_quantize_windows_compact_u8 with their origins (a map is zero outside its window); `map`: RoI r reads entry map[r].
+struct PrmSrc { const uint8_t* prm; const int* map; const int* org; int win; };
+struct PrmView { const uint8_t* p; int win, oz, oy, ox; };
+__device__ inline PrmView prm_view(const PrmSrc& s, int r, size_t DHW) {
+  const int e = s.map ? s.map[r] : r;
+  PrmView v;
+  v.win = s.win;
+  if (s.win == 0) { v.p = s.prm + (size_t)e * DHW; v.oz = v.oy = v.ox = 0; }
+  else { v.p = s.prm + (size_t)e * s.win * s.win * s.win; v.oz = s.org[3 * e]; v.oy = s.org[3 * e + 1]; v.ox = s.org[3 * e + 2]; }
+  return v;
+}
+__device__ inline int prm_at(const PrmView& v, size_t idx, int z, int y, int x) {
+  if (v.win == 0) return v.p[idx];
+  const unsigned wz = (unsigned)(z - v.oz), wy = (unsigned)(y - v.oy), wx = (unsigned)(x - v.ox), w = (unsigned)v.win;
+  return (wz < w && wy < w && wx < w) ? v.p[((size_t)wz * w + wy) * w + wx] : 0;
+}
+
+__global__ __launch_bounds__(256) void roi_stats_kernel(const uint16_t* __restrict__ image, PrmSrc src,
                                                         const int* __restrict__ boxes, const int64_t* __restrict__ offsets, int D,
                                                         int H, int W, RoiStat* __restrict__ st) {
   const int r = blockIdx.y;
   int x1, y1, z1, ex, ey; long long V;
   if (!roi_box(boxes, offsets, r, x1, y1, z1, ex, ey, V)) return;
-  const uint8_t* pm = prm + (size_t)r * D * H * W;
+  const PrmView pv = prm_view(src, r, (size_t)D * H * W);
   int gmax = 0, gmin = 65535, pmax = 0, pmin = 255;
   const int Vi = (int)V, exy = ex * ey;                              // 32-bit index arithmetic: a crop is a sub-box of one tile
   for (int e = blockIdx.x * 256 + threadIdx.x; e < Vi; e += gridDim.x * 256) {
     const int zq = e / exy, rq = e - zq * exy, yq = rq / ex;
     const int x = x1 + (rq - yq * ex), y = y1 + yq, z = z1 + zq;
     const size_t idx = ((size_t)z * H + y) * W + x;
-    const int g = image[idx], p = pm[idx];
+    const int g = image[idx], p = prm_at(pv, idx, z, y, x);
     gmax = max(gmax, g); gmin = min(gmin, g); pmax = max(pmax, p); pmin = min(pmin, p);
   }
 #pragma unroll
@@ -213,20 +239,26 @@ __global__ __launch_bounds__(256) void roi_stats_kernel(const uint16_t* __restri
     gmax = max(gmax, __shfl_down(gmax, o, 64)); gmin = min(gmin, __shfl_down(gmin, o, 64));
     pmax = max(pmax, __shfl_down(pmax, o, 64)); pmin = min(pmin, __shfl_down(pmin, o, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(&st[r].gmax, gmax); atomicMin(&st[r].gmin, gmin); atomicMax(&st[r].pmax, pmax); atomicMin(&st[r].pmin, pmin);
+  __shared__ int s_r[4][4];                                        // one atomic set per workgroup, not per wave (see winq_stats_kernel)
+  if ((threadIdx.x & 63) == 0) { int* q = s_r[threadIdx.x >> 6]; q[0] = gmax; q[1] = gmin; q[2] = pmax; q[3] = pmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMax(&st[r].gmax, max(max(s_r[0][0], s_r[1][0]), max(s_r[2][0], s_r[3][0])));
+    atomicMin(&st[r].gmin, min(min(s_r[0][1], s_r[1][1]), min(s_r[2][1], s_r[3][1])));
+    atomicMax(&st[r].pmax, max(max(s_r[0][2], s_r[1][2]), max(s_r[2][2], s_r[3][2])));
+    atomicMin(&st[r].pmin, min(min(s_r[0][3], s_r[1][3]), min(s_r[2][3], s_r[3][3])));
   }
 }
 
 // mode 0 (soma): writes both crops.  mode 1 (nuclei): writes the (stretched) image crop and the range of the values written.
-__global__ __launch_bounds__(256) void roi_apply1_kernel(const uint16_t* __restrict__ image, const uint8_t* __restrict__ prm,
+__global__ __launch_bounds__(256) void roi_apply1_kernel(const uint16_t* __restrict__ image, PrmSrc src,
                                                          const int* __restrict__ boxes, const int64_t* __restrict__ offsets, int D,
                                                          int H, int W, int mode, RoiStat* __restrict__ st,
                                                          uint16_t* __restrict__ out_img, uint16_t* __restrict__ out_prm) {
   const int r = blockIdx.y;
   int x1, y1, z1, ex, ey; long long V;
   if (!roi_box(boxes, offsets, r, x1, y1, z1, ex, ey, V)) return;
-  const uint8_t* pm = prm + (size_t)r * D * H * W;
+  const PrmView pv = prm_view(src, r, (size_t)D * H * W);
   uint16_t* oi = out_img + offsets[r];
   uint16_t* op = out_prm + offsets[r];
   const RoiStat s = st[r];
@@ -242,7 +274,7 @@ __global__ __launch_bounds__(256) void roi_apply1_kernel(const uint16_t* __restr
       double f = (double)image[idx] / gmaxd * 300.0;                  // binarization_soma.py:86-87
       f = f < 0.0 ? 0.0 : (f > 300.0 ? 300.0 : f);                    // np.clip
       oi[e] = (uint16_t)(f + 30.0);                                   // astype(np.uint16)
-      const double q = (double)pm[idx] / pmaxd * 300.0 + 30.0;        // :90-91
+      const double q = (double)prm_at(pv, idx, z, y, x) / pmaxd * 300.0 + 30.0;        // :90-91
       op[e] = (uint16_t)rint(q);                                      // np.round (half to even)
     } else {
       uint16_t v = image[idx];
@@ -259,13 +291,13 @@ __global__ __launch_bounds__(256) void roi_apply1_kernel(const uint16_t* __restr
 }
 
 // nuclei: PRM mapped into [gray_min, gray_max] of the (stretched) image crop (binarization_nuclei.py:118-121)
-__global__ __launch_bounds__(256) void roi_apply2_kernel(const uint8_t* __restrict__ prm, const int* __restrict__ boxes,
+__global__ __launch_bounds__(256) void roi_apply2_kernel(PrmSrc src, const int* __restrict__ boxes,
                                                          const int64_t* __restrict__ offsets, int D, int H, int W,
                                                          const RoiStat* __restrict__ st, uint16_t* __restrict__ out_prm) {
   const int r = blockIdx.y;
   int x1, y1, z1, ex, ey; long long V;
   if (!roi_box(boxes, offsets, r, x1, y1, z1, ex, ey, V)) return;
-  const uint8_t* pm = prm + (size_t)r * D * H * W;
+  const PrmView pv = prm_view(src, r, (size_t)D * H * W);
   uint16_t* op = out_prm + offsets[r];
   const RoiStat s = st[r];
   const double pmaxd = (double)s.pmax, pmind = (double)s.pmin;
@@ -275,7 +307,7 @@ __global__ __launch_bounds__(256) void roi_apply2_kernel(const uint8_t* __restri
     const int zq = e / exy, rq = e - zq * exy, yq = rq / ex;
     const int x = x1 + (rq - yq * ex), y = y1 + yq, z = z1 + zq;
     const size_t idx = ((size_t)z * H + y) * W + x;
-    const double q = ((double)pm[idx] - pmind) / (pmaxd - pmind) * span + base;
+    const double q = ((double)prm_at(pv, idx, z, y, x) - pmind) / (pmaxd - pmind) * span + base;
     op[e] = (uint16_t)rint(q);
   }
 }
@@ -329,7 +361,9 @@ M3D_API int m3d_prm_quantize_windows_u8(const float* d_windows, const float* d_s
   const int w3 = win * win * win;
   int chunks = (w3 + 255) / 256;
   chunks = chunks > 64 ? 64 : chunks;
-  hipLaunchKernelGGL(winq_stats_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
+  int schunks = (4096 + num_peaks - 1) / num_peaks;            // the statistics pass ends in atomics on one record per peak: ~4 k workgroups in all
+  schunks = schunks < 1 ? 1 : (schunks > chunks ? chunks : schunks);
+  hipLaunchKernelGGL(winq_stats_kernel, dim3(schunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q);
   hipLaunchKernelGGL(winq_apply_kernel<false>, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q, d_out);
@@ -353,16 +387,25 @@ M3D_API int m3d_prm_quantize_windows_compact_u8(const float* d_windows, const fl
   const int w3 = win * win * win;
   int chunks = (w3 + 255) / 256;
   chunks = chunks > 64 ? 64 : chunks;
-  hipLaunchKernelGGL(winq_stats_kernel, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
+  int schunks = (4096 + num_peaks - 1) / num_peaks;
+  schunks = schunks < 1 ? 1 : (schunks > chunks ? chunks : schunks);
+  hipLaunchKernelGGL(winq_stats_kernel, dim3(schunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q);
   hipLaunchKernelGGL(winq_apply_kernel<true>, dim3(chunks, num_peaks), dim3(256), 0, st, d_windows, d_sums, d_origins, win, depth, height,
                      width, q, d_out_windows);
   return m3d::check_launch("prm_quantize_windows_compact_u8");
 }
 
-M3D_API int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,
-                                 int num_rois, int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
-                                 uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream) {
+/* m3d_roi_normalize_ws with an indirection and an optional compact source: RoI r reads map d_map_index[r] (NULL: r) of d_prm_u8, which
+ * is the dense stack [*, depth, height, width] (win = 0) or the uint8 windows [*, win^3] of m3d_prm_quantize_windows_compact_u8 at
+ * d_win_origins (int32 [*, 3]; a map is zero outside its window).  The detections with a valid crop box are a subset of a tile's peaks:
+ * gathering their maps was a 200 MB copy per soma tile, the dense maps themselves 210 MB written to be read at the crop boxes only. */
+M3D_API int m3d_roi_normalize_idx(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_map_index, int win,
+                                  const int32_t* d_win_origins, const int32_t* d_boxes, const int64_t* d_offsets, int num_rois,
+                                  int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
+                                  uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream) {
+  if (win < 0 || (win > 0 && !d_win_origins)) return M3D_EINVAL;
+  const PrmSrc src{d_prm_u8, d_map_index, d_win_origins, win};
   if (num_rois < 0 || depth <= 0 || height <= 0 || width <= 0 || (mode != 0 && mode != 1)) return M3D_EINVAL;
   if (num_rois == 0) return M3D_OK;
   if (!d_image || !d_prm_u8 || !d_boxes || !d_offsets || !d_out_image || !d_out_prm || !d_ws) return M3D_EINVAL;
@@ -375,11 +418,18 @@ M3D_API int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u
   const int chunks = (int)(c < 1 ? 1 : (c > 1024 ? 1024 : c));
   const dim3 grid(chunks, num_rois), block(256);
   hipLaunchKernelGGL(roi_stat_init_kernel, dim3((num_rois + 255) / 256), dim3(256), 0, st, rs, num_rois);
-  hipLaunchKernelGGL(roi_stats_kernel, grid, block, 0, st, d_image, d_prm_u8, d_boxes, d_offsets, depth, height, width, rs);
-  hipLaunchKernelGGL(roi_apply1_kernel, grid, block, 0, st, d_image, d_prm_u8, d_boxes, d_offsets, depth, height, width, mode, rs,
+  hipLaunchKernelGGL(roi_stats_kernel, grid, block, 0, st, d_image, src, d_boxes, d_offsets, depth, height, width, rs);
+  hipLaunchKernelGGL(roi_apply1_kernel, grid, block, 0, st, d_image, src, d_boxes, d_offsets, depth, height, width, mode, rs,
                      d_out_image, d_out_prm);
   if (mode == 1)
-    hipLaunchKernelGGL(roi_apply2_kernel, grid, block, 0, st, d_prm_u8, d_boxes, d_offsets, depth, height, width, (const RoiStat*)rs,
+    hipLaunchKernelGGL(roi_apply2_kernel, grid, block, 0, st, src, d_boxes, d_offsets, depth, height, width, (const RoiStat*)rs,
                        d_out_prm);
-  return m3d::check_launch("roi_normalize_ws");
+  return m3d::check_launch("roi_normalize_idx");
+}
+
+M3D_API int m3d_roi_normalize_ws(const uint16_t* d_image, const uint8_t* d_prm_u8, const int32_t* d_boxes, const int64_t* d_offsets,
+                                 int num_rois, int64_t total_voxels, int depth, int height, int width, int mode, uint16_t* d_out_image,
+                                 uint16_t* d_out_prm, void* d_ws, size_t ws_bytes, void* stream) {
+  return m3d_roi_normalize_idx(d_image, d_prm_u8, nullptr, 0, nullptr, d_boxes, d_offsets, num_rois, total_voxels, depth, height, width, mode, d_out_image,
+                               d_out_prm, d_ws, ws_bytes, stream);
 }

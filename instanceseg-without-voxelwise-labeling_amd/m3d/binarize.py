@@ -31,7 +31,7 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
     ok = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
          (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < S)
-    q, _ = _quantised(prms, (S, H, W))                                      # what the reference reads back from its TIFFs
+    q, _, _ = _quantised(prms, (S, H, W))                                   # what the reference reads back from its TIFFs
     idx = np.nonzero(ok)[0]
     out = [(boxes[i], None, 0, 0) for i in range(len(boxes))]
     if len(idx) == 0:
@@ -49,9 +49,10 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     return out
 
 
-def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all=None):
+def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all=None, win_origins=None):
     """Device pipeline for the detections of one tile: crop + normalise -> 2D-Otsu -> largest 26-connected component
-    (-> hole fill -> 6-closing for nuclei).  image_u16 [S,H,W] CUDA, q uint8 [P,S,H,W] CUDA (quantised PRMs),
+    (-> hole fill -> 6-closing for nuclei).  image_u16 [S,H,W] CUDA, q uint8 [P,S,H,W] CUDA (quantised PRMs; with win_origins int32
+    [P,3]: their compact form [P,n,n,n], the maps being zero outside their windows - nothing dense is built),
     boxes int32 ndarray [P,6] inclusive tile coordinates.  Returns (masks uint8 flat, offsets, boxes CUDA int32 [n,6],
     idx LongTensor [n] (rows of `boxes` that were processed), ok bool [n] (False: the reference skips / fails))."""
     S, H, W = image_u16.shape
@@ -63,24 +64,33 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all
         return None
     idx_t = ops.upload(idx, dev)
     bsel = ops.upload(boxes[idx], dev)
-    qs = q if len(idx) == q.shape[0] else q[idx_t].contiguous()          # every detection has a valid crop: no 200 MB gather
-    oi, op, offs = ops.roi_normalize(image_u16, qs, bsel, mode, boxes_host=boxes[idx])
+    # detections with a valid crop are a subset of the tile's peaks: the crop kernels read map idx[r] of the full stack (a gathered copy
+    # of the maps was 200 MB per soma tile)
+    sub = len(idx) != q.shape[0]
+    oi, op, offs = ops.roi_normalize(image_u16, q, bsel, mode, boxes_host=boxes[idx], map_index=ops.upload(idx.astype(np.int32), dev) if sub else None,
+                                     win_origins=win_origins)
     mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
     dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
     cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))
     if mode == "nuclei":
         cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
         cc = ops.binary_closing6_batch(cc, offs, dims)
-    nonempty = nonempty_all[idx_t] if nonempty_all is not None else qs.reshape(len(idx), -1).amax(1) > 0   # binarization_soma.py:74-76
+    nonempty = nonempty_all[idx_t] if nonempty_all is not None else (q[idx_t] if sub else q).reshape(len(idx), -1).amax(1) > 0   # binarization_soma.py:74-76
     return cc, offs, bsel, idx_t, (st_otsu == 0) & (st_cc == 0) & nonempty
 
 
-def _quantised(prms, shape):
+def _quantised(prms, shape, compact=False):
     """uint8 maps from dense float maps [P,S,H,W], or straight from the back-propagation's cone-cropped windows when `prms` is the
-    triple (windows, sums, origins) of PRMEngine.prm_tile(dense=False) - the dense float maps are then never built."""
+    triple (windows, sums, origins) of PRMEngine.prm_tile(dense=False) - the dense float maps are then never built.  compact (triple
+    only): the uint8 WINDOWS [P,n,n,n] instead of dense uint8 maps (the crop kernels read them through the origins).
+    Returns (maps, nonempty flags or None, window origins or None)."""
     if isinstance(prms, (tuple, list)):
-        return ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
-    return ops.prm_quantize_u8(prms), None
+        if compact:
+            q, ne = ops.prm_quantize_windows_compact_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
+            return q, ne, prms[2].contiguous()
+        q, ne = ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
+        return q, ne, None
+    return ops.prm_quantize_u8(prms), None, None
 
 
 def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_id=1):
@@ -98,8 +108,8 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     if P == 0:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
-    q, nonempty = _quantised(prms, (S, H, W))
-    r = _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty)
+    q, nonempty, worg = _quantised(prms, (S, H, W), compact=True)           # windows only: the crops are cut out of them directly
+    r = _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty, win_origins=worg)
     if r is None:
         return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
     cc, offs, bsel, idx_t, ok = r

@@ -914,7 +914,7 @@ def prm_quantize_windows_u8(windows, sums, origins, shape, return_nonempty=False
     return out
 
 
-def prm_quantize_windows_compact_u8(windows, sums, origins, shape, out=None):
+def prm_quantize_windows_compact_u8(windows, sums, origins, shape, out=None, return_nonempty=False):
     """The uint8 values of prm_quantize_windows_u8 as windows [P,Wn,Wn,Wn] (0 outside the tile): with `origins`, everything a writer
     needs to rebuild each uint8 map (m3d.io.encode_window_stack_u8)."""
     _need_gpu(windows, sums, origins)
@@ -926,17 +926,24 @@ def prm_quantize_windows_compact_u8(windows, sums, origins, shape, out=None):
     ws = torch.empty((max(16 * P, 16),), dtype=torch.uint8, device=windows.device)
     check(lib().m3d_prm_quantize_windows_compact_u8(_ptr(windows), _ptr(_f32c(sums)), _ptr(origins.contiguous()), P, Wn, D, H, W, _ptr(out),
                                                     _ptr(ws), C.c_size_t(ws.numel()), _stream()), "prm_quantize_windows_compact_u8")
+    if return_nonempty:
+        return out, ws[:16 * P].view(torch.int32).view(P, 4)[:, 3] != 0
     return out
 
 
-def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None):
+def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None, map_index=None, win_origins=None):
     """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
     Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch.
-    boxes_host: the same boxes as an ndarray when the caller has them (saves the device read-back that sizes the crops)."""
+    boxes_host: the same boxes as an ndarray when the caller has them (saves the device read-back that sizes the crops).
+    map_index (int32 [R] on the device): RoI r reads prm_u8[map_index[r]] - prm_u8 then holds ALL maps of the tile, not a gathered subset.
+    win_origins (int32 [P,3]): prm_u8 is the COMPACT form [P,n,n,n] of prm_quantize_windows_compact_u8 (zero outside each window)."""
     _need_gpu(image_u16, prm_u8, boxes)
     assert image_u16.dtype == torch.uint16 and prm_u8.dtype == torch.uint8 and boxes.dtype == torch.int32
     R = boxes.shape[0]
     D, H, W = image_u16.shape
+    win = 0 if win_origins is None else int(prm_u8.shape[1])
+    if win_origins is not None:
+        assert prm_u8.dim() == 4 and prm_u8.shape[1] == prm_u8.shape[2] == prm_u8.shape[3] and win_origins.dtype == torch.int32 and win_origins.is_contiguous()
     b = (np.asarray(boxes_host) if boxes_host is not None else boxes.cpu().numpy()).astype(np.int64)
     sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
     assert R == 0 or (sizes.min() > 0 and b[:, :3].min() >= 0 and b[:, 3].max() < W and b[:, 4].max() < H and b[:, 5].max() < D)
@@ -948,7 +955,9 @@ def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None):
     if R == 0:
         return oi, op, offs
     ws = torch.empty((24 * R,), dtype=torch.uint8, device=image_u16.device)
-    check(lib().m3d_roi_normalize_ws(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(boxes.contiguous()), _ptr(offs),
+    if map_index is not None:
+        assert map_index.dtype == torch.int32 and map_index.is_cuda and map_index.numel() == R
+    check(lib().m3d_roi_normalize_idx(_ptr(image_u16.contiguous()), _ptr(prm_u8.contiguous()), _ptr(map_index), win, _ptr(win_origins), _ptr(boxes.contiguous()), _ptr(offs),
                                      R, C.c_int64(total), D, H, W, {"soma": 0, "nuclei": 1}[mode], _ptr(oi), _ptr(op), _ptr(ws),
                                      C.c_size_t(ws.numel()), _stream()), "roi_normalize")
     return oi, op, offs

@@ -509,3 +509,30 @@ def test_pipelined_volume_driver_writes_the_serial_drivers_files_byte_for_byte(t
         assert open(str(tmp_path / "serial" / f), "rb").read() == open(str(tmp_path / "piped" / f), "rb").read(), f
     n_piped = sum(len(names) for _, _, names in os.walk(str(tmp_path / "piped")))
     assert n_piped == len(files)
+
+
+@pytest.mark.parametrize("mode", ["soma", "nuclei"])
+def test_crops_from_compact_windows_and_a_map_index_equal_the_dense_gathered_route(mode):
+    """m3d_roi_normalize_idx: crops cut out of the uint8 WINDOWS (zero outside; one window covers the whole tile and carries a non-zero
+    minimum) for a SUBSET of the peaks (map index) == m3d_roi_normalize_ws on the gathered dense maps, bit for bit."""
+    import m3d
+    g = torch.Generator().manual_seed(11)
+    (D, H, W), Wn, P = (10, 14, 12), 16, 7
+    img = torch.randint(50, 4000, (D, H, W), generator=g).to(torch.uint16).cuda()
+    win = (torch.rand((P, Wn, Wn, Wn), generator=g) * (torch.rand((P, Wn, Wn, Wn), generator=g) > 0.2)).cuda()
+    org = torch.stack([torch.randint(-Wn + 3, D - 2, (P,), generator=g), torch.randint(-Wn + 3, H - 2, (P,), generator=g),
+                       torch.randint(-Wn + 3, W - 2, (P,), generator=g)], 1).to(torch.int32)
+    org[0] = torch.tensor([-2, -1, -3])                                   # covers the 10 x 14 x 12 tile
+    org = org.cuda()
+    win[0] += 0.5
+    sums = win.reshape(P, -1).sum(1)
+    dense = m3d.prm_quantize_windows_u8(win, sums, org, (D, H, W))
+    comp = m3d.ops.prm_quantize_windows_compact_u8(win, sums, org, (D, H, W))
+    sel = np.array([0, 2, 3, 6], np.int32)
+    boxes = np.array([[0, 0, 0, W - 1, H - 1, D - 1], [1, 2, 1, 8, 9, 6], [3, 3, 2, 11, 13, 9], [5, 0, 4, 5, 0, 4]], np.int32)
+    bd = torch.from_numpy(boxes).cuda()
+    a = m3d.ops.roi_normalize(img, dense[torch.from_numpy(sel).long().cuda()].contiguous(), bd, mode, boxes_host=boxes)
+    b = m3d.ops.roi_normalize(img, comp, bd, mode, boxes_host=boxes, map_index=torch.from_numpy(sel).cuda(), win_origins=org)
+    c = m3d.ops.roi_normalize(img, dense, bd, mode, boxes_host=boxes, map_index=torch.from_numpy(sel).cuda())
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
