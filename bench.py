@@ -261,6 +261,9 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()                                            # (see bench_detect: a full collection over ~10^6 objects costs 40-60 ms)
     probe = Probe()
     pr["probe"], pr["left"] = probe, PROBE_STEPS
     dt = timed_loop(step, args.steps, 0, dist, torch.cuda.synchronize)
@@ -384,6 +387,9 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                 shutil.rmtree(d, ignore_errors=True)
                 return dt_, res_, nfiles, nbytes
             run("warm", minfer.infer_prm)                                  # first launches, pinned pools, thread pool
+            import gc
+            gc.collect()
+            gc.freeze()
             times = []
             for k in range(reps):
                 dt_, res_, nfiles, nbytes = run("p%d" % k, minfer.infer_prm)
@@ -628,6 +634,11 @@ def bench_detect(args, rank, world, dist):
     for _ in range(args.warmup):
         headline()
     torch.cuda.synchronize()
+    # everything built so far (torch's module graph, the model, the batches: ~10^6 tracked objects) moves to the permanent generation:
+    # a full collection that walks it takes 40-60 ms and would land in some 0.09 s timed region (the collector itself stays enabled)
+    import gc
+    gc.collect()
+    gc.freeze()
     main_probe = Probe()
     arm(main_probe, PROBE_STEPS)
     del rois_seen[:]
@@ -644,6 +655,7 @@ def bench_detect(args, rank, world, dist):
 
     # ---- the same steps with the raw volumes resident in HBM (the `value` of rounds 1-3)
     resident = None
+    rkern = None
     if not backbone_only:
         for _ in range(2):
             step_resident()
@@ -663,7 +675,8 @@ def bench_detect(args, rank, world, dist):
             d_ = sync_max_time(d_, dist, "cpu" if via_host else "cuda")
             res_runs.append(d_ / args.steps * 1e3)
             dtr = min(dtr, d_)
-        rfam, _ = conv_family_roofline(det, det.conv_work(nvol, (VOL, VOL, VOL)), rprobe.mean_ms(), nvol, "the rank's batch of %d volumes" % nvol)
+        rkern = rprobe.mean_ms()
+        rfam, _ = conv_family_roofline(det, det.conv_work(nvol, (VOL, VOL, VOL)), rkern, nvol, "the rank's batch of %d volumes" % nvol)
         rprobe.spans.clear()
         resident = {"value": n_items * args.steps * VOL ** 3 / dtr, "unit": "voxels/s", "ms_per_step": dtr / args.steps * 1e3,
                     "ms_per_step_runs": [round(r_, 4) for r_ in res_runs],
@@ -868,7 +881,15 @@ def bench_detect(args, rank, world, dist):
     wino = det.wino_mode
     kern = {k: round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])}
     work = det.conv_work(nvol, (VOL, VOL, VOL))
-    conv_family, roofs = conv_family_roofline(det, work, kern_ms, nvol, "the rank's batch of %d volumes" % nvol)
+    # the spans of the RESIDENT loop feed the rooflines: in the host-to-host loop the launching thread also issues the pinned uploads
+    # (~0.5 ms of host time per step), launches arrive late and an event span then holds queue idle time as well as the kernel
+    # (conv family 2.95 ms by those spans against 2.69 ms by rocprofv3's kernel trace and 2.7 ms by the resident spans)
+    span_ms = rkern if rkern else kern_ms
+    conv_family, roofs = conv_family_roofline(det, work, span_ms, nvol, "the rank's batch of %d volumes" % nvol)
+    if conv_family is not None:
+        conv_family["region"] = ("HIP-event spans of the first %d steps of the `resident` timed loop (same kernels, same batches, no upload issued by the "
+                                 "launching thread between the launches); the host-to-host loop's spans are config.kernel_ms_per_launch" % PROBE_STEPS) \
+            if rkern else "HIP-event spans of the first %d timed steps" % PROBE_STEPS
     if "conv2b" in roofs:
         w2 = "conv3d_wino24_kernel<4, 16, 2, 1, true" if "F(2x4" in work["conv2b"]["kernel"] else "conv3d_wino2e_kernel<4, 32, 2, 2, true>"
         roofs["conv2b"].update(pmc_traffic({2: w2, 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
@@ -876,8 +897,8 @@ def bench_detect(args, rank, world, dist):
     if conv_family is not None:
         conv_family["traffic"] = (roofs.get("conv2b", {}) or {}).get("traffic")
         conv_family["traffic_what"] = "HBM bytes per launch of the largest member (conv2b), PMC: " + str((roofs.get("conv2b", {}) or {}).get("traffic_source"))
-    if "fc1" in kern_ms and rois_probed:
-        ms = kern_ms["fc1"]
+    if "fc1" in span_ms and rois_probed:
+        ms = span_ms["fc1"]
         M = int(round(rois_probed))
         Kf, Nf = 256 * 343, cfg.mlp_dim
         fl = 2.0 * M * Nf * Kf
@@ -908,8 +929,8 @@ def bench_detect(args, rank, world, dist):
                  "note": "every multiply-add of the GEMM is issued (no Winograd): achieved = 2*M*N*K / time of the GEMM + its split-K reduction"}
             r.update(pmc_traffic("fc_gemm_kernel"))
         roofs["fc1"] = r
-    if "roi_align3d" in kern_ms and rois_probed:
-        ms = kern_ms["roi_align3d"]
+    if "roi_align3d" in span_ms and rois_probed:
+        ms = span_ms["roi_align3d"]
         byt = rois_probed * 256 * 343 * 4.0
         r = {"bound": "hbm", "kernel": "roi_class_kernel + roi_align3d_fwd_v3_kernel (+ complement pass)", "achieved": byt / (ms * 1e-3) / 1e9,
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byt / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms,
