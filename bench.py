@@ -235,7 +235,8 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     nuclei = args.workload == "prm-nuclei"
     cfg = Cfg.nuclei(score_thresh=0.0) if nuclei else Cfg.soma()
     P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
-    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), norm_stream=bool(getattr(args, "prm_norm_stream", 1)),
+                    backward_streams=int(getattr(args, "prm_backward_streams", 1)))
     S, H, W = cfg.in_size
     vol = torch.from_numpy(tiling.norm1(synth_volume(rank, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
     from m3d import binarize
@@ -306,6 +307,8 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
                                   (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
                                    "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks,
                       "phase_ms": {k: round(v, 4) for k, v in sorted(ph.items(), key=lambda kv: -kv[1])},
+                      "phase_note": ("norm_convs is a span on the SECOND stream: it runs beside proposals / box_head and the first layers of backward, so "
+                                     "the phases do not add up to the step") if eng.norm_stream else "all phases on one stream",
                       "prm_forward_ms": fwd_ms, "prm_backward_ms": back_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0,
                       "step_starts_ms_host": [round((b - a) * 1e3, 2) for a, b in zip(stamps[args.warmup:-1], stamps[args.warmup + 1:])][:args.steps]},
            "roofline": roof,
@@ -1045,6 +1048,8 @@ def main():
     ap.add_argument("--interleaved", action="store_true", help="also time the one-stream begin(k+1) / finish(k) loop (N = 1)")
     ap.add_argument("--pipelined", action="store_true", help="also time the two-stream begin(k+1) / finish(k) loop (N = 1)")
     ap.add_argument("--stress-rois", action="store_true", help="RPN NMS threshold 1.0: every volume gives RPN_POST_NMS_TOP_N = 1000 RoIs to the box head")
+    ap.add_argument("--prm-norm-stream", type=int, default=1, help="PRM workloads: 0 = norm convs queued on the tile's own stream instead of a second one (A/B)")
+    ap.add_argument("--prm-backward-streams", type=int, default=1, help="PRM workloads: 2 = the peaks' back-propagation as two halves on two streams (A/B)")
     ap.add_argument("--no-subrecords", action="store_true", help="default workload at N = 1: skip configs1_backbone / stress_rois / configs3_prm_soma / prm_nuclei_tile / volume_pipeline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")

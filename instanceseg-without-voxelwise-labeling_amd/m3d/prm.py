@@ -15,8 +15,20 @@ from .model import DetectorM3D, _NOSPAN
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
-                 strip_f24=True, strip_f24_min=17):
+                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8):
         self.det = det
+        # norm_stream: prm_tile runs the norm convs on a second HIP stream next to proposals / box head / peak selection (launches of
+        # 1-128 workgroups that leave most of the chip idle) instead of queueing them behind those launches on the tile's stream
+        self.norm_stream = bool(norm_stream)
+        self._side = None
+        # backward_streams = 2: the tile's peaks are back-propagated as two halves on two HIP streams - while one half's element-wise
+        # `prepare` pass streams through HBM the other half's window convolution holds the matrix cores, and each launch's last,
+        # partly filled round of workgroups is filled from the other chain.  A half's launches are the ones the one-stream engine issues
+        # for that half alone; against the all-peaks batch a window can differ in the last bits (the library picks tile and K split from the
+        # batch's shape), as it already does between `peak_chunk` settings.
+        self.backward_streams = int(backward_streams)
+        self.backward_split_min = int(backward_split_min)
+        self._bstreams = None
         self.cfg = det.cfg
         self.probe = None                             # optional m3d.model.Probe: HIP-event spans around the phases of prm_tile (bench.py)
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
@@ -112,10 +124,24 @@ class PRMEngine:
         top = dict(h=h[0], off_h=None, n_cls=None, prob=prob[0])
         return feat, prob, deltas, saved, top
 
-    def forward_norms(self, saved, top, layers=None, cls=True):
+    def forward_norms(self, saved, top, layers=None, cls=True, top_first=False):
         """The norm convs (+ input minima, + the stem's denominator map) of saved[i] for i in `layers` (default: all that are still
-        missing) and, with cls, of the RPN_cls_score conv."""
-        for i in (range(len(saved)) if layers is None else layers):
+        missing) and, with cls, of the RPN_cls_score conv.  top_first: in the order the backward consumes them (RPN_cls_score, then the
+        layers from the top down), each followed by an event on the current stream (rec["ready"]) that backward_windows waits for - the
+        side-stream mode of prm_tile, where the backward of the small top windows runs beside the norm convs of the large bottom layers."""
+        def cls_norm():
+            if cls and top["n_cls"] is None:
+                h = top["h"].unsqueeze(0)
+                top["off_h"] = ops.reduce_min(h)
+                top["n_cls"] = self.cls_norm_conv(h, in_offset=top["off_h"])[0]
+                if top_first:
+                    top["ready"] = torch.cuda.Event()
+                    top["ready"].record()
+
+        if top_first:
+            cls_norm()
+        idx = list(range(len(saved)) if layers is None else layers)
+        for i in (reversed(idx) if top_first else idx):
             rec = saved[i]
             if rec["n"] is not None:
                 continue
@@ -124,10 +150,11 @@ class PRMEngine:
             rec["n"] = rec["norm_conv"](x, in_offset=rec["off"])[0]
             if rec["k"] == 5 and rec["pool"] and self.fused_stem:
                 rec["den"] = ops.prm_den_pool(rec["argmax"], rec["xnext"], rec["n"])      # peak-independent part of the prepare step
-        if cls and top["n_cls"] is None:
-            h = top["h"].unsqueeze(0)
-            top["off_h"] = ops.reduce_min(h)
-            top["n_cls"] = self.cls_norm_conv(h, in_offset=top["off_h"])[0]
+            if top_first:
+                rec["ready"] = torch.cuda.Event()
+                rec["ready"].record()
+        if not top_first:
+            cls_norm()
 
     def forward(self, data):
         feat, prob, deltas, saved, top = self.forward_response(data)
@@ -159,6 +186,8 @@ class PRMEngine:
 
         def run_layer(rec, wb, origin, border):
             dims = (wb["P"], wb["C"], wb["U"])
+            if rec.get("ready") is not None:                 # norm conv of this layer on prm_tile's side stream
+                torch.cuda.current_stream().wait_event(rec["ready"])
             if fused(rec, wb):                   # un-pool + prepare + stem dgrad + PreHook in one MFMA kernel
                 w, s, origin = ops.prm_stem_dgrad_fused(wb["t"], origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa,
                                                         data[0, 0], rec["off"], strip=wb["strip"],
@@ -215,16 +244,41 @@ class PRMEngine:
             wins = torch.cat([o[0][0] for o in outs]); sums = torch.cat([o[0][1] for o in outs]); orig = torch.cat([o[1] for o in outs])
             return (wins, sums), orig
 
+        def chain(pk):
+            if top.get("ready") is not None:
+                torch.cuda.current_stream().wait_event(top["ready"])
+            g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
+            origin = pk[:, 1:4].contiguous()
+            wb = dict(t=g, strip=0, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
+            return tail(list(reversed(saved)), wb, origin)
+
         pk = peaks_ashw.contiguous()
-        g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
-        origin = pk[:, 1:4].contiguous()
-        wb = dict(t=g, strip=0, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
+        P = pk.shape[0]
         try:
-            (win, sums), origins = tail(list(reversed(saved)), wb, origin)
+            if self.backward_streams >= 2 and P >= self.backward_split_min:
+                if self._bstreams is None:
+                    self._bstreams = [torch.cuda.Stream() for _ in range(self.backward_streams)]
+                main = torch.cuda.current_stream()
+                start = torch.cuda.Event()
+                start.record()
+                ns = self.backward_streams
+                cuts = [P * i // ns for i in range(ns + 1)]
+                parts = []
+                for st, c0, c1 in zip(self._bstreams, cuts[:-1], cuts[1:]):
+                    with torch.cuda.stream(st):
+                        st.wait_event(start)
+                        parts.append(chain(pk[c0:c1].contiguous()))
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    main.wait_event(ev)                                  # the halves' tensors go back to their streams' pools after this
+                win = torch.cat([q[0][0] for q in parts]); sums = torch.cat([q[0][1] for q in parts]); origins = torch.cat([q[1] for q in parts])
+                parts = None
+            else:
+                (win, sums), origins = chain(pk)
         finally:
             # `tail` calls itself, so the function object and its closure cell form a reference cycle that also holds `saved` (every
             # forward tensor of the tile) until the cyclic collector runs - by then the next tile has allocated its own: break it here
-            tail = run_layer = take = fused = wino = None
+            tail = run_layer = take = fused = wino = chain = None
         return win, sums, origins
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193
@@ -246,6 +300,20 @@ class PRMEngine:
         if not det._fused_ok(prob) or not det.has_head:
             self.forward_norms(saved, top)
             return self._prm_tile_unfused(data, feat, prob, deltas, saved, top, peak_threshold, dense)
+        norms_done = None
+        if self.norm_stream:
+            # the norm convs read what forward_response wrote on this stream and allocate on the side stream; the backward (this stream)
+            # waits for them, so the side stream's blocks are never reused before this stream has read them (next tile: same order)
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            fwd = torch.cuda.Event()
+            fwd.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(fwd)
+                with self.span("norm_convs"):                            # events on the side stream: this span overlaps the ones below
+                    self.forward_norms(saved, top, top_first=True)
+                norms_done = torch.cuda.Event()                          # the backward waits layer by layer (rec["ready"]); a tile that
+                norms_done.record()                                      # ends before its backward waits here, before its tensors are freed
         with self.span("proposals"):
             rois_b, probs_b, kidx_b, num = ops.generate_proposals3d_batched(prob, deltas, det.anchors, float(c.stride), im_info, c.pre_nms_topN,
                                                                             c.post_nms_topN, c.rpn_nms_thresh, c.rpn_min_size)
@@ -256,12 +324,15 @@ class PRMEngine:
             ready.record()
         nl = len(saved)
         late = [i for i in (0, 1) if i < nl - 1]                      # conv1a / conv2a: the last layers the backward reaches
-        with self.span("norm_convs"):
-            self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
+        if norms_done is None:
+            with self.span("norm_convs"):
+                self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
         ready.synchronize()                                           # host wait 1 (covered by the norm convs above)
         R = int(num_host[0])
         det._release_counts(num_host)
         if R == 0:
+            if norms_done is not None:
+                torch.cuda.current_stream().wait_event(norms_done)
             return None                                               # nothing survives -> the reference returns five Nones (:190)
         rois, keep_idx = rois_b[0, :R], kidx_b[0, :R]
         with self.span("box_head"):
@@ -270,12 +341,15 @@ class PRMEngine:
                                                     c.detections_per_im, R)                                          # :124
             A = prob.shape[1]
             sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:])          # :125,136-139,161-163
-        with self.span("norm_convs_late"):
-            self.forward_norms(saved, top, layers=late, cls=False)
+        if norms_done is None:
+            with self.span("norm_convs_late"):
+                self.forward_norms(saved, top, layers=late, cls=False)
         sel["event"].synchronize()                                    # host wait 2 (covered by the two norm convs above)
         P = int(sel["host"]["num"][0])
         if P == 0:
             sel["release"]()
+            if norms_done is not None:
+                torch.cuda.current_stream().wait_event(norms_done)
             return None                                # no score above peak_threshold (:161-162 never true, :189-190)
         hp = sel["host"]["peaks"][:P]
         peaks = torch.from_numpy(np.concatenate((np.zeros((P, 1), np.int64), hp.astype(np.int64)), 1))          # (b,a,s,h,w), b = 0

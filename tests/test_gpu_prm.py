@@ -536,3 +536,40 @@ def test_crops_from_compact_windows_and_a_map_index_equal_the_dense_gathered_rou
     c = m3d.ops.roi_normalize(img, dense, bd, mode, boxes_host=boxes, map_index=torch.from_numpy(sel).cuda())
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+@pytest.mark.parametrize("stride,shape", [(8, (24, 56, 48)), (4, (16, 40, 48))])
+def test_streamed_tile_equals_the_one_stream_tile(stride, shape):
+    """prm_tile with the norm convs on a second stream launches the same kernels on the same data: identical bit for bit.  With the
+    peaks back-propagated as two halves on two streams every launch is the one the one-stream engine issues for that HALF: identical bit
+    for bit to the halves back-propagated one after the other on one stream (no cross-stream hazard - the second and third tile reuse the
+    blocks the first one returned to the side streams' pools), and equal to the all-peaks batch to rounding (the library picks its tile
+    and K split from the batch's shape, so the summation order of a peak's window may differ between batch compositions: 1e-7 relative)."""
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    P = O.make_params(stride=stride, num_anchors=35 if stride == 8 else 14, mlp_dim=32, seed=3)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=32, score_thresh=0.0)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    one = PRMEngine(det)
+    ns = PRMEngine(det, norm_stream=True)
+    two = PRMEngine(det, norm_stream=True, backward_streams=2, backward_split_min=2)
+    rs = np.random.RandomState(5)
+    for it in range(3):
+        vol = torch.from_numpy(rs.rand(1, 1, *shape).astype(np.float32)).cuda()
+        a = one.prm_tile(vol, peak_threshold=0.0, dense=False)
+        b = ns.prm_tile(vol, peak_threshold=0.0, dense=False)
+        c = two.prm_tile(vol, peak_threshold=0.0, dense=False)
+        assert a is not None and b is not None and c is not None and a["peaks"].shape[0] >= 2
+        torch.cuda.synchronize()
+        for k in ("peaks", "dets", "windows", "sums", "origins"):
+            assert torch.equal(a[k], b[k]), (it, k)
+        for k in ("peaks", "dets", "origins"):
+            assert torch.equal(a[k], c[k]), (it, k)
+        feat, prob, deltas, saved, top = one.forward(vol)
+        pk = a["peaks_dev"]
+        h = pk.shape[0] // 2
+        halves = [one.backward_windows(q.contiguous(), saved, top, vol) for q in (pk[:h], pk[h:])]
+        assert torch.equal(torch.cat([q[0] for q in halves]), c["windows"]) and torch.equal(torch.cat([q[1] for q in halves]), c["sums"]), it
+        scale = float(a["windows"].abs().max())
+        assert float((a["windows"] - c["windows"]).abs().max()) <= 2e-6 * scale
+        assert torch.allclose(a["sums"], c["sums"], rtol=1e-5, atol=0)
