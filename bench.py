@@ -234,7 +234,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     from m3d import tiling
     nuclei = args.workload == "prm-nuclei"
     cfg = Cfg.nuclei(score_thresh=0.0) if nuclei else Cfg.soma()
-    P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
+    P = prm_params(cfg, args)
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), norm_stream=bool(getattr(args, "prm_norm_stream", 1)),
                     backward_streams=int(getattr(args, "prm_backward_streams", 1)))
     S, H, W = cfg.in_size
@@ -245,6 +245,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     npk, nlab = [], []
     stamps = []
     pr = {"probe": None, "left": 0}
+    bstream = torch.cuda.Stream() if int(getattr(args, "prm_binarize_stream", 1)) else None
 
     def step():
         """one tile: PRM forward + box head + peak back-propagation -> uint8 quantisation (from the windows; no dense float maps) -> per-detection crop +
@@ -255,8 +256,12 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
         out = eng.prm_tile(vol, dense=False)
         npk.append(0 if out is None else int(out["peaks"].shape[0]))
         if out is not None:
-            with eng.span("binarize"):
-                labels, painted = binarize.segment_tile(raw, (out["windows"], out["sums"], out["origins"]), out["dets"], mode=mode)
+            if bstream is not None:                        # on a second stream: beside the next tile's forward (span events on that stream)
+                labels, painted, _ = binarize.segment_tile_on(bstream, raw, (out["windows"], out["sums"], out["origins"]), out["dets"],
+                                                              span=eng.span("binarize"), mode=mode)
+            else:
+                with eng.span("binarize"):
+                    labels, painted = binarize.segment_tile(raw, (out["windows"], out["sums"], out["origins"]), out["dets"], mode=mode)
             nlab.append(painted)
     pr["probe"], pr["left"] = Probe(), args.warmup         # throw-away probe on the warm-up steps (event pool)
     for _ in range(args.warmup):
@@ -307,8 +312,10 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
                                   (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
                                    "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks,
                       "phase_ms": {k: round(v, 4) for k, v in sorted(ph.items(), key=lambda kv: -kv[1])},
-                      "phase_note": ("norm_convs is a span on the SECOND stream: it runs beside proposals / box_head and the first layers of backward, so "
-                                     "the phases do not add up to the step") if eng.norm_stream else "all phases on one stream",
+                      "phase_note": "; ".join(
+                          (["norm_convs is a span on a SECOND stream: it runs beside proposals / box_head and the first layers of backward"] if eng.norm_stream else []) +
+                          (["binarize is a span on a THIRD stream: tile k's binarisation runs beside tile k+1's forward (ms_per_step = time of the timed "
+                            "steps / steps, every stream drained before the clock stops)"] if bstream is not None else [])) or "all phases on one stream",
                       "prm_forward_ms": fwd_ms, "prm_backward_ms": back_ms, "instances_painted": int(nlab[-1].sum()) if nlab else 0,
                       "step_starts_ms_host": [round((b - a) * 1e3, 2) for a, b in zip(stamps[args.warmup:-1], stamps[args.warmup + 1:])][:args.steps]},
            "roofline": roof,
@@ -374,7 +381,7 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
     for ds in datasets:
         cfg = Cfg.nuclei(score_thresh=0.0) if ds == "nuclei" else Cfg.soma()
         shape = (59, 350, 350) if ds == "nuclei" else (96, 256, 256)
-        P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
+        P = prm_params(cfg, args)
         eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
         im = synth_volume(100 + rank, shape)
         scratch = tempfile.mkdtemp(prefix="m3d_vol_", dir=base)
@@ -456,6 +463,22 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
 # ------------------------------------------------------------------------------------------------ detect / backbone
 NB = 3                 # distinct batches rotating through every detect loop (the same step on the same data measures a warm cache)
 _params_cache = {}
+
+
+def prm_params(cfg, args):
+    """Parameters of the PRM workloads.  The nuclei net's random init gives RPN class logits of +-40: the sigmoid of every top-ranked
+    position is exactly 1.0f, its derivative (1 - y) y exactly 0, and the reference's back-propagation then returns 0 / 0 maps for
+    EVERY kept peak of the tile (rounds 1-3 timed that: the kernels' time does not depend on the values, but the binarisation stage and
+    the LZW writer saw all-zero maps).  RPN_cls_score's weight and bias are therefore scaled by --prm-rpn-logit-scale (default 0.25:
+    logits of +-10 as a trained net has; the ranking of the proposals is the same monotone function of the same logits); 1.0
+    reproduces the earlier rounds' workload."""
+    P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
+    a = float(getattr(args, "prm_rpn_logit_scale", 0.25))
+    if cfg.stride == 8 and a != 1.0:
+        P = dict(P)
+        for k in ("RPN.RPN_cls_score.weight", "RPN.RPN_cls_score.bias"):
+            P[k] = P[k] * a
+    return P
 
 
 def cached_params(**kw):
@@ -1049,6 +1072,8 @@ def main():
     ap.add_argument("--pipelined", action="store_true", help="also time the two-stream begin(k+1) / finish(k) loop (N = 1)")
     ap.add_argument("--stress-rois", action="store_true", help="RPN NMS threshold 1.0: every volume gives RPN_POST_NMS_TOP_N = 1000 RoIs to the box head")
     ap.add_argument("--prm-norm-stream", type=int, default=1, help="PRM workloads: 0 = norm convs queued on the tile's own stream instead of a second one (A/B)")
+    ap.add_argument("--prm-rpn-logit-scale", type=float, default=0.25, help="PRM workloads, nuclei net: factor on the random-init RPN class logits (1.0 = rounds 1-3: saturated sigmoids, all-zero maps)")
+    ap.add_argument("--prm-binarize-stream", type=int, default=1, help="PRM workloads: 0 = a tile's binarisation stage on the tile's stream instead of its own (where it runs beside the next tile's forward) (A/B)")
     ap.add_argument("--prm-backward-streams", type=int, default=1, help="PRM workloads: 2 = the peaks' back-propagation as two halves on two streams (A/B)")
     ap.add_argument("--no-subrecords", action="store_true", help="default workload at N = 1: skip configs1_backbone / stress_rois / configs3_prm_soma / prm_nuclei_tile / volume_pipeline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])

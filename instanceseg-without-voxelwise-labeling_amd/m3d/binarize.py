@@ -121,6 +121,28 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     return labels, present
 
 
+def segment_tile_on(stream, image_u16, prms, dets, span=None, **kw):
+    """segment_tile queued on `stream` behind everything the current stream holds; returns (labels, painted, done event) at once.
+    The binarisation stage is a chain of small launches (a workgroup or a few per detection): on its own stream it runs beside the NEXT
+    tile's convolutions instead of in front of them.  The inputs are marked as in use by `stream` (record_stream), so the allocator
+    does not hand their blocks to the next tile before the stage has read them; the results belong to `stream` - wait for `done`
+    (or synchronize) before reading them elsewhere."""
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(stream):
+        stream.wait_event(ev)
+        if span is not None:                                    # a HIP-event span (m3d.model.Probe) recorded on `stream`
+            with span:
+                labels, painted = segment_tile(image_u16, prms, dets, **kw)
+        else:
+            labels, painted = segment_tile(image_u16, prms, dets, **kw)
+        done = torch.cuda.Event()
+        done.record()
+    for t in ([image_u16] + list(prms if isinstance(prms, (tuple, list)) else [prms]) + ([dets] if torch.is_tensor(dets) and dets.is_cuda else [])):
+        t.record_stream(stream)
+    return labels, painted, done
+
+
 # ----------------------------------------------------------------------------- whole-volume drivers
 def soma_tiles():
     """binarization_soma.py:42-52: (num, ss, hs, ws) of the fixed 3 x 2 x 2 tile grid (64 x 160 x 160 tiles)."""

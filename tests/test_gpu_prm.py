@@ -338,6 +338,33 @@ def test_segment_tile_from_windows_equals_the_dense_route():
         assert not bool(p1[4])
 
 
+def test_segment_tile_on_another_stream_equals_the_in_stream_stage():
+    """binarize.segment_tile_on: the stage on its own stream, its inputs released by the caller at once (the allocator must keep their
+    blocks until the stage has read them - record_stream), tile after tile while the main stream keeps allocating and overwriting."""
+    from m3d import binarize
+    g = torch.Generator().manual_seed(4)
+    D, H, W, Wn, P = 24, 40, 36, 16, 6
+    img = torch.randint(50, 4000, (D, H, W), generator=g).to(torch.uint16).cuda()
+    side = torch.cuda.Stream()
+    dets = torch.tensor([[6, 5, 4, 17, 16, 15, 0.9], [22, 12, 0, 33, 22, 9, 0.8], [27, 32, 12, 35, 39, 22, 0.7],
+                         [8, 8, 8, 19, 19, 19, 0.6], [3, 3, 3, 12, 12, 12, 0.5], [20, 20, 10, 30, 30, 20, 0.4]], dtype=torch.float64)
+    org = torch.tensor([[2, 3, 4], [-5, 10, 20], [10, 30, 25], [6, 6, 6], [1, 1, 1], [8, 18, 18]], dtype=torch.int32).cuda()
+    for mode in ("soma", "nuclei"):
+        pending = []
+        for it in range(4):
+            win = torch.rand((P, Wn, Wn, Wn), generator=g).cuda()
+            sums = win.reshape(P, -1).sum(1)
+            ref = binarize.segment_tile(img, (win, sums, org), dets, mode=mode)
+            l1, p1, done = binarize.segment_tile_on(side, img, (win.clone(), sums.clone(), org.clone()), dets, mode=mode)
+            pending.append((ref, l1, p1, done))
+            junk = [torch.full((P, Wn, Wn, Wn), float("nan"), device="cuda") for _ in range(3)]      # takes the released blocks if they are free
+            del junk
+        for ref, l1, p1, done in pending:
+            done.synchronize()
+            assert torch.equal(ref[0], l1) and torch.equal(ref[1], p1), mode
+        assert int(pending[-1][2].sum()) >= 1
+
+
 def _soma_tile_setup():
     """BASELINE.json configs[3] exactly: the soma net (stride 4, 14 anchors, MLP 1024) on its shipped tile 1x64x160x160."""
     from m3d.config import Cfg
