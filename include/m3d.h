@@ -453,6 +453,21 @@ int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const float* 
                                 const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
                                 const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
                                 float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
+/* Depth-clipped ("slab") strips, round 4: [C, zn, n, L] with zn = the depth of the LAYER's map - plane k of every window is plane k
+ * of the map - instead of the n planes of each window.  Where a tile is thinner than the receptive-field cone (the nuclei tile's
+ * stride-2 maps: 32 planes against windows of 38 / 40) the planes of a window outside the volume carry zero gradient in and are never
+ * read out (peak_backprop_3d.py:30-33 only ever divides inside the map); a slab strip does not store, convolve or stream them.  y / x
+ * geometry, separators and origins are those of the window strips (origins stay the cone's, z possibly negative).
+ *   in_slab / out_slab / gup_slab != 0: that strip is a slab strip (d_gup: up_depth planes; d_out: depth planes); strip layouts only. */
+int m3d_prm_prepare_ex2(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool, int border,
+                        const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width, const float* d_scale,
+                        const float* d_norm, int depth, int height, int width, int in_strip, int in_slab, int out_strip, int out_slab,
+                        const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream);
+int m3d_prm_stem_dgrad_fused_ex2(const float* d_gup, int gup_strip, int gup_slab, const float* d_xnext, const float* d_up_offset,
+                                 const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den,
+                                 const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
+                                 const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
+                                 float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
 
 /* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
  * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on

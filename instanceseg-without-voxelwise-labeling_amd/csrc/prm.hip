@@ -115,16 +115,23 @@ struct PrepParams {
   int out_sep;             // strip output: zero columns after each window (pitch - Wn), zero-filled here
   int out_lead, out_tail;  // strip output: zero columns before window 0 / after the last window's separator
   const float* xoff;       // non-null: gup is a bare backward-data result; the PreHook multiply by (X_{L+1} - *xoff) happens here
+  // Depth-clipped strips ("slab" strips, izn / ozn > 0): a strip [C, zn, n, L] stores the planes of the LAYER (plane k of every window =
+  // plane k of the layer's map, zn = the layer's depth) instead of the n planes of each window.  Where the tile is thinner than the cone
+  // (nuclei: 32 planes against 38 / 40-plane windows) the planes of a window that lie outside the volume - zero gradient in, results
+  // never read - are then not stored, convolved or streamed at all; in y and x the layout is unchanged.
+  int izn, ozn;
 };
 
 // One thread per output voxel (no pooling between this layer and the upper one).  grid = (chunks, C, P): a workgroup walks
 // its share of the (p, c) window in strides of 256 voxels - a million 256-voxel workgroups were bound by the dispatch rate, not
 // by memory - and channel and peak come from the block index (no 64-bit div/mod chains).
 __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
-  const int w3 = q.Wn * q.Wn * q.Wn;
+  const int w3 = (q.ozn ? q.ozn : q.Wn) * q.Wn * q.Wn;
   const int c = blockIdx.y, p = blockIdx.z;
   const int oz = q.origin_up[3 * p] - q.border, oy = q.origin_up[3 * p + 1] - q.border, ox = q.origin_up[3 * p + 2] - q.border;
   if (blockIdx.x == 0 && threadIdx.x == 0 && c == 0) { q.origin_out[3 * p] = oz; q.origin_out[3 * p + 1] = oy; q.origin_out[3 * p + 2] = ox; }
+  const int zshift = q.ozn ? oz : 0;                                          // stored plane k holds window plane k - zshift
+  const int izshift = q.izn ? q.origin_up[3 * p] : 0;                        // window plane iz of gup is stored at iz + izshift
   const float sc = q.scale ? q.scale[c] : 1.f;
   const float xoff = q.xoff ? *q.xoff : 0.f;
   const float* gup = q.gup + (size_t)p * q.ips + (size_t)c * q.ics;
@@ -134,14 +141,15 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   const float inv_w = 1.0f / (float)q.Wn;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
     const int r = (int)(((float)e + 0.5f) * inv_w), x = e - r * q.Wn;      // exact for e < 2^22 (Wn <= 100)
-    const int z = (int)(((float)r + 0.5f) * inv_w), y = r - z * q.Wn;
+    const int zk = (int)(((float)r + 0.5f) * inv_w), y = r - zk * q.Wn;
+    const int z = zk - zshift;
     const int iz = z - q.border, iy = y - q.border, ix = x - q.border;       // inner (un-padded) window coords == upper coords
     const int qz = oz + z, qy = oy + y, qx = ox + x;                         // position in this layer's tensor (== X_{L+1})
     float g = 0.f;
     if ((iz >= 0) & (iz < q.U) & (iy >= 0) & (iy < q.U) & (ix >= 0) & (ix < q.U) & (qz >= 0) & (qz < q.D) & (qy >= 0) & (qy < q.H) &
         (qx >= 0) & (qx < q.W)) {
       const size_t pos = ((size_t)qz * q.H + qy) * q.W + qx;
-      g = gup[(size_t)iz * q.izs + (size_t)iy * q.iys + ix];
+      g = gup[(size_t)(iz + izshift) * q.izs + (size_t)iy * q.iys + ix];     // slab input: plane qz < D = izn
       const float xn = xnext[pos];
       if (q.xoff) g = (xn - xoff) * g;                                       // PreHook of the layer above, peak_backprop_3d.py:16-18
       if (!(xn > 0.f)) g = 0.f;                                              // ReLU backward (output > 0)
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
       const float n = norm[pos];
       g = (n < kEps) ? 0.f : g / (fabsf(n) + kEps);                          // PostHook, peak_backprop_3d.py:30-33
     }
-    float* o = out + (size_t)z * q.ozs + (size_t)y * q.oys + x;
+    float* o = out + (size_t)zk * q.ozs + (size_t)y * q.oys + x;
     o[0] = g;
     if (q.out_sep && x == q.Wn - 1) {
       const int nz = q.out_sep + (p == q.P - 1 ? q.out_tail : 0);
@@ -177,12 +185,13 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
   const float* norm = q.norm + (size_t)c * q.D * q.H * q.W;
   float* o = q.out + (size_t)p * q.ops + (size_t)c * q.ocs;
   const float inv_u = 1.0f / (float)UB;
-  const int ub3 = UB * UB * UB;
+  // slab output: the z blocks are the pooling blocks of the LAYER (az = 0 .. ceil(ozn / 2)), so that every stored plane is written
+  const int ub3 = (q.ozn ? (q.ozn + 1) / 2 : UB) * UB * UB;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < ub3; e += gridDim.x * 256) {
     // block b covers inner coordinates 2*(b-1) .. 2*(b-1)+1 shifted so that every window voxel belongs to one block:
     // window coordinate w = inner + border; blocks are aligned to the INNER grid (pooling windows).
     const int r = (int)(((float)e + 0.5f) * inv_u), bx = e - r * UB - 1;           // upper-window voxel index, -1 .. U
-    const int rz = (int)(((float)r + 0.5f) * inv_u), by = r - rz * UB - 1, bz = rz - 1;
+    const int rz = (int)(((float)r + 0.5f) * inv_u), by = r - rz * UB - 1, bz = q.ozn ? rz - uz0 : rz - 1;
     float vals[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) vals[k] = 0.f;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
     if ((bz >= 0) & (bz < q.U) & (by >= 0) & (by < q.U) & (bx >= 0) & (bx < q.U) & (az >= 0) & (az < q.UD) & (ay >= 0) & (ay < q.UH) &
         (ax >= 0) & (ax < q.UW)) {
       const size_t upos = umap + ((size_t)az * q.UH + ay) * q.UW + ax;
-      float g = gup[(size_t)bz * q.izs + (size_t)by * q.iys + bx];
+      float g = gup[(size_t)(q.izn ? az : bz) * q.izs + (size_t)by * q.iys + bx];
       const float xn = q.xnext[upos];
       if (q.xoff) g = (xn - xoff) * g;                                               // PreHook of the layer above
       if (!(xn > 0.f)) g = 0.f;                                                      // ReLU backward on the pooled value
@@ -204,8 +213,9 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int wz = 2 * bz + (k >> 2) + q.border, wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
-      if ((wz >= 0) & (wz < q.Wn) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
+      const int wy = 2 * by + ((k >> 1) & 1) + q.border, wx = 2 * bx + (k & 1) + q.border;
+      const int wz = q.ozn ? 2 * (uz0 + bz) + (k >> 2) : 2 * bz + (k >> 2) + q.border;          // stored plane (slab: the layer's plane)
+      if ((wz >= 0) & (wz < (q.ozn ? q.ozn : q.Wn)) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
         float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
         d[0] = vals[k];
         if (q.out_sep && wx == q.Wn - 1) {
@@ -454,7 +464,19 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
                                int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
                                const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip,
                                int out_strip, const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream) {
+  return m3d_prm_prepare_ex2(d_gup, d_origin_up, num_peaks, channels, up_size, pool, border, d_argmax, d_xnext, up_depth, up_height, up_width,
+                             d_scale, d_norm, depth, height, width, in_strip, 0, out_strip, 0, d_up_offset, d_out, d_origin_out, stream);
+}
+
+/* in_slab / out_slab != 0: that strip stores the LAYER's planes (up_depth planes for d_gup, `depth` for d_out) instead of each window's
+ * (PrepParams: depth-clipped strips); only with the strip layouts. */
+M3D_API int m3d_prm_prepare_ex2(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                                int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                                const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip, int in_slab,
+                                int out_strip, int out_slab, const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream) {
   if (num_peaks < 0 || channels <= 0 || up_size <= 0 || border < 0) return M3D_EINVAL;
+  if ((in_slab && !in_strip) || (out_slab && !out_strip) || depth <= 0 || up_depth <= 0) return M3D_EINVAL;
+  if (!pool && (up_depth != depth || up_height != height || up_width != width)) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
   if (!d_gup || !d_origin_up || !d_xnext || !d_norm || !d_out || !d_origin_out || (pool && !d_argmax)) return M3D_EINVAL;
   PrepParams q;
@@ -463,13 +485,14 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
   q.Wn = (pool ? 2 : 1) * up_size + 2 * border; q.border = border; q.pool = pool ? 1 : 0;
   q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
   q.xoff = d_up_offset; q.out_sep = 0; q.out_lead = 0; q.out_tail = 0;
+  q.izn = in_slab ? up_depth : 0; q.ozn = out_slab ? depth : 0;
   long long ibase = 0, obase = 0;
-  auto strides = [&](int n, int strip, long long* ps, long long* cs, int* zs, int* ys, long long* base, bool is_out) {
+  auto strides = [&](int n, int zn, int strip, long long* ps, long long* cs, int* zs, int* ys, long long* base, bool is_out) {
     if (strip) {
       int pitch, lead; long long L;
       m3d::strip_geom(n, strip, num_peaks, &pitch, &lead, &L);
       if ((long long)n * L >= 0x7FFFFFFFll) return false;
-      *ps = pitch; *cs = (long long)n * n * L; *zs = (int)(n * L); *ys = (int)L; *base = lead;
+      *ps = pitch; *cs = (long long)(zn ? zn : n) * n * L; *zs = (int)(n * L); *ys = (int)L; *base = lead;
       if (is_out) { q.out_sep = pitch - n; q.out_lead = lead; q.out_tail = (int)(L - ((long long)num_peaks * pitch + lead)); }
     } else {
       *ps = (long long)channels * n * n * n; *cs = (long long)n * n * n; *zs = n * n; *ys = n; *base = 0;
@@ -477,22 +500,22 @@ M3D_API int m3d_prm_prepare_ex(const float* d_gup, const int32_t* d_origin_up, i
     return true;
   };
   if (in_strip < 0 || in_strip > 2 || out_strip < 0 || out_strip > 2) return M3D_EINVAL;
-  if (!strides(up_size, in_strip, &q.ips, &q.ics, &q.izs, &q.iys, &ibase, false) ||
-      !strides(q.Wn, out_strip, &q.ops, &q.ocs, &q.ozs, &q.oys, &obase, true))
+  if (!strides(up_size, q.izn, in_strip, &q.ips, &q.ics, &q.izs, &q.iys, &ibase, false) ||
+      !strides(q.Wn, q.ozn, out_strip, &q.ops, &q.ocs, &q.ozs, &q.oys, &obase, true))
     return M3D_EUNSUPPORTED;
   q.gup = d_gup + ibase; q.out = d_out + obase;
   if (channels > 65535 || num_peaks > 65535) return M3D_EUNSUPPORTED;
   if (pool) {
     if (border > 2) return M3D_EUNSUPPORTED;      // the one-block shell covers borders of 1 or 2 voxels
     const int ub = up_size + 2;
-    if (ub > 100) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
-    const int blocks = (ub * ub * ub + 255) / 256;
+    if (ub > 100 || q.ozn > 200) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
+    const int blocks = ((q.ozn ? (q.ozn + 1) / 2 : ub) * ub * ub + 255) / 256;
     int chunks = (int)((16384 + (long long)channels * num_peaks - 1) / ((long long)channels * num_peaks));
     chunks = chunks < 1 ? 1 : (chunks > blocks ? blocks : chunks);
     hipLaunchKernelGGL(prm_prepare_pool_kernel, dim3(chunks, channels, num_peaks), dim3(256), 0, m3d::as_stream(stream), q);
   } else {
-    if (q.Wn > 100) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
-    const int blocks = (q.Wn * q.Wn * q.Wn + 255) / 256;
+    if (q.Wn > 100 || q.ozn > 100) return M3D_EUNSUPPORTED;        // float reciprocal index split in the kernel
+    const int blocks = ((q.ozn ? q.ozn : q.Wn) * q.Wn * q.Wn + 255) / 256;
     int chunks = (int)((16384 + (long long)channels * num_peaks - 1) / ((long long)channels * num_peaks));   // >= 16 k workgroups
     chunks = chunks < 1 ? 1 : (chunks > blocks ? blocks : chunks);
     hipLaunchKernelGGL(prm_prepare_kernel, dim3(chunks, channels, num_peaks), dim3(256), 0, m3d::as_stream(stream), q);

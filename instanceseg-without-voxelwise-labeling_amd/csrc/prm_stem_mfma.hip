@@ -90,6 +90,7 @@ struct StemMArgs {
   int gcs, gzs, gys;
   const float* xnext;      // with up_off: [32, UD, UH, UW] pooled stem activation - gup is a bare backward-data result and the PreHook
   const float* up_off;     // multiply by (xnext - *up_off) of the layer above happens in the staging
+  int gzabs;               // strip gup stores the pooled LAYER's planes (plane = uz0 + window plane; prm.hip PrepParams "slab" strips)
 };
 
 constexpr int kNCell = 2;    // coarse cells staged per thread and chunk
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     const int bz = (z0 >> 1) - 2 + bzl;
     const int az = uz0 + bz, ax = ux0 + bx;
     const bool ok = (e < ncell) & (bz >= 0) & (bz < U) & (az >= 0) & (az < q.UD) & (ax >= 0) & (ax < q.UW);
-    cg[i] = ok ? cc * q.gcs + bz * q.gzs + bx : -1;
+    cg[i] = ok ? cc * q.gcs + (q.gzabs ? az : bz) * q.gzs + bx : -1;
     cm[i] = ok ? (cc * q.UD + az) * q.UH * q.UW + ax : 0;
     cl[i] = e < ncell ? cc * CS + (2 * bzl) * 2 * NX + 2 * bx : -1;
     ccv[i] = e < ncell ? cc : 0;
@@ -468,7 +469,18 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
                                         const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den, const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height,
                                      int up_width, const float* d_wa, const float* d_data, const float* d_data_offset, int depth,
                                      int height, int width, float* d_out, float* d_sums, int32_t* d_origins_out, void* stream) {
-  if (num_peaks < 0 || channels <= 0 || up_size <= 0) return M3D_EINVAL;
+  return m3d_prm_stem_dgrad_fused_ex2(d_gup, gup_strip, 0, d_xnext, d_up_offset, d_origin_up, num_peaks, channels, up_size, d_den, d_argmax, d_scale,
+                                      up_depth, up_height, up_width, d_wa, d_data, d_data_offset, depth, height, width, d_out, d_sums, d_origins_out,
+                                      stream);
+}
+
+/* gup_slab != 0 (strip layouts only): d_gup stores the up_depth planes of the pooled layer instead of each window's up_size planes */
+M3D_API int m3d_prm_stem_dgrad_fused_ex2(const float* d_gup, int gup_strip, int gup_slab, const float* d_xnext, const float* d_up_offset,
+                                         const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den,
+                                         const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
+                                         const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
+                                         float* d_out, float* d_sums, int32_t* d_origins_out, void* stream) {
+  if (num_peaks < 0 || channels <= 0 || up_size <= 0 || (gup_slab && !gup_strip)) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
   if (!d_gup || !d_origin_up || !d_den || !d_argmax || !d_wa || !d_data || !d_data_offset || !d_out || !d_sums || !d_origins_out)
     return M3D_EINVAL;
@@ -481,15 +493,16 @@ M3D_API int m3d_prm_stem_dgrad_fused_ex(const float* d_gup, int gup_strip, const
   q.data_off = d_data_offset; q.out = d_out; q.sums = d_sums; q.origins_out = d_origins_out; q.P = num_peaks; q.U = up_size;
   q.ZW = pl.zw; q.UD = up_depth; q.UH = up_height; q.UW = up_width; q.D = depth; q.H = height; q.W = width;
   if ((d_up_offset != nullptr) != (d_xnext != nullptr)) return M3D_EINVAL;
-  q.xnext = d_xnext; q.up_off = d_up_offset;
+  q.xnext = d_xnext; q.up_off = d_up_offset; q.gzabs = gup_slab ? 1 : 0;
   {
     const long long n = up_size;
     if (gup_strip) {
       if (gup_strip < 0 || gup_strip > 2) return M3D_EINVAL;
       int pitch, lead; long long L;
       m3d::strip_geom(up_size, gup_strip, num_peaks, &pitch, &lead, &L);
-      if (n * n * L >= 0x7FFFFFFFll / 32) return M3D_EUNSUPPORTED;     // 32-bit offsets inside the gradient tensor
-      q.gps = pitch; q.gcs = (int)(n * n * L); q.gzs = (int)(n * L); q.gys = (int)L;
+      const long long zn = gup_slab ? up_depth : n;
+      if (zn * n * L >= 0x7FFFFFFFll / 32) return M3D_EUNSUPPORTED;    // 32-bit offsets inside the gradient tensor
+      q.gps = pitch; q.gcs = (int)(zn * n * L); q.gzs = (int)(n * L); q.gys = (int)L;
       q.gup = d_gup + lead;
     } else {
       q.gps = 32 * n * n * n; q.gcs = (int)(n * n * n); q.gzs = (int)(n * n); q.gys = (int)n;

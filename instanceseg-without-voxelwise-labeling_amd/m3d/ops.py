@@ -763,24 +763,28 @@ def strip_geometry(n, mode, P):
     return pitch.value, lead.value, int(L)
 
 
-def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_strip=False, out_strip=False, up_off=None, dims=None):
+def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_strip=False, out_strip=False, up_off=None, dims=None,
+                in_slab=False, out_slab=False):
     """gup [P,C,U,U,U]; xnext [C,UD,UH,UW]; norm [C,D,H,W] -> (window [P,C,Wn,Wn,Wn], origin int32 [P,3]).
     Strip layout (in_strip / out_strip): the P windows side by side along x with one separator column after each,
     [C,n,n,P*(n+1)] - what the Winograd kernel convolves as one wide volume; dims = (P, C, U) is then required.
     up_off (1-element tensor): gup is the bare backward-data of the layer above and its PreHook multiply by (xnext - up_off)
-    (peak_backprop_3d.py:16-18) is applied here."""
+    (peak_backprop_3d.py:16-18) is applied here.
+    in_slab / out_slab (strips only): the strip stores the planes of the layer's map - [C, xnext depth, U, L] / [C, norm depth, Wn, L] -
+    instead of each window's (m3d.h: depth-clipped strips)."""
     _need_gpu(gup, origin_up, xnext, norm)
     P, Cc, U = dims if dims is not None else (gup.shape[0], gup.shape[1], gup.shape[2])
     in_strip, out_strip = int(in_strip), int(out_strip)                       # 0 batch-major, 1 strip (pitch n + 1), 2 quad-aligned strip
-    assert tuple(gup.shape) == ((Cc, U, U, strip_geometry(U, in_strip, P)[2]) if in_strip else (P, Cc, U, U, U))
+    in_slab, out_slab = bool(in_slab) and bool(in_strip), bool(out_slab) and bool(out_strip)
+    assert tuple(gup.shape) == ((Cc, xnext.shape[1] if in_slab else U, U, strip_geometry(U, in_strip, P)[2]) if in_strip else (P, Cc, U, U, U))
     Wn = (2 if pool else 1) * U + 2 * border
-    out = torch.empty((Cc, Wn, Wn, strip_geometry(Wn, out_strip, P)[2]) if out_strip else (P, Cc, Wn, Wn, Wn), dtype=torch.float32,
-                      device=gup.device)
+    out = torch.empty((Cc, norm.shape[1] if out_slab else Wn, Wn, strip_geometry(Wn, out_strip, P)[2]) if out_strip else (P, Cc, Wn, Wn, Wn),
+                      dtype=torch.float32, device=gup.device)
     oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
-    check(lib().m3d_prm_prepare_ex(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
-                                   xnext.shape[1], xnext.shape[2], xnext.shape[3], _ptr(scale), _ptr(norm), norm.shape[1],
-                                   norm.shape[2], norm.shape[3], in_strip, out_strip, _ptr(up_off), _ptr(out),
-                                   _ptr(oo), _stream()), "prm_prepare")
+    check(lib().m3d_prm_prepare_ex2(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
+                                    xnext.shape[1], xnext.shape[2], xnext.shape[3], _ptr(scale), _ptr(norm), norm.shape[1],
+                                    norm.shape[2], norm.shape[3], in_strip, int(in_slab), out_strip, int(out_slab), _ptr(up_off), _ptr(out),
+                                    _ptr(oo), _stream()), "prm_prepare")
     return out, oo
 
 
@@ -834,7 +838,7 @@ def prm_stem_dgrad_fused_supported(channels, up_size):
     return bool(lib().m3d_prm_stem_dgrad_fused_supported(int(channels), int(up_size)))
 
 
-def prm_stem_dgrad_fused(gup, origin_up, den, argmax, scale, wa, data, data_off, strip=False, xnext=None, up_off=None, dims=None):
+def prm_stem_dgrad_fused(gup, origin_up, den, argmax, scale, wa, data, data_off, strip=False, xnext=None, up_off=None, dims=None, slab=False):
     """Max-unpool + ReLU + BN + PostHook + backward-data of conv1a + PreHook in one MFMA kernel.  gup [P,32,U,U,U] (gradient
     w.r.t. the pooled stem output; strip=True: [32,U,U,P*(U+1)], dims = (P, 32, U)), origin_up int32 [P,3] (pooled
     coordinates), den = prm_den_pool(...), argmax uint8 [32,UD,UH,UW], scale [32] or None, wa = prm_stem_mfma_weights(W),
@@ -843,13 +847,14 @@ def prm_stem_dgrad_fused(gup, origin_up, den, argmax, scale, wa, data, data_off,
     _need_gpu(gup, origin_up, den, argmax, wa, data, data_off)
     P, Cc, U = dims if dims is not None else (gup.shape[0], gup.shape[1], gup.shape[2])
     strip = int(strip)
-    assert tuple(gup.shape) == ((Cc, U, U, strip_geometry(U, strip, P)[2]) if strip else (P, Cc, U, U, U)) and gup.is_contiguous()
+    slab = bool(slab) and bool(strip)                                            # gup stores the pooled layer's planes (den.shape[1] of them)
+    assert tuple(gup.shape) == ((Cc, den.shape[1] if slab else U, U, strip_geometry(U, strip, P)[2]) if strip else (P, Cc, U, U, U)) and gup.is_contiguous()
     assert (xnext is None) == (up_off is None)
     Wn = 2 * U + 4
     out = torch.empty((P, Wn, Wn, Wn), dtype=torch.float32, device=gup.device)
     sums = torch.empty((P,), dtype=torch.float32, device=gup.device)
     oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
-    check(lib().m3d_prm_stem_dgrad_fused_ex(_ptr(gup), strip, _ptr(xnext), _ptr(up_off), _ptr(origin_up), P, Cc, U,
+    check(lib().m3d_prm_stem_dgrad_fused_ex2(_ptr(gup), strip, int(slab), _ptr(xnext), _ptr(up_off), _ptr(origin_up), P, Cc, U,
                                             _ptr(den), _ptr(argmax), _ptr(scale), den.shape[1], den.shape[2], den.shape[3],
                                             _ptr(wa), _ptr(data), _ptr(data_off), data.shape[0], data.shape[1], data.shape[2],
                                             _ptr(out), _ptr(sums), _ptr(oo), _stream()), "prm_stem_dgrad_fused")

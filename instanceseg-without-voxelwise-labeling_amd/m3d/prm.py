@@ -15,12 +15,16 @@ from .model import DetectorM3D, _NOSPAN
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
-                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8):
+                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True):
         self.det = det
         # norm_stream: prm_tile runs the norm convs on a second HIP stream next to proposals / box head / peak selection (launches of
         # 1-128 workgroups that leave most of the chip idle) instead of queueing them behind those launches on the tile's stream
         self.norm_stream = bool(norm_stream)
         self._side = None
+        # slab_strips: where a layer's map has fewer planes than the window (a thin tile: the nuclei net's stride-2 maps are 32 planes
+        # deep, its windows there 38 / 40), the strip stores the LAYER's planes instead of each window's - the planes of a cone outside
+        # the volume (zero gradient in, never read out) are not stored, convolved or streamed (m3d.h: depth-clipped strips)
+        self.slab_strips = bool(slab_strips)
         # backward_streams = 2: the tile's peaks are back-propagated as two halves on two HIP streams - while one half's element-wise
         # `prepare` pass streams through HBM the other half's window convolution holds the matrix cores, and each launch's last,
         # partly filled round of workgroups is filled from the other chain.  A half's launches are the ones the one-stream engine issues
@@ -192,25 +196,27 @@ class PRMEngine:
                 w, s, origin = ops.prm_stem_dgrad_fused(wb["t"], origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa,
                                                         data[0, 0], rec["off"], strip=wb["strip"],
                                                         xnext=rec["xnext"] if wb["up_off"] is not None else None,
-                                                        up_off=wb["up_off"], dims=dims)
+                                                        up_off=wb["up_off"], dims=dims, slab=wb.get("slab", False))
                 return (w, s), origin
             Wn = (2 if rec["pool"] else 1) * wb["U"] + 2 * border
             strip = wino(rec, Wn)
+            slab = bool(strip) and self.slab_strips and rec["n"].shape[1] < Wn       # the layer's map is thinner than the window
             gn, origin = ops.prm_prepare(wb["t"], origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"],
-                                         in_strip=wb["strip"], out_strip=strip, up_off=wb["up_off"], dims=dims)
+                                         in_strip=wb["strip"], out_strip=strip, up_off=wb["up_off"], dims=dims,
+                                         in_slab=wb.get("slab", False), out_slab=slab)
             if rec["k"] == 5:                    # conv1a: 5^3, one input channel -> VALU stem dgrad
                 w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
                 return (w, s), origin
             cout = rec["x"].shape[0]
             if strip:                            # Winograd over the whole strip; its PreHook multiply moves to the consumer
                 y = (rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"])(gn.unsqueeze(0))[0]
-                return dict(t=y, strip=strip, P=wb["P"], C=cout, U=Wn, up_off=rec["off"]), origin
+                return dict(t=y, strip=strip, P=wb["P"], C=cout, U=Wn, up_off=rec["off"], slab=slab), origin
             small = rec.get("dgrad_small")
             if small is not None and Wn in small.SIZES:      # 3^3 / 5^3 / 7^3: all peaks in one dense GEMM (csrc/prm_small.hip)
                 y = small(gn, rec["x"], rec["off"], origin)
             else:
                 y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
-            return dict(t=y, strip=0, P=wb["P"], C=cout, U=Wn, up_off=None), origin
+            return dict(t=y, strip=0, P=wb["P"], C=cout, U=Wn, up_off=None, slab=False), origin
 
         def take(wb, c0, c1):
             """peaks [c0, c1) of a window batch"""

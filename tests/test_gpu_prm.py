@@ -600,3 +600,30 @@ def test_streamed_tile_equals_the_one_stream_tile(stride, shape):
         scale = float(a["windows"].abs().max())
         assert float((a["windows"] - c["windows"]).abs().max()) <= 2e-6 * scale
         assert torch.allclose(a["sums"], c["sums"], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("stride,shape", [(8, (24, 104, 96)), (8, (40, 56, 48)), (4, (16, 72, 80)), (8, (20, 56, 52))])
+def test_depth_clipped_strips_equal_the_window_strips(stride, shape):
+    """slab_strips: where the layer's map has fewer planes than the window the strip stores the map's planes (the part of the cone
+    outside the volume is neither stored nor convolved).  Same sums of the same products - the planes that are dropped only ever
+    held zeros - so the windows agree with the window-strip engine to the last bits (the library may pick another tile / K split for
+    the thinner volume), including odd depths (20 -> 10 -> 5 planes) and peaks on the z border."""
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    P = O.make_params(stride=stride, num_anchors=35 if stride == 8 else 14, mlp_dim=32, seed=6)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=32, score_thresh=0.0)
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    slab, cube = PRMEngine(det, slab_strips=True), PRMEngine(det, slab_strips=False)
+    vol = torch.from_numpy(np.random.RandomState(8).rand(1, 1, *shape).astype(np.float32)).cuda()
+    feat, prob, deltas, saved, top = slab.forward(vol)
+    A, s_, h_, w_ = prob.shape[1:]
+    pk = torch.tensor([(0, 0, 0, 0), (A - 1, s_ - 1, h_ - 1, w_ - 1), (3, s_ // 2, h_ // 2, w_ // 2), (5, 0, h_ // 2, 1), (7, s_ - 1, 2, w_ // 2)],
+                      dtype=torch.int32).cuda()
+    a = slab.backward_windows(pk, saved, top, vol)
+    b = cube.backward_windows(pk, saved, top, vol)
+    assert torch.equal(a[2], b[2])
+    for i in range(pk.shape[0]):
+        scale = float(b[0][i].abs().max())
+        assert scale > 0
+        assert float((a[0][i] - b[0][i]).abs().max()) <= 2e-6 * scale, i
+    assert torch.allclose(a[1], b[1], rtol=1e-5, atol=0)
