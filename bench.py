@@ -206,19 +206,33 @@ def run_dry(args, rank, world, dist):
 
 
 # ------------------------------------------------------------------------------------------------ PRM workloads
-def cone_limited_gflop_per_peak(stride):
+def cone_limited_gflop_per_peak(stride, in_size=None):
     """(algorithmic, issued) GFLOP of one peak's back-propagation when every layer only computes its receptive-field window (SURVEY
     8a-12): window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per
-    voxel.  Issued: windows of 16 voxels and more run on the strip Winograd kernel (4/9), the 5^3 stem occupies 32 MFMA rows for its
-    25 (dy, dx) taps, the small windows issue every product."""
+    voxel of the n^3 window.  Issued = what the kernels put on the matrix cores: every product for the small windows; for the strips
+    the voxels the strip really holds (planes: min(n, depth of the layer's map) - the depth-clipped strips -, rows n, columns the
+    strip's pitch) x 4/9 (16-voxel windows, F(2x2,3x3)) or 1/3 (from 18 voxels, F(2x4,3x3)); the 5^3 stem occupies 32 MFMA rows for
+    its 25 (dy, dx) taps."""
     if stride == 8:
-        L = [(256, 256, 3, 3), (256, 256, 3, 5), (256, 128, 3, 7), (128, 128, 3, 16), (128, 64, 3, 18), (64, 64, 3, 38), (64, 32, 3, 40),
-             (32, 1, 5, 84)]
+        L = [(256, 256, 3, 3, 8), (256, 256, 3, 5, 8), (256, 128, 3, 7, 8), (128, 128, 3, 16, 4), (128, 64, 3, 18, 4), (64, 64, 3, 38, 2),
+             (64, 32, 3, 40, 2), (32, 1, 5, 84, 1)]
     else:
-        L = [(128, 128, 3, 3), (128, 128, 3, 5), (128, 64, 3, 7), (64, 64, 3, 16), (64, 32, 3, 18), (32, 1, 5, 40)]
-    alg = sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n in L) / 1e9
-    issued = sum(2.0 * a * b * k ** 3 * n ** 3 * (32.0 / 25.0 if k == 5 else (4.0 / 9.0 if n >= 16 else 1.0)) for a, b, k, n in L) / 1e9
-    return alg, issued
+        L = [(128, 128, 3, 3, 4), (128, 128, 3, 5, 4), (128, 64, 3, 7, 4), (64, 64, 3, 16, 2), (64, 32, 3, 18, 2), (32, 1, 5, 40, 1)]
+    depth = (in_size[0] if in_size else 64)
+    alg = sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n, _ in L) / 1e9
+    issued = 0.0
+    for a, b, k, n, down in L:
+        if k == 5:
+            vox, f = n ** 3, 32.0 / 25.0
+        elif n >= 18:
+            pitch = 4 * ((n + (1 if n % 4 else 0) + 3) // 4) if n % 4 else n + 4      # quad-aligned strip (strip_geom mode 2): 18 -> 20, 38 -> 40, 40 -> 44
+            vox, f = min(n, depth // down) * n * pitch, 1.0 / 3.0
+        elif n >= 16:
+            vox, f = min(n, depth // down) * n * (n + 1), 4.0 / 9.0
+        else:
+            vox, f = n ** 3, 1.0
+        issued += 2.0 * a * b * k ** 3 * vox * f
+    return alg, issued / 1e9
 
 
 def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
@@ -285,9 +299,9 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     fwd_ms = (ph.get("forward_response", 0.0) + ph.get("norm_convs", 0.0) + ph.get("norm_convs_late", 0.0)) or None
     otsu_ms = ph.get("binarize")
     # cone-limited work of the back-propagation: receptive-field windows per layer, dgrad with relu(W); algorithmic =
-    # 2*Cin*Cout*k^3 per window voxel, issued = what the kernels put on the matrix cores (strip Winograd 4/9 for windows >= 16 voxels,
-    # every product for the small-window GEMMs, 32/25 for the stem whose 25 (dy, dx) taps occupy 32 MFMA rows)
-    cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride)
+    # 2*Cin*Cout*k^3 per window voxel, issued = what the kernels put on the matrix cores (strips: 4/9 or 1/3 of the products of the voxels
+    # the strip holds, every product for the small-window GEMMs, 32/25 for the stem whose 25 (dy, dx) taps occupy 32 MFMA rows)
+    cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
     dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if nuclei else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"     # the largest backward launch
     roof = None
     if back_ms and npeaks:
@@ -298,8 +312,11 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
                 "frac_algorithmic": npeaks * cone / back_ms / FP32_MFMA_PEAK_TFLOPS,
                 "algorithmic_tflops": npeaks * cone / back_ms,
                 "cone_limited_gflop_per_peak": cone, "issued_gflop_per_peak": cone_issued, "backward_ms": back_ms,
-                "frac_definition": "frac = fp32 MFMA FLOPs issued by the window convolutions of all peaks / backward_ms / 157.3 TF; "
-                                   "frac_algorithmic = the cone-limited direct count over the same time"}
+                "frac_definition": "frac = fp32 MFMA FLOPs issued by the window convolutions of all peaks / backward_ms / 157.3 TF (round 4: the "
+                                   "issued count follows the kernels - F(2x4) strips issue 1/3, depth-clipped strips hold fewer planes - so it is "
+                                   "lower than the 4/9-of-n^3 count of rounds 2-3 for the same time); frac_algorithmic = the cone-limited direct "
+                                   "count (n^3 windows) over the same time.  backward_ms is a span on the tile's stream and includes the time the "
+                                   "first layers share the chip with the norm convs of the second stream"}
         t = pmc_traffic(dom, which="largest")
         roof["traffic"] = t.get("traffic")
         roof["traffic_what"] = "HBM bytes per launch of the largest backward kernel (%s), PMC: %s" % (dom, t.get("traffic_source"))

@@ -9,6 +9,7 @@ if [[ $PHASE == *A* ]]; then
 python bench.py > $P/${R}_bench_default_line.json 2> $P/bench_detect.err          # the driver's command: headline + every sub-record
 python bench.py --workload prm 2>/dev/null | tail -1 > $P/${R}_bench_prm_soma.json
 python bench.py --workload prm-nuclei 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei.json
+python bench.py --workload prm-nuclei --prm-rpn-logit-scale 1.0 --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei_saturated_init.json   # rounds 1-3 workload
 python bench.py --workload volume 2>/dev/null | tail -1 > $P/${R}_bench_volume.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d /tmp/rp_det -o det -- python3 /root/repo/bench.py --no-cpu-baseline --no-subrecords > $P/${R}_bench_detect_under_rocprof.json 2>/tmp/rp_det.err
