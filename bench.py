@@ -261,32 +261,50 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     pr = {"probe": None, "left": 0}
     bstream = torch.cuda.Stream() if int(getattr(args, "prm_binarize_stream", 1)) else None
 
+    from m3d.prm import TilePipeline
+    pipe = TilePipeline(eng, dense=False) if int(getattr(args, "prm_pipeline", 0)) else None
+
+    def post(out):
+        """a tile's maps -> instance labels (binarization_*.py loop body)"""
+        npk.append(0 if out is None else int(out["peaks"].shape[0]))
+        if out is None:
+            return
+        if bstream is not None:                        # on a second stream: beside the next tile's forward (span events on that stream)
+            labels, painted, _ = binarize.segment_tile_on(bstream, raw, (out["windows"], out["sums"], out["origins"]), out["dets"],
+                                                          span=eng.span("binarize"), mode=mode)
+        else:
+            with eng.span("binarize"):
+                labels, painted = binarize.segment_tile(raw, (out["windows"], out["sums"], out["origins"]), out["dets"], mode=mode)
+        nlab.append(painted)
+
     def step():
         """one tile: PRM forward + box head + peak back-propagation -> uint8 quantisation (from the windows; no dense float maps) -> per-detection crop +
-        normalisation -> 2D-Otsu -> largest component (+ hole fill / closing) -> instance labels (binarization_*.py loop body)"""
+        normalisation -> 2D-Otsu -> largest component (+ hole fill / closing) -> instance labels.  With the tile pipeline a step enqueues tile k's
+        forward and FINISHES tile k - 1 (m3d.prm.TilePipeline); `drain` finishes the last tile inside the timed region."""
         stamps.append(time.perf_counter())
         eng.probe = eng.det.probe = pr["probe"] if pr["left"] > 0 else None
         pr["left"] -= 1
-        out = eng.prm_tile(vol, dense=False)
-        npk.append(0 if out is None else int(out["peaks"].shape[0]))
-        if out is not None:
-            if bstream is not None:                        # on a second stream: beside the next tile's forward (span events on that stream)
-                labels, painted, _ = binarize.segment_tile_on(bstream, raw, (out["windows"], out["sums"], out["origins"]), out["dets"],
-                                                              span=eng.span("binarize"), mode=mode)
-            else:
-                with eng.span("binarize"):
-                    labels, painted = binarize.segment_tile(raw, (out["windows"], out["sums"], out["origins"]), out["dets"], mode=mode)
-            nlab.append(painted)
+        if pipe is None:
+            post(eng.prm_tile(vol, dense=False))
+        else:
+            for _, out in pipe.push(None, vol):
+                post(out)
+
+    def drain():
+        if pipe is not None:
+            for _, out in pipe.flush():
+                post(out)
+        torch.cuda.synchronize()
     pr["probe"], pr["left"] = Probe(), args.warmup         # throw-away probe on the warm-up steps (event pool)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    drain()
     import gc
     gc.collect()
     gc.freeze()                                            # (see bench_detect: a full collection over ~10^6 objects costs 40-60 ms)
     probe = Probe()
     pr["probe"], pr["left"] = probe, PROBE_STEPS
-    dt = timed_loop(step, args.steps, 0, dist, torch.cuda.synchronize)
+    dt = timed_loop(step, args.steps, 0, dist, drain)
     dt = sync_max_time(dt, dist, "cuda")
     torch.cuda.synchronize()
     eng.probe = eng.det.probe = None
@@ -1090,6 +1108,7 @@ def main():
     ap.add_argument("--stress-rois", action="store_true", help="RPN NMS threshold 1.0: every volume gives RPN_POST_NMS_TOP_N = 1000 RoIs to the box head")
     ap.add_argument("--prm-norm-stream", type=int, default=1, help="PRM workloads: 0 = norm convs queued on the tile's own stream instead of a second one (A/B)")
     ap.add_argument("--prm-rpn-logit-scale", type=float, default=0.25, help="PRM workloads, nuclei net: factor on the random-init RPN class logits (1.0 = rounds 1-3: saturated sigmoids, all-zero maps)")
+    ap.add_argument("--prm-pipeline", type=int, default=0, help="PRM tile workloads: 1 = the two-tile software pipeline (m3d.prm.TilePipeline) instead of one prm_tile call per step (A/B: no faster)")
     ap.add_argument("--prm-binarize-stream", type=int, default=1, help="PRM workloads: 0 = a tile's binarisation stage on the tile's stream instead of its own (where it runs beside the next tile's forward) (A/B)")
     ap.add_argument("--prm-backward-streams", type=int, default=1, help="PRM workloads: 2 = the peaks' back-propagation as two halves on two streams (A/B)")
     ap.add_argument("--no-subrecords", action="store_true", help="default workload at N = 1: skip configs1_backbone / stress_rois / configs3_prm_soma / prm_nuclei_tile / volume_pipeline")

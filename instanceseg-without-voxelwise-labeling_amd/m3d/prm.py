@@ -295,9 +295,21 @@ class PRMEngine:
         [P,4] / dets_dev float32 [P,7] (device), windows/sums/origins (cone-cropped maps) and, with dense=True, prms [P,S,H,W]
         (each map divided by its sum).
 
-        Two host waits per tile - the RoI count that sizes the box head and the peak count that sizes the back-propagation - and both
-        are covered: the norm convs of the forward, which only the backward needs, are queued behind the launches the host waits
-        for."""
+        Two host waits per tile - the RoI count that sizes the box head and the peak count that sizes the back-propagation.  The norm
+        convs of the forward, which only the backward needs, run on a second stream beside the launches the host waits for (or, with
+        norm_stream=False, queued behind them); what is still exposed of the second wait (the host is woken and builds the backward's
+        launches: ~0.1 ms) disappears when tiles are fed through `TilePipeline`, which enqueues the next tile's forward in front of it."""
+        g = self.prm_tile_phases(data, peak_threshold, dense)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
+
+    def prm_tile_phases(self, data, peak_threshold=0.1, dense=True):
+        """prm_tile as a generator that yields in front of each host wait ("rois": the forward and the proposals are enqueued; "peaks":
+        box head and peak selection are enqueued) and returns prm_tile's result; a tile on the per-stage path returns at the first
+        `next`.  Whoever drives it may enqueue other work at a yield (TilePipeline: the next tile's forward)."""
         det, c = self.det, self.cfg
         S, H, W = data.shape[-3:]
         im_info = np.array([S, H, W, 1.0], np.float64)
@@ -333,6 +345,7 @@ class PRMEngine:
         if norms_done is None:
             with self.span("norm_convs"):
                 self.forward_norms(saved, top, layers=[i for i in range(nl) if i not in late], cls=True)
+        yield "rois"
         ready.synchronize()                                           # host wait 1 (covered by the norm convs above)
         R = int(num_host[0])
         det._release_counts(num_host)
@@ -350,7 +363,8 @@ class PRMEngine:
         if norms_done is None:
             with self.span("norm_convs_late"):
                 self.forward_norms(saved, top, layers=late, cls=False)
-        sel["event"].synchronize()                                    # host wait 2 (covered by the two norm convs above)
+        yield "peaks"
+        sel["event"].synchronize()                                    # host wait 2 (covered by the two norm convs above / the next tile)
         P = int(sel["host"]["num"][0])
         if P == 0:
             sel["release"]()
@@ -398,3 +412,59 @@ class PRMEngine:
         if dense:
             out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
         return out
+
+
+
+class TilePipeline:
+    """(A/B option - measured no faster than one prm_tile call per tile, DESIGN.md "Round 4" 8.)  Tiles through PRMEngine.prm_tile,
+    software-pipelined over the two host waits of a tile: tile k+1's forward and proposals are
+    enqueued BEFORE the host waits for tile k's peak count, so that wait (and the building of the backward's launches behind it) has a
+    millisecond of queued work in front of it, and tile k+1's RoI count has long arrived when the host asks for it.  Stream order:
+    forward(k+1) proposals(k+1) | backward(k) [caller's post-processing of k] | box head(k+1) selection(k+1) | forward(k+2) ...
+    Results come back in the order the tiles went in; two tiles' forward tensors are alive at a time.
+
+        pipe = TilePipeline(engine, dense=False)
+        for key, data in tiles:
+            for k, out in pipe.push(key, data): ...      # 0, 1 or 2 finished tiles (out is None for an empty tile)
+        for k, out in pipe.flush(): ...
+    """
+
+    def __init__(self, engine, peak_threshold=0.1, dense=False):
+        self.engine, self.peak_threshold, self.dense = engine, peak_threshold, dense
+        self.pending = None                                     # (key, generator suspended in front of the peak-count wait)
+
+    @staticmethod
+    def _advance(g):
+        try:
+            return False, next(g)
+        except StopIteration as e:
+            return True, e.value
+
+    def _finish(self, g):
+        while True:
+            done, v = self._advance(g)
+            if done:
+                return v
+
+    def push(self, key, data):
+        g = self.engine.prm_tile_phases(data, self.peak_threshold, self.dense)
+        done, v = self._advance(g)                              # forward + proposals enqueued (or: the per-stage path ran to its end)
+        out = []
+        if self.pending is not None:
+            pk, pg = self.pending
+            self.pending = None
+            out.append((pk, self._finish(pg)))                  # previous tile: peak count -> backward
+        if not done:
+            done, v = self._advance(g)                          # RoI count (arrived long ago) -> box head + peak selection enqueued
+        if done:
+            out.append((key, v))
+        else:
+            self.pending = (key, g)
+        return out
+
+    def flush(self):
+        if self.pending is None:
+            return []
+        pk, pg = self.pending
+        self.pending = None
+        return [(pk, self._finish(pg))]

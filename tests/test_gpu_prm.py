@@ -520,7 +520,7 @@ def test_pipelined_volume_driver_writes_the_serial_drivers_files_byte_for_byte(t
     rs = np.random.RandomState(7)
     im = (rs.rand(*shape) * 900 + 50).astype(np.uint16)
     a = infer_prm_serial(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=str(tmp_path / "serial"))
-    b = infer_prm(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=str(tmp_path / "piped"))
+    b = infer_prm(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=str(tmp_path / "piped"), tile_pipeline=(shape[0] == 20))
     h = infer_prm_serial(eng, im, dataset=dataset, patch=patch, overlap=overlap, out_dir=None, device_norm=False)
     assert len(a) == len(b) == len(h) >= 1
     for ra, rb, rh in zip(a, b, h):
@@ -627,3 +627,31 @@ def test_depth_clipped_strips_equal_the_window_strips(stride, shape):
         assert scale > 0
         assert float((a[0][i] - b[0][i]).abs().max()) <= 2e-6 * scale, i
     assert torch.allclose(a[1], b[1], rtol=1e-5, atol=0)
+
+
+def test_tile_pipeline_returns_what_prm_tile_returns_in_tile_order():
+    """TilePipeline (the next tile's forward enqueued in front of a tile's peak-count wait) against one prm_tile call per tile: same
+    tiles in the same order, every tensor identical, empty tiles (None) in their place - also as first and last tile."""
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine, TilePipeline
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=3)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0)
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
+    rs = np.random.RandomState(9)
+    vols = [torch.from_numpy(rs.rand(1, 1, 24, 56, 48).astype(np.float32)).cuda() for _ in range(4)]
+    for thr, expect_none in ((0.0, False), (2.0, True)):               # 2.0: no score passes -> every tile is empty
+        ref = [eng.prm_tile(v, peak_threshold=thr, dense=False) for v in vols]
+        pipe = TilePipeline(eng, peak_threshold=thr, dense=False)
+        got = []
+        for i, v in enumerate(vols):
+            got += pipe.push(i, v)
+            assert len(got) <= i + 1
+        got += pipe.flush()
+        assert pipe.flush() == []
+        assert [k for k, _ in got] == list(range(len(vols)))
+        torch.cuda.synchronize()
+        for (k, o), r in zip(got, ref):
+            assert (o is None) == (r is None) == expect_none
+            if o is not None:
+                for name in ("peaks", "dets", "windows", "sums", "origins"):
+                    assert torch.equal(o[name], r[name]), (k, name)
