@@ -469,6 +469,19 @@ int m3d_prm_stem_dgrad_fused_ex2(const float* d_gup, int gup_strip, int gup_slab
                                  const float* d_wa, const float* d_data, const float* d_data_offset, int depth, int height, int width,
                                  float* d_out, float* d_sums, int32_t* d_origins_out, void* stream);
 
+/* 3x3x3 "same" convolution at fp32 accuracy on the bf16 matrix cores (csrc/conv3d_x3.hip; round 4): out = conv3d(x - *d_in_offset, W',
+ * padding = 1) with W' = W or relu(W) chosen at pack time - the norm convolution of lib/prm/peak_backprop_3d.py:37-44 (pr_conv3d's second
+ * F.conv3d: N = conv(X - min X, relu(W))), which has to stay an exact sum of products.  Both fp32 operands are cut into three bf16 pieces
+ * (exact), six bf16 MFMA products per fp32 product: the error is the fp32 kernel's, non-negative operands give exact zeros exactly where
+ * the fp32 sum has them.  cin must be a multiple of 16 (m3d_conv3d_x3_supported); zero padding applies to the SHIFTED input.
+ *   m3d_conv3d_x3_packed_bytes / _pack   weight [cout, cin, 3, 3, 3] fp32 -> packed pieces (once per model; relu_weights: relu(W))
+ *   m3d_conv3d_x3_forward                 x [B, cin, D, H, W] -> out [B, cout, D, H, W]; d_in_offset: device scalar or null */
+size_t m3d_conv3d_x3_packed_bytes(int cin, int cout);
+int m3d_conv3d_x3_supported(int cin, int cout);
+int m3d_conv3d_x3_pack(const float* d_weight, int cin, int cout, int relu_weights, void* d_packed, void* stream);
+int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                          int width, const float* d_in_offset, void* stream);
+
 /* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
  * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on
  * dgrad-packed weights: d_gn [P, cout_fwd, win^3] -> d_out [P, cin_fwd, win^3] = (d_full[co][origin + v] - *d_full_offset) *

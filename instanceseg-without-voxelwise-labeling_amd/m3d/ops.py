@@ -12,7 +12,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "compact_rows2", "box_head_outputs", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "linear_roi_fused", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "X3Conv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -379,6 +379,42 @@ class PackedConv3d:
         check(lib().m3d_conv3d_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, self.k,
                                        _ptr(in_offset), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(mul), _stream()),
               "conv3d_forward")
+        return out
+
+
+class X3Conv3d:
+    """A 3x3x3 'same' conv at fp32 accuracy on the bf16 matrix cores (csrc/conv3d_x3.hip: exact three-way bf16 cut of both operands,
+    six products per fp32 product) - the exact direct kernel for the PRM norm convs: out = conv3d(x - in_offset, W or relu(W), padding 1).
+    weight [cout, cin, 3, 3, 3]; mode W_PLAIN or W_RELU."""
+
+    @staticmethod
+    def supported(weight):
+        return weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and bool(lib().m3d_conv3d_x3_supported(weight.shape[1], weight.shape[0]))
+
+    def __init__(self, weight, mode=W_PLAIN):
+        _need_gpu(weight)
+        weight = _f32c(weight)
+        assert mode in (W_PLAIN, W_RELU) and X3Conv3d.supported(weight)
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        nbytes = lib().m3d_conv3d_x3_packed_bytes(self.cin, self.cout)
+        self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+        check(lib().m3d_conv3d_x3_pack(_ptr(weight), self.cin, self.cout, int(mode == W_RELU), _ptr(self.packed), _stream()), "conv3d_x3_pack")
+
+    def workgroups(self, shape):
+        """launch size for x of `shape` [B, cin, D, H, W]: 64 output channels x (16 x 4 x 4) voxels per workgroup"""
+        B, _, D, H, W = shape
+        return B * ((D + 3) // 4) * ((H + 3) // 4) * ((W + 15) // 16) * ((self.cout + 63) // 64)
+
+    def __call__(self, x, in_offset=None, out=None):
+        _need_gpu(x)
+        x = _f32c(x)
+        B, Cin, D, H, W = x.shape
+        if Cin != self.cin:
+            raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
+        if out is None:
+            out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_x3_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, _ptr(in_offset), _stream()),
+              "conv3d_x3_forward")
         return out
 
 

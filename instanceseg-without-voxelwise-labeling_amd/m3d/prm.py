@@ -15,7 +15,7 @@ from .model import DetectorM3D, _NOSPAN
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
-                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True):
+                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True):
         self.det = det
         # norm_stream: prm_tile runs the norm convs on a second HIP stream next to proposals / box head / peak selection (launches of
         # 1-128 workgroups that leave most of the chip idle) instead of queueing them behind those launches on the tile's stream
@@ -25,6 +25,9 @@ class PRMEngine:
         # deep, its windows there 38 / 40), the strip stores the LAYER's planes instead of each window's - the planes of a cone outside
         # the volume (zero gradient in, never read out) are not stored, convolved or streamed (m3d.h: depth-clipped strips)
         self.slab_strips = bool(slab_strips)
+        # x3_norm: the 3^3 norm convs on the bf16 matrix cores at fp32 accuracy (ops.X3Conv3d: exact bf16x3 cut, six products) instead of
+        # the fp32-MFMA direct kernel; sums of non-negative products either way, so the exact zeros are the same
+        self.x3_norm = bool(x3_norm)
         # backward_streams = 2: the tile's peaks are back-propagated as two halves on two HIP streams - while one half's element-wise
         # `prepare` pass streams through HBM the other half's window convolution holds the matrix cores, and each launch's last,
         # partly filled round of workgroups is filled from the other chain.  A half's launches are the ones the one-stream engine issues
@@ -57,13 +60,13 @@ class PRMEngine:
         for (conv, scale, shift, pool), cname in zip(det.body, names):
             w = P["Conv_Body.%s.weight" % cname]
             self.layers.append(dict(name=cname, conv=conv, scale=scale, shift=shift, pool=pool, k=w.shape[2],
-                                    norm_conv=ops.PackedConv3d(w, ops.W_RELU),
+                                    norm_conv=self._norm_conv(w),
                                     dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU),
                                     dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None,
                                     dgrad_wino24=self._dgrad_wino(w, local=False) if (strip_wino and strip_f24 and w.shape[2] == 3) else None,
                                     dgrad_small=ops.SmallWindowDgrad(w) if (small_gemm and w.shape[2] == 3) else None, weight=w))
         w = P["RPN.RPN_conv.weight"]
-        self.rpn = dict(norm_conv=ops.PackedConv3d(w, ops.W_RELU), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU),
+        self.rpn = dict(norm_conv=self._norm_conv(w), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU),
                         dgrad_small=ops.SmallWindowDgrad(w) if small_gemm else None)
         self.stem_wf = ops.prm_stem_prepare_weights(P["Conv_Body.conv1a.weight"])
         # stem step on the matrix cores with the un-pool/prepare fused (csrc/prm_stem_mfma.hip); fused_stem=False keeps the
@@ -76,6 +79,18 @@ class PRMEngine:
 
     def span(self, name):
         return self.probe(name) if self.probe is not None else _NOSPAN
+
+    def _norm_conv(self, w):
+        direct = ops.PackedConv3d(w, ops.W_RELU)
+        if not (self.x3_norm and ops.X3Conv3d.supported(w)):
+            return direct
+        x3 = ops.X3Conv3d(w, ops.W_RELU)
+
+        def conv(x, in_offset=None):
+            # the bf16x3 kernel's 64-channel x 16 x 4 x 4-voxel workgroups need about a round of the chip to pay (8 x 25 x 25 maps of the
+            # nuclei net: 112 workgroups, slower than the fp32 kernel's small tiles; 16 x 40 x 40 and up: 1.3-1.7 x faster)
+            return (x3 if x3.workgroups(x.shape) >= 192 else direct)(x, in_offset=in_offset)
+        return conv
 
     @staticmethod
     def _dgrad_wino(w, local=True):

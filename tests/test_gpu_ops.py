@@ -1041,3 +1041,34 @@ def test_fc1_with_the_roialign_gather_in_its_operand_loader_equals_the_two_launc
     got = m3d.linear_roi_fused(lin, feat, rois, 0.125, relu=True)
     assert float(x[1].abs().max()) == 0.0
     assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,shape,batch", [(32, 64, (8, 20, 36), 1), (64, 64, (5, 9, 17), 2), (16, 128, (4, 4, 16), 1), (128, 96, (7, 13, 21), 1),
+                                                  (64, 256, (8, 25, 25), 1)])
+def test_bf16x3_direct_conv_has_fp32_accuracy_and_the_fp32_kernels_exact_zeros(cin, cout, shape, batch):
+    """m3d_conv3d_x3_forward (three-way bf16 cut of both operands, six bf16 MFMA products per fp32 product) as the PRM norm conv
+    N = conv3d(X - min X, relu(W), padding 1) (peak_backprop_3d.py:37-44): against float64 its error is the fp32-MFMA kernel's; ragged
+    tiles in all three axes, a channel count that is not a multiple of the 64-channel tile, batches; and where the inputs under every
+    positive weight are zero the result is exactly 0.0 - the same voxels as the fp32 kernel's (the backward's `N < 1e-10` test)."""
+    import m3d
+    from m3d import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.rand((batch, cin) + shape, generator=g) * (torch.rand((batch, cin) + shape, generator=g) > 0.3)
+    x = x + 0.25
+    x[:, :, : max(3, shape[0] // 2), : max(3, shape[1] // 2)] = 0.25          # a constant block at the minimum: exact zeros after the shift
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.1
+    xc, wc = x.cuda(), w.cuda()
+    off = ops.reduce_min(xc)
+    assert float(off) == 0.25
+    got = ops.X3Conv3d(wc, ops.W_RELU)(xc, in_offset=off).cpu()
+    f32 = ops.PackedConv3d(wc, ops.W_RELU)(xc, in_offset=off).cpu()
+    ref = torch.nn.functional.conv3d((x - 0.25).double(), torch.relu(w).double(), padding=1)
+    scale = float(ref.abs().max())
+    e_x3, e_f32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
+    assert e_x3 < 4e-6 and e_x3 <= max(3.0 * e_f32, 1e-6), (e_x3, e_f32)
+    zero = ref == 0
+    assert int(zero.sum()) > 0
+    assert torch.equal(got == 0, zero) and torch.equal(f32 == 0, zero)
+    plain = ops.X3Conv3d(wc, ops.W_PLAIN)(xc).cpu()                          # signed weights, no offset
+    ref2 = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
+    assert float((plain.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6

@@ -1,0 +1,7 @@
+#!/bin/bash
+# ablation timings of conv3d_x3_kernel (make -C .../csrc x3_ablate first)
+cd /root/repo
+echo "== release"; python tools/dbg_x3b.py 2>/dev/null | head -2
+for e in 1 2 4 8 16 6 14 30; do
+  echo "== X3_EXP=$e"; M3D_LIB_PATH=/root/repo/instanceseg-without-voxelwise-labeling_amd/csrc/libm3d_x3abl$e.so python tools/dbg_x3b.py 2>/dev/null | head -2
+done
