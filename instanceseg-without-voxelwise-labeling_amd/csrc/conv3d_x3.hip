@@ -20,7 +20,7 @@
 // Roofline: MFMA (bf16, 2.5 PFLOP/s dense): 6 x 2 x 27 x Cin x Cout issued FLOP per voxel.
 #include "m3d_common.h"
 
-// timing-only ablation builds (make x3_ablate, tools/dbg_x3b.py; WRONG results): 1 = no MFMAs, 2 = no fragment reads, 4 = no weight
+// timing-only ablation builds (make x3_ablate, tools/bench_x3.py; WRONG results): 1 = no MFMAs, 2 = no fragment reads, 4 = no weight
 // staging (loads, LDS writes), 8 = no per-step barrier, 16 = no flush
 #ifndef X3_EXP
 #define X3_EXP 0
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   // one chunk = 27 steps; `par` = parity of its first step (27 is odd: the parity of the chunk index), a literal at both call sites so that
   // register-set choices fold to constants in the unrolled taps.  During the 24 MFMAs of a step the 12 fragments of the NEXT step are read,
   // two ds_read_b128 per four MFMAs (the LDS array keeps up with that rate beside the matrix pipe; reads bunched in front of the MFMAs
-  // that need them cost 40 % of the kernel: tools/dbg_x3c.sh), except over a chunk boundary, where the next input tile is not in LDS yet.
+  // that need them cost 40 % of the kernel: tools/x3_ablate.sh), except over a chunk boundary, where the next input tile is not in LDS yet.
   auto run_chunk = [&](int c, const int par) __attribute__((always_inline)) {
     const int s0 = c * 27;
 #pragma unroll
