@@ -1044,7 +1044,7 @@ def test_fc1_with_the_roialign_gather_in_its_operand_loader_equals_the_two_launc
 
 
 @pytest.mark.parametrize("cin,cout,shape,batch", [(32, 64, (8, 20, 36), 1), (64, 64, (5, 9, 17), 2), (16, 128, (4, 4, 16), 1), (128, 96, (7, 13, 21), 1),
-                                                  (64, 256, (8, 25, 25), 1)])
+                                                  (64, 256, (8, 25, 25), 1), (48, 64, (6, 10, 20), 1), (80, 32, (3, 5, 33), 3)])
 def test_bf16x3_direct_conv_has_fp32_accuracy_and_the_fp32_kernels_exact_zeros(cin, cout, shape, batch):
     """m3d_conv3d_x3_forward (three-way bf16 cut of both operands, six bf16 MFMA products per fp32 product) as the PRM norm conv
     N = conv3d(X - min X, relu(W), padding 1) (peak_backprop_3d.py:37-44): against float64 its error is the fp32-MFMA kernel's; ragged
