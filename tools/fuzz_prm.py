@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the batched peak back-propagation (default PRMEngine: strip Winograd on window / depth-clipped strips, MFMA
+stem, small-window GEMM, bf16x3 norm convolutions on their own stream) against the CPU oracle's restatement of the reference's per-peak
+autograd backward (lib/prm/peak_response_mapping_3d.py:157-172, peak_backprop_3d.py:8-44): random nets (stride 4 / 8), tile shapes
+(thin, ragged, odd), seeds and peaks (borders, corners, random), each map held to tests/test_gpu_prm.py's tolerance (1e-4 relative
+outside the measured conditioning band, 2e-3 inside; the fp64 run that measures the band is only made for a map that misses the tight
+tolerance).  The rule has a second ill-conditioned spot besides the `N < 1e-10` cut: MaxPool's arg-max.  Two candidates of a pooling
+cell that agree to 1e-6 are ordered by the last bits of the convolution's rounding, and the whole gradient of that cell goes to one or
+the other; where the device's arg-max differs from the oracle's AND the two candidates agree to 1e-5, the oracle back-propagates with
+the device's choice (counted per case as `ties`); a difference at a wider margin fails the case.
+Test infrastructure: the only place besides tests/ that calls the oracle for PRM.
+  python tools/fuzz_prm.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instanceseg-without-voxelwise-labeling_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, m3d
+import oracle as O
+from m3d.model import DetectorM3D
+from m3d.prm import PRMEngine
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+torch.set_num_threads(max(1, (os.cpu_count() or 2)))
+
+
+def maps_close(got, ref32, ref64):
+    got = np.asarray(got, np.float64); ref32 = np.asarray(ref32, np.float64); ref64 = np.asarray(ref64, np.float64)
+    mx = float(np.abs(ref32).max())
+    band = np.abs(ref32 - ref64) > 5e-5 * np.abs(ref64) + 1e-6 * mx
+    err = np.abs(got - ref32)
+    tight = err <= 1e-4 * np.abs(ref32) + 2e-6 * mx
+    loose = err <= 2e-3 * np.abs(ref32) + 2e-6 * mx
+    ok = bool(tight[~band].all()) and bool(loose[band].all()) and band.mean() < 1e-2
+    return ok, float((err * ~band).max()) / mx, int(band.sum())
+
+
+bad = 0
+t0 = time.time()
+for ci in range(cases):
+    rs = np.random.RandomState(seed0 * 1000 + ci)
+    stride = int(rs.choice([4, 8]))
+    A = 35 if stride == 8 else 14
+    m = stride * 2                                                # two cells of the RPN map at least per axis
+    shape = tuple(int(stride * rs.randint(2, 6) + rs.choice([0, 0, 2, 3])) for _ in range(3))
+    shape = (min(shape[0], 40), min(shape[1] + 16, 72), min(shape[2] + 16, 72))
+    P = O.make_params(stride=stride, num_anchors=A, mlp_dim=32, seed=int(rs.randint(1000)))
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0) if stride == 8 else O.Cfg.soma(mlp_dim=32, score_thresh=0.0)
+    if stride == 8:                                               # unsaturated RPN logits (bench.prm_params): maps that are not 0 / 0
+        P = dict(P)
+        for k in ("RPN.RPN_cls_score.weight", "RPN.RPN_cls_score.bias"):
+            P[k] = P[k] * 0.25
+    vol = torch.from_numpy((rs.rand(1, 1, *shape) * (rs.rand(1, 1, *shape) > 0.2)).astype(np.float32))
+    eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
+    data = vol.cuda()
+    feat, prob, deltas, saved, top = eng.forward(data)
+    with torch.no_grad():
+        _, p2, _, osaved = O.prm_forward(P, cfg, vol)
+    # arg-max near-ties: adopt the device's routing in the oracle where the two candidates agree to 1e-5
+    ties, wide = 0, 0
+    opools = [r for r in osaved if r["kind"] == "pool"]
+    j = 0
+    patches = []
+    for i, rec in enumerate(saved):
+        if not rec["pool"]:
+            continue
+        po = opools[j]; j += 1
+        am = rec["argmax"].cpu().long()
+        C, UD, UH, UW = am.shape
+        D, H, W = po["shape"][2:]
+        flat = ((torch.arange(UD).view(1, UD, 1, 1) * 2 + (am >> 2)) * H + (torch.arange(UH).view(1, 1, UH, 1) * 2 + ((am >> 1) & 1))) * W + \
+               (torch.arange(UW).view(1, 1, 1, UW) * 2 + (am & 1))
+        diff = flat != po["idx"][0]
+        if bool(diff.any()):
+            L = eng.layers[i]
+            y = L["conv"](rec["x"].unsqueeze(0), scale=L["scale"], shift=L["shift"], relu=True)[0].cpu().reshape(C, -1)
+            cidx = torch.arange(C).view(C, 1, 1, 1).expand_as(flat)
+            va, vb = y[cidx[diff], flat[diff]], y[cidx[diff], po["idx"][0][diff]]
+            near = (va - vb).abs() <= 1e-5 * va.abs().clamp(min=1e-30)
+            ties += int(near.sum()); wide += int((~near).sum())
+            new_idx = po["idx"].clone()
+            new_idx[0][diff] = flat[diff]
+            patches.append((j - 1, new_idx))
+    for jj, new_idx in patches:
+        opools[jj]["idx"] = new_idx
+    s_, h_, w_ = p2.shape[-3:]
+    peaks = [(0, 0, 0, 0, 0), (0, A - 1, s_ - 1, h_ - 1, w_ - 1)] + [(0, int(rs.randint(A)), int(rs.randint(s_)), int(rs.randint(h_)), int(rs.randint(w_))) for _ in range(2)]
+    pk = torch.tensor([p[1:] for p in peaks], dtype=torch.int32).cuda()
+    win, sums, origins = eng.backward_windows(pk, saved, top, data)
+    dense = m3d.prm_scatter(win, sums, origins, vol.shape[-3:]).cpu().numpy()
+    line = []
+    o64 = None
+    for i, p in enumerate(peaks):
+        with torch.no_grad():
+            ref = O.prm_backward(P, osaved, p, p2.shape)[0].numpy()
+        if not np.isfinite(ref).all():                            # a saturated peak: 0 / 0 in the reference; the windows are all zero here
+            ok = float(sums[i]) == 0.0
+            line.append("0/0:%s" % ("ok" if ok else "BAD"))
+        else:
+            ok, worst, nband = maps_close(dense[i], ref, ref)      # no band: the tight tolerance everywhere
+            if not ok:                                            # measure the conditioning band with an fp64 run of the same rule
+                if o64 is None:
+                    Pd = {k: v.double() for k, v in P.items()}
+                    with torch.no_grad():
+                        _, p64, _, osaved64 = O.prm_forward(Pd, cfg, vol.double())
+                    for jj, new_idx in patches:
+                        [r for r in osaved64 if r["kind"] == "pool"][jj]["idx"] = new_idx
+                    o64 = (Pd, osaved64)
+                with torch.no_grad():
+                    ref64 = O.prm_backward(o64[0], o64[1], p, p2.shape)[0].numpy()
+                ok, worst, nband = maps_close(dense[i], ref, ref64)
+            line.append("%.1e/%d%s" % (worst, nband, "" if ok else ":BAD"))
+        bad += 0 if ok else 1
+    bad += 1 if wide else 0
+    print("case %2d stride %d tile %-14s prob err %.1e  arg-max ties adopted %d%s  maps (worst error outside the band / band voxels): %s" %
+          (ci, stride, shape, float((prob.cpu() - p2).abs().max()), ties, (" WIDE-MARGIN ARG-MAX DIFFERENCES %d" % wide) if wide else "", "  ".join(line)), flush=True)
+print("fuzz_prm: %d cases, %d maps out of tolerance, %.0f s" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
