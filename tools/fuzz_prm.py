@@ -22,7 +22,7 @@ from m3d.prm import PRMEngine
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-torch.set_num_threads(max(1, (os.cpu_count() or 2)))
+torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))      # cpu_count() is the HOST's: 256 threads on a 16-core share crawl
 
 
 def maps_close(got, ref32, ref64):
