@@ -6,7 +6,8 @@ autograd backward (lib/prm/peak_response_mapping_3d.py:157-172, peak_backprop_3d
 outside the measured conditioning band, 2e-3 inside; the fp64 run that measures the band is only made for a map that misses the tight
 tolerance).  The rule has a second ill-conditioned spot besides the `N < 1e-10` cut: MaxPool's arg-max.  Two candidates of a pooling
 cell that agree to 1e-6 are ordered by the last bits of the convolution's rounding, and the whole gradient of that cell goes to one or
-the other; where the device's arg-max differs from the oracle's AND the two candidates agree to 1e-5, the oracle back-propagates with
+the other; where the device's arg-max differs from the oracle's AND the two candidates agree to 1e-5 (or to 2e-5 of the layer's largest
+value: the accuracy of the Winograd response convs is relative to that), the oracle back-propagates with
 the device's choice (counted per case as `ties`); a difference at a wider margin fails the case.
 Test infrastructure: the only place besides tests/ that calls the oracle for PRM.
   python tools/fuzz_prm.py [cases] [seed]"""
@@ -77,8 +78,12 @@ for ci in range(cases):
             y = L["conv"](rec["x"].unsqueeze(0), scale=L["scale"], shift=L["shift"], relu=True)[0].cpu().reshape(C, -1)
             cidx = torch.arange(C).view(C, 1, 1, 1).expand_as(flat)
             va, vb = y[cidx[diff], flat[diff]], y[cidx[diff], po["idx"][0][diff]]
-            near = (va - vb).abs() <= 1e-5 * va.abs().clamp(min=1e-30)
+            # the response convs run through Winograd F(2x4,3x3), whose error is relative to the layer's largest value (<= 6e-6 of it,
+            # tests/test_gpu_ops.py), not to each value: candidates closer than 2e-5 of the layer's maximum can be ordered either way
+            near = (va - vb).abs() <= torch.maximum(1e-5 * va.abs(), 2e-5 * y.abs().max())
             ties += int(near.sum()); wide += int((~near).sum())
+            if bool((~near).any()):
+                print("   wide: layer %d values %s vs %s, layer max %.3g" % (i, va[~near].tolist()[:3], vb[~near].tolist()[:3], float(y.abs().max())), flush=True)
             new_idx = po["idx"].clone()
             new_idx[0][diff] = flat[diff]
             patches.append((j - 1, new_idx))
