@@ -507,13 +507,10 @@ def prm_params(cfg, args):
     the LZW writer saw all-zero maps).  RPN_cls_score's weight and bias are therefore scaled by --prm-rpn-logit-scale (default 0.25:
     logits of +-10 as a trained net has; the ranking of the proposals is the same monotone function of the same logits); 1.0
     reproduces the earlier rounds' workload."""
+    from m3d.synth import unsaturated_rpn
     P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
     a = float(getattr(args, "prm_rpn_logit_scale", 0.25))
-    if cfg.stride == 8 and a != 1.0:
-        P = dict(P)
-        for k in ("RPN.RPN_cls_score.weight", "RPN.RPN_cls_score.bias"):
-            P[k] = P[k] * a
-    return P
+    return unsaturated_rpn(P, a) if (cfg.stride == 8 and a != 1.0) else P
 
 
 def cached_params(**kw):

@@ -42,6 +42,17 @@ def make_params(stride=8, num_anchors=35, mlp_dim=1024, roi_res=7, num_classes=2
     return P
 
 
+def unsaturated_rpn(P, scale=0.25):
+    """A copy of `P` with RPN_cls_score's weight and bias scaled.  The random init of the stride-8 net gives RPN class logits of +-40: the
+    sigmoid of every top-ranked position is exactly 1.0f, its derivative (1 - y) y exactly 0, and the reference's peak back-propagation then
+    returns 0 / 0 maps for every kept peak (lib/prm/peak_response_mapping_3d.py:164-171).  Logits of +-10, as a trained net has, keep the
+    proposals' ranking (a monotone function of the same logits, up to the former ties) and give the PRM workloads maps that are not empty."""
+    P = dict(P)
+    for k in ("RPN.RPN_cls_score.weight", "RPN.RPN_cls_score.bias"):
+        P[k] = P[k] * scale
+    return P
+
+
 def synth_volume(i, shape=(128, 128, 128)):
     """N(100,10) background + 40 isotropic Gaussian blobs, clipped to uint16; returns the raw uint16 volume."""
     rng = np.random.RandomState(1234 + i)

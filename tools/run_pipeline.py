@@ -13,7 +13,7 @@ import numpy as np, torch
 from m3d.config import Cfg
 from m3d.model import DetectorM3D
 from m3d.prm import PRMEngine
-from m3d.synth import make_params, synth_volume
+from m3d.synth import make_params, synth_volume, unsaturated_rpn
 from m3d.infer import infer_prm
 from m3d.binarize import binarize_volume
 from m3d import io as mio
@@ -31,7 +31,7 @@ def main():
         P = make_params(stride=4, num_anchors=14, seed=0)
     else:
         cfg, shape = Cfg.nuclei(), (64, 300, 300)
-        P = make_params(stride=8, num_anchors=35, seed=0)
+        P = unsaturated_rpn(make_params(stride=8, num_anchors=35, seed=0))      # saturated RPN sigmoids would give 0 / 0 maps for every peak
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg))
     vol = synth_volume(0, shape)
     name = "img0"
