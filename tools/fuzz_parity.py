@@ -349,7 +349,61 @@ def f_quant_segment(rs):
     assert torch.equal(l0, l1) and torch.equal(p0, p1), ("segment", D, H, W, Wn, mode)
 
 
-ops = [("quantise/segment", f_quant_segment), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
+def f_segment_oracle(rs):
+    """binarize.segment_tile (device: quantised windows -> crops -> 2D-Otsu -> components -> painting) against the oracle's loop body of
+    tools/binarization_soma.py:65-105 / binarization_nuclei.py:92-150 on the same uint8 maps and integer boxes: labels and painted flags
+    identical."""
+    from m3d import binarize
+    D, H, W = int(rs.randint(6, 24)), int(rs.randint(8, 40)), int(rs.randint(8, 40))
+    Wn = int(rs.choice([8, 12, 20]))
+    P = int(rs.randint(1, 6))
+    win = (rs.rand(P, Wn, Wn, Wn) ** 2 * (rs.rand(P, Wn, Wn, Wn) > rs.choice([0.0, 0.3, 0.8]))).astype(np.float32)
+    if rs.rand() < 0.25:
+        win[rs.randint(P)] = 0
+    org = np.stack([rs.randint(-Wn // 2, D - 2, P), rs.randint(-Wn // 2, H - 2, P), rs.randint(-Wn // 2, W - 2, P)], 1).astype(np.int32)
+    sums = np.maximum(win.reshape(P, -1).sum(1), 1e-6).astype(np.float32)
+    w_, s_, o_ = dev(win), dev(sums), dev(org)
+    shape = (D, H, W)
+    q = m3d.prm_quantize_windows_u8(w_, s_, o_, shape).cpu().numpy()
+    img_np = (rs.randint(0, 3000, shape) * (rs.rand(*shape) > 0.1)).astype(np.uint16)
+    c = np.stack([rs.uniform(0, W, P), rs.uniform(0, H, P), rs.uniform(0, D, P)], 1); e = rs.uniform(2, 20, (P, 3))
+    dets = np.hstack((c - e / 2, c + e / 2, rs.uniform(0.4, 1, (P, 1))))
+    mode = "soma" if rs.rand() < 0.5 else "nuclei"
+    boxes = binarize.det_boxes_int(dets, shape, mode)
+    okb = (boxes[:, 3] >= boxes[:, 0]) & (boxes[:, 4] >= boxes[:, 1]) & (boxes[:, 5] >= boxes[:, 2]) & (boxes[:, :3].min(1) >= 0) & \
+          (boxes[:, 3] < W) & (boxes[:, 4] < H) & (boxes[:, 5] < D)
+    if not okb.all():                                    # the reference's slicing of an inverted / outside box is a different code path: boxes inside only
+        return
+    l1, p1 = binarize.segment_tile(dev(img_np), (w_, s_, o_), dets, mode=mode)
+    seg, painted = O.segment_tile(img_np, q, boxes, mode)
+    got = l1.cpu().numpy()
+    got = np.where(got < 0, 0, got).astype(np.uint16)
+    assert np.array_equal(got, seg), ("segment labels", shape, Wn, mode, int((got != seg).sum()))
+    assert np.array_equal(p1.cpu().numpy().astype(bool), painted), ("painted", shape, mode)
+
+
+def f_x3conv(rs):
+    """m3d_conv3d_x3_forward (bf16x3 cut on the bf16 matrix cores) as conv3d(x - min x, relu(W), padding 1) against float64: fp32-level
+    error, exact zeros where the inputs under every positive weight are zero; ragged shapes, odd chunk counts, batches."""
+    from m3d import ops as mops
+    cin = int(16 * rs.randint(1, 9)); cout = int(rs.choice([8, 32, 64, 96, 128, 200]))
+    D, H, W = int(rs.randint(1, 10)), int(rs.randint(1, 14)), int(rs.randint(1, 40))
+    B = int(rs.randint(1, 3))
+    x = (rs.rand(B, cin, D, H, W) * (rs.rand(B, cin, D, H, W) > rs.choice([0.0, 0.5, 0.95]))).astype(np.float32) + 0.5
+    if rs.rand() < 0.5:
+        x[:, :, : max(1, D // 2)] = 0.5
+    w = (rs.randn(cout, cin, 3, 3, 3) * 0.1).astype(np.float32)
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    xc, wc = xt.cuda(), wt.cuda()
+    off = mops.reduce_min(xc)
+    got = mops.X3Conv3d(wc, mops.W_RELU)(xc, in_offset=off).cpu().double()
+    ref = torch.nn.functional.conv3d((xt - float(off)).double(), torch.relu(wt).double(), padding=1)
+    scale = float(ref.abs().max()) or 1.0
+    assert float((got - ref).abs().max()) <= 4e-6 * scale, ("x3 conv error", cin, cout, (D, H, W), float((got - ref).abs().max()) / scale)
+    assert torch.equal(got == 0, ref == 0), ("x3 conv zeros", cin, cout, (D, H, W))
+
+
+ops = [("quantise/segment", f_quant_segment), ("segment_tile vs oracle", f_segment_oracle), ("conv3d bf16x3", f_x3conv), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
        ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3", f_linear), ("mask paste", f_mask_paste), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
