@@ -1165,6 +1165,21 @@ def main():
                     except Exception as e:                   # a sub-record must not lose the headline
                         res[key] = {"error": "%s: %s" % (type(e).__name__, e)}
                     torch.cuda.empty_cache()
+                # the nuclei tile of rounds 1-3 (saturated RPN sigmoids: 67 peaks whose maps are all 0 / 0, see prm_params) beside the repaired
+                # one, so that the round-over-round trend reads off the line
+                try:
+                    sub = copy.copy(args)
+                    sub.workload, sub.steps, sub.warmup, sub.prm_rpn_logit_scale, sub.no_cpu_baseline = "prm-nuclei", 10, 5, 1.0, True
+                    old = bench_prm(sub, rank, world, dist)
+                    if isinstance(res.get("prm_nuclei_tile"), dict) and old is not None:
+                        res["prm_nuclei_tile"]["rounds_1_3_workload"] = {
+                            "ms_per_step": old["ms_per_step"], "peaks_per_tile": old["config"]["peaks_per_tile"],
+                            "instances_painted": old["config"]["instances_painted"],
+                            "what": "the same code on the random init of rounds 1-3: every kept peak's RPN sigmoid is exactly 1.0f and its map 0 / 0"}
+                except Exception as e:
+                    if isinstance(res.get("prm_nuclei_tile"), dict):
+                        res["prm_nuclei_tile"]["rounds_1_3_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
                 try:
                     res["volume_pipeline"] = condensed(bench_volume(args, rank, world, dist, reps=2, cpu_budget_s=10.0))
                 except Exception as e:
