@@ -211,7 +211,7 @@ def cone_limited_gflop_per_peak(stride, in_size=None):
     8a-12): window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per
     voxel of the n^3 window.  Issued = what the kernels put on the matrix cores: every product for the small windows; for the strips
     the voxels the strip really holds (planes: min(n, depth of the layer's map) - the depth-clipped strips -, rows n, columns the
-    strip's pitch) x 4/9 (16-voxel windows, F(2x2,3x3)) or 1/3 (from 18 voxels, F(2x4,3x3)); the 5^3 stem occupies 32 MFMA rows for
+    strip's pitch) x 1/3 (F(2x4,3x3), from 16 voxels); the 5^3 stem occupies 32 MFMA rows for
     its 25 (dy, dx) taps."""
     if stride == 8:
         L = [(256, 256, 3, 3, 8), (256, 256, 3, 5, 8), (256, 128, 3, 7, 8), (128, 128, 3, 16, 4), (128, 64, 3, 18, 4), (64, 64, 3, 38, 2),
@@ -224,11 +224,9 @@ def cone_limited_gflop_per_peak(stride, in_size=None):
     for a, b, k, n, down in L:
         if k == 5:
             vox, f = n ** 3, 32.0 / 25.0
-        elif n >= 18:
-            pitch = 4 * ((n + (1 if n % 4 else 0) + 3) // 4) if n % 4 else n + 4      # quad-aligned strip (strip_geom mode 2): 18 -> 20, 38 -> 40, 40 -> 44
-            vox, f = min(n, depth // down) * n * pitch, 1.0 / 3.0
         elif n >= 16:
-            vox, f = min(n, depth // down) * n * (n + 1), 4.0 / 9.0
+            pitch = 4 * ((n + (1 if n % 4 else 0) + 3) // 4) if n % 4 else n + 4      # quad-aligned strip (strip_geom mode 2): 16 -> 20, 18 -> 20, 38 -> 40, 40 -> 44
+            vox, f = min(n, depth // down) * n * pitch, 1.0 / 3.0
         else:
             vox, f = n ** 3, 1.0
         issued += 2.0 * a * b * k ** 3 * vox * f
@@ -250,7 +248,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     cfg = Cfg.nuclei(score_thresh=0.0) if nuclei else Cfg.soma()
     P = prm_params(cfg, args)
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), norm_stream=bool(getattr(args, "prm_norm_stream", 1)),
-                    backward_streams=int(getattr(args, "prm_backward_streams", 1)))
+                    backward_streams=int(getattr(args, "prm_backward_streams", 1)), strip_f24_min=int(getattr(args, "prm_f24_min", 16)))
     S, H, W = cfg.in_size
     vol = torch.from_numpy(tiling.norm1(synth_volume(rank, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
     from m3d import binarize
@@ -1106,6 +1104,7 @@ def main():
     ap.add_argument("--prm-norm-stream", type=int, default=1, help="PRM workloads: 0 = norm convs queued on the tile's own stream instead of a second one (A/B)")
     ap.add_argument("--prm-rpn-logit-scale", type=float, default=0.25, help="PRM workloads, nuclei net: factor on the random-init RPN class logits (1.0 = rounds 1-3: saturated sigmoids, all-zero maps)")
     ap.add_argument("--prm-pipeline", type=int, default=0, help="PRM tile workloads: 1 = the two-tile software pipeline (m3d.prm.TilePipeline) instead of one prm_tile call per step (A/B: no faster)")
+    ap.add_argument("--prm-f24-min", type=int, default=16, help="PRM workloads: smallest window that takes the F(2x4) strip family (A/B)")
     ap.add_argument("--prm-binarize-stream", type=int, default=1, help="PRM workloads: 0 = a tile's binarisation stage on the tile's stream instead of its own (where it runs beside the next tile's forward) (A/B)")
     ap.add_argument("--prm-backward-streams", type=int, default=1, help="PRM workloads: 2 = the peaks' back-propagation as two halves on two streams (A/B)")
     ap.add_argument("--no-subrecords", action="store_true", help="default workload at N = 1: skip configs1_backbone / stress_rois / configs3_prm_soma / prm_nuclei_tile / volume_pipeline")

@@ -15,7 +15,7 @@ from .model import DetectorM3D, _NOSPAN
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
-                 strip_f24=True, strip_f24_min=17, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True):
+                 strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True):
         self.det = det
         # norm_stream: prm_tile runs the norm convs on a second HIP stream next to proposals / box head / peak selection (launches of
         # 1-128 workgroups that leave most of the chip idle) instead of queueing them behind those launches on the tile's stream
@@ -43,8 +43,9 @@ class PRMEngine:
         self.strip_wino = bool(strip_wino)
         # windows >= strip_f24_min wide take the F(2x4,3x3) family (1/3 instead of 4/9 of the MFMA work) on the QUAD-ALIGNED strip layout
         # (ops.strip_geometry mode 2: no output quad of one window reads another window's columns, so F(4,3)'s rounding-level footprint
-        # stays inside the peak); the alignment costs columns (38 -> pitch 40 instead of 39, 16 -> 20 instead of 17), which is why the
-        # small windows keep the exactly-local F(2x2) family on the dense layout
+        # stays inside the peak); the alignment costs columns (38 -> pitch 40 instead of 39, 16 -> 20 instead of 17): at 16 voxels the two
+        # nearly cancel (3/4 of the MFMAs x 20/17 of the columns; measured -0.7 % of a tile), below 16 there are no strips at all.
+        # strip_f24_min = 17 keeps the exactly-local F(2x2) family on the dense layout for the 16-voxel windows (rounds 3 / 4 first half)
         self.strip_f24 = bool(strip_f24) and self.strip_wino
         self.strip_f24_min = int(strip_f24_min)
         # forward: the RESPONSE convs of the un-pooled layers may take the detection path's Winograd kernels (values differ from the
