@@ -481,6 +481,11 @@ int m3d_conv3d_x3_supported(int cin, int cout);
 int m3d_conv3d_x3_pack(const float* d_weight, int cin, int cout, int relu_weights, void* d_packed, void* stream);
 int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                           int width, const float* d_in_offset, void* stream);
+/* The same with a caller workspace (m3d_conv3d_x3_workspace_bytes; 0 = none needed): maps too small to fill the chip are cut along K into
+ * up to four ranges of input channels, one workgroup each, whose partial sums a second kernel adds in range order (deterministic). */
+size_t m3d_conv3d_x3_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
+int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                             int width, const float* d_in_offset, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
  * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on

@@ -78,6 +78,8 @@ struct X3Args {
   const float* x; const u32x4* wp; float* out; const float* in_off;
   int B, cin, cout, D, H, W;
   int tx, ty, tz, ntile, per_xcd, units;
+  int ksplit;              // > 1: the input channels are cut into `ksplit` ranges of whole chunk pairs, one workgroup each; range k writes its
+  float* part;             // partial sums to part + k * B * cout * D * H * W and conv3d_x3_reduce_kernel adds them in range order
 };
 
 // column (lane % 32) of a 32-voxel block -> (x, y) inside its 16 x 2 patch
@@ -90,6 +92,8 @@ __device__ __forceinline__ void col_xy(int c, int* x, int* y) {
   else { *x = c - 16; *y = 1; }
 }
 
+// SPLIT: the launch cuts K into a.ksplit ranges (small maps); the unsplit instantiation keeps its compile-time zero range start
+template <bool SPLIT>
 __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   extern __shared__ float lds_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(lds_f);              // [input: 6 * NHV][weights: 2 * 6 * TM] units
@@ -98,15 +102,19 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int u = xcd * a.per_xcd + idx;
   if (idx >= a.per_xcd || u >= a.units) return;
-  const int ct = u % a.ntile;
-  int sp = u / a.ntile;
+  const int ks = SPLIT ? u % a.ksplit : 0;                         // K range fastest, then the cout tile: neighbours share the input tile in L2
+  const int ct = SPLIT ? (u / a.ksplit) % a.ntile : u % a.ntile;
+  int sp = SPLIT ? u / (a.ksplit * a.ntile) : u / a.ntile;
   const int bx = sp % a.tx; sp /= a.tx;
   const int by = sp % a.ty; sp /= a.ty;
   const int bz = sp % a.tz;
   const int b = sp / a.tz;
   const int x0 = bx * TX, y0 = by * TY, z0 = bz * TZ;
   const size_t HW = (size_t)a.H * a.W, DHW = HW * a.D;
-  const int chunks = a.cin / 16, steps = chunks * 27;
+  const int pairs = (a.cin / 16 + 1) / 2;                          // ranges start on even chunks: the parity-unrolled chunk bodies below
+  const int cb0 = SPLIT ? 2 * (int)((long long)ks * pairs / a.ksplit) : 0;
+  const int chunks = SPLIT ? min(a.cin / 16, 2 * (int)((long long)(ks + 1) * pairs / a.ksplit)) : a.cin / 16;
+  const int steps = chunks * 27;                                   // (names as in the unsplit kernel: `chunks` / `steps` = END of this range)
   const float off = a.in_off ? *a.in_off : 0.f;
 
   // ---- staging tasks of this thread: task = tid + NT * i -> (8-channel group g = task / NHV, halo voxel hv = task % NHV)
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
     }
   };
   // ---- weights: one tap = 384 units; thread -> unit tid (+ unit 256 + tid for tid < 128)
-  const u32x4* const wsrc = a.wp + (size_t)ct * steps * W_UNITS;
+  const u32x4* const wsrc = a.wp + (size_t)ct * (a.cin / 16) * 27 * W_UNITS;      // the tile's steps of ALL chunks (`steps` ends this range)
   // two register sets, one per step parity, and three LDS slots (slot of step s = tap % 3; 27 taps: the same in every chunk): the weights
   // of step s + 4 are requested when step s ends, written to LDS when step s + 2 ends and first read (prefetched) during step s + 3
   u32x4 sw[2][2];
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   // eight times the fp32 kernel's error.  Restarting the run every second chunk (324 steps) bounds the drift by the run's length (3e-7); the read-modify-write
   // of the 64 KB output tile per chunk stays in L2.
   const int z = z0 + wave;
-  float* const ob = a.out + ((size_t)b * a.cout + ct * TM) * DHW;
+  float* const ob = (SPLIT ? a.part + (size_t)ks * a.B * a.cout * DHW : a.out) + ((size_t)b * a.cout + ct * TM) * DHW;
   auto flush = [&](bool first) __attribute__((always_inline)) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
@@ -241,16 +249,17 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
     else f.b[k - 2][p] = __builtin_bit_cast(bf16x8, lds[(X3_EXP & 2) ? hvB : hvB + (dz * HY + 2 * (k - 2) + dy) * HX + dx + p * 2 * NHV]);
   };
 
-  fetch_in(0);
-  fetch_w(0, 0);
-  if (steps > 1) fetch_w(1, 1);
+  const int sb0 = cb0 * 27;                                        // first step of the range (even: register set 0, LDS slot 0)
+  fetch_in(cb0);
+  fetch_w(sb0, 0);
+  if (sb0 + 1 < steps) fetch_w(sb0 + 1, 1);
   commit_in();
   commit_w(0, 0);
-  if (steps > 1) commit_w(1, 1);
+  if (sb0 + 1 < steps) commit_w(1, 1);
   __syncthreads();
-  if (steps > 2) fetch_w(2, 0);
-  if (steps > 3) fetch_w(3, 1);
-  if (chunks > 1) fetch_in(1);
+  if (sb0 + 2 < steps) fetch_w(sb0 + 2, 0);
+  if (sb0 + 3 < steps) fetch_w(sb0 + 3, 1);
+  if (cb0 + 1 < chunks) fetch_in(cb0 + 1);
 #pragma unroll
   for (int i = 0; i < 12; ++i) read_frag(F0, i, 0, 0);
 
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
       __syncthreads();
     }
     // the accumulators restart every second chunk (see `flush`): runs of at most 324 accumulation steps
-    if ((c & 1) || c + 1 == chunks) { if (!(X3_EXP & 16) || c + 1 == chunks) flush(c < 2); }
+    if ((c & 1) || c + 1 == chunks) { if (!(X3_EXP & 16) || c + 1 == chunks) flush(c < cb0 + 2); }
     if (c + 2 < chunks) fetch_in(c + 2);
     if (c + 1 < chunks) {
       Frags& first = par ? F0 : F1;                                 // parity of the next chunk's first step
@@ -300,9 +309,21 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
     }
   };
 #pragma unroll 1
-  for (int c = 0; c < chunks; c += 2) {
+  for (int c = cb0; c < chunks; c += 2) {
     run_chunk(c, 0);
     if (c + 1 < chunks) run_chunk(c + 1, 1);
+  }
+}
+
+// out[e] = part[0][e] + part[1][e] + ... in range order (deterministic); n4 = elements / 4
+__global__ __launch_bounds__(256) void conv3d_x3_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ out, long long n4, int ksplit) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    float4 s = part[e];
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 v = part[(size_t)k * n4 + e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[e] = s;
   }
 }
 
@@ -326,8 +347,35 @@ M3D_API int m3d_conv3d_x3_pack(const float* d_weight, int cin, int cout, int rel
   return m3d::check_launch("conv3d_x3_pack");
 }
 
+namespace {
+// K ranges for a launch: none while the (spatial tile, cout tile) units give most CUs a workgroup; below 192 units up to 4 ranges of whole
+// chunk pairs (the nuclei net's 8 x 25 x 25 maps: 112 units -> 4 ranges, 0.313 -> 0.164 ms; a 16 x 40 x 40 map's 240 units gained 2-6 % in
+// isolation and nothing in the tile - the partial sums and the reduce launch cost what the second range saves - and stays whole)
+int x3_ksplit(long long units, int cin, size_t out_elems) {
+  const int pairs = (cin / 16 + 1) / 2;
+  int s = 1;
+  while (units < 192 && s < 4 && units * s < 384 && 2 * s <= pairs) s *= 2;
+  return (out_elems % 4 == 0) ? s : 1;                             // the reduce kernel adds float4s
+}
+}  // namespace
+
+M3D_API size_t m3d_conv3d_x3_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0 || cin % 16) return 0;
+  const long long units = (long long)batch * ((width + TX - 1) / TX) * ((height + TY - 1) / TY) * ((depth + TZ - 1) / TZ) * ((cout + TM - 1) / TM);
+  const size_t elems = (size_t)batch * cout * depth * height * width;
+  const int s = x3_ksplit(units, cin, elems);
+  return s > 1 ? (size_t)s * elems * sizeof(float) : 0;
+}
+
 M3D_API int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                                   int width, const float* d_in_offset, void* stream) {
+  return m3d_conv3d_x3_forward_ws(d_x, d_packed, d_out, batch, cin, cout, depth, height, width, d_in_offset, nullptr, 0, stream);
+}
+
+/* With a workspace of m3d_conv3d_x3_workspace_bytes the launch may cut K into ranges (small maps: more workgroups, partial sums added in
+ * range order by a second kernel - deterministic); without one (null / too small) every workgroup runs all of K. */
+M3D_API int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                                     int width, const float* d_in_offset, void* d_workspace, size_t workspace_bytes, void* stream) {
   if (batch < 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
   if (batch == 0) return M3D_OK;
   if (!d_x || !d_packed || !d_out) return M3D_EINVAL;
@@ -337,11 +385,26 @@ M3D_API int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float*
   a.x = d_x; a.wp = reinterpret_cast<const u32x4*>(d_packed); a.out = d_out; a.in_off = d_in_offset;
   a.B = batch; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width;
   a.tx = (width + TX - 1) / TX; a.ty = (height + TY - 1) / TY; a.tz = (depth + TZ - 1) / TZ; a.ntile = (cout + TM - 1) / TM;
-  const long long units = (long long)batch * a.tx * a.ty * a.tz * a.ntile;
+  long long units = (long long)batch * a.tx * a.ty * a.tz * a.ntile;
+  const size_t elems = (size_t)batch * cout * depth * height * width;
+  a.ksplit = x3_ksplit(units, cin, elems);
+  if (a.ksplit > 1 && (!d_workspace || workspace_bytes < (size_t)a.ksplit * elems * sizeof(float))) a.ksplit = 1;
+  a.part = a.ksplit > 1 ? reinterpret_cast<float*>(d_workspace) : nullptr;
+  units *= a.ksplit;
   if (units > 0x3FFFFFFFll) return M3D_EUNSUPPORTED;
   a.units = (int)units; a.per_xcd = (int)((units + 7) / 8);
-  auto kern = conv3d_x3_kernel;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.per_xcd)), dim3(NT), LDS_BYTES, m3d::as_stream(stream), a);
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.per_xcd)), dim3(NT), LDS_BYTES, m3d::as_stream(stream), a);
+  };
+  if (a.ksplit > 1) launch(conv3d_x3_kernel<true>);
+  else launch(conv3d_x3_kernel<false>);
+  if (a.ksplit > 1) {
+    const long long n4 = (long long)(elems / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3d_x3_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream),
+                       reinterpret_cast<const float4*>(a.part), reinterpret_cast<float4*>(d_out), n4, a.ksplit);
+  }
   return m3d::check_launch("conv3d_x3_forward");
 }

@@ -401,9 +401,14 @@ class X3Conv3d:
         check(lib().m3d_conv3d_x3_pack(_ptr(weight), self.cin, self.cout, int(mode == W_RELU), _ptr(self.packed), _stream()), "conv3d_x3_pack")
 
     def workgroups(self, shape):
-        """launch size for x of `shape` [B, cin, D, H, W]: 64 output channels x (16 x 4 x 4) voxels per workgroup"""
+        """launch size for x of `shape` [B, cin, D, H, W]: 64 output channels x (16 x 4 x 4) voxels per workgroup, times the K ranges the
+        library cuts a small launch into (m3d_conv3d_x3_forward_ws: up to 4, whole pairs of 16-channel chunks)"""
         B, _, D, H, W = shape
-        return B * ((D + 3) // 4) * ((H + 3) // 4) * ((W + 15) // 16) * ((self.cout + 63) // 64)
+        units = B * ((D + 3) // 4) * ((H + 3) // 4) * ((W + 15) // 16) * ((self.cout + 63) // 64)
+        pairs, s = (self.cin // 16 + 1) // 2, 1
+        while units < 192 and s < 4 and units * s < 384 and 2 * s <= pairs:
+            s *= 2
+        return units * s
 
     def __call__(self, x, in_offset=None, out=None):
         _need_gpu(x)
@@ -413,8 +418,16 @@ class X3Conv3d:
             raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
-        check(lib().m3d_conv3d_x3_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, _ptr(in_offset), _stream()),
-              "conv3d_x3_forward")
+        wsb = lib().m3d_conv3d_x3_workspace_bytes(B, Cin, self.cout, D, H, W)
+        ws = None
+        if wsb:
+            key = (torch.cuda.current_stream().cuda_stream, x.device)           # one scratch buffer per stream (the norm convs run on their own)
+            cache = self.__dict__.setdefault("_ws", {})
+            ws = cache.get(key)
+            if ws is None or ws.numel() < wsb:
+                ws = cache[key] = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+        check(lib().m3d_conv3d_x3_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, _ptr(in_offset), _ptr(ws),
+                                             C.c_size_t(wsb), _stream()), "conv3d_x3_forward")
         return out
 
 
