@@ -1069,6 +1069,14 @@ def test_bf16x3_direct_conv_has_fp32_accuracy_and_the_fp32_kernels_exact_zeros(c
     zero = ref == 0
     assert int(zero.sum()) > 0
     assert torch.equal(got == 0, zero) and torch.equal(f32 == 0, zero)
+    # without a workspace the library runs every workgroup over all of K (no split): same sums in another order
+    import ctypes as C
+    from m3d._lib import lib, check
+    conv = ops.X3Conv3d(wc, ops.W_RELU)
+    whole = torch.empty_like(got, device="cuda")
+    check(lib().m3d_conv3d_x3_forward(C.c_void_p(xc.data_ptr()), C.c_void_p(conv.packed.data_ptr()), C.c_void_p(whole.data_ptr()), batch, cin, cout,
+                                      shape[0], shape[1], shape[2], C.c_void_p(off.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "x3")
+    assert float((whole.cpu().double() - ref).abs().max()) / scale < 4e-6 and torch.equal(whole.cpu() == 0, zero)
     plain = ops.X3Conv3d(wc, ops.W_PLAIN)(xc).cpu()                          # signed weights, no offset
     ref2 = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
     assert float((plain.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6
