@@ -197,12 +197,20 @@ def run_dry(args, rank, world, dist):
             assert t.shape == ((i % 7) + 1, 7) and float(t[0, 0]) == float(i), (i, t.shape)
     dt = timed_loop(step, args.steps, args.warmup, dist, lambda: None)
     dt = sync_max_time(dt, dist, "cpu")
+    xchg = None
+    if dist is not None:                                   # the exchange alone, as the GPU line reports it
+        mine_t = [fake(i) for i in mine]
+        nx = 10
+        dtx = timed_loop(lambda: shard.all_gather_detections(mine_t, cap, n_items, dist), nx, 2, dist, lambda: None)
+        xchg = {"us": sync_max_time(dtx, dist, "cpu") / nx * 1e6, "ranks": world, "backend": dist.get_backend(),
+                "bytes_per_rank": int(nvol * (cap + 1) * 7 * 4)}
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry": True,
-                          "config": {"workload": "DRY RUN (no GPU): launcher + one all_gather of [%d,%d,7] per rank, stub detect step"
-                                     % (nvol, cap + 1), "volumes_per_step": n_items, "backend": args.backend}}))
+        print(compact_line({"metric": METRIC, "value": 0.0, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+                            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry": True,
+                            "config": {"workload": "DRY RUN (no GPU): launcher + one all_gather of [%d,%d,7] per rank, stub detect step"
+                                       % (nvol, cap + 1), "volumes_per_step": n_items, "volumes_per_rank": nvol, "backend": args.backend},
+                            "exchange": xchg}), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------ PRM workloads
@@ -439,6 +447,14 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                 times.append(dt_)
             dt_p = min(times)
             dt_s, res_s, nfiles_s, _ = run("serial", minfer.infer_prm_serial)
+            # one more (untimed) pipelined pass with HIP-event spans around every tile's back-propagation: the volume's roofline
+            from m3d.model import Probe
+            vp = Probe()
+            eng.probe = vp
+            run("probe", minfer.infer_prm)
+            eng.probe = None
+            back_ms = sum(a_.elapsed_time(b_) for a_, b_ in vp.spans.get("backward", []))
+            vp.spans.clear()
             vox = float(np.prod(shape))
             peaks = int(sum(len(r_["dets"]) for r_ in res_))
             rec = {"value": vox / dt_p, "unit": "voxels/s", "seconds_per_volume": dt_p, "seconds_per_volume_runs": [round(t, 4) for t in times],
@@ -449,6 +465,15 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                                              "device norm1)"},
                    "what": "host uint16 volume -> per-peak LZW TIFFs + dets.npy in a scratch directory (%s), pipelined; best of %d"
                            % ("tmpfs" if base else "tmp", reps)}
+            cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
+            if back_ms > 0 and peaks:
+                dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if ds == "nuclei" else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"
+                rec["roofline"] = {"bound": "mfma", "kernel": "peak back-propagation of the volume's %d peaks over %d tiles (backward kernels only, "
+                                                              "HIP-event spans of one extra untimed pass)" % (peaks, len(res_)),
+                                   "achieved": peaks * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": peaks * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                                   "frac_algorithmic": peaks * cone / back_ms / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": back_ms,
+                                   "share_of_volume_time": back_ms * 1e-3 / dt_p, "traffic": pmc_traffic(dom, which="largest").get("traffic")}
             if rank == 0 and not args.no_cpu_baseline and world == 1:
                 # CPU leg: the oracle's PRM tile on ONE tile of this volume with a capped number of peaks, extrapolated to all tiles and
                 # peaks, + the reference-style per-page Python TIFF writer on the dense uint8 maps of that sample
@@ -490,7 +515,7 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
             "n_gpus": world, "steps": reps, "warmup": 1, "ms_per_step": lead["seconds_per_volume"] * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "whole-volume PRM-mode infer_simple (tools/infer_simple.py:176-247): host array -> tiles -> PRM -> per-peak LZW TIFFs + dets.npy"},
-            "roofline": None, "volumes": out, "cpu_baseline": lead.get("cpu_baseline")}
+            "roofline": lead.get("roofline"), "volumes": out, "cpu_baseline": lead.get("cpu_baseline")}
 
 
 # ------------------------------------------------------------------------------------------------ detect / backbone
@@ -882,7 +907,7 @@ def bench_detect(args, rank, world, dist):
         nx = 50
         dt5 = timed_loop(lambda: exchange(packed0), nx, 5, dist, torch.cuda.synchronize)
         dt5 = sync_max_time(dt5, dist, "cpu" if via_host else "cuda")
-        xchg = {"microseconds_per_all_gather": dt5 / nx * 1e6, "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+        xchg = {"us": dt5 / nx * 1e6, "microseconds_per_all_gather": dt5 / nx * 1e6, "ranks": dist.get_world_size(), "backend": dist.get_backend(),
                 "bytes_per_rank": int(nvol * (cap + 1) * 7 * 4),
                 "what": "one all_gather_into_tensor of the packed [%d,%d,7] block per rank, issued back to back" % (nvol, cap + 1)}
         if nvol != 8:
@@ -1122,8 +1147,106 @@ def condensed(r):
     keep = ("value", "unit", "ms_per_step", "ms_per_step_median", "steps", "warmup", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "otsu", "volumes")
     out = {k: r[k] for k in keep if k in r}
     out["config"] = {k: v for k, v in r.get("config", {}).items() if k in ("workload", "peaks_per_tile", "phase_ms", "prm_forward_ms", "prm_backward_ms",
-                                                                             "rois_per_volume", "instances_painted")}
+                                                                             "rois_per_volume", "instances_painted", "launches_per_tile")}
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the ONE stdout line
+LINE_MAX = 8000        # the driver keeps ~9 KB of stdout tail: a longer final line cannot be parsed (round 4: 25.9 KB -> `parsed: null`)
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "kernel_ms", "traffic")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def _num(x, sig=6):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (sig, x))
+
+
+def _txt(s, n):
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _pick(d, keys, text=100):
+    if not isinstance(d, dict):
+        return None
+    return {k: (_txt(d[k], text) if isinstance(d[k], str) else _num(d[k])) for k in keys if k in d}
+
+
+def compact_line(res, full_path=None):
+    """The final stdout line: contract keys, `roofline`, `cpu_baseline`, and for every sub-record only value / ms_per_step /
+    roofline.frac+traffic / cpu_baseline.value / config.workload.  Everything else lives in the full record (stderr + `full_path`).
+    Always json-parseable and shorter than LINE_MAX (tests/test_bench_line.py)."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "dry")
+    out = {k: _num(res[k], 17) for k in top if k in res}
+    cfg = res.get("config", {}) or {}
+    out["config"] = {k: (_txt(v, 330) if isinstance(v, str) else _num(v)) for k, v in cfg.items()
+                     if k in ("workload", "volumes_per_step", "volumes_per_rank", "rois_per_volume", "dets_per_volume", "backend", "peaks_per_tile")
+                     and v is not None}
+    if res.get("roofline") is not None:
+        out["roofline"] = _pick(res["roofline"], ROOF_KEYS, 150)
+    elif "roofline" in res:
+        out["roofline"] = None
+    if res.get("cpu_baseline") is not None:
+        out["cpu_baseline"] = _pick(res["cpu_baseline"], CPU_KEYS, 220)
+        if "speedup_vs_cpu_baseline" in res:
+            out["speedup_vs_cpu_baseline"] = _num(res["speedup_vs_cpu_baseline"], 4)
+    for k in ("resident", "warm_host_to_host", "sustained", "without_exchange", "single_gpu_same_batch", "configs4_shape", "pipelined", "interleaved"):
+        if isinstance(res.get(k), dict):
+            out[k] = _pick(res[k], ("value", "ms_per_step", "volumes_per_step", "volumes_per_rank"))
+    if isinstance(res.get("exchange"), dict):
+        out["exchange"] = _pick(res["exchange"], ("us", "ranks", "backend", "bytes_per_rank", "collective"), 60)
+    for k in ("configs1_backbone", "stress_rois", "configs3_prm_soma", "prm_nuclei_tile", "volume_pipeline"):
+        r = res.get(k)
+        if not isinstance(r, dict):
+            continue
+        if "error" in r:
+            out[k] = {"error": _txt(str(r["error"]), 200)}
+            continue
+        sub = {"value": _num(r.get("value")), "ms_per_step": _num(r.get("ms_per_step"))}
+        if isinstance(r.get("roofline"), dict):
+            sub["roofline"] = _pick(r["roofline"], ("bound", "kernel", "frac", "frac_algorithmic", "kernel_ms", "traffic"), 90)
+        else:
+            sub["roofline"] = None
+        if isinstance(r.get("cpu_baseline"), dict):
+            sub["cpu_baseline"] = _pick(r["cpu_baseline"], ("value", "cores", "kind"))
+        c = r.get("config", {}) or {}
+        sub["config"] = {kk: (_txt(v, 150) if isinstance(v, str) else _num(v)) for kk, v in c.items()
+                         if kk in ("workload", "peaks_per_tile", "rois_per_volume", "prm_backward_ms", "prm_forward_ms", "launches_per_tile") and v is not None}
+        if isinstance(r.get("volumes"), dict):
+            sub["volumes"] = {n: _pick(v, ("value", "seconds_per_volume", "peaks")) for n, v in r["volumes"].items() if isinstance(v, dict)}
+        out[k] = sub
+    if full_path:
+        out["full_record"] = full_path
+    line = json.dumps(out)
+    if len(line) >= LINE_MAX:                        # cannot happen with the caps above; never emit an unparseable line
+        for k in ("volume_pipeline", "prm_nuclei_tile", "configs3_prm_soma", "stress_rois", "configs1_backbone", "sustained", "warm_host_to_host"):
+            if k in out and len(line) >= LINE_MAX:
+                out[k] = {"value": (out[k] or {}).get("value"), "ms_per_step": (out[k] or {}).get("ms_per_step")}
+                line = json.dumps(out)
+    assert len(line) < LINE_MAX, len(line)
+    return line
+
+
+def emit(res, tag):
+    """Full record -> stderr + gpurun_out/bench_full_<tag>.json (profiles/ keeps the judged copies); compact line -> stdout, LAST."""
+    full = json.dumps(res)
+    path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_full_%s.json" % tag)
+        with open(path, "w") as f:
+            f.write(full + "\n")
+        path = os.path.relpath(path, ROOT)
+    except OSError:
+        path = None
+    sys.stderr.write("[bench.py full record] " + full + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(res, path), flush=True)
 
 
 def main():
@@ -1219,7 +1342,7 @@ def main():
                 except Exception as e:
                     res["volume_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0 and res is not None:
-            print(json.dumps(res))
+            emit(res, "%s_n%d%s" % (args.workload, world, "_stress" if args.stress_rois else ""))
     if dist is not None:
         dist.destroy_process_group()
 

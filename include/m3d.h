@@ -486,6 +486,9 @@ int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, 
 size_t m3d_conv3d_x3_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
 int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                              int width, const float* d_in_offset, void* d_workspace, size_t workspace_bytes, void* stream);
+/* Workgroups m3d_conv3d_x3_forward_ws launches for this shape when given its workspace (spatial x cout tiles, times the K ranges): the
+ * library's own decision, for callers that choose between this kernel and m3d_conv3d_forward by how well a launch fills the chip. */
+long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int depth, int height, int width);
 
 /* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
  * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on

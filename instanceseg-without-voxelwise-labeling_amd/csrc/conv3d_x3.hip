@@ -367,6 +367,12 @@ M3D_API size_t m3d_conv3d_x3_workspace_bytes(int batch, int cin, int cout, int d
   return s > 1 ? (size_t)s * elems * sizeof(float) : 0;
 }
 
+M3D_API long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int depth, int height, int width) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0 || cin % 16) return 0;
+  const long long units = (long long)batch * ((width + TX - 1) / TX) * ((height + TY - 1) / TY) * ((depth + TZ - 1) / TZ) * ((cout + TM - 1) / TM);
+  return units * x3_ksplit(units, cin, (size_t)batch * cout * depth * height * width);
+}
+
 M3D_API int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                                   int width, const float* d_in_offset, void* stream) {
   return m3d_conv3d_x3_forward_ws(d_x, d_packed, d_out, batch, cin, cout, depth, height, width, d_in_offset, nullptr, 0, stream);

@@ -875,7 +875,25 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
  * x[m, :] = RoIAlign3D(features, roi m) (7^3 bins, sampling grid 2, the reference's memory order) is COMPUTED by the loader from the
  * feature maps and the tap tables of m3d_roi_align3d_tap_tables - the [M, C*343] intermediate never exists.  Same tiles, cut, MFMA loop
  * and split-K as m3d_linear_bf16x3_forward (256 x 128 tiles).  Measured against the two-launch path in profiles/r04_f1_ab.json. */
-M3D_API size_t m3d_linear_bf16x3_roi_workspace_bytes(int M, int N, int K) { return m3d_linear_bf16x3_workspace_bytes(M, N, K); }
+namespace {
+// the plan m3d_linear_bf16x3_roi_forward launches: x3_plan's when it is the 256-row tile (the fused loader's only instance), else a
+// 256-row plan of its own - ONE helper for the workspace query and the launch, so the reported bytes cover the `s` that runs
+X3Plan x3_roi_plan(int M, int N, int K) {
+  X3Plan p = x3_plan(M, N, K);
+  if (p.wr != 4) {
+    const int mt = (M + 255) / 256, nt = (N + BN - 1) / BN, tiles = mt * nt;
+    int s = 256 / tiles; s = s < 1 ? 1 : (s > K / 256 + 1 ? K / 256 + 1 : s);
+    p = X3Plan{4, mt, nt, s, (tiles * s + 7) / 8};
+  }
+  return p;
+}
+}  // namespace
+
+M3D_API size_t m3d_linear_bf16x3_roi_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  const X3Plan p = x3_roi_plan(M, N, K);
+  return p.slices > 1 ? (size_t)p.slices * M * N * sizeof(float) : 16;
+}
 
 M3D_API int m3d_linear_bf16x3_roi_forward(const float* d_features, int batch, int channels, int slices, int height, int width, const void* d_tab,
                                           const int32_t* d_roi_batch, const void* d_packed, const float* d_bias, float* d_out, int M, int N,
@@ -885,12 +903,7 @@ M3D_API int m3d_linear_bf16x3_roi_forward(const float* d_features, int batch, in
   if (M == 0) return M3D_OK;
   if (!d_features || !d_tab || !d_roi_batch || !d_packed || !d_out) return M3D_EINVAL;
   if (K % 32 != 0 || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
-  X3Plan p = x3_plan(M, N, K);
-  if (p.wr != 4) {                                                 // the fused loader is instantiated for the 256-row tile
-    const int mt = (M + 255) / 256, nt = (N + BN - 1) / BN, tiles = mt * nt;
-    int s = 256 / tiles; s = s < 1 ? 1 : (s > K / 256 + 1 ? K / 256 + 1 : s);
-    p = X3Plan{4, mt, nt, s, (tiles * s + 7) / 8};
-  }
+  const X3Plan p = x3_roi_plan(M, N, K);                           // the fused loader is instantiated for the 256-row tile
   const int s = p.slices;
   if (s > 1 && (!d_ws || ws_bytes < (size_t)s * M * N * sizeof(float))) return M3D_EWORKSPACE;
   FcX3Args a{nullptr, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, s, K / 32, relu, p.per_xcd};

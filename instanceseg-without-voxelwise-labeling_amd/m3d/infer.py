@@ -58,9 +58,8 @@ def _device_volume(im, patch_s):
     if im.dtype in (np.uint8, np.uint16):
         raw = ops.upload(np.ascontiguousarray(im.astype(np.uint16, copy=False)).view(np.uint16), "cuda")
         vol = ops.norm1(raw, f32_arith=False)
-    elif im.dtype == np.float32:
-        vol = ops.norm1(ops.upload(np.ascontiguousarray(im), "cuda"), f32_arith=False)
-    else:
+    else:                                                                     # float32 included: NumPy keeps mean / std / the quotient in the
+        # array's own dtype there (:180-183 on a float32 ndarray is float32 pairwise arithmetic), which the host call reproduces as is
         vol = ops.upload(tiling.norm1(im, np.float64).astype(np.float32), "cuda")
     pad_s = 0
     if slices < patch_s:                                                      # :188-195
@@ -150,9 +149,18 @@ class _WriterPool:
         self.pending.append(self.drain.submit(fn, *a))
 
     def finish(self):
-        for f in self.pending:
-            f.result()
-        self.pending = []
+        """Wait for every submitted task; the list is swapped out first, so a failed task is reported ONCE (the first error, after
+        all the others have been waited for) and never again by a later, unrelated finish()."""
+        pending, self.pending = self.pending, []
+        first = None
+        for f in pending:
+            try:
+                f.result()
+            except BaseException as e:                                        # noqa: B902 - collected, re-raised below
+                if first is None:
+                    first = e
+        if first is not None:
+            raise first
 
     def close(self):
         self.finish()
@@ -190,16 +198,17 @@ def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, 
     results = []
 
     def finish_tile(rec, ev, hbuf, P, wn, origins_h, tile_dir):
-        ev.synchronize()                                                      # the windows have landed
-        wins = hbuf.numpy()[:P * wn ** 3].reshape(P, wn, wn, wn)
-        org = origins_h.copy()
-
-        if tile_dir is not None:                                              # every `{ch}.tif` of the tile in one foreign call (C worker threads)
-            mio.write_window_stacks_u8(tile_dir, wins, org, z_first, pages, patch[1], patch[2], threads=pool.workers)
-            np.save(os.path.join(tile_dir, "dets.npy"), np.asarray(rec["dets"]))
-        if keep_maps:
-            rec["prm_u8"] = [mio.window_to_dense_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2]) for ch in range(P)]
-        pool.give(hbuf)
+        try:
+            ev.synchronize()                                                  # the windows have landed
+            wins = hbuf.numpy()[:P * wn ** 3].reshape(P, wn, wn, wn)
+            org = origins_h.copy()
+            if tile_dir is not None:                                          # every `{ch}.tif` of the tile in one foreign call (C worker threads)
+                mio.write_window_stacks_u8(tile_dir, wins, org, z_first, pages, patch[1], patch[2], threads=pool.workers)
+                np.save(os.path.join(tile_dir, "dets.npy"), np.asarray(rec["dets"]))
+            if keep_maps:
+                rec["prm_u8"] = [mio.window_to_dense_u8(wins[ch], org[ch], z_first, pages, patch[1], patch[2]) for ch in range(P)]
+        finally:
+            pool.give(hbuf)                                                   # also when a write fails: the pinned buffer goes back
 
     def post(key, out):
         """a finished tile: quantise its windows, start their copy, hand the rest to the writer pool"""

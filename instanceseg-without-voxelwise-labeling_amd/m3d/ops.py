@@ -2,6 +2,7 @@
 launches on the current torch stream; none of them synchronises unless the result size is data dependent."""
 import ctypes as C
 import math
+import threading
 
 import numpy as np
 import torch
@@ -401,14 +402,10 @@ class X3Conv3d:
         check(lib().m3d_conv3d_x3_pack(_ptr(weight), self.cin, self.cout, int(mode == W_RELU), _ptr(self.packed), _stream()), "conv3d_x3_pack")
 
     def workgroups(self, shape):
-        """launch size for x of `shape` [B, cin, D, H, W]: 64 output channels x (16 x 4 x 4) voxels per workgroup, times the K ranges the
-        library cuts a small launch into (m3d_conv3d_x3_forward_ws: up to 4, whole pairs of 16-channel chunks)"""
+        """launch size for x of `shape` [B, cin, D, H, W]: the library's own count (64 output channels x 16 x 4 x 4 voxels per
+        workgroup, times the K ranges m3d_conv3d_x3_forward_ws cuts a small launch into)"""
         B, _, D, H, W = shape
-        units = B * ((D + 3) // 4) * ((H + 3) // 4) * ((W + 15) // 16) * ((self.cout + 63) // 64)
-        pairs, s = (self.cin // 16 + 1) // 2, 1
-        while units < 192 and s < 4 and units * s < 384 and 2 * s <= pairs:
-            s *= 2
-        return units * s
+        return int(lib().m3d_conv3d_x3_launch_units(int(B), self.cin, self.cout, int(D), int(H), int(W)))
 
     def __call__(self, x, in_offset=None, out=None):
         _need_gpu(x)
@@ -717,6 +714,7 @@ class _StagingRing:
         self.pool = torch.empty((n * self.SLOT,), dtype=torch.uint8).pin_memory()       # ONE pinning call (each costs milliseconds)
         self.slots = [self.pool[k * self.SLOT:(k + 1) * self.SLOT] for k in range(n)]
         self.events, self.i, self.n, self.big = [None] * n, 0, n, []
+        self.lock = threading.Lock()       # slot choice + fill + copy + event are one critical section: drivers own worker threads
 
     def put(self, arr, device):
         arr = np.ascontiguousarray(arr)
@@ -725,6 +723,10 @@ class _StagingRing:
         out = torch.empty(arr.shape, dtype=dt, device=device)
         if nb == 0:
             return out
+        with self.lock:
+            return self._put_locked(arr, nb, out)
+
+    def _put_locked(self, arr, nb, out):
         if nb > self.SLOT:                                     # big tables: a one-off pinned buffer
             t = torch.from_numpy(arr).pin_memory()
             out.copy_(t, non_blocking=True)
@@ -761,15 +763,21 @@ class PinnedPool:
 
     def __init__(self):
         self.free = {}
+        self.lock = threading.Lock()
 
     def take(self, nbytes):
-        lst = self.free.setdefault(int(nbytes), [])
-        if not lst:
-            lst.extend(torch.empty((int(nbytes),), dtype=torch.uint8).pin_memory() for _ in range(2))
-        return lst.pop()
+        with self.lock:
+            lst = self.free.setdefault(int(nbytes), [])
+            if lst:
+                return lst.pop()
+        fresh = [torch.empty((int(nbytes),), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        with self.lock:
+            self.free[int(nbytes)].append(fresh[1])
+        return fresh[0]
 
     def give(self, buf):
-        self.free.setdefault(int(buf.numel()), []).append(buf)
+        with self.lock:
+            self.free.setdefault(int(buf.numel()), []).append(buf)
 
 
 _peak_pool = PinnedPool()

@@ -538,6 +538,33 @@ def test_pipelined_volume_driver_writes_the_serial_drivers_files_byte_for_byte(t
     assert n_piped == len(files)
 
 
+def test_float32_volumes_are_normalised_in_their_own_dtype_like_numpy(tmp_path):
+    """tools/infer_simple.py:180-183 on a float32 ndarray stays float32 (NumPy's mean / std / quotient in the array's dtype): infer_prm
+    on a float32 volume must give the files of the reference statements on the host (infer_prm_serial(device_norm=False)), byte for
+    byte - the float64 device norm1 is for integer volumes only."""
+    import os
+    from m3d.infer import infer_prm, infer_prm_serial
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=32, seed=2)
+    cfg = O.Cfg(mlp_dim=32, score_thresh=0.0)
+    eng = _engine(P, cfg)
+    rs = np.random.RandomState(9)
+    im = (rs.rand(12, 40, 40) * 900 + 50).astype(np.float32)
+    im[rs.rand(12, 40, 40) < 0.1] = 0.0                                    # the mask (im > 0) matters
+    h = infer_prm_serial(eng, im, dataset="nuclei", patch=(16, 24, 24), overlap=8, out_dir=str(tmp_path / "host"), device_norm=False)
+    b = infer_prm(eng, im, dataset="nuclei", patch=(16, 24, 24), overlap=8, out_dir=str(tmp_path / "piped"))
+    assert len(h) == len(b) >= 1
+    for rh, rb in zip(h, b):
+        assert rh["num"] == rb["num"] and np.array_equal(rh["dets"], rb["dets"]) and np.array_equal(rh["peaks"], rb["peaks"])
+        assert all(np.array_equal(x, y) for x, y in zip(rh["prm_u8"], rb["prm_u8"]))
+    n = 0
+    for root, _, names in os.walk(str(tmp_path / "host")):
+        for f in names:
+            rel = os.path.relpath(os.path.join(root, f), str(tmp_path / "host"))
+            assert open(os.path.join(root, f), "rb").read() == open(str(tmp_path / "piped" / rel), "rb").read(), rel
+            n += 1
+    assert n >= 2
+
+
 @pytest.mark.parametrize("mode", ["soma", "nuclei"])
 def test_crops_from_compact_windows_and_a_map_index_equal_the_dense_gathered_route(mode):
     """m3d_roi_normalize_idx: crops cut out of the uint8 WINDOWS (zero outside; one window covers the whole tile and carries a non-zero

@@ -252,10 +252,11 @@ def _detect_all_worker(rank, world, port, q, shape):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,ntiles", [((8, 53, 24), 10), ((8, 32, 16), 3)])
-def test_im_detect_all_sharded_over_four_ranks_uneven_and_empty_ranks(shape, ntiles):
+@pytest.mark.parametrize("shape,ntiles,world", [((8, 53, 24), 10, 4), ((8, 32, 16), 3, 4), ((8, 100, 100), 64, 8)])
+def test_im_detect_all_sharded_over_four_ranks_uneven_and_empty_ranks(shape, ntiles, world):
     """im_detect_all(dist=...) end to end on 4 gloo ranks: 10 tiles (3 + 3 + 2 + 2) and 3 tiles (rank 3 holds NONE and must still enter
-    the path's one collective) - every rank ends with the single-process result, after exactly one all_gather."""
+    the path's one collective) - every rank ends with the single-process result, after exactly one all_gather.  And BASELINE
+    configs[4]'s partition: 64 work items over 8 ranks, 8 each (gloo stands in for RCCL, which has never run here: no 8-GPU node)."""
     import sys
     import torch.multiprocessing as mp
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -271,13 +272,59 @@ def test_im_detect_all_sharded_over_four_ranks_uneven_and_empty_ranks(shape, nti
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_detect_all_worker, args=(r, 4, port, q, shape)) for r in range(4)]
+    ps = [ctx.Process(target=_detect_all_worker, args=(r, world, port, q, shape)) for r in range(world)]
     for p in ps:
         p.start()
-    got = [q.get(timeout=180) for _ in range(4)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in ps:
         p.join(60)
-    assert sorted(g[0] for g in got) == [0, 1, 2, 3]
+    assert sorted(g[0] for g in got) == list(range(world))
     for rank, ncalls, res, _ in got:
         assert ncalls == 1, (rank, ncalls)                                # one collective per rank, also on the rank without a tile
         assert res == single, rank
+
+
+def test_bench_dry_run_at_world_8_is_configs4_shape_and_a_compact_line():
+    """`bench.py --gpus 8 --vols-per-rank 8 --backend gloo --dry`: BASELINE configs[4]'s partition (64 volumes, 8 per rank) through the
+    launcher and the path's one all_gather on 8 gloo ranks; the line is as compact as the N = 1 line and names the exchange."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--vols-per-rank", "8", "--backend", "gloo", "--dry",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < 8000
+    d = json.loads(last)
+    assert d["n_gpus"] == 8 and d["config"]["volumes_per_step"] == 64 and d["config"]["volumes_per_rank"] == 8 and d["scaling"] == "weak"
+    assert d["exchange"]["ranks"] == 8 and d["exchange"]["backend"] == "gloo" and d["exchange"]["us"] > 0
+
+
+def test_writer_pool_reports_a_failed_task_once_and_keeps_working():
+    """m3d.infer._WriterPool.finish(): a failed tile write is raised by the finish() that waited for it - after every other task of
+    that batch has been waited for - and NOT again by the next volume's finish() (the pool is process-global)."""
+    from m3d.infer import _WriterPool
+    pool = _WriterPool(workers=2)
+    done = []
+
+    def bad():
+        raise IOError("disk full")
+
+    def good(tag):
+        done.append(tag)
+    pool.submit(bad)
+    pool.submit(good, "a")
+    with pytest.raises(IOError, match="disk full"):
+        pool.finish()
+    assert done == ["a"] and pool.pending == []            # the good task of the same batch ran and was waited for
+    pool.submit(good, "b")
+    pool.finish()                                          # no stale exception
+    assert done == ["a", "b"] and pool.pending == []
+    pool.submit(bad)
+    pool.submit(bad)
+    with pytest.raises(IOError):
+        pool.finish()
+    pool.finish()
+    pool.close()
