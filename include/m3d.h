@@ -66,6 +66,13 @@ int m3d_roi_align3d_forward_exact(int aligned_slices, int aligned_height, int al
                                   int sampling_ratio, const float* d_features, int batch, int channels, int slices,
                                   int height, int width, const float* d_rois, int num_rois, int roi_cols,
                                   float* d_output, void* stream);
+/* m3d_roi_align3d_forward with a caller workspace (m3d_roi_align3d_workspace_bytes(num_rois) bytes, contents irrelevant): the launch takes
+ * the RoIs in descending order of their work instead of index order, so the few large RoIs do not form its tail.  Identical results. */
+size_t m3d_roi_align3d_workspace_bytes(int num_rois);
+int m3d_roi_align3d_forward_ws(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
+                               int sampling_ratio, const float* d_features, int batch, int channels, int slices,
+                               int height, int width, const float* d_rois, int num_rois, int roi_cols,
+                               float* d_output, void* d_workspace, size_t workspace_bytes, void* stream);
 int m3d_roi_align3d_backward(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
                              int sampling_ratio, const float* d_top_grad, const float* d_rois, int num_rois,
                              int roi_cols, float* d_bottom_grad, int batch, int channels, int slices, int height,
@@ -388,7 +395,8 @@ int m3d_norm1_batched(const void* d_in, int in_dtype, int batch, int64_t n, int 
  *   m3d_prm_stem_prepare_weights  d_weight [C,1,5,5,5] -> d_wf [C,125] = flipped relu(W) (once per model).
  *   m3d_prm_stem_dgrad backward-data of conv1a (5^3, one output channel) with d_wf, times (data - offset),
  *                     clamp(min=0); d_out [P,Wn^3]; d_sums [P] = per-peak sum (for prm / prm.sum()).
- *   m3d_prm_scatter   dense [P,D,H,W] = window / sum at each peak's origin (caller zero-fills d_dense).
+ *   m3d_prm_scatter   dense [P,D,H,W] = window / sum at each peak's origin, 0 / sum elsewhere (every voxel is written: a peak whose
+ *                     map sums to 0 - saturated sigmoid - gives NaN everywhere, as the reference's prm / prm.sum() does).
  * ------------------------------------------------------------------------------------------------------- */
 int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
                  const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,

@@ -1103,7 +1103,7 @@ int choose_xt(int fam, int batch, int cin, int cout, int D, int H, int W, double
 
 m3d_w2q::Epi quad_epi(const W2Epi& e) {
   m3d_w2q::Epi q{};
-  q.scale = e.scale; q.shift = e.shift; q.relu = e.relu; q.xcd_map = xcd_map_enabled2();
+  q.scale = e.scale; q.shift = e.shift; q.relu = e.relu; q.xcd_map = m3d::opt(m3d::OPT_XCD_MAP);   // 0 off, 1 on (tile order chosen per shape), 2 / 3: A/B
   q.ksplit = e.ksplit; q.cps = e.cps; q.slice_stride = e.slice_stride; q.argmax = e.argmax;
   return q;
 }

@@ -145,7 +145,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   // XCD-contiguous order with the cout tile FASTEST, z tiles in groups of 4 inside the y sweep (as conv3d_wino2.hip)
   if (ep.xcd_map) bid = xcd_contiguous24(bid, gridDim.x);
   const int cot = bid % co_tiles; bid /= co_tiles;
-  const int tx = bid % tiles_x; bid /= tiles_x;
+  // Wide volumes (the PRM strips: every peak's window side by side along x, 36 tiles of 64 columns) take the x tile SLOWEST: the ~64
+  // workgroups an XCD holds at a time are then a compact (z, y) brick of one x range, whose halo rows and planes (6 rows for 4, 4 planes
+  // for 2: 3.1 x the tile's own voxels) are in that XCD's L2 while the neighbours fetch them, instead of 32 x tiles of one (y, z) row that
+  // share nothing (round 4's PMC: 2.97 GB fetched for 0.71 GB of strip).  xcd_map 2 / 3 force the x-fast / x-slow order (A/B).
+  const bool x_slow = ep.xcd_map == 3 || (ep.xcd_map == 1 && tiles_x > 4);
+  int tx;
+  if (x_slow) { const int per_x = tiles_y * tiles_z; tx = bid / per_x; bid -= tx * per_x; }
+  else { tx = bid % tiles_x; bid /= tiles_x; }
   constexpr int ZG = 4;
   int ty, tz;
   {

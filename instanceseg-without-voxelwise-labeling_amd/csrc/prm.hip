@@ -409,7 +409,20 @@ __global__ __launch_bounds__(1024) void window_sums_kernel(const float* __restri
   if (tid == 0) sums[p] = red[0];
 }
 
-// ---- normalise + scatter windows into dense [P, D, H, W] maps (zero elsewhere; caller memsets) ----
+// ---- dense [P, D, H, W] maps: every voxel outside a peak's window is 0 / sum - 0 for a regular peak, NaN for the degenerate one whose
+// back-propagated map is all zero (a saturated RPN sigmoid: y (1 - y) == 0), where the reference's `prm / prm.sum()` is 0 / 0 at EVERY voxel
+// (peak_response_mapping_3d.py:170-171; tests/golden/prm_saturated.npz)
+__global__ __launch_bounds__(256) void prm_fill_kernel(const float* __restrict__ sums, long long n4, float4* __restrict__ dense) {
+  const float v = 0.f / sums[blockIdx.y];
+  float4* d = dense + (size_t)blockIdx.y * n4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) d[e] = make_float4(v, v, v, v);
+}
+__global__ __launch_bounds__(256) void prm_fill_tail_kernel(const float* __restrict__ sums, long long n, long long from, float* __restrict__ dense) {
+  const float v = 0.f / sums[blockIdx.y];
+  for (long long e = from + threadIdx.x; e < n; e += 256) dense[(size_t)blockIdx.y * n + e] = v;
+}
+
+// ---- normalise + scatter windows into the dense maps ----
 __global__ __launch_bounds__(256) void prm_scatter_kernel(const float* __restrict__ win, const float* __restrict__ sums,
                                                           const int* __restrict__ origins, int P, int Wn, int D, int H, int W,
                                                           float* __restrict__ dense) {
@@ -604,7 +617,17 @@ M3D_API int m3d_prm_scatter(const float* d_windows, const float* d_sums, const i
                             int depth, int height, int width, float* d_dense, void* stream) {
   if (num_peaks < 0 || win <= 0) return M3D_EINVAL;
   if (num_peaks == 0) return M3D_OK;
-  if (!d_windows || !d_sums || !d_origins || !d_dense) return M3D_EINVAL;
+  if (!d_windows || !d_sums || !d_origins || !d_dense || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (num_peaks > 65535) return M3D_EUNSUPPORTED;
+  const long long n = (long long)depth * height * width;
+  if (n % 4 == 0 && ((uintptr_t)d_dense & 15) == 0) {
+    long long fb = (n / 4 + 255) / 256;
+    if (fb > 1024) fb = 1024;
+    hipLaunchKernelGGL(prm_fill_kernel, dim3((unsigned)fb, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_sums, n / 4,
+                       reinterpret_cast<float4*>(d_dense));
+  } else {
+    hipLaunchKernelGGL(prm_fill_tail_kernel, dim3(1, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_sums, n, 0ll, d_dense);
+  }
   const long long total = (long long)num_peaks * win * win * win;
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;

@@ -37,9 +37,9 @@ def _f32c(t):
 
 
 # ------------------------------------------------------------------ RoIAlign3D
-def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio, exact=False):
+def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio, exact=False, ordered=True):
     """exact=True: the reference kernel's fp32 operation order (bit-identical to the oracle); default: the
-    separable fast form (same samples and weights, different summation order)."""
+    separable fast form (same samples and weights, different summation order).  ordered=False: RoIs launched in index order (A/B)."""
     _need_gpu(features, rois)
     features, rois = _f32c(features), _f32c(rois)
     B, Cc, S, H, W = features.shape
@@ -47,10 +47,14 @@ def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_rati
     # functions/roi_align_3d.py:24 zero-fills before the call; every forward kernel here writes every output element
     # (RoIs without a valid sample included), so the 351 MB memset is not repeated
     out = torch.empty((R, Cc, AS, AH, AW), dtype=torch.float32, device=features.device)
-    fn = lib().m3d_roi_align3d_forward_exact if exact else lib().m3d_roi_align3d_forward
-    check(fn(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio),
-                                        _ptr(features), B, Cc, S, H, W, _ptr(rois), R, int(rois.shape[1]) if rois.dim() == 2 else 0,
-                                        _ptr(out), _stream()), "roi_align3d_forward")
+    cols = int(rois.shape[1]) if rois.dim() == 2 else 0
+    if exact:
+        check(lib().m3d_roi_align3d_forward_exact(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
+                                                  _ptr(rois), R, cols, _ptr(out), _stream()), "roi_align3d_forward_exact")
+        return out
+    ws = torch.empty((max(R, 1),), dtype=torch.int32, device=features.device) if ordered else None        # the launch order (heavy RoIs first)
+    check(lib().m3d_roi_align3d_forward_ws(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
+                                           _ptr(rois), R, cols, _ptr(out), _ptr(ws), C.c_size_t(4 * R if ordered else 0), _stream()), "roi_align3d_forward")
     return out
 
 
@@ -943,7 +947,7 @@ def prm_scatter(windows, sums, origins, shape):
     _need_gpu(windows, sums, origins)
     P, Wn = windows.shape[0], windows.shape[1]
     D, H, W = shape
-    dense = torch.zeros((P, D, H, W), dtype=torch.float32, device=windows.device)
+    dense = torch.empty((P, D, H, W), dtype=torch.float32, device=windows.device)     # the library writes every voxel
     check(lib().m3d_prm_scatter(_ptr(windows), _ptr(sums), _ptr(origins), P, Wn, D, H, W, _ptr(dense), _stream()), "prm_scatter")
     return dense
 

@@ -142,6 +142,12 @@ def test_roi_align_fast_and_complement_kernels_share_the_rois(m3d, C):
     fast = m3d.roi_align3d_forward(dev(f), dev(rois), 7, 7, 7, 0.125, 2).cpu().numpy()
     assert not np.isnan(fast).any()
     assert np.abs(fast - ref).max() <= 1e-5 * np.abs(f).max()
+    # the heavy-first launch order (m3d_roi_align3d_forward_ws: RoIs taken by descending work) changes WHICH workgroup computes a row,
+    # nothing of the row: bit-identical with the index-order launch, duplicated RoIs (equal cost: ties by index) included
+    rois2 = np.vstack((rois, rois[:7], rois[::-1][:5])).astype(np.float32)
+    a_ = m3d.roi_align3d_forward(dev(f), dev(rois2), 7, 7, 7, 0.125, 2, ordered=True)
+    b_ = m3d.roi_align3d_forward(dev(f), dev(rois2), 7, 7, 7, 0.125, 2, ordered=False)
+    assert torch.equal(a_, b_) and torch.equal(a_[:R].cpu(), torch.from_numpy(fast))
 
 
 def test_roi_align_bad_cols_and_empty(m3d):
@@ -1041,6 +1047,17 @@ def test_fc1_with_the_roialign_gather_in_its_operand_loader_equals_the_two_launc
     got = m3d.linear_roi_fused(lin, feat, rois, 0.125, relu=True)
     assert float(x[1].abs().max()) == 0.0
     assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-6
+    # and against the ORACLE, not only against the library's own two-launch path: the oracle's RoIAlign3D (the line-by-line restatement of
+    # roi_align_kernel_3d.cu:81-151, incl. its (y, x, z) memory order) followed by a float64 linear + ReLU (fast_rcnn_heads.py:114)
+    xo = O.roi_align_3d_forward(feat.cpu().numpy(), rois.cpu().numpy(), 7, 7, 7, 0.125, 2).reshape(R, -1)
+    ref64 = np.maximum(xo.astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + b.cpu().numpy().astype(np.float64), 0.0)
+    scale = float(np.abs(ref64).max())
+    assert float(np.abs(got.cpu().numpy().astype(np.float64) - ref64).max()) <= 2e-5 * scale + 1e-6
+    assert float(np.abs(ref.cpu().numpy().astype(np.float64) - ref64).max()) <= 2e-5 * scale + 1e-6
+    # the workspace query covers the plan the fused entry point really launches (small M re-plans to the 256-row tile)
+    from m3d._lib import lib
+    for M_ in (1, 7, R, 300, 1200):
+        assert lib().m3d_linear_bf16x3_roi_workspace_bytes(M_, 128, C * 343) >= 16
 
 
 @pytest.mark.parametrize("cin,cout,shape,batch", [(32, 64, (8, 20, 36), 1), (64, 64, (5, 9, 17), 2), (16, 128, (4, 4, 16), 1), (128, 96, (7, 13, 21), 1),

@@ -14,12 +14,19 @@ def _engine(P, cfg):
     return PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), peak_chunk=7)
 
 
+# Voxels of each fixture's conditioning band as measured on the MI355X box (gpurun_out/r4_t4.log; the band is the ORACLE's own
+# fp32-vs-fp64 disagreement, so it does not depend on the kernels).  A fixture may show at most twice its measured count (+ 4 voxels
+# for the ones measured at 0: the oracle's torch-CPU sums may change order with the host's thread count).
+BAND_MEASURED = {"nuclei tile peak 1": 7664, "soma tile peak 1": 71}
+
+
 def _maps_close(got, ref32, ref64=None, what=""):
     """PRM maps against the reference arithmetic: 1e-4 relative (+ 2e-6 of the map's maximum) at every voxel OUTSIDE the conditioning
-    band, 2e-3 relative inside it.  The band is measured, not assumed: the voxels where the reference's own fp32 evaluation (torch on the
-    CPU) departs from an fp64 evaluation of the same rule by more than half of the tight tolerance - the rule divides by |N| + 1e-10
-    and cuts at N < 1e-10 layer after layer (peak_backprop_3d.py:30-33), and a voxel beside that cut flips in ANY fp32 evaluation.
-    Without an fp64 run (ref64 None) the band is empty.  Prints the band's size; returns it."""
+    band; INSIDE it the error is held to 1e-4 of the map's maximum (measured: 2.9e-5).  The band is measured, not assumed: the voxels
+    where the reference's own fp32 evaluation (torch on the CPU) departs from an fp64 evaluation of the same rule by more than half of
+    the tight tolerance - the rule divides by |N| + 1e-10 and cuts at N < 1e-10 layer after layer (peak_backprop_3d.py:30-33), and a
+    voxel beside that cut flips in ANY fp32 evaluation.  Without an fp64 run (ref64 None) the band is empty.  The band's size is
+    capped per fixture at twice what was measured (BAND_MEASURED).  Prints the band's size; returns it."""
     got = np.asarray(got, np.float64); ref32 = np.asarray(ref32, np.float64)
     mx = float(np.abs(ref32).max())
     band = np.zeros(ref32.shape, bool)
@@ -28,14 +35,15 @@ def _maps_close(got, ref32, ref64=None, what=""):
         band = np.abs(ref32 - ref64) > 5e-5 * np.abs(ref64) + 1e-6 * mx
     err = np.abs(got - ref32)
     tight = err <= 1e-4 * np.abs(ref32) + 2e-6 * mx
-    loose = err <= 2e-3 * np.abs(ref32) + 2e-6 * mx
-    print("PRM map check %s: %d voxels, %d in the conditioning band (held to 2e-3), worst error outside the band %.3g of max, inside %.3g"
-          % (what, ref32.size, int(band.sum()), float((err * ~band).max()) / mx, float((err * band).max()) / mx))
+    loose = err <= 1e-4 * mx
+    cap = 2 * BAND_MEASURED.get(what, 0) + 4
+    print("PRM map check %s: %d voxels, %d in the conditioning band (cap %d; held to 1e-4 of max), worst error outside the band %.3g of max, inside %.3g"
+          % (what, ref32.size, int(band.sum()), cap, float((err * ~band).max()) / mx, float((err * band).max()) / mx))
     assert bool(tight[~band].all()), ("outside the band", what, float((err * ~band).max()) / mx, int((~tight & ~band).sum()))
     assert bool(loose[band].all()), ("inside the band", what, float((err * band).max()) / mx)
     # one flipped `N < 1e-10` decision in an upper layer moves every voxel of the cone below it: thousands of voxels of an 84^3 window
     # (measured: 7 664 of 2.56 M on the nuclei tile's interior peak, 71 on the soma tile's), never a sizeable share of the map
-    assert band.mean() < 1e-2, ("the band must stay a small share of the map", what, int(band.sum()))
+    assert int(band.sum()) <= cap, ("the band must stay at its measured size", what, int(band.sum()), cap)
     return int(band.sum())
 
 
@@ -79,6 +87,59 @@ def test_prm_golden(golden, tag):
     for i in range(got.shape[0]):
         _maps_close(got[i], g["o_prms"][i], o64[i], "golden forward tuple %s map %d" % (tag, i))
     assert np.allclose(out["prms"].sum((1, 2, 3)).cpu().numpy(), 1.0, atol=1e-4)
+
+
+def test_saturated_peaks_give_the_references_nan_maps_and_all_zero_pages(golden, tmp_path):
+    """The degenerate peak, pinned by the reference (tests/golden/gen_saturated.py: PeakResponseMapping_3d.forward + the statements of
+    tools/infer_simple.py:233-238 run through the harness): where the RPN sigmoid of a kept peak is exactly 1.0f the returned map is
+    prm / prm.sum() = 0 / 0 = NaN at EVERY voxel (peak_response_mapping_3d.py:170-171), its uint8 quantisation is all zero and so is
+    every TIFF page.  The product must return the same peaks, NaN maps for the same peaks (everywhere, not only inside the cone), the
+    same bytes from both quantisers, and pages of zeros on disk; the other peaks' maps keep the usual tolerance."""
+    import m3d
+    from m3d import io as mio
+    g = golden("prm_saturated")
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=int(g["seed"]))
+    P["RPN.RPN_cls_score.weight"] = P["RPN.RPN_cls_score.weight"] * float(g["scale"])
+    P["RPN.RPN_cls_score.bias"] = P["RPN.RPN_cls_score.bias"] * float(g["scale"])
+    cfg = O.Cfg(mlp_dim=64, score_thresh=0.0)
+    eng = _engine(P, cfg)
+    vol_t = torch.from_numpy(g["vol"])
+    out = eng.prm_tile(vol_t.cuda())
+    nan = g["nan_maps"]
+    assert nan.any() and (~nan).any()
+    assert np.array_equal(out["peaks"].cpu().numpy(), g["o_peaks"])
+    assert np.allclose(out["dets"].cpu().numpy(), g["o_dets"], rtol=1e-4, atol=1e-3)
+    prms = out["prms"].cpu().numpy()
+    idx = g["o_prms_idx"]                                                              # maps stored as floats: the NaN ones + 7 regular ones
+    assert np.array_equal(np.isnan(prms).all((1, 2, 3)), nan) and np.array_equal(np.isnan(prms).any((1, 2, 3)), nan)   # NaN at EVERY voxel of exactly those
+    assert np.array_equal(np.isnan(prms[idx]), np.isnan(g["o_prms"]))
+    assert float(out["sums"].cpu().numpy()[nan].max()) == 0.0
+    o64 = _oracle_maps(P, cfg, vol_t, g["o_peaks"][idx], True)
+    for j, i in enumerate(idx):
+        if not nan[i]:
+            _maps_close(prms[i], g["o_prms"][j], o64[j], "saturated fixture map %d" % i)
+    # infer_simple.py:233-238: the dense quantiser, the window quantiser and its compact form
+    S, H, W = g["vol"].shape[-3:]
+    q_dense = m3d.prm_quantize_u8(out["prms"]).cpu().numpy()
+    q_win = m3d.prm_quantize_windows_u8(out["windows"], out["sums"], out["origins"], (S, H, W)).cpu().numpy()
+    assert np.array_equal(q_dense[nan], g["o_u8"][nan]) and np.array_equal(q_win[nan], g["o_u8"][nan]) and int(g["o_u8"][nan].max()) == 0
+    for q in (q_dense, q_win):                                                          # finite maps: a level can flip at a rounding edge
+        d = np.abs(q[~nan].astype(np.int16) - g["o_u8"][~nan].astype(np.int16))
+        assert int(d.max()) <= 1 and float((d > 0).mean()) < 2e-3
+    # :241-245 the pages on disk, through the pipelined driver's writer (uint8 WINDOWS -> pages rebuilt around them -> LZW TIFF)
+    comp = m3d.ops.prm_quantize_windows_compact_u8(out["windows"], out["sums"], out["origins"], (S, H, W)).cpu().numpy()
+    org = out["origins"].cpu().numpy()
+    d_ = str(tmp_path / "inst")
+    import os
+    os.makedirs(d_)
+    mio.write_window_stacks_u8(d_, comp, org, 0, S, H, W, threads=2)
+    for ch in range(len(nan)):
+        page = mio.read_tiff_stack(os.path.join(d_, "%d.tif" % ch))
+        assert page.dtype == np.uint8 and page.shape == (S, H, W)
+        assert np.array_equal(page, q_win[ch])
+        if nan[ch]:
+            assert not page.any() and np.array_equal(page, g["o_u8"][ch])
+            assert open(os.path.join(d_, "%d.tif" % ch), "rb").read() == bytes(mio.encode_tiff_stack(g["o_u8"][ch]))   # = the file of the reference's bytes
 
 
 def test_prm_vs_oracle_border_peaks():

@@ -133,6 +133,35 @@ def test_net_and_prm_small(golden, tag):
     assert np.allclose(prms.numpy(), g["o_prms"], rtol=1e-3, atol=1e-6 * float(g["o_prms"].max()))
 
 
+def test_saturated_peaks_the_oracle_returns_the_references_nan_maps_and_zero_bytes(golden):
+    """tests/golden/prm_saturated.npz (the reference's PeakResponseMapping_3d.forward + tools/infer_simple.py:233-238 on a net whose
+    RPN sigmoid saturates for a part of the kept peaks): the oracle gives the same peaks, NaN at every voxel of exactly the same maps
+    (prm / prm.sum() = 0 / 0, peak_response_mapping_3d.py:170-171) and the same uint8 bytes."""
+    import warnings
+    import torch
+    torch.set_num_threads(4)
+    g = golden("prm_saturated")
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=int(g["seed"]))
+    P["RPN.RPN_cls_score.weight"] = P["RPN.RPN_cls_score.weight"] * float(g["scale"])
+    P["RPN.RPN_cls_score.bias"] = P["RPN.RPN_cls_score.bias"] * float(g["scale"])
+    cfg = O.Cfg(mlp_dim=64, score_thresh=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        crm, peaks, prms, dets = O.prm_tile(P, cfg, torch.from_numpy(g["vol"]))
+        u8 = np.stack([O.quantize_prm_u8(m) for m in prms.numpy()])
+    nan = g["nan_maps"]
+    assert np.array_equal(peaks, g["o_peaks"]) and np.allclose(dets, g["o_dets"], rtol=1e-5, atol=1e-4)
+    idx = g["o_prms_idx"]                                                  # the maps stored as floats: the NaN ones + 7 regular ones
+    mine = prms.numpy()
+    assert np.array_equal(np.isnan(mine).all((1, 2, 3)), nan) and np.array_equal(np.isnan(mine).any((1, 2, 3)), nan) and 0 < int(nan.sum()) < len(nan)
+    assert np.array_equal(np.isnan(mine[idx]), np.isnan(g["o_prms"]))
+    fin = ~nan[idx]
+    assert np.allclose(mine[idx][fin], g["o_prms"][fin], rtol=1e-3, atol=1e-6 * float(np.nanmax(g["o_prms"])))
+    assert np.array_equal(u8[nan], g["o_u8"][nan]) and not u8[nan].any()
+    d = np.abs(u8[~nan].astype(np.int16) - g["o_u8"][~nan].astype(np.int16))
+    assert int(d.max()) <= 1 and float((d > 0).mean()) < 1e-3
+
+
 def _raw_grad(O, P, saved, peak, shape):
     import torch
     F = torch.nn.functional
