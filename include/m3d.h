@@ -256,6 +256,11 @@ int m3d_maxpool3d_2x_backward(const float* d_grad_out, const uint8_t* d_argmax, 
  * lib/prm/peak_backprop_3d.py:38); stays on device so the PRM convs never synchronise with the host. */
 size_t m3d_reduce_min_workspace_bytes(void);
 int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_t ws_bytes, void* stream);
+/* The minima of up to 12 arrays in two launches (the PRM forward: one `input.min()` per patched conv): d_ins / counts are HOST arrays of
+ * `count` device pointers / element counts, d_out [count] on the device. */
+size_t m3d_reduce_min_multi_workspace_bytes(void);
+int m3d_reduce_min_multi(const float* const* d_ins, const int64_t* counts, int count, float* d_out, void* d_ws, size_t ws_bytes,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Batched, fused box post-processing: ONE launch per stage for a whole batch of tiles, one workgroup per tile, no host
@@ -401,6 +406,10 @@ int m3d_norm1_batched(const void* d_in, int in_dtype, int batch, int64_t n, int 
 int m3d_prm_seed(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
                  const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
                  float* d_out, void* stream);
+/* the same + d_origin_out int32 [P,3] (or null): every peak's (s, h, w), the origin of its 1^3 window */
+int m3d_prm_seed_ex(const int32_t* d_peaks, int num_peaks, const float* d_prob, const float* d_norm_cls,
+                    const float* d_w_cls, const float* d_h, const float* d_h_offset, int A, int C, int S, int H, int W,
+                    float* d_out, int32_t* d_origin_out, void* stream);
 /* Peak selection on the device (lib/prm/peak_response_mapping_3d.py:124-139,161-163): class 1's kept detections d_dets [rows,7]
  * (x1,y1,z1,x2,y2,z2,score; the first *d_count rows are valid) with their flat score indices d_keep_idx into (S,H,W,A)
  * (generate_proposals_3d.py:160) -> the detections whose score > peak_threshold, in order: *d_num (<= cap), d_peaks int32 [cap,4] =
@@ -605,6 +614,13 @@ int m3d_paint_instances(const uint8_t* d_mask, const int64_t* d_offsets, const i
 /* After the last m3d_paint_instances: sentinel 0xFFFFFFFF -> 0 and d_present[id] = 1 (uint8 [max_id + 1], caller zero-fills; may be
  * NULL) for every id in [1, max_id] that occurs in the volume (`mask_id in np.unique(seg)`, binarization_soma.py:103). */
 int m3d_paint_finish(uint32_t* d_volume, int64_t num_voxels, int max_id, uint8_t* d_present, void* stream);
+/* A tile's painting starts with ONE launch: the volume to the 0xFFFFFFFF sentinel, d_present [num_present] to 0 and the paint id of each
+ * of the num_rois processed detections: d_ids[r] = d_idx[r] + first_id, or -1 (never paints) where the Otsu / component stage failed
+ * (status != 0) or the detection's response map is all zero (d_map_stats: the workspace m3d_prm_quantize_windows*_u8 filled, 4 words
+ * per map; null: not tested) - binarization_soma.py:74-76,94-98. */
+int m3d_paint_begin(uint32_t* d_volume, int64_t num_voxels, uint8_t* d_present, int num_present, const int32_t* d_status_otsu,
+                    const int32_t* d_status_cc, const int32_t* d_map_stats, const int64_t* d_idx, int num_rois, int first_id,
+                    int32_t* d_ids, void* stream);
 
 #ifdef __cplusplus
 }

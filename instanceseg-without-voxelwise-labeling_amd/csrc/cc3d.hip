@@ -265,6 +265,28 @@ __global__ __launch_bounds__(256) void paint_finish_kernel(uint32_t* __restrict_
   }
 }
 
+// Start of a tile's painting in ONE launch: the label volume to the 0xFFFFFFFF sentinel, the `present` flags to 0, and the id of every
+// processed detection - idx[r] + first_id when its Otsu and component stages succeeded and its response map is not all zero
+// (binarization_soma.py:74-76, :94-98), else 0xFFFFFFFF (never paints).  Replaces a chain of seven element-wise launches.
+__global__ __launch_bounds__(256) void paint_begin_kernel(uint32_t* __restrict__ vol, long long n, uint8_t* __restrict__ present, int npresent,
+                                                          const int32_t* __restrict__ st_otsu, const int32_t* __restrict__ st_cc,
+                                                          const int32_t* __restrict__ qstat /*[maps][4], word 3 = map has a non-zero voxel*/,
+                                                          const int64_t* __restrict__ idx, int num_rois, int first_id, int32_t* __restrict__ ids) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+  if ((n & 3) == 0 && ((uintptr_t)vol & 15) == 0) {
+    uint4* v4 = reinterpret_cast<uint4*>(vol);
+    for (long long i = t; i < (n >> 2); i += step) v4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  } else {
+    for (long long i = t; i < n; i += step) vol[i] = 0xFFFFFFFFu;
+  }
+  for (long long i = t; i < npresent; i += step) present[i] = 0;
+  for (long long r = t; r < num_rois; r += step) {
+    const long long m = idx[r];
+    const bool ok = st_otsu[r] == 0 && st_cc[r] == 0 && (qstat == nullptr || qstat[4 * m + 3] != 0);
+    ids[r] = ok ? (int32_t)(m + first_id) : -1;
+  }
+}
+
 }  // namespace
 
 constexpr size_t kCcKeyBytes = 65536 * sizeof(unsigned long long);   // one selection key per RoI (grid.y <= 65535)
@@ -334,4 +356,18 @@ M3D_API int m3d_paint_finish(uint32_t* d_volume, int64_t num_voxels, int max_id,
   const int blocks = (int)min((long long)4096, (long long)((num_voxels + 255) / 256));
   hipLaunchKernelGGL(paint_finish_kernel, dim3(blocks), dim3(256), 0, m3d::as_stream(stream), d_volume, (long long)num_voxels, max_id, d_present);
   return m3d::check_launch("paint_finish");
+}
+
+/* Sentinel fill of the label volume + zero fill of d_present [num_present] + the paint ids of num_rois processed detections (d_ids[r] =
+ * d_idx[r] + first_id, or -1 where d_status_otsu[r] / d_status_cc[r] != 0 or map d_idx[r] is all zero: d_map_stats = the workspace of
+ * m3d_prm_quantize_windows*_u8, null = every map counts as non-empty), in one launch.  Then m3d_paint_instances, m3d_paint_finish. */
+M3D_API int m3d_paint_begin(uint32_t* d_volume, int64_t num_voxels, uint8_t* d_present, int num_present, const int32_t* d_status_otsu,
+                            const int32_t* d_status_cc, const int32_t* d_map_stats, const int64_t* d_idx, int num_rois, int first_id,
+                            int32_t* d_ids, void* stream) {
+  if (!d_volume || num_voxels <= 0 || num_present < 0 || num_rois < 0) return M3D_EINVAL;
+  if ((num_present && !d_present) || (num_rois && (!d_status_otsu || !d_status_cc || !d_idx || !d_ids))) return M3D_EINVAL;
+  const int blocks = (int)min((long long)2048, (long long)((num_voxels / 4 + 255) / 256 + 1));
+  hipLaunchKernelGGL(paint_begin_kernel, dim3(blocks), dim3(256), 0, m3d::as_stream(stream), d_volume, (long long)num_voxels, d_present,
+                     num_present, d_status_otsu, d_status_cc, d_map_stats, d_idx, num_rois, first_id, d_ids);
+  return m3d::check_launch("paint_begin");
 }

@@ -77,6 +77,35 @@ __global__ __launch_bounds__(256) void min_final_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
 }
 
+// the same for up to 12 arrays at once (blockIdx.y = array): the PRM forward needs the minimum of every layer's input (one norm conv
+// each, peak_backprop_3d.py:38) - two launches for all of them instead of two per layer
+constexpr int kMinMulti = 12, kMinBlocks = 128;
+struct MinMultiArgs { const float* in[kMinMulti]; long long n[kMinMulti]; };
+__global__ __launch_bounds__(256) void min_partial_multi_kernel(MinMultiArgs a, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  const float* in = a.in[blockIdx.y];
+  const long long n = a.n[blockIdx.y];
+  float v = INFINITY;
+  if ((n & 3) == 0 && ((uintptr_t)in & 15) == 0) {
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (n >> 2); e += (long long)gridDim.x * 256) {
+      const float4 q = in4[e];
+      v = fminf(fminf(v, fminf(q.x, q.y)), fminf(q.z, q.w));
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) v = fminf(v, in[e]);
+  }
+  v = wave_min(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * kMinBlocks + blockIdx.x] = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(64) void min_final_multi_kernel(const float* __restrict__ partial, float* __restrict__ out) {
+  float v = fminf(partial[blockIdx.x * kMinBlocks + threadIdx.x], partial[blockIdx.x * kMinBlocks + 64 + threadIdx.x]);
+  v = wave_min(v);
+  if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
+
 inline unsigned grid_for(long long total) {
   long long b = (total + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -115,4 +144,25 @@ M3D_API int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_w
                      (float*)d_ws);
   hipLaunchKernelGGL(min_final_kernel, dim3(1), dim3(256), 0, m3d::as_stream(stream), (const float*)d_ws, (int)blocks, d_out);
   return m3d::check_launch("reduce_min");
+}
+
+/* Minima of `count` (<= 12) device fp32 arrays in two launches: d_out[i] = min(d_ins[i][0 .. counts[i])).  d_ins / counts are HOST arrays
+ * (the pointers travel in the kernel arguments); d_ws: m3d_reduce_min_multi_workspace_bytes() bytes. */
+M3D_API size_t m3d_reduce_min_multi_workspace_bytes(void) { return sizeof(float) * kMinMulti * kMinBlocks; }
+
+M3D_API int m3d_reduce_min_multi(const float* const* d_ins, const int64_t* counts, int count, float* d_out, void* d_ws, size_t ws_bytes,
+                                 void* stream) {
+  if (count < 0 || count > kMinMulti) return M3D_EINVAL;
+  if (count == 0) return M3D_OK;
+  if (!d_ins || !counts || !d_out || !d_ws) return M3D_EINVAL;
+  if (ws_bytes < sizeof(float) * kMinMulti * kMinBlocks) return M3D_EWORKSPACE;
+  MinMultiArgs a;
+  for (int i = 0; i < kMinMulti; ++i) {
+    const int k = i < count ? i : 0;
+    if (!d_ins[k] || counts[k] <= 0) return M3D_EINVAL;
+    a.in[i] = d_ins[k]; a.n[i] = counts[k];
+  }
+  hipLaunchKernelGGL(min_partial_multi_kernel, dim3(kMinBlocks, count), dim3(256), 0, m3d::as_stream(stream), a, (float*)d_ws);
+  hipLaunchKernelGGL(min_final_multi_kernel, dim3(count), dim3(64), 0, m3d::as_stream(stream), (const float*)d_ws, d_out);
+  return m3d::check_launch("reduce_min_multi");
 }

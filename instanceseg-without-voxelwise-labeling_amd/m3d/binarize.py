@@ -49,7 +49,7 @@ def binarize_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192):
     return out
 
 
-def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all=None, win_origins=None):
+def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all=None, win_origins=None, raw_status=False):
     """Device pipeline for the detections of one tile: crop + normalise -> 2D-Otsu -> largest 26-connected component
     (-> hole fill -> 6-closing for nuclei).  image_u16 [S,H,W] CUDA, q uint8 [P,S,H,W] CUDA (quantised PRMs; with win_origins int32
     [P,3]: their compact form [P,n,n,n], the maps being zero outside their windows - nothing dense is built),
@@ -62,31 +62,33 @@ def _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty_all
     idx = np.nonzero(okb)[0]
     if len(idx) == 0:
         return None
-    idx_t = ops.upload(idx, dev)
-    bsel = ops.upload(boxes[idx], dev)
+    bh = boxes[idx]
+    # every index table of the tile in ONE staged copy: the processed rows, their boxes, crop extents (ez, ey, ex), the map of each row, crop offsets
+    dims_h = np.stack([bh[:, 5] - bh[:, 2] + 1, bh[:, 4] - bh[:, 1] + 1, bh[:, 3] - bh[:, 0] + 1], 1).astype(np.int32)
+    idx_t, bsel, dims, midx, offs_d = ops.upload_packed([idx.astype(np.int64), bh.astype(np.int32), dims_h, idx.astype(np.int32), ops.crop_offsets(bh)], dev)
     # detections with a valid crop are a subset of the tile's peaks: the crop kernels read map idx[r] of the full stack (a gathered copy
     # of the maps was 200 MB per soma tile)
     sub = len(idx) != q.shape[0]
-    oi, op, offs = ops.roi_normalize(image_u16, q, bsel, mode, boxes_host=boxes[idx], map_index=ops.upload(idx.astype(np.int32), dev) if sub else None,
-                                     win_origins=win_origins)
+    oi, op, offs = ops.roi_normalize(image_u16, q, bsel, mode, boxes_host=bh, map_index=midx if sub else None, win_origins=win_origins, offsets=offs_d)
     mask, _, st_otsu = ops.otsu2d_batch(oi, op, offs, max_gray_range)
-    dims = torch.stack([bsel[:, 5] - bsel[:, 2] + 1, bsel[:, 4] - bsel[:, 1] + 1, bsel[:, 3] - bsel[:, 0] + 1], 1).to(torch.int32)
     cc, st_cc = ops.cc_largest_batch(mask, offs, dims, invert=False, tie_last=(mode == "soma"))
     if mode == "nuclei":
         cc, _ = ops.cc_largest_batch(cc, offs, dims, invert=True, tie_last=False)         # fill holes
         cc = ops.binary_closing6_batch(cc, offs, dims)
+    if raw_status:                                   # segment_tile: the three conditions meet inside m3d_paint_begin
+        return cc, offs, bsel, idx_t, (st_otsu, st_cc)
     nonempty = nonempty_all[idx_t] if nonempty_all is not None else (q[idx_t] if sub else q).reshape(len(idx), -1).amax(1) > 0   # binarization_soma.py:74-76
     return cc, offs, bsel, idx_t, (st_otsu == 0) & (st_cc == 0) & nonempty
 
 
-def _quantised(prms, shape, compact=False):
+def _quantised(prms, shape, compact=False, stats=False):
     """uint8 maps from dense float maps [P,S,H,W], or straight from the back-propagation's cone-cropped windows when `prms` is the
     triple (windows, sums, origins) of PRMEngine.prm_tile(dense=False) - the dense float maps are then never built.  compact (triple
     only): the uint8 WINDOWS [P,n,n,n] instead of dense uint8 maps (the crop kernels read them through the origins).
     Returns (maps, nonempty flags or None, window origins or None)."""
     if isinstance(prms, (tuple, list)):
         if compact:
-            q, ne = ops.prm_quantize_windows_compact_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
+            q, ne = ops.prm_quantize_windows_compact_u8(prms[0], prms[1], prms[2], shape, return_nonempty="stats" if stats else True)
             return q, ne, prms[2].contiguous()
         q, ne = ops.prm_quantize_windows_u8(prms[0], prms[1], prms[2], shape, return_nonempty=True)
         return q, ne, None
@@ -104,20 +106,24 @@ def segment_tile(image_u16, prms, dets, mode="soma", max_gray_range=8192, first_
     S, H, W = image_u16.shape
     P = int((prms[0] if isinstance(prms, (tuple, list)) else prms).shape[0])
     dev = image_u16.device
-    painted = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P == 0:
-        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
+        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), torch.zeros((P,), dtype=torch.bool, device=dev)
     boxes = det_boxes_int(dets.cpu().numpy() if torch.is_tensor(dets) else dets, (S, H, W), mode)
-    q, nonempty, worg = _quantised(prms, (S, H, W), compact=True)           # windows only: the crops are cut out of them directly
-    r = _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty, win_origins=worg)
+    windows = isinstance(prms, (tuple, list))
+    q, nonempty, worg = _quantised(prms, (S, H, W), compact=True, stats=windows)   # windows only: the crops are cut out of them directly
+    r = _tile_instance_masks(image_u16, q, boxes, mode, max_gray_range, nonempty, win_origins=worg, raw_status=windows)
     if r is None:
-        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), painted
+        return torch.zeros((S, H, W), dtype=torch.int32, device=dev), torch.zeros((P,), dtype=torch.bool, device=dev)
     cc, offs, bsel, idx_t, ok = r
-    ids = (idx_t + first_id).to(torch.int32)
-    ids = torch.where(ok, ids, torch.full_like(ids, -1))                                   # skipped: never paints
-    labels = torch.full((S, H, W), -1, dtype=torch.int32, device=dev)                       # 0xFFFFFFFF sentinel
+    if windows:                                       # sentinel fill + present flags + paint ids (skipped detections: -1) in one launch
+        labels, present, ids = ops.paint_begin((S, H, W), first_id + P, ok[0], ok[1], nonempty, idx_t, first_id, dev)
+    else:
+        ids = (idx_t + first_id).to(torch.int32)
+        ids = torch.where(ok, ids, torch.full_like(ids, -1))                               # skipped: never paints
+        labels = torch.full((S, H, W), -1, dtype=torch.int32, device=dev)                   # 0xFFFFFFFF sentinel
+        present = None
     ops.paint_instances_into(labels, cc, offs, bsel, ids)
-    present = ops.paint_finish(labels, first_id + P - 1)[first_id:first_id + P]           # (torch.bincount would make the host wait here)
+    present = ops.paint_finish(labels, first_id + P - 1, present)[first_id:first_id + P]  # (torch.bincount would make the host wait here)
     return labels, present
 
 

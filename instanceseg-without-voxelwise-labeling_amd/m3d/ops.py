@@ -12,8 +12,8 @@ from ._lib import lib, check, M3DError
 BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "compact_rows2", "box_head_outputs", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
-           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "norm1", "norm1_batched", "linear", "SplitLinear", "linear_roi_fused", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "X3Conv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "reduce_min_multi", "norm1", "norm1_batched", "linear", "SplitLinear", "linear_roi_fused", "mask_paste3d",
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "X3Conv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "paint_begin", "crop_offsets", "upload_packed", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -462,6 +462,20 @@ def reduce_min(x):
     return out
 
 
+def reduce_min_multi(xs):
+    """Minima of up to 12 tensors in two launches -> float32 [len(xs)] (slice i:i+1 is the device scalar of tensor i)."""
+    _need_gpu(*xs)
+    xs = [_f32c(x) for x in xs]
+    n = len(xs)
+    out = torch.empty((max(n, 1),), dtype=torch.float32, device=xs[0].device)
+    wsb = lib().m3d_reduce_min_multi_workspace_bytes()
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=xs[0].device)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    cnts = (C.c_int64 * n)(*[x.numel() for x in xs])
+    check(lib().m3d_reduce_min_multi(ptrs, cnts, n, _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min_multi")
+    return out
+
+
 def linear(x, weight, bias=None, relu=False, out=None):
     """act(x @ weight.T + bias) on the split-K fp32 MFMA GEMM (m3d_linear_forward): x [M,K], weight [N,K] (nn.Linear layout),
     bias [N] or None -> [M,N].  fast_rcnn_heads.py:84-85,114-115,15-19."""
@@ -645,8 +659,8 @@ def otsu2d_batch(image, prm, offsets, max_gray_range=4096):
     assert image.dtype == torch.uint16 and prm.dtype == torch.uint16 and offsets.dtype == torch.int64
     R = offsets.numel() - 1
     mask = torch.empty(image.shape, dtype=torch.uint8, device=image.device)
-    kb = torch.zeros((R, 2), dtype=torch.int32, device=image.device)
-    status = torch.zeros((R,), dtype=torch.int32, device=image.device)
+    kb = torch.empty((R, 2), dtype=torch.int32, device=image.device)          # otsu_eval_kernel writes both for every RoI, on every path
+    status = torch.empty((R,), dtype=torch.int32, device=image.device)
     wsb = lib().m3d_otsu2d_workspace_bytes(R, int(max_gray_range))
     ws = torch.empty((wsb,), dtype=torch.uint8, device=image.device)
     check(lib().m3d_otsu2d_batch(_ptr(image), _ptr(prm), _ptr(offsets), R, int(max_gray_range), _ptr(mask), _ptr(kb),
@@ -696,16 +710,18 @@ class SmallWindowDgrad:
         return out
 
 
-def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off):
-    """peaks int32 [P,4] (a,s,h,w); prob/norm_cls [A,S,H,W]; w_cls [A,C]; h [C,S,H,W] -> [P,C,1,1,1]."""
+def prm_seed(peaks, prob, norm_cls, w_cls, h, h_off, return_origin=False):
+    """peaks int32 [P,4] (a,s,h,w); prob/norm_cls [A,S,H,W]; w_cls [A,C]; h [C,S,H,W] -> [P,C,1,1,1] (+ with return_origin the peaks'
+    (s,h,w) as int32 [P,3], written by the same launch)."""
     _need_gpu(peaks, prob, norm_cls, w_cls, h, h_off)
     P = peaks.shape[0]
     A, S, H, W = prob.shape
     Cc = h.shape[0]
     out = torch.empty((P, Cc, 1, 1, 1), dtype=torch.float32, device=prob.device)
-    check(lib().m3d_prm_seed(_ptr(peaks), P, _ptr(prob), _ptr(norm_cls), _ptr(w_cls), _ptr(h), _ptr(h_off), A, Cc, S, H, W,
-                             _ptr(out), _stream()), "prm_seed")
-    return out
+    org = torch.empty((P, 3), dtype=torch.int32, device=prob.device) if return_origin else None
+    check(lib().m3d_prm_seed_ex(_ptr(peaks), P, _ptr(prob), _ptr(norm_cls), _ptr(w_cls), _ptr(h), _ptr(h_off), A, Cc, S, H, W,
+                                _ptr(out), _ptr(org), _stream()), "prm_seed")
+    return (out, org) if return_origin else out
 
 
 class _StagingRing:
@@ -759,6 +775,24 @@ def upload(arr, device="cuda"):
     if ring is None:
         ring = _staging[key] = _StagingRing()
     return ring.put(arr, device)
+
+
+def upload_packed(arrays, device="cuda"):
+    """Several small host arrays -> device tensors through ONE staged copy (each array at a 16-byte aligned offset of one buffer)."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    host = np.zeros((max(total, 16),), np.uint8)
+    for a, o in zip(arrays, offs):
+        host[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = upload(host, device)
+    out = []
+    for a, o in zip(arrays, offs):
+        dt = torch.from_numpy(np.empty((0,), a.dtype)).dtype
+        out.append(dev[o:o + a.nbytes].view(dt).view(a.shape) if a.nbytes else torch.empty(a.shape, dtype=dt, device=device))
+    return out
 
 
 class PinnedPool:
@@ -992,12 +1026,14 @@ def prm_quantize_windows_compact_u8(windows, sums, origins, shape, out=None, ret
     ws = torch.empty((max(16 * P, 16),), dtype=torch.uint8, device=windows.device)
     check(lib().m3d_prm_quantize_windows_compact_u8(_ptr(windows), _ptr(_f32c(sums)), _ptr(origins.contiguous()), P, Wn, D, H, W, _ptr(out),
                                                     _ptr(ws), C.c_size_t(ws.numel()), _stream()), "prm_quantize_windows_compact_u8")
+    if return_nonempty == "stats":                   # the raw per-map words (word 3 != 0: the map has a non-zero voxel), for paint_begin
+        return out, ws[:16 * P].view(torch.int32).view(P, 4)
     if return_nonempty:
         return out, ws[:16 * P].view(torch.int32).view(P, 4)[:, 3] != 0
     return out
 
 
-def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None, map_index=None, win_origins=None):
+def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None, map_index=None, win_origins=None, offsets=None):
     """image_u16 [D,H,W] uint16 CUDA; prm_u8 [R,D,H,W] uint8; boxes int32 [R,6] inclusive (x1,y1,z1,x2,y2,z2).
     Returns (img crops uint16 flat, prm crops uint16 flat, offsets int64 [R+1]) - the inputs of otsu2d_batch.
     boxes_host: the same boxes as an ndarray when the caller has them (saves the device read-back that sizes the crops).
@@ -1014,7 +1050,7 @@ def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None, map_index=Non
     sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
     assert R == 0 or (sizes.min() > 0 and b[:, :3].min() >= 0 and b[:, 3].max() < W and b[:, 4].max() < H and b[:, 5].max() < D)
     offs_h = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
-    offs = upload(offs_h, image_u16.device)
+    offs = upload(offs_h, image_u16.device) if offsets is None else offsets     # offsets: the caller uploaded crop_offsets(boxes_host) itself
     total = int(offs_h[-1]) if R else 0
     oi = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
     op = torch.empty((total,), dtype=torch.uint16, device=image_u16.device)
@@ -1220,7 +1256,7 @@ def cc_largest_batch(mask, offsets, dims, invert=False, tie_last=True):
     R = dims.shape[0]
     total = int(mask.numel())
     out = torch.empty_like(mask)
-    status = torch.zeros((R,), dtype=torch.int32, device=mask.device)
+    status = torch.empty((R,), dtype=torch.int32, device=mask.device)        # cc_init (bad crop: 2) / cc_write (0 / 1) write every entry
     wsb = lib().m3d_cc_workspace_bytes(C.c_int64(total))
     ws = torch.empty((wsb,), dtype=torch.uint8, device=mask.device)
     check(lib().m3d_cc_largest_batch(_ptr(mask), _ptr(offsets), _ptr(dims.contiguous()), R, C.c_int64(total), int(bool(invert)),
@@ -1251,13 +1287,39 @@ def paint_instances_into(vol, mask, offsets, boxes, ids):
     return vol
 
 
-def paint_finish(vol, max_id):
-    """In place: sentinel -> 0; returns bool [max_id + 1]: id occurs in the volume (index 0 unused).  No host synchronisation."""
+def paint_finish(vol, max_id, present=None):
+    """In place: sentinel -> 0; returns bool [max_id + 1]: id occurs in the volume (index 0 unused).  No host synchronisation.
+    present: a zeroed uint8 [max_id + 1] buffer (paint_begin's), else one is made here."""
     _need_gpu(vol)
     assert vol.dtype == torch.int32 and vol.is_contiguous()
-    present = torch.zeros((int(max_id) + 1,), dtype=torch.uint8, device=vol.device)
+    if present is None:
+        present = torch.zeros((int(max_id) + 1,), dtype=torch.uint8, device=vol.device)
+    assert present.numel() == int(max_id) + 1 and present.dtype == torch.uint8
     check(lib().m3d_paint_finish(_ptr(vol), C.c_int64(vol.numel()), int(max_id), _ptr(present), _stream()), "paint_finish")
     return present.view(torch.bool)
+
+
+def crop_offsets(boxes_host):
+    """int64 [R+1]: start of each box's crop in the concatenated crop buffers (boxes inclusive (x1,y1,z1,x2,y2,z2))."""
+    b = np.asarray(boxes_host).astype(np.int64)
+    sizes = (b[:, 3] - b[:, 0] + 1) * (b[:, 4] - b[:, 1] + 1) * (b[:, 5] - b[:, 2] + 1)
+    return np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+
+
+def paint_begin(shape, num_present, st_otsu, st_cc, map_stats, idx, first_id, device):
+    """One launch: label volume int32 [D,H,W] at the 0xFFFFFFFF sentinel, present uint8 [num_present] at 0, ids int32 [R] (idx + first_id,
+    -1 where a stage failed or the detection's map is all zero).  Returns (volume, present, ids)."""
+    _need_gpu(st_otsu, st_cc, idx)
+    R = int(idx.numel())
+    assert idx.dtype == torch.int64 and st_otsu.dtype == torch.int32 and st_cc.dtype == torch.int32 and st_otsu.numel() == R == st_cc.numel()
+    vol = torch.empty(tuple(shape), dtype=torch.int32, device=device)
+    present = torch.empty((int(num_present),), dtype=torch.uint8, device=device)
+    ids = torch.empty((R,), dtype=torch.int32, device=device)
+    if map_stats is not None:
+        assert map_stats.dtype == torch.int32 and map_stats.is_contiguous()
+    check(lib().m3d_paint_begin(_ptr(vol), C.c_int64(vol.numel()), _ptr(present), int(num_present), _ptr(st_otsu), _ptr(st_cc), _ptr(map_stats),
+                                _ptr(idx), R, int(first_id), _ptr(ids), _stream()), "paint_begin")
+    return vol, present, ids
 
 
 def paint_instances(mask, offsets, boxes, ids, shape):

@@ -149,10 +149,20 @@ class PRMEngine:
         missing) and, with cls, of the RPN_cls_score conv.  top_first: in the order the backward consumes them (RPN_cls_score, then the
         layers from the top down), each followed by an event on the current stream (rec["ready"]) that backward_windows waits for - the
         side-stream mode of prm_tile, where the backward of the small top windows runs beside the norm convs of the large bottom layers."""
+        idx = [i for i in (range(len(saved)) if layers is None else layers) if saved[i]["n"] is None]
+        need_cls = cls and top["n_cls"] is None
+        # every `input.min()` of this call (peak_backprop_3d.py:38) in TWO launches, not two per layer
+        xs = [saved[i]["x"] for i in idx] + ([top["h"]] if need_cls else [])
+        if xs:
+            mins = ops.reduce_min_multi(xs)
+            for k, i in enumerate(idx):
+                saved[i]["off"] = mins[k:k + 1]
+            if need_cls:
+                top["off_h"] = mins[len(idx):len(idx) + 1]
+
         def cls_norm():
-            if cls and top["n_cls"] is None:
+            if need_cls:
                 h = top["h"].unsqueeze(0)
-                top["off_h"] = ops.reduce_min(h)
                 top["n_cls"] = self.cls_norm_conv(h, in_offset=top["off_h"])[0]
                 if top_first:
                     top["ready"] = torch.cuda.Event()
@@ -160,13 +170,9 @@ class PRMEngine:
 
         if top_first:
             cls_norm()
-        idx = list(range(len(saved)) if layers is None else layers)
         for i in (reversed(idx) if top_first else idx):
             rec = saved[i]
-            if rec["n"] is not None:
-                continue
             x = rec["x"].unsqueeze(0)
-            rec["off"] = ops.reduce_min(x)
             rec["n"] = rec["norm_conv"](x, in_offset=rec["off"])[0]
             if rec["k"] == 5 and rec["pool"] and self.fused_stem:
                 rec["den"] = ops.prm_den_pool(rec["argmax"], rec["xnext"], rec["n"])      # peak-independent part of the prepare step
@@ -269,8 +275,7 @@ class PRMEngine:
         def chain(pk):
             if top.get("ready") is not None:
                 torch.cuda.current_stream().wait_event(top["ready"])
-            g = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"])
-            origin = pk[:, 1:4].contiguous()
+            g, origin = ops.prm_seed(pk, top["prob"], top["n_cls"], self.w_cls2d, top["h"], top["off_h"], return_origin=True)
             wb = dict(t=g, strip=0, P=g.shape[0], C=g.shape[1], U=1, up_off=None)
             return tail(list(reversed(saved)), wb, origin)
 

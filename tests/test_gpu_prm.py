@@ -142,6 +142,44 @@ def test_saturated_peaks_give_the_references_nan_maps_and_all_zero_pages(golden,
             assert open(os.path.join(d_, "%d.tif" % ch), "rb").read() == bytes(mio.encode_tiff_stack(g["o_u8"][ch]))   # = the file of the reference's bytes
 
 
+@pytest.mark.parametrize("U,border,slab", [(38, 1, False), (38, 1, True), (16, 1, False), (14, 1, True), (18, 1, False)])
+def test_quad_prepare_kernel_writes_the_element_kernels_strip_bit_for_bit(U, border, slab):
+    """prm_prepare_quad_kernel (four columns per thread, quad-aligned output strip, 16-byte stores) against the one-voxel-per-thread
+    kernel on the batch-major layout: every window voxel identical (same expression, same order), every other strip column zero -
+    windows that stick out of the map on all sides, the up_off PreHook, BatchNorm scales of both signs, exact zeros in the norm map,
+    layer-plane ("slab") strips."""
+    import m3d
+    from m3d import ops
+    g = torch.Generator().manual_seed(U + border)
+    P, Cc = 5, 6
+    D, H, W = (12 if slab else 48), 52, 60
+    xnext = (torch.randn((Cc, D, H, W), generator=g) * (torch.rand((Cc, D, H, W), generator=g) > 0.3)).cuda()
+    norm = (torch.rand((Cc, D, H, W), generator=g) * (torch.rand((Cc, D, H, W), generator=g) > 0.2)).cuda()
+    scale = (torch.rand((Cc,), generator=g) - 0.4).cuda()
+    gup = torch.randn((P, Cc, U, U, U), generator=g).cuda()
+    org = torch.stack([torch.randint(-U + 3, D - 2, (P,), generator=g), torch.randint(-U + 3, H - 2, (P,), generator=g),
+                       torch.randint(-U + 3, W - 2, (P,), generator=g)], 1).to(torch.int32)
+    org[0] = torch.tensor([0, 1, 2]); org[1] = torch.tensor([D - U, H - U - 1, W - U])
+    org = org.cuda()
+    off = torch.tensor([0.125], device="cuda")
+    Wn = U + 2 * border
+    for up_off in (None, off):
+        ref, o1 = ops.prm_prepare(gup, org, False, border, None, xnext, scale, norm, up_off=up_off)
+        got, o2 = ops.prm_prepare(gup, org, False, border, None, xnext, scale, norm, out_strip=2, up_off=up_off, dims=(P, Cc, U), out_slab=slab)
+        assert torch.equal(o1, o2)
+        pitch, lead, L = ops.strip_geometry(Wn, 2, P)
+        assert got.shape == (Cc, D if slab else Wn, Wn, L)
+        exp = torch.zeros_like(got)
+        for p_ in range(P):
+            oz = int(o1[p_, 0])
+            for zk in range(got.shape[1]):
+                z = zk - oz if slab else zk                     # stored plane zk holds window plane zk - origin (slab: the layer's planes)
+                if 0 <= z < Wn:
+                    exp[:, zk, :, lead + p_ * pitch:lead + p_ * pitch + Wn] = ref[p_, :, z]
+        assert torch.equal(got, exp), (U, slab, up_off is not None, int((got != exp).sum()))
+    assert int((ref != 0).sum()) > 0
+
+
 def test_prm_vs_oracle_border_peaks():
     """Peaks whose cones stick out of the tile on every side (virtual-window handling)."""
     P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=5)
