@@ -256,7 +256,8 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     cfg = Cfg.nuclei(score_thresh=0.0) if nuclei else Cfg.soma()
     P = prm_params(cfg, args)
     eng = PRMEngine(DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg), norm_stream=bool(getattr(args, "prm_norm_stream", 1)),
-                    backward_streams=int(getattr(args, "prm_backward_streams", 1)), strip_f24_min=int(getattr(args, "prm_f24_min", 16)))
+                    backward_streams=int(getattr(args, "prm_backward_streams", 1)), strip_f24_min=int(getattr(args, "prm_f24_min", 16)),
+                    fused_prepare=bool(int(getattr(args, "prm_fused_prepare", 1))))
     S, H, W = cfg.in_size
     vol = torch.from_numpy(tiling.norm1(synth_volume(rank, (S, H, W)), np.float32).astype(np.float32)).reshape(1, 1, S, H, W).cuda()
     from m3d import binarize
@@ -1265,6 +1266,7 @@ def main():
     ap.add_argument("--prm-f24-min", type=int, default=16, help="PRM workloads: smallest window that takes the F(2x4) strip family (A/B)")
     ap.add_argument("--prm-binarize-stream", type=int, default=1, help="PRM workloads: 0 = a tile's binarisation stage on the tile's stream instead of its own (where it runs beside the next tile's forward) (A/B)")
     ap.add_argument("--prm-backward-streams", type=int, default=1, help="PRM workloads: 2 = the peaks' back-propagation as two halves on two streams (A/B)")
+    ap.add_argument("--prm-fused-prepare", type=int, default=1, help="PRM workloads: 0 = strip conv and the next layer's prepare as two launches (A/B)")
     ap.add_argument("--no-subrecords", action="store_true", help="default workload at N = 1: skip configs1_backbone / stress_rois / configs3_prm_soma / prm_nuclei_tile / volume_pipeline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")

@@ -507,6 +507,16 @@ int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, float* d_ou
  * library's own decision, for callers that choose between this kernel and m3d_conv3d_forward by how well a launch fills the chip. */
 long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int depth, int height, int width);
 
+/* Round 5: backward-data of a 3^3 conv on the quad-aligned strip FUSED with the prepare step of the layer below (no pooling between them):
+ * d_gn [cin, in_planes, window, L(window)] (m3d_prm_prepare_ex2's out_strip = 2 layout; in_slab: the map's planes), d_packed =
+ * m3d_conv3d_wino2_pack_weights of the backward-data weights -> d_out [cout, out_planes, window + 2, L(window + 2)], the strip
+ * m3d_prm_prepare_ex2(in_strip = 2, out_strip = 2, pool = 0, border = 1, d_up_offset) would have made of the conv's result, bit for bit;
+ * d_origin_out = d_origin - 1.  d_out is zero-filled by the call.  M3D_EUNSUPPORTED: take the two-launch path. */
+int m3d_prm_strip_dgrad_prepare(const float* d_gn, const float* d_packed, int cin, int cout, int num_peaks, int window, int in_slab,
+                                const int32_t* d_origin, const float* d_xnext, const float* d_norm, const float* d_scale,
+                                const float* d_up_offset, int depth, int height, int width, int out_slab, float* d_out,
+                                int32_t* d_origin_out, void* stream);
+
 /* Backward-data of a 3x3x3 conv with relu(W) on batches of SMALL windows (win in {3, 5, 7}: the stride-8 / 4 stages of the peak
  * back-propagation), peaks batched densely into the GEMM N dimension; same operation as m3d_conv3d_forward_windowed on
  * dgrad-packed weights: d_gn [P, cout_fwd, win^3] -> d_out [P, cin_fwd, win^3] = (d_full[co][origin + v] - *d_full_offset) *

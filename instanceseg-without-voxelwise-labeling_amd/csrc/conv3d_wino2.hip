@@ -1205,6 +1205,45 @@ int forward_ws_family(int fam, const float* d_in, const float* d_packed, float* 
 }
 }  // namespace
 
+/* Peak back-propagation through a 3^3 conv on the quad-aligned strip layout FUSED with the next layer's prepare step (csrc/conv3d_wino24.h
+ * PrepEpi): d_gn = the prepared gradient strip of the conv being back-propagated [cin, in_planes, window, L(window)] (in_planes = window,
+ * or with in_slab the map's depth), d_packed = m3d_conv3d_wino2_pack_weights of that conv's backward-data weights (flipped, transposed
+ * relu(W): cin -> cout).  Writes the prepared strip of the layer below, d_out [cout, out_planes, window + 2, L(window + 2)] (out_planes =
+ * window + 2, or with out_slab the map's depth), zero-filled here, and d_origin_out = d_origin - 1.  d_xnext / d_norm / d_scale /
+ * d_up_offset: as m3d_prm_prepare_ex2 of the layer below with pool = 0, border = 1.  M3D_EUNSUPPORTED when the library would run this
+ * shape through another kernel family or with split-K (the caller then takes the two-launch path: conv, then m3d_prm_prepare_ex2). */
+M3D_API int m3d_prm_strip_dgrad_prepare(const float* d_gn, const float* d_packed, int cin, int cout, int num_peaks, int window, int in_slab,
+                                        const int32_t* d_origin, const float* d_xnext, const float* d_norm, const float* d_scale,
+                                        const float* d_up_offset, int depth, int height, int width, int out_slab, float* d_out,
+                                        int32_t* d_origin_out, void* stream) {
+  if (num_peaks < 0 || cin <= 0 || cout <= 0 || window <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_gn || !d_packed || !d_origin || !d_xnext || !d_norm || !d_up_offset || !d_out || !d_origin_out) return M3D_EINVAL;
+  const int fam = family_for(family(), cout);
+  if (fam != 4 || m3d::opt(m3d::OPT_TUNE_WINO2) >= 0) return M3D_EUNSUPPORTED;
+  int pitchA, leadA, pitchB, leadB; long long LA, LB;
+  m3d::strip_geom(window, 2, num_peaks, &pitchA, &leadA, &LA);
+  m3d::strip_geom(window + 2, 2, num_peaks, &pitchB, &leadB, &LB);
+  const int ZA = in_slab ? depth : window, ZB = out_slab ? depth : window + 2;
+  if ((size_t)cin * ZA * window * LA * sizeof(float) >= 0x7FFFFFFFull || (long long)(window + 2) * LB >= 0x7FFFFFFFll || LA >= (1 << 22))
+    return M3D_EUNSUPPORTED;
+  if ((long long)cout * depth * height * width >= 0x7FFFFFFFll || width < 4) return M3D_EUNSUPPORTED;   // 32-bit map offsets, 16-byte row reads
+  const int xt = choose_xt(fam, 1, cin, cout, ZA, window, (int)LA);
+  if (xt != 32 && xt != 16 && !(xt == 8 && plan_splitk(fam, 1, cin, cout, ZA, window, (int)LA).ksplit <= 1)) return M3D_EUNSUPPORTED;
+  hipStream_t st = m3d::as_stream(stream);
+  const size_t out_bytes = (size_t)cout * ZB * (window + 2) * LB * sizeof(float);
+  if (hipMemsetAsync(d_out, 0, out_bytes, st) != hipSuccess) return M3D_ELAUNCH;
+  m3d_w24::PrepEpi pe{};
+  pe.xnext = d_xnext; pe.norm = d_norm; pe.scale = d_scale; pe.xoff = d_up_offset; pe.origin = d_origin; pe.origin_out = d_origin_out;
+  pe.P = num_peaks; pe.U = window; pe.MD = depth; pe.MH = height; pe.MW = width;
+  pe.pitchA = pitchA; pe.leadA = leadA; pe.slabA = in_slab ? 1 : 0;
+  pe.pitchB = pitchB; pe.leadB = leadB; pe.slabB = out_slab ? 1 : 0;
+  pe.LB = LB; pe.ocs = (long long)ZB * (window + 2) * LB; pe.ozs = (int)((window + 2) * LB);
+  pe.inv_pitchA = 1.0f / (float)pitchA;
+  W2Epi ep{nullptr, nullptr, 0, 0, 1, 0, 0};
+  return m3d_w24::launch_prep(xt, d_gn, d_packed + pack22_floats(cin, cout), d_out, cin, cout, ZA, window, (int)LA, quad_epi(ep), pe, st);
+}
+
 M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                         int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                         void* d_ws, size_t ws_bytes, void* stream) {

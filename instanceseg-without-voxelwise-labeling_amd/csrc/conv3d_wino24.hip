@@ -128,10 +128,11 @@ struct Cfg24 {
   static_assert(SMEM_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
-template <int CC, int XQ, int WZ, int WY, bool POOL, bool AM>
+template <int CC, int XQ, int WZ, int WY, bool POOL, bool AM, bool PREP = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                                                               float* __restrict__ out, int cin, int cout, int D, int H, int W,
-                                                              int tiles_x, int tiles_y, int tiles_z, int ncb_total, m3d_w2q::Epi ep) {
+                                                              int tiles_x, int tiles_y, int tiles_z, int ncb_total, m3d_w2q::Epi ep,
+                                                              m3d_w24::PrepEpi pe) {
   using C = Cfg24<CC, XQ, WZ, WY, POOL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -526,6 +527,105 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   }
 
   if (!(z < D && y < H && x < W)) return;
+  if constexpr (PREP) {
+    // ---- fused `prepare` of the layer below (see PrepEpi): strip column x -> (peak, window column), then element by element
+    constexpr float kEpsP = 1e-10f;                                    // peak_backprop_3d.py:29
+    const int p = (int)(((float)x + 0.5f) * pe.inv_pitchA);            // exact: x < 2^22
+    if (p >= pe.P) return;                                             // the A strip's tail columns
+    const int cx = x - p * pe.pitchA, ix0 = cx - pe.leadA;
+    const int oz = pe.origin[3 * p], oy = pe.origin[3 * p + 1], ox = pe.origin[3 * p + 2];
+    if (z == 0 && y == 0 && cx == 0 && co0 == 0) { pe.origin_out[3 * p] = oz - 1; pe.origin_out[3 * p + 1] = oy - 1; pe.origin_out[3 * p + 2] = ox - 1; }
+    const int iz = pe.slabA ? z - oz : z;
+    if (iz < 0 || iz >= pe.U) return;
+    const int qz = oz + iz;
+    if (pe.slabB && (qz < 0 || qz >= pe.MD)) return;                   // B stores the map's planes only
+    const int zB = pe.slabB ? qz : iz + 1;
+    const float xoff = *pe.xoff;
+    const long long colB = (long long)p * pe.pitchB + pe.leadB + ix0 + 1;      // B column of the quad's first element
+    const bool quadB = ((colB & 3) == 0) && colB >= 0 && colB + 3 < pe.LB;
+    const int MHW = pe.MH * pe.MW;
+    // Branch-free: ALL 64 map reads of the lane (2 rows x 4 channels x 4 columns x 2 maps; clamped addresses where an element is not
+    // valid) are issued before the first use.  With a `continue` per row / channel the compiler kept each (row, channel)'s eight loads
+    // behind the previous one's stores - eight dependent memory round trips in a workgroup that is alone on its CU (measured: the
+    // fused launch 1 ms slower than conv + prepare).
+    bool okr[2], okc[4], okx[4];
+    int rbase[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int qy = oy + y + r;
+      okr[r] = (y + r < H) & (qz >= 0) & (qz < pe.MD) & (qy >= 0) & (qy < pe.MH);
+      rbase[r] = okr[r] ? qz * MHW + qy * pe.MW : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int ix = ix0 + c, qx = ox + ix; okx[c] = (ix >= 0) & (ix < pe.U) & (qx >= 0) & (qx < pe.MW); }
+    const int MV = pe.MD * MHW;
+    float xn[2][4][4], nn[2][4][4], scv2[4];
+    // A quad whose four columns are all valid (or all invalid) is read as ONE 16-byte load per map (dword-aligned: the maps' rows are not
+    // quad-aligned to the strip); only a wave that holds a quad CROSSING the map's x border reads element by element - with four
+    // 4-byte loads per quad the epilogue was bound by the L1's instruction rate (lanes 16 bytes apart: a quarter of every line per load)
+    const bool allx = okx[0] & okx[1] & okx[2] & okx[3], anyx = okx[0] | okx[1] | okx[2] | okx[3];
+    const bool wave_fast = __builtin_amdgcn_ballot_w64(anyx & !allx) == 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      okc[j] = co0 + j < cout;
+      scv2[j] = (pe.scale && okc[j]) ? pe.scale[co0 + j] : 1.f;
+    }
+    if (wave_fast) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cb = okc[j] ? (co0 + j) * MV : 0;                    // (host: cout * MV < 2^31)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int pos = cb + rbase[r] + ((okr[r] & allx) ? ox + ix0 : 0);
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+          const f32x4u a = *reinterpret_cast<const f32x4u*>(pe.xnext + pos), b = *reinterpret_cast<const f32x4u*>(pe.norm + pos);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { xn[r][j][c] = a[c]; nn[r][j][c] = b[c]; }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cb = okc[j] ? (co0 + j) * MV : 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int pos = cb + rbase[r] + ((okr[r] & okx[c]) ? ox + ix0 + c : 0);
+            xn[r][j][c] = pe.xnext[pos];
+            nn[r][j][c] = pe.norm[pos];
+          }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = r == 0 ? r0[c][j] : r1[c][j];
+          v = (xn[r][j][c] - xoff) * v;                                // PreHook of the layer just back-propagated (:16-18)
+          if (!(xn[r][j][c] > 0.f)) v = 0.f;                           // ReLU backward
+          if (pe.scale) v = v * scv2[j];                               // eval-BatchNorm backward
+          v = (nn[r][j][c] < kEpsP) ? 0.f : v / (fabsf(nn[r][j][c]) + kEpsP);   // PostHook (:30-33)
+          g[c] = (okr[r] & okx[c]) ? v : 0.f;
+        }
+        if (!(okc[j] & (y + r < H))) continue;
+        float* dst = out + (size_t)(co0 + j) * pe.ocs + (size_t)zB * pe.ozs + (size_t)(y + r + 1) * pe.LB + colB;
+        if (quadB) {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{g[0], g[1], g[2], g[3]};
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {                                // B window columns 0 .. U + 1 only (others belong to other cells)
+            const int ix = ix0 + c;
+            if (ix >= -1 && ix <= pe.U && colB + c >= 0 && colB + c < pe.LB) dst[c] = g[c];
+          }
+        }
+      }
+    }
+    return;
+  }
   const bool quad_ok = ((W & 3) == 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -554,8 +654,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   W24_STAMP(4); W24_STAMP(6);
 }
 
-template <int XQ, int WZ, int WY, bool POOL, bool AM>
-int launch24(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, m3d_w2q::Epi ep, hipStream_t st) {
+template <int XQ, int WZ, int WY, bool POOL, bool AM, bool PREP = false>
+int launch24(const float* in, const float* wp, float* out, int B, int cin, int cout, int D, int H, int W, m3d_w2q::Epi ep, hipStream_t st,
+             const m3d_w24::PrepEpi& pe = m3d_w24::PrepEpi{}) {
   using C = Cfg24<4, XQ, WZ, WY, POOL>;
   const int tiles_x = (W + C::TX - 1) / C::TX, tiles_y = (H + C::TY - 1) / C::TY, tiles_z = (D + C::TZ - 1) / C::TZ;
   const int ncb_total = ((cout + 31) / 32 + 1) / 2 * 2;
@@ -566,11 +667,11 @@ int launch24(const float* in, const float* wp, float* out, int B, int cin, int c
 #ifdef M3D_W2_STAMPS
   ep.stamps = g_w24_stamps;
 #endif
-  auto kern = conv3d_wino24_kernel<4, XQ, WZ, WY, POOL, AM>;
+  auto kern = conv3d_wino24_kernel<4, XQ, WZ, WY, POOL, AM, PREP>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, B, ep.ksplit > 1 ? ep.ksplit : 1), dim3(C::NT), lds, st, in, wp, out, cin, cout, D, H, W,
-                     tiles_x, tiles_y, tiles_z, ncb_total, ep);
+                     tiles_x, tiles_y, tiles_z, ncb_total, ep, pe);
   return m3d::check_launch("conv3d_wino24");
 }
 
@@ -604,6 +705,15 @@ int launch(int xt, bool pool, bool argmax, const float* in, const float* wp, flo
     return launch24<8, 2, 1, true, true>(in, wp, out, B, cin, cout, D, H, W, ep, st);
   }
   if (xt == 8 && !pool) return launch24<4, 2, 1, false, false>(in, wp, out, B, cin, cout, D, H, W, ep, st);
+  return M3D_EUNSUPPORTED;
+}
+
+int launch_prep(int xt, const float* in, const float* wp, float* out, int cin, int cout, int D, int H, int W, m3d_w2q::Epi ep, const PrepEpi& pe,
+                hipStream_t st) {
+  if (ep.ksplit > 1 || ep.scale || ep.shift || ep.relu) return M3D_EINVAL;       // the fused epilogue is the whole epilogue
+  if (xt == 32) return launch24<16, 2, 1, false, false, true>(in, wp, out, 1, cin, cout, D, H, W, ep, st, pe);
+  if (xt == 16) return launch24<8, 2, 1, false, false, true>(in, wp, out, 1, cin, cout, D, H, W, ep, st, pe);
+  if (xt == 8) return launch24<4, 2, 1, false, false, true>(in, wp, out, 1, cin, cout, D, H, W, ep, st, pe);
   return M3D_EUNSUPPORTED;
 }
 

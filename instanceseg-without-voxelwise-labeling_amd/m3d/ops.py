@@ -1129,6 +1129,27 @@ class WinoConv3d(object):
                         int(bool(relu)), _stream()), "conv3d_wino_forward")
         return out
 
+    def strip_prepare(self, gn, dims, origin, xnext, scale, norm, up_off, in_slab=False, out_slab=False):
+        """PRM strips: this conv's backward-data on the prepared strip `gn` [cin, planes, U, L(U)] (quad-aligned layout, dims = (P, cin, U))
+        FUSED with the prepare step of the layer below (xnext / scale / norm / up_off as ops.prm_prepare with pool = False, border = 1):
+        returns (strip [cout, planes', U + 2, L(U + 2)], origin - 1), exactly what prm_prepare(out_strip=2) would make of this conv's
+        result - or None when the library runs this shape through another kernel (the caller then takes the two launches)."""
+        _need_gpu(gn, origin, xnext, norm, up_off)
+        assert self.two_d and not self.local
+        P, cin, U = (int(v) for v in dims)
+        assert cin == self.cin and xnext.shape[0] == self.cout == norm.shape[0] and xnext.shape == norm.shape
+        MD, MH, MW = (int(v) for v in norm.shape[1:])
+        in_slab, out_slab = bool(in_slab), bool(out_slab)
+        assert tuple(gn.shape) == (cin, MD if in_slab else U, U, strip_geometry(U, 2, P)[2]) and gn.is_contiguous()
+        out = torch.empty((self.cout, MD if out_slab else U + 2, U + 2, strip_geometry(U + 2, 2, P)[2]), dtype=torch.float32, device=gn.device)
+        oo = torch.empty((P, 3), dtype=torch.int32, device=gn.device)
+        rc = lib().m3d_prm_strip_dgrad_prepare(_ptr(gn), _ptr(self.packed), cin, self.cout, P, U, int(in_slab), _ptr(origin), _ptr(xnext), _ptr(norm),
+                                               _ptr(scale), _ptr(up_off), MD, MH, MW, int(out_slab), _ptr(out), _ptr(oo), _stream())
+        if rc == -4:                                        # M3D_EUNSUPPORTED
+            return None
+        check(rc, "prm_strip_dgrad_prepare")
+        return out, oo
+
     def supports_pool(self, width):
         return width >= (24 if self.two_d else 48)
 

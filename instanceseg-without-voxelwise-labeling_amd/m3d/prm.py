@@ -15,8 +15,14 @@ from .model import DetectorM3D, _NOSPAN
 
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
-                 strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True):
+                 strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True,
+                 fused_prepare=True):
         self.det = det
+        # fused_prepare: where two consecutive layers both run on the quad-aligned strip with no pooling between them (conv3b -> conv3a,
+        # conv2b -> conv2a), the upper conv's backward-data writes the lower layer's PREPARED strip from its epilogue
+        # (ops.WinoConv3d.strip_prepare): the bare gradient strip is never stored and re-read, and the prepare launch disappears.
+        # False keeps conv + prm_prepare as two launches (what the tests compare the fused path with, bit for bit)
+        self.fused_prepare = bool(fused_prepare)
         # norm_stream: prm_tile runs the norm convs on a second HIP stream next to proposals / box head / peak selection (launches of
         # 1-128 workgroups that leave most of the chip idle) instead of queueing them behind those launches on the tile's stream
         self.norm_stream = bool(norm_stream)
@@ -210,10 +216,13 @@ class PRMEngine:
                 return 0
             return 2 if (self.strip_f24 and rec.get("dgrad_wino24") is not None and Wn >= self.strip_f24_min) else 1
 
-        def run_layer(rec, wb, origin, border):
+        def run_layer(rec, wb, origin, border, nxt=None):
             dims = (wb["P"], wb["C"], wb["U"])
             if rec.get("ready") is not None:                 # norm conv of this layer on prm_tile's side stream
                 torch.cuda.current_stream().wait_event(rec["ready"])
+            if wb.get("prepared"):                           # the layer above wrote this layer's prepared strip from its epilogue
+                gn, Wn, strip, slab = wb["t"], wb["U"], wb["strip"], wb.get("slab", False)
+                return conv_strip(rec, gn, wb["P"], Wn, strip, slab, origin, nxt)
             if fused(rec, wb):                   # un-pool + prepare + stem dgrad + PreHook in one MFMA kernel
                 w, s, origin = ops.prm_stem_dgrad_fused(wb["t"], origin, rec["den"], rec["argmax"], rec["scale"], self.stem_wa,
                                                         data[0, 0], rec["off"], strip=wb["strip"],
@@ -231,14 +240,28 @@ class PRMEngine:
                 return (w, s), origin
             cout = rec["x"].shape[0]
             if strip:                            # Winograd over the whole strip; its PreHook multiply moves to the consumer
-                y = (rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"])(gn.unsqueeze(0))[0]
-                return dict(t=y, strip=strip, P=wb["P"], C=cout, U=Wn, up_off=rec["off"], slab=slab), origin
+                return conv_strip(rec, gn, wb["P"], Wn, strip, slab, origin, nxt)
             small = rec.get("dgrad_small")
             if small is not None and Wn in small.SIZES:      # 3^3 / 5^3 / 7^3: all peaks in one dense GEMM (csrc/prm_small.hip)
                 y = small(gn, rec["x"], rec["off"], origin)
             else:
                 y = ops.conv3d_windowed(rec["dgrad"], gn, rec["x"], rec["off"], origin)
             return dict(t=y, strip=0, P=wb["P"], C=cout, U=Wn, up_off=None, slab=False), origin
+
+        def conv_strip(rec, gn, P, Wn, strip, slab, origin, nxt):
+            """backward-data of `rec`'s conv on its prepared strip; with the next layer (`nxt`) on the quad-aligned strip too and no pool
+            between them, that layer's prepare runs in this conv's epilogue"""
+            cout = rec["x"].shape[0]
+            if self.fused_prepare and strip == 2 and nxt is not None and nxt["k"] == 3 and not nxt["pool"] and wino(nxt, Wn + 2) == 2:
+                if nxt.get("ready") is not None:
+                    torch.cuda.current_stream().wait_event(nxt["ready"])
+                nslab = self.slab_strips and nxt["n"].shape[1] < Wn + 2
+                r = rec["dgrad_wino24"].strip_prepare(gn, (P, gn.shape[0], Wn), origin, nxt["xnext"], nxt["scale"], nxt["n"], rec["off"],
+                                                      in_slab=slab, out_slab=nslab)
+                if r is not None:
+                    return dict(t=r[0], strip=2, P=P, C=cout, U=Wn + 2, up_off=None, slab=nslab, prepared=True), r[1]
+            y = (rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"])(gn.unsqueeze(0))[0]
+            return dict(t=y, strip=strip, P=P, C=cout, U=Wn, up_off=rec["off"], slab=slab), origin
 
         def take(wb, c0, c1):
             """peaks [c0, c1) of a window batch"""
@@ -255,7 +278,7 @@ class PRMEngine:
             rec = layers[0]
             border = 2 if rec["k"] == 5 else 1
             P, Cc, U = wb["P"], rec["n"].shape[0], wb["U"]
-            Wn = (2 if rec["pool"] else 1) * U + 2 * border
+            Wn = U if wb.get("prepared") else (2 if rec["pool"] else 1) * U + 2 * border     # prepared: U is already this conv's window
             cmax = max(Cc, rec["x"].shape[0])
             per_peak = 4 * Wn ** 3 * cmax * 2                            # prepare output + conv output
             if fused(rec, wb):
@@ -266,7 +289,7 @@ class PRMEngine:
                 pitch = ops.strip_geometry(Wn, sm, 1)[0]
                 chunk = max(1, min(chunk, (2 ** 31 - 1) // (4 * cmax * Wn * Wn * pitch) - 1))
             if chunk >= P:
-                out, o2 = run_layer(rec, wb, origin, border)
+                out, o2 = run_layer(rec, wb, origin, border, layers[1] if len(layers) > 1 else None)
                 return (out, o2) if rec["k"] == 5 else tail(layers[1:], out, o2)
             outs = [tail(layers, take(wb, c0, min(P, c0 + chunk)), origin[c0:c0 + chunk].contiguous()) for c0 in range(0, P, chunk)]
             wins = torch.cat([o[0][0] for o in outs]); sums = torch.cat([o[0][1] for o in outs]); orig = torch.cat([o[1] for o in outs])
@@ -305,7 +328,7 @@ class PRMEngine:
         finally:
             # `tail` calls itself, so the function object and its closure cell form a reference cycle that also holds `saved` (every
             # forward tensor of the tile) until the cyclic collector runs - by then the next tile has allocated its own: break it here
-            tail = run_layer = take = fused = wino = chain = None
+            tail = run_layer = take = fused = wino = chain = conv_strip = None
         return win, sums, origins
 
     # ---------------------------------------------------------------- lib/prm/peak_response_mapping_3d.py:85-193

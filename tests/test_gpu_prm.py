@@ -236,6 +236,13 @@ def test_fused_mfma_stem_equals_the_two_kernel_path(stride, shape):
         for i in range(pk.shape[0]):
             assert np.allclose(a[i], b[i], rtol=rtol, atol=rtol * 1e-2 * b[i].max()), (i, rtol)
         assert np.allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=rtol)
+    # the upper strip conv writing the lower layer's PREPARED strip from its epilogue (m3d_prm_strip_dgrad_prepare) against conv +
+    # m3d_prm_prepare_ex2 as two launches: the same expression per element in the same order -> the same windows, bit for bit
+    assert strip.fused_prepare
+    two = PRMEngine(det, fused_prepare=False)
+    wf, sf, of = strip.backward_windows(pk, saved, top, data)
+    wt, st_, ot = two.backward_windows(pk, saved, top, data)
+    assert torch.equal(of, ot) and torch.equal(wf, wt) and torch.equal(sf, st_)
     # peak chunking cuts strips between windows
     chunked = PRMEngine(det, peak_chunk=3)
     w2, s2, o2 = chunked.backward_windows(pk, saved, top, data)
