@@ -3,7 +3,7 @@
 stem, small-window GEMM, bf16x3 norm convolutions on their own stream) against the CPU oracle's restatement of the reference's per-peak
 autograd backward (lib/prm/peak_response_mapping_3d.py:157-172, peak_backprop_3d.py:8-44): random nets (stride 4 / 8), tile shapes
 (thin, ragged, odd), seeds and peaks (borders, corners, random), each map held to tests/test_gpu_prm.py's tolerance (1e-4 relative
-outside the measured conditioning band, 2e-3 inside; the fp64 run that measures the band is only made for a map that misses the tight
+outside the measured conditioning band, 1e-4 of the map's maximum inside; the fp64 run that measures the band is only made for a map that misses the tight
 tolerance).  The rule has a second ill-conditioned spot besides the `N < 1e-10` cut: MaxPool's arg-max.  Two candidates of a pooling
 cell that agree to 1e-6 are ordered by the last bits of the convolution's rounding, and the whole gradient of that cell goes to one or
 the other; where the device's arg-max differs from the oracle's AND the two candidates agree to 1e-5 (or to 2e-5 of the layer's largest
@@ -32,7 +32,7 @@ def maps_close(got, ref32, ref64):
     band = np.abs(ref32 - ref64) > 5e-5 * np.abs(ref64) + 1e-6 * mx
     err = np.abs(got - ref32)
     tight = err <= 1e-4 * np.abs(ref32) + 2e-6 * mx
-    loose = err <= 2e-3 * np.abs(ref32) + 2e-6 * mx
+    loose = err <= 1e-4 * mx                                       # inside the band: 1e-4 of the map's maximum (tests/test_gpu_prm.py, round 5)
     ok = bool(tight[~band].all()) and bool(loose[band].all()) and band.mean() < 1e-2
     return ok, float((err * ~band).max()) / mx, int(band.sum())
 
