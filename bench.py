@@ -948,7 +948,10 @@ def bench_detect(args, rank, world, dist):
                       "roofline": ({"bound": "hbm", "kernel": "roi_align3d_fwd_v3_kernel (RoIAlign3D forward, the step's HBM-write-bound launch)",
                                     "achieved": ra_bytes / (km["roi_align3d"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": ra_bytes / (km["roi_align3d"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": km["roi_align3d"],
-                                    "algorithmic_bytes_per_launch": ra_bytes, "traffic": None} if "roi_align3d" in km else None)}
+                                    "algorithmic_bytes_per_launch": ra_bytes,
+                                    # PMC pass of the same stress step (tools/pmc_probe.py, the launch with the largest grid)
+                                    "traffic": pmc_traffic("roi_align3d_fwd_v3_kernel", which="largest").get("traffic")}
+                                   if "roi_align3d" in km else None)}
             del n0
         finally:
             cfg.rpn_nms_thresh = keep_thr

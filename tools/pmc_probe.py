@@ -30,6 +30,14 @@ for _ in range(3):
     r = det.detect_batch(x, as_dicts=False)
     m3d.nms3d_batched(r["cls_boxes"][:, 1], r["cls_counts"][:, 1], cfg.nms, pack_cap=300, want_keep=False)
 torch.cuda.synchronize()
+# the stress step of the bench (`stress_rois`: RPN NMS off, RPN_POST_NMS_TOP_N = 1000 RoIs per volume reach RoIAlign3D and the box head)
+keep_thr = cfg.rpn_nms_thresh
+cfg.rpn_nms_thresh = 1.0
+for _ in range(2):
+    r_s = det.detect_batch(x, as_dicts=False)
+torch.cuda.synchronize()
+print("stress rois", r_s["num_rois"])
+cfg.rpn_nms_thresh = keep_thr
 # configs[1]: the backbone alone on ONE volume (the sub-record `configs1_backbone`; same kernels, a quarter of the grid)
 for _ in range(3):
     det.conv_body(x[:1].contiguous())
