@@ -371,24 +371,24 @@ __global__ __launch_bounds__(kNT, 1) void prm_stem_dgrad_mfma_kernel(StemMArgs q
     if (g + 1 < steps) fetch_a(g + 1);
     if (r == 0) {
       if (ch == 0) zero_acc();
-      if (g + 1 < steps) fetch(g + 1);
+      if (!(STEM_EXP & 4) && g + 1 < steps) fetch(g + 1);
       if (ch == 7) prefetch_data(2 * by);
       if (row_in) mfma_step(tile);
       if (!(STEM_EXP & 1) && ch == 7) fold(2 * by);
-      if (g + 1 < steps) commit(next);
+      if (!(STEM_EXP & 2) && g + 1 < steps) commit(next);
     } else {
       if (ch == 0) {
         if (!(STEM_EXP & 1) && g > 0) fold(2 * by - 1);                // row 1 of the previous pair, after the early half's row 0
         zero_acc();
       }
-      if (g + 1 < steps) commit(next);
-      if (g + 2 < steps) fetch(g + 2);
+      if (!(STEM_EXP & 2) && g + 1 < steps) commit(next);
+      if (!(STEM_EXP & 4) && g + 2 < steps) fetch(g + 2);
       if (ch == 7) prefetch_data(2 * by + 1);
       if (row_in) mfma_step(tile);
     }
 #pragma unroll
     for (int s = 0; s < 10; ++s) a_cur[s] = a_next[s];
-    __syncthreads();
+    if (!(STEM_EXP & 16)) __syncthreads();
   }
   if (r == 1) {
     if (!(STEM_EXP & 1)) fold(NX - 1);
