@@ -67,7 +67,8 @@ int m3d_roi_align3d_forward_exact(int aligned_slices, int aligned_height, int al
                                   int height, int width, const float* d_rois, int num_rois, int roi_cols,
                                   float* d_output, void* stream);
 /* m3d_roi_align3d_forward with a caller workspace (m3d_roi_align3d_workspace_bytes(num_rois) bytes, contents irrelevant): the launch takes
- * the RoIs in descending order of their work instead of index order, so the few large RoIs do not form its tail.  Identical results. */
+ * the RoIs in descending order of their work instead of index order, so the few large RoIs do not form its tail, and the per-RoI set-up
+ * (sample tables, folds) is computed once and kept in the workspace instead of once per workgroup.  Identical results. */
 size_t m3d_roi_align3d_workspace_bytes(int num_rois);
 int m3d_roi_align3d_forward_ws(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
                                int sampling_ratio, const float* d_features, int batch, int channels, int slices,

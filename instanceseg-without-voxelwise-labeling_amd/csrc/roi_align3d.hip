@@ -11,6 +11,8 @@
 // [R,C,343] output — the HBM-write-bound part, 351 MB at R=1000 — is written fully coalesced.
 // This translation unit is compiled with -ffp-contract=off: the fp32 operation order is the contract
 // with oracle/m3d_oracle.c.
+#include <stddef.h>
+
 #include "m3d_common.h"
 
 namespace {
@@ -453,6 +455,23 @@ __device__ inline V3Dims v3_setup(const float* __restrict__ rois, int n, float s
   return d;
 }
 
+// The part of V3Shared the passes read (folds, geometry, ranges, s_ok: the members from `fz` to the end) as a per-RoI record in global
+// memory: roi_class_kernel runs the set-up ONCE per RoI and stores it, the working groups of the v3 launch load it (one coalesced read,
+// one barrier) instead of repeating the set-up - geometry on one thread, 42 samples, three serial range scans, 21 folds, six barriers -
+// in every one of them.  Ablation (round 5, timing-only builds): with passes, LDS-DMA and stores compiled out the launch set still took
+// 0.087 of 0.232 ms at R = 1281 and 0.353 of 0.974 ms at R = 3582 (883 large RoIs x 32 channel octets = 28 k set-ups).
+constexpr int kV3TabWords = (int)((sizeof(V3Shared) - offsetof(V3Shared, fz)) / sizeof(int));
+__device__ inline void v3_store_tab(const V3Shared& sh, int* __restrict__ tab) {
+  const int* src = reinterpret_cast<const int*>(&sh.fz);
+  for (int t = threadIdx.x; t < kV3TabWords; t += 256) tab[t] = src[t];
+}
+__device__ inline V3Dims v3_load_tab(const int* __restrict__ tab, V3Shared& sh) {
+  int* dst = reinterpret_cast<int*>(&sh.fz);
+  for (int t = threadIdx.x; t < kV3TabWords; t += 256) dst[t] = tab[t];
+  __syncthreads();
+  return v3_dims(sh.rng);
+}
+
 // waves that work on a RoI: all 4 with a quarter of the LDS each, or - sub-volume + intermediates too large for that - 2 or 1 with
 // a half / all of it
 __device__ inline int v3_waves(const V3Dims& d) {
@@ -490,13 +509,14 @@ __device__ inline int roi_cost(const float* __restrict__ r, float scale, int S, 
 // index), so that the few long RoIs start first instead of forming the launch's tail (measured on the bench's RoIs: 0.269 -> 0.214 ms).
 // Every workgroup ranks its own RoI against all R (R / 256 cost evaluations per thread): no second launch, no atomics.
 __global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict__ rois, float* __restrict__ out, int B, int C, int S, int H,
-                                                        int W, float scale, int R, int* __restrict__ order) {
+                                                        int W, float scale, int R, int* __restrict__ order, int* __restrict__ tabs) {
   __shared__ V3Shared sh;
   __shared__ int s_rank[4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const V3Dims d = v3_setup(rois, n, scale, B, S, H, W, sh);
   const unsigned int cls = !sh.s_ok ? kDeclinedBits : (v3_waves(d) == 4 ? kSmallBits : kMedBits);
   for (int k = tid; 8 * k < C; k += 256) out[((size_t)n * C + 8 * k) * 343] = __uint_as_float(cls);
+  if (tabs) v3_store_tab(sh, tabs + (size_t)n * kV3TabWords);
   if (order) {
     const int mine = roi_cost(rois + 7 * (size_t)n, scale, S, H, W);
     int before = 0;
@@ -516,7 +536,8 @@ __global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict_
 // every workgroup does the set-up and takes its ch_per_block channels if the RoI qualifies.
 __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
                                                                  float* __restrict__ out, int B, int C, int S, int H, int W, float scale,
-                                                                 int ch_per_block, int marks, const int* __restrict__ order) {
+                                                                 int ch_per_block, int marks, const int* __restrict__ order,
+                                                                 const int* __restrict__ tabs) {
   __shared__ V3Shared sh;
   extern __shared__ float dyn[];
   const int n = order ? order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;   // launch order: heavy RoIs first (roi_class_kernel)
@@ -527,7 +548,7 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __
     else if (m == kSmallBits && blockIdx.y == 0) { c0 = 0; c1 = C; }
     else return;
   }
-  const V3Dims d = v3_setup(rois, n, scale, B, S, H, W, sh);
+  const V3Dims d = tabs ? v3_load_tab(tabs + (size_t)n * kV3TabWords, sh) : v3_setup(rois, n, scale, B, S, H, W, sh);
   if (!sh.s_ok) return;                                     // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI
   const RoiGeom g = sh.sg;
   const int wave = tid >> 6;
@@ -826,14 +847,16 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
     // the per-RoI work split travels through markers in the output (every 8th channel); usable when all chunk starts fall there
     const int marks = (C % 32 == 0 && ccpb % 8 == 0) ? 1 : 0;
     if (v3 && marks) {              // work split per RoI through markers in the output (roi_class_kernel)
-      int* order = (ws && ws_bytes >= sizeof(int) * (size_t)R) ? reinterpret_cast<int*>(ws) : nullptr;    // heavy-first launch order
-      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale, R, order);
+      // workspace: [R] launch order (heaviest RoI first) + [R][kV3TabWords] set-up records (see v3_store_tab)
+      int* order = (ws && ws_bytes >= sizeof(int) * (size_t)R * (1 + kV3TabWords)) ? reinterpret_cast<int*>(ws) : nullptr;
+      int* tabs = order ? order + R : nullptr;
+      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale, R, order, tabs);
       hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, scale,
-                         8, 1, (const int*)order);
+                         8, 1, (const int*)order, (const int*)tabs);
     } else if (v3) {                // 32 channels per workgroup
       const int cpb3 = 32;
       hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S,
-                         H, W, scale, cpb3, 0, (const int*)nullptr);
+                         H, W, scale, cpb3, 0, (const int*)nullptr, (const int*)nullptr);
     }
     hipLaunchKernelGGL(roi_align3d_fwd_sep_kernel<0>, v3 ? dim3(R, (C + ccpb - 1) / ccpb) : grid, block, lds, m3d::as_stream(stream), a,
                        rois, o, B, C, S, H, W, AS, AH, AW, scale, ratio, v3 ? ccpb : cpb, v3 ? (marks ? 2 : 1) : 0);
@@ -858,7 +881,7 @@ M3D_API int m3d_roi_align3d_forward(int AS, int AH, int AW, float spatial_scale,
 /* The same forward with a caller workspace of m3d_roi_align3d_workspace_bytes(num_rois): the launch then takes the RoIs in descending
  * order of their work (sub-volume size) instead of index order - identical results (each output row is written by the same arithmetic),
  * a shorter tail.  A null / too small workspace gives the index order. */
-M3D_API size_t m3d_roi_align3d_workspace_bytes(int num_rois) { return num_rois > 0 ? sizeof(int) * (size_t)num_rois : 0; }
+M3D_API size_t m3d_roi_align3d_workspace_bytes(int num_rois) { return num_rois > 0 ? sizeof(int) * (size_t)num_rois * (1 + kV3TabWords) : 0; }
 
 M3D_API int m3d_roi_align3d_forward_ws(int AS, int AH, int AW, float spatial_scale, int sampling_ratio, const float* d_features,
                                        int batch, int channels, int slices, int height, int width, const float* d_rois,

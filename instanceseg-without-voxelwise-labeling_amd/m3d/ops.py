@@ -52,9 +52,10 @@ def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_rati
         check(lib().m3d_roi_align3d_forward_exact(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
                                                   _ptr(rois), R, cols, _ptr(out), _stream()), "roi_align3d_forward_exact")
         return out
-    ws = torch.empty((max(R, 1),), dtype=torch.int32, device=features.device) if ordered else None        # the launch order (heavy RoIs first)
+    wsb = int(lib().m3d_roi_align3d_workspace_bytes(R)) if ordered else 0          # launch order (heaviest RoI first) + per-RoI set-up records
+    ws = torch.empty((max(wsb, 4),), dtype=torch.uint8, device=features.device) if ordered else None
     check(lib().m3d_roi_align3d_forward_ws(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
-                                           _ptr(rois), R, cols, _ptr(out), _ptr(ws), C.c_size_t(4 * R if ordered else 0), _stream()), "roi_align3d_forward")
+                                           _ptr(rois), R, cols, _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "roi_align3d_forward")
     return out
 
 
