@@ -264,6 +264,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     raw = torch.from_numpy(synth_volume(rank, (S, H, W)).astype(np.uint16)).cuda()
     mode = "nuclei" if nuclei else "soma"
     npk, nlab = [], []
+    last = {"out": None}
     stamps = []
     pr = {"probe": None, "left": 0}
     bstream = torch.cuda.Stream() if int(getattr(args, "prm_binarize_stream", 1)) else None
@@ -274,6 +275,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     def post(out):
         """a tile's maps -> instance labels (binarization_*.py loop body)"""
         npk.append(0 if out is None else int(out["peaks"].shape[0]))
+        last["out"] = out
         if out is None:
             return
         if bstream is not None:                        # on a second stream: beside the next tile's forward (span events on that stream)
@@ -320,6 +322,9 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     ph = probe.median_ms()
     probe.spans.clear()
     npeaks = npk[-1] if npk else 0
+    # peaks whose RPN sigmoid is saturated are skipped by the engine (their map is exactly 0 / 0, m3d.prm skip_dead_peaks): only the
+    # back-propagated ones count as work
+    nlive = int((last["out"]["sums"] > 0).sum().item()) if last["out"] is not None else 0
     back_ms = ph.get("backward")
     fwd_ms = (ph.get("forward_response", 0.0) + ph.get("norm_convs", 0.0) + ph.get("norm_convs_late", 0.0)) or None
     otsu_ms = ph.get("binarize")
@@ -329,13 +334,14 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
     dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if nuclei else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"     # the largest backward launch
     roof = None
-    if back_ms and npeaks:
-        roof = {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks: prm_seed, prm_prepare*, the strip-Winograd / small-window / "
-                                           "stem dgrad kernels, window sums - the backward kernels ONLY (HIP-event span around them)" % npeaks,
-                "achieved": npeaks * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": npeaks * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
-                "frac_algorithmic": npeaks * cone / back_ms / FP32_MFMA_PEAK_TFLOPS,
-                "algorithmic_tflops": npeaks * cone / back_ms,
+    if back_ms and nlive:
+        roof = {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks (%d back-propagated, the rest saturated: map 0 / 0): prm_seed, "
+                                           "prm_prepare*, the strip-Winograd / small-window / stem dgrad kernels, window sums - the backward kernels "
+                                           "ONLY (HIP-event span around them)" % (npeaks, nlive),
+                "achieved": nlive * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": nlive * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                "frac_algorithmic": nlive * cone / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                "algorithmic_tflops": nlive * cone / back_ms,
                 "cone_limited_gflop_per_peak": cone, "issued_gflop_per_peak": cone_issued, "backward_ms": back_ms,
                 "frac_definition": "frac = fp32 MFMA FLOPs issued by the window convolutions of all peaks / backward_ms / 157.3 TF (round 4: the "
                                    "issued count follows the kernels - F(2x4) strips issue 1/3, depth-clipped strips hold fewer planes - so it is "
@@ -352,7 +358,7 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": ("PRM tile 1x%dx%dx%d %s net: PRM forward + box head + batched peak back-propagation + per-detection 2D-Otsu -> instance labels%s" %
                                   (S, H, W, "nuclei (stride 8, 35 anchors)" if nuclei else "soma (stride 4, 14 anchors)",
-                                   "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks,
+                                   "" if nuclei else " [configs[3]]")), "peaks_per_tile": npeaks, "peaks_back_propagated": nlive,
                       "phase_ms": {k: round(v, 4) for k, v in sorted(ph.items(), key=lambda kv: -kv[1])},
                       "phase_note": "; ".join(
                           (["norm_convs is a span on a SECOND stream: it runs beside proposals / box_head and the first layers of backward"] if eng.norm_stream else []) +
@@ -1337,7 +1343,8 @@ def main():
                         res["prm_nuclei_tile"]["rounds_1_3_workload"] = {
                             "ms_per_step": old["ms_per_step"], "peaks_per_tile": old["config"]["peaks_per_tile"],
                             "instances_painted": old["config"]["instances_painted"],
-                            "what": "the same code on the random init of rounds 1-3: every kept peak's RPN sigmoid is exactly 1.0f and its map 0 / 0"}
+                            "what": "the same code on the random init of rounds 1-3: every kept peak's RPN sigmoid is exactly 1.0f and its map 0 / 0 "
+                                    "(round 5: the engine skips the back-propagation of such peaks)"}
                 except Exception as e:
                     if isinstance(res.get("prm_nuclei_tile"), dict):
                         res["prm_nuclei_tile"]["rounds_1_3_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -420,6 +420,11 @@ int m3d_prm_seed_ex(const int32_t* d_peaks, int num_peaks, const float* d_prob, 
 int m3d_prm_select_peaks(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
                          int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
                          int32_t* h_peaks, float* h_out_dets, void* stream);
+/* the same + d_prob [A,S,H,W] (the class response map, may be null) -> d_dead / h_dead int32 [cap] (each may be null): 1 for a peak whose
+ * sigmoid derivative (1 - y) y is exactly 0 - its back-propagated map is all zero (`prm / prm.sum()` = 0 / 0) and need not be computed */
+int m3d_prm_select_peaks_ex(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
+                            int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
+                            int32_t* h_peaks, float* h_out_dets, const float* d_prob, int32_t* d_dead, int32_t* h_dead, void* stream);
 /* Geometry of the strip layouts [C, n, n, L] of a window batch (all peaks side by side along x; see m3d_prm_prepare_ex): mode 1 =
  * pitch n + 1 for the exactly-local F(2x2,3x3) kernel, mode 2 = quad-aligned windows for the F(2x4,3x3) kernel (no output quad of one
  * window reads another window's columns).  Returns L; window p occupies columns lead + p * pitch .. + n - 1, all others are zero. */

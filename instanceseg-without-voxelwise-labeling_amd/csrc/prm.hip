@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void prm_select_peaks_kernel(const float* __re
                                                                const int* __restrict__ count, int rows, float thr, int A, int S, int H, int W,
                                                                int cap, int* __restrict__ num, int* __restrict__ peaks /*[cap,4]*/,
                                                                float* __restrict__ out /*[cap,7]*/, int* __restrict__ h_num,
-                                                               int* __restrict__ h_peaks, float* __restrict__ h_out) {
+                                                               int* __restrict__ h_peaks, float* __restrict__ h_out,
+                                                               const float* __restrict__ prob /*[A,S,H,W] or null*/, int* __restrict__ dead /*[cap] or null*/,
+                                                               int* __restrict__ h_dead) {
   __shared__ int wave_tot[4];
   __shared__ int base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,6 +84,14 @@ __global__ __launch_bounds__(256) void prm_select_peaks_kernel(const float* __re
       if (h_out) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) h_out[(size_t)pos * 7 + k] = d[k];
+      }
+      if (prob) {
+        // a peak whose sigmoid derivative (1 - y) y is exactly 0 (prm_seed_kernel's expression: y == 1.0f, a saturated RPN score)
+        // seeds an all-zero gradient: every layer of its back-propagation is zero and its map is 0 / 0 (peak_response_mapping_3d.py:170-171)
+        const float y = prob[(size_t)a * S * H * W + ((size_t)s_ * H + h_) * W + w_];
+        const int dd = ((1.f - y) * y == 0.f) ? 1 : 0;
+        if (dead) dead[pos] = dd;
+        if (h_dead) h_dead[pos] = dd;
       }
     }
     __syncthreads();
@@ -534,10 +544,19 @@ M3D_API int m3d_prm_seed_ex(const int32_t* d_peaks, int num_peaks, const float* 
 M3D_API int m3d_prm_select_peaks(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
                                  int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
                                  int32_t* h_peaks, float* h_out_dets, void* stream) {
+  return m3d_prm_select_peaks_ex(d_dets, d_keep_idx, d_count, rows, peak_threshold, A, S, H, W, cap, d_num, d_peaks, d_out_dets, h_num, h_peaks,
+                                 h_out_dets, nullptr, nullptr, nullptr, stream);
+}
+
+/* + d_prob [A,S,H,W] (the class response map) -> d_dead / h_dead int32 [cap] (each may be null): 1 where the peak's sigmoid derivative
+ * (1 - y) y is exactly 0, i.e. where the whole back-propagation of that peak is zero (callers may skip it: its map is 0 / 0) */
+M3D_API int m3d_prm_select_peaks_ex(const float* d_dets, const int64_t* d_keep_idx, const int32_t* d_count, int rows, float peak_threshold,
+                                    int A, int S, int H, int W, int cap, int32_t* d_num, int32_t* d_peaks, float* d_out_dets, int32_t* h_num,
+                                    int32_t* h_peaks, float* h_out_dets, const float* d_prob, int32_t* d_dead, int32_t* h_dead, void* stream) {
   if (!d_dets || !d_keep_idx || !d_count || !d_num || !d_peaks || !d_out_dets) return M3D_EINVAL;
   if (rows <= 0 || cap <= 0 || A <= 0 || S <= 0 || H <= 0 || W <= 0) return M3D_EINVAL;
   hipLaunchKernelGGL(prm_select_peaks_kernel, dim3(1), dim3(256), 0, m3d::as_stream(stream), d_dets, (const long long*)d_keep_idx, d_count, rows,
-                     peak_threshold, A, S, H, W, cap, d_num, d_peaks, d_out_dets, h_num, h_peaks, h_out_dets);
+                     peak_threshold, A, S, H, W, cap, d_num, d_peaks, d_out_dets, h_num, h_peaks, h_out_dets, d_prob, d_dead, h_dead);
   return m3d::check_launch("prm_select_peaks");
 }
 

@@ -822,11 +822,13 @@ class PinnedPool:
 _peak_pool = PinnedPool()
 
 
-def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=None):
+def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=None, prob=None):
     """Device-side peak selection (peak_response_mapping_3d.py:124-139,161-163): dets [rows,7] (class 1's kept detections), keep_idx
     int64 [rows], count int32 [1] (all on the device) -> dict(num int32 [1], peaks int32 [cap,4] = (a,s,h,w), dets f32 [cap,7]) on the
     device plus `host`: a pinned mirror the SAME kernel writes (host["num"] int32 [1], host["peaks"], host["dets"] as NumPy views),
-    valid once the returned `event` has completed; call `release()` after reading it.  No host synchronisation here."""
+    valid once the returned `event` has completed; call `release()` after reading it.  No host synchronisation here.
+    prob ([A,S,H,W], the class response map): the mirror also carries host["dead"] int32 [cap] - 1 where the peak's sigmoid derivative is
+    exactly 0 (a saturated score): its back-propagated map is all zero and the engine skips it."""
     _need_gpu(dets, keep_idx, count)
     assert dets.dtype == torch.float32 and dets.is_contiguous() and dets.dim() == 2 and dets.shape[1] == 7
     assert keep_idx.dtype == torch.int64 and keep_idx.is_contiguous() and count.dtype == torch.int32
@@ -838,16 +840,21 @@ def prm_select_peaks(dets, keep_idx, count, peak_threshold, A, fmap_shape, cap=N
     peaks = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     out = torch.empty((cap, 7), dtype=torch.float32, device=dev)
     capb = max(cap, fused_max_boxes())                      # ONE buffer size for every tile (a new size would pin new memory)
-    buf = _peak_pool.take(64 + capb * 44)
+    buf = _peak_pool.take(64 + capb * 48)
     base = buf.data_ptr()
-    check(lib().m3d_prm_select_peaks(_ptr(dets), _ptr(keep_idx), _ptr(count), rows, C.c_float(np.float32(peak_threshold)), int(A), S, H, W,
-                                     cap, _ptr(num), _ptr(peaks), _ptr(out), C.c_void_p(base), C.c_void_p(base + 64),
-                                     C.c_void_p(base + 64 + capb * 16), _stream()), "prm_select_peaks")
+    if prob is not None:
+        _need_gpu(prob)
+        assert prob.dtype == torch.float32 and prob.is_contiguous() and tuple(prob.shape[-4:]) == (int(A), S, H, W)
+    check(lib().m3d_prm_select_peaks_ex(_ptr(dets), _ptr(keep_idx), _ptr(count), rows, C.c_float(np.float32(peak_threshold)), int(A), S, H, W,
+                                        cap, _ptr(num), _ptr(peaks), _ptr(out), C.c_void_p(base), C.c_void_p(base + 64),
+                                        C.c_void_p(base + 64 + capb * 16), _ptr(prob), None,
+                                        C.c_void_p(base + 64 + capb * 44) if prob is not None else None, _stream()), "prm_select_peaks")
     ev = torch.cuda.Event()
     ev.record()
     hb = buf.numpy()
     host = dict(num=hb[:4].view(np.int32), peaks=hb[64:64 + cap * 16].view(np.int32).reshape(cap, 4),
-                dets=hb[64 + capb * 16:64 + capb * 16 + cap * 28].view(np.float32).reshape(cap, 7))
+                dets=hb[64 + capb * 16:64 + capb * 16 + cap * 28].view(np.float32).reshape(cap, 7),
+                dead=hb[64 + capb * 44:64 + capb * 44 + cap * 4].view(np.int32) if prob is not None else None)
     return dict(num=num, peaks=peaks, dets=out, host=host, event=ev, release=lambda: _peak_pool.give(buf))
 
 

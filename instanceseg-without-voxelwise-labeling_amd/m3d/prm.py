@@ -16,8 +16,15 @@ from .model import DetectorM3D, _NOSPAN
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
                  strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True,
-                 fused_prepare=True):
+                 fused_prepare=True, skip_dead_peaks=True):
         self.det = det
+        # skip_dead_peaks: a kept peak whose RPN sigmoid is exactly 1.0f has the derivative (1 - y) y == 0: its seed, every layer of its
+        # back-propagation and its map are exactly zero (the reference then returns 0 / 0 = NaN for it, peak_response_mapping_3d.py:170-171).
+        # The selection kernel flags such peaks and prm_tile back-propagates only the others; the dead ones get zero windows, sum 0 and the
+        # origin the kernels would have written - what the full batch gives for them, bit for bit (the live peaks' windows agree with
+        # the full batch's up to summation order, as between any two batch sizes; tests/test_gpu_prm.py).  Trained detectors
+        # saturate on their confident detections; rounds 1-3 of the nuclei bench were 67 dead peaks out of 67.
+        self.skip_dead_peaks = bool(skip_dead_peaks)
         # fused_prepare: where two consecutive layers both run on the quad-aligned strip with no pooling between them (conv3b -> conv3a,
         # conv2b -> conv2a), the upper conv's backward-data writes the lower layer's PREPARED strip from its epilogue
         # (ops.WinoConv3d.strip_prepare): the bare gradient strip is never stored and re-read, and the prepare launch disappears.
@@ -403,7 +410,8 @@ class PRMEngine:
             cb, ck, cnt = ops.box_results3d_batched(cls, pred, keep_idx, offs_dev, c.num_classes, c.score_thresh, c.nms,
                                                     c.detections_per_im, R)                                          # :124
             A = prob.shape[1]
-            sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:])          # :125,136-139,161-163
+            sel = ops.prm_select_peaks(cb[0, 1], ck[0, 1], cnt[0, 1:2], peak_threshold, A, prob.shape[-3:],          # :125,136-139,161-163
+                                       prob=prob[0] if self.skip_dead_peaks else None)
         if norms_done is None:
             with self.span("norm_convs_late"):
                 self.forward_norms(saved, top, layers=late, cls=False)
@@ -418,14 +426,43 @@ class PRMEngine:
         hp = sel["host"]["peaks"][:P]
         peaks = torch.from_numpy(np.concatenate((np.zeros((P, 1), np.int64), hp.astype(np.int64)), 1))          # (b,a,s,h,w), b = 0
         dets = torch.from_numpy(sel["host"]["dets"][:P].astype(np.float64))                                     # :163
+        dead = None if sel["host"]["dead"] is None else (sel["host"]["dead"][:P] != 0)
+        if dead is not None and dead.any():
+            hp = np.array(hp, copy=True)                                   # the pinned mirror goes back to the pool below
         sel["release"]()
         with self.span("backward"):
-            win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
+            if dead is not None and dead.any():
+                win, sums, origins = self._backward_live(hp, dead, saved, top, data)
+            else:
+                win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
         out = dict(crm=prob, peaks=peaks, dets=dets, peaks_dev=sel["peaks"][:P], dets_dev=sel["dets"][:P], windows=win, sums=sums,
                    origins=origins)
         if dense:
             out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
         return out
+
+    def _backward_live(self, peaks_host, dead, saved, top, data):
+        """backward_windows for the peaks that are not `dead` (see skip_dead_peaks); the dead ones: zero windows, sum 0, and the window
+        origin every layer's rule gives (prepare: (pool ? 2 o : o) - border, top to bottom) - what the kernels write for them."""
+        P = len(peaks_host)
+        o = peaks_host[:, 1:4].astype(np.int64)
+        U = 1
+        for rec in reversed(saved):
+            border = 2 if rec["k"] == 5 else 1
+            o = (2 * o if rec["pool"] else o) - border
+            U = (2 if rec["pool"] else 1) * U + 2 * border
+        live = np.nonzero(~dead)[0]
+        dev = data.device
+        win = torch.zeros((P, U, U, U), dtype=torch.float32, device=dev)
+        sums = torch.zeros((P,), dtype=torch.float32, device=dev)
+        origins = ops.upload(o.astype(np.int32), dev)
+        if len(live):
+            w, s_, og = self.backward_windows(ops.upload(np.ascontiguousarray(peaks_host[live]).astype(np.int32), dev), saved, top, data)
+            assert tuple(w.shape[1:]) == (U, U, U)
+            idx = ops.upload(live.astype(np.int64), dev)
+            win.index_copy_(0, idx, w)
+            sums.index_copy_(0, idx, s_)
+        return win, sums, origins
 
     def _prm_tile_unfused(self, data, feat, prob, deltas, saved, top, peak_threshold, dense):
         """pre_nms_topN beyond the fused box kernels' capacity (or a model without a box head): the per-stage path with a host read

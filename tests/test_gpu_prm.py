@@ -180,6 +180,46 @@ def test_quad_prepare_kernel_writes_the_element_kernels_strip_bit_for_bit(U, bor
     assert int((ref != 0).sum()) > 0
 
 
+def test_dead_peaks_are_skipped_and_the_result_is_the_full_batchs():
+    """A peak whose RPN sigmoid is exactly 1.0f has (1 - y) y == 0: its back-propagation is zero at every layer.  The engine flags such
+    peaks in the selection kernel and back-propagates only the others (skip_dead_peaks).  Against the full batch on a net where most
+    kept peaks are dead: the same origins, exactly zero windows and sums for exactly the dead peaks, and the live peaks' windows equal
+    up to the summation order (the library picks tiles and K splits from the batch's shape, as between any two peak_chunk settings)."""
+    import m3d
+    P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=21)
+    P["RPN.RPN_cls_score.weight"] = P["RPN.RPN_cls_score.weight"] * 6.0
+    P["RPN.RPN_cls_score.bias"] = P["RPN.RPN_cls_score.bias"] * 6.0
+    cfg = O.Cfg(mlp_dim=64, score_thresh=0.0)
+    from m3d.model import DetectorM3D
+    from m3d.prm import PRMEngine
+    det = DetectorM3D({k: v.cuda() for k, v in P.items()}, cfg)
+    skip, full = PRMEngine(det), PRMEngine(det, skip_dead_peaks=False)
+    data = torch.randn((1, 1, 24, 40, 32), generator=torch.Generator().manual_seed(2)).cuda()
+    a, b = skip.prm_tile(data, dense=False), full.prm_tile(data, dense=False)
+    assert a is not None and b is not None
+    assert torch.equal(a["peaks"], b["peaks"]) and torch.equal(a["dets"], b["dets"])
+    sums = b["sums"].cpu().numpy()
+    ndead = int((sums == 0).sum())
+    assert 0 < ndead < len(sums), (ndead, len(sums))                       # both kinds in one tile
+    pr = a["crm"][0].cpu().numpy()
+    pk = a["peaks"].numpy()
+    y = np.array([pr[p_[1], p_[2], p_[3], p_[4]] for p_ in pk], np.float32)
+    assert np.array_equal((np.float32(1) - y) * y == 0, sums == 0)         # dead <=> zero sum
+    assert torch.equal(a["origins"], b["origins"])
+    wa, wb = a["windows"].cpu().numpy(), b["windows"].cpu().numpy()
+    dead = sums == 0
+    assert not wa[dead].any() and not wb[dead].any() and np.array_equal(a["sums"].cpu().numpy() == 0, dead)
+    for i in np.nonzero(~dead)[0]:
+        assert np.allclose(wa[i], wb[i], rtol=1e-5, atol=1e-7 * float(wb[i].max())), i
+    assert np.allclose(a["sums"].cpu().numpy(), sums, rtol=1e-5)
+    S, H, W = data.shape[-3:]
+    qa = m3d.prm_quantize_windows_u8(a["windows"], a["sums"], a["origins"], (S, H, W)).cpu().numpy()
+    qb = m3d.prm_quantize_windows_u8(b["windows"], b["sums"], b["origins"], (S, H, W)).cpu().numpy()
+    assert np.array_equal(qa[dead], qb[dead]) and not qa[dead].any()
+    d = np.abs(qa.astype(np.int16) - qb.astype(np.int16))
+    assert int(d.max()) <= 1 and float((d > 0).mean()) < 1e-3
+
+
 def test_prm_vs_oracle_border_peaks():
     """Peaks whose cones stick out of the tile on every side (virtual-window handling)."""
     P = O.make_params(stride=8, num_anchors=35, mlp_dim=64, seed=5)
