@@ -1157,7 +1157,7 @@ def condensed(r):
     keep = ("value", "unit", "ms_per_step", "ms_per_step_median", "steps", "warmup", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "otsu", "volumes")
     out = {k: r[k] for k in keep if k in r}
     out["config"] = {k: v for k, v in r.get("config", {}).items() if k in ("workload", "peaks_per_tile", "phase_ms", "prm_forward_ms", "prm_backward_ms",
-                                                                             "rois_per_volume", "instances_painted", "launches_per_tile")}
+                                                                             "rois_per_volume", "instances_painted", "launches_per_tile", "peaks_back_propagated")}
     return out
 
 
@@ -1224,7 +1224,8 @@ def compact_line(res, full_path=None):
             sub["cpu_baseline"] = _pick(r["cpu_baseline"], ("value", "cores", "kind"))
         c = r.get("config", {}) or {}
         sub["config"] = {kk: (_txt(v, 150) if isinstance(v, str) else _num(v)) for kk, v in c.items()
-                         if kk in ("workload", "peaks_per_tile", "rois_per_volume", "prm_backward_ms", "prm_forward_ms", "launches_per_tile") and v is not None}
+                         if kk in ("workload", "peaks_per_tile", "peaks_back_propagated", "rois_per_volume", "prm_backward_ms", "prm_forward_ms", "launches_per_tile")
+                         and v is not None}
         if isinstance(r.get("volumes"), dict):
             sub["volumes"] = {n: _pick(v, ("value", "seconds_per_volume", "peaks")) for n, v in r["volumes"].items() if isinstance(v, dict)}
         out[k] = sub
