@@ -1097,3 +1097,53 @@ def test_bf16x3_direct_conv_has_fp32_accuracy_and_the_fp32_kernels_exact_zeros(c
     plain = ops.X3Conv3d(wc, ops.W_PLAIN)(xc).cpu()                          # signed weights, no offset
     ref2 = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
     assert float((plain.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6
+
+
+def test_reduce_min_multi_equals_the_single_array_minima(m3d):
+    """m3d_reduce_min_multi (every `input.min()` of a PRM forward in two launches): up to 12 arrays of any size / alignment, each minimum
+    bit-equal to torch's and to the single-array entry point."""
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 3, 4, 257, 4096, 65537, 1 << 20, 12345, 64, 999999, 31, 2048]
+    base = torch.randn(sum(sizes) + 7, generator=g).cuda()
+    xs, o = [], 3                                              # views at odd offsets: not 16-byte aligned
+    for n in sizes:
+        xs.append(base[o:o + n]); o += n
+    got = m3d.ops.reduce_min_multi(xs).cpu()
+    assert got.shape == (12,)
+    for i, x in enumerate(xs):
+        assert float(got[i]) == float(x.min()) == float(m3d.reduce_min(x.contiguous()))
+    assert float(m3d.ops.reduce_min_multi(xs[:1])[0]) == float(xs[0].min())
+    with pytest.raises(m3d.M3DError):
+        m3d.ops.reduce_min_multi(xs + [xs[0]])                 # 13 arrays: over the entry point's limit
+
+
+def test_paint_begin_fills_the_sentinel_and_derives_the_ids(m3d):
+    """m3d_paint_begin: label volume at 0xFFFFFFFF, present flags at 0, ids = idx + first_id where both stages succeeded and the
+    detection's map has a non-zero voxel, else -1 (binarization_soma.py:66,74-76,94-98) - one launch for seven element-wise ones."""
+    from m3d import ops
+    R, P = 9, 14
+    idx = torch.tensor([0, 2, 3, 5, 6, 8, 9, 12, 13], dtype=torch.int64).cuda()
+    st_o = torch.tensor([0, 0, 1, 0, 3, 0, 0, 0, 2], dtype=torch.int32).cuda()
+    st_c = torch.tensor([0, 1, 0, 0, 0, 2, 0, 0, 0], dtype=torch.int32).cuda()
+    stats = torch.zeros((P, 4), dtype=torch.int32)
+    stats[:, 3] = torch.tensor([1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 7, 1])          # map 9 is all zero
+    stats = stats.cuda()
+    for shape in ((5, 6, 8), (3, 5, 7)):                       # voxel counts divisible by 4 and not
+        vol, present, ids = ops.paint_begin(shape, 5 + P, st_o, st_c, stats, idx, 5, "cuda")
+        assert vol.dtype == torch.int32 and tuple(vol.shape) == shape and bool((vol == -1).all())
+        assert present.dtype == torch.uint8 and present.numel() == 5 + P and not bool(present.any())
+        assert ids.cpu().tolist() == [5, -1, -1, 10, -1, -1, -1, 17, -1]
+        _, _, ids2 = ops.paint_begin(shape, 5 + P, st_o, st_c, None, idx, 5, "cuda")            # no map statistics: maps count as non-empty
+        assert ids2.cpu().tolist() == [5, -1, -1, 10, -1, -1, 14, 17, -1]
+
+
+def test_upload_packed_is_one_copy_with_the_arrays_values(m3d):
+    from m3d import ops
+    rs = np.random.RandomState(3)
+    arrs = [rs.randint(0, 1 << 40, (17,)).astype(np.int64), rs.randint(0, 99, (17, 6)).astype(np.int32), rs.randint(0, 9, (17, 3)).astype(np.int32),
+            np.zeros((0,), np.int32), rs.rand(5).astype(np.float32), rs.randint(0, 255, (3,)).astype(np.uint8)]
+    outs = ops.upload_packed(arrs, "cuda")
+    torch.cuda.synchronize()
+    for a, t in zip(arrs, outs):
+        assert tuple(t.shape) == a.shape and np.array_equal(t.cpu().numpy(), a)
+        assert t.numel() == 0 or t.data_ptr() % 16 == 0
