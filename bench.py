@@ -399,11 +399,11 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
         c0 = time.perf_counter()
         O.segment_tile(raw.cpu().numpy(), qc, bx, mode)
         per_roi = (time.perf_counter() - c0) / cap_peaks
-        t_tile = t_fwd + npeaks * (per_peak + per_roi)
+        t_tile = t_fwd + nlive * per_peak + npeaks * per_roi        # like for like: the peaks the GPU back-propagated; every detection binarised
         res["cpu_baseline"] = {"value": S * H * W / t_tile, "unit": "voxels/s", "cores": ncpu, "kind": "port",
                                "sample": "the same tile through the oracle's restatement (torch-CPU convs with %d threads, oracle C box ops): forward + box "
                                          "head %.2f s measured; %d of the tile's %d peaks back-propagated (%.2f s per peak) and binarised (%.3f s per "
-                                         "detection), extrapolated per peak to all %d" % (ncpu, t_fwd, cap_peaks, npeaks, per_peak, per_roi, npeaks),
+                                         "detection), extrapolated to the %d peaks the GPU back-propagated and all %d detections" % (ncpu, t_fwd, cap_peaks, npeaks, per_peak, per_roi, nlive, npeaks),
                                "seconds_per_tile_extrapolated": t_tile}
         res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
     return res
@@ -464,8 +464,10 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
             vp.spans.clear()
             vox = float(np.prod(shape))
             peaks = int(sum(len(r_["dets"]) for r_ in res_))
+            # saturated peaks are skipped by the engine (m3d.prm skip_dead_peaks): only the back-propagated ones count as work
+            live = int(sum(r_.get("peaks_back_propagated", len(r_["dets"])) for r_ in res_))
             rec = {"value": vox / dt_p, "unit": "voxels/s", "seconds_per_volume": dt_p, "seconds_per_volume_runs": [round(t, 4) for t in times],
-                   "volume": "%dx%dx%d uint16 (%s net)" % (shape + (ds,)), "tiles_with_detections": len(res_), "peaks": peaks,
+                   "volume": "%dx%dx%d uint16 (%s net)" % (shape + (ds,)), "tiles_with_detections": len(res_), "peaks": peaks, "peaks_back_propagated": live,
                    "files_written": nfiles, "bytes_written": nbytes, "writer_threads": minfer.writer_pool().workers,
                    "serial_driver": {"value": vox / dt_s, "seconds_per_volume": dt_s, "files_written": nfiles_s,
                                      "what": "infer_prm_serial: dense uint8 maps copied back and written tile by tile (round 3's driver with the "
@@ -473,13 +475,14 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                    "what": "host uint16 volume -> per-peak LZW TIFFs + dets.npy in a scratch directory (%s), pipelined; best of %d"
                            % ("tmpfs" if base else "tmp", reps)}
             cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
-            if back_ms > 0 and peaks:
+            if back_ms > 0 and live:
                 dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if ds == "nuclei" else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"
-                rec["roofline"] = {"bound": "mfma", "kernel": "peak back-propagation of the volume's %d peaks over %d tiles (backward kernels only, "
-                                                              "HIP-event spans of one extra untimed pass)" % (peaks, len(res_)),
-                                   "achieved": peaks * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": peaks * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
-                                   "frac_algorithmic": peaks * cone / back_ms / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": back_ms,
+                rec["roofline"] = {"bound": "mfma", "kernel": "peak back-propagation of the volume's %d peaks (%d back-propagated, the rest saturated: map "
+                                                              "0 / 0) over %d tiles (backward kernels only, HIP-event spans of one extra untimed pass)"
+                                                              % (peaks, live, len(res_)),
+                                   "achieved": live * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": live * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                                   "frac_algorithmic": live * cone / back_ms / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": back_ms,
                                    "share_of_volume_time": back_ms * 1e-3 / dt_p, "traffic": pmc_traffic(dom, which="largest").get("traffic")}
             if rank == 0 and not args.no_cpu_baseline and world == 1:
                 # CPU leg: the oracle's PRM tile on ONE tile of this volume with a capped number of peaks, extrapolated to all tiles and
@@ -504,11 +507,12 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                     mio.write_tiff_stack(os.path.join(scratch, "cpu.tif"), q)
                     t_wr = time.perf_counter() - c0
                 ntiles = len(tiling.enumerate_tiles(*tiling.tile_grid(vol64.shape, patch, cfg.crop_ovlp, ds)))
-                t_vol = ntiles * t_fwd + peaks * (t_pk + t_wr)
+                t_vol = ntiles * t_fwd + live * t_pk + peaks * t_wr
                 rec["cpu_baseline"] = {"value": vox / t_vol, "unit": "voxels/s", "cores": ncpu, "kind": "port",
                                        "sample": "one %dx%dx%d tile of the volume through the oracle (forward + box head %.2f s; %d peaks back-propagated, "
-                                                 "%.2f s each; one map quantised + written, %.3f s), extrapolated to the volume's %d tiles and %d peaks"
-                                                 % (patch + (t_fwd, capk, t_pk, t_wr, ntiles, peaks)),
+                                                 "%.2f s each; one map quantised + written, %.3f s), extrapolated to the volume's %d tiles, the %d peaks "
+                                                 "the GPU back-propagated (saturated ones cost the CPU leg nothing either) and %d maps written"
+                                                 % (patch + (t_fwd, capk, t_pk, t_wr, ntiles, live, peaks)),
                                        "seconds_per_volume_extrapolated": t_vol}
             out[ds] = rec
         finally:
@@ -536,11 +540,12 @@ def prm_params(cfg, args):
     EVERY kept peak of the tile (rounds 1-3 timed that: the kernels' time does not depend on the values, but the binarisation stage and
     the LZW writer saw all-zero maps).  RPN_cls_score's weight and bias are therefore scaled by --prm-rpn-logit-scale (default 0.25:
     logits of +-10 as a trained net has; the ranking of the proposals is the same monotone function of the same logits); 1.0
-    reproduces the earlier rounds' workload."""
+    reproduces the earlier rounds' workload.  Round 6: the soma net (stride 4) is scaled too - rounds 1-5 left it saturated, a quarter
+    of configs[3]'s 128 peaks and most of the soma volume's were dead (and skipped since round 5), which flattered those records."""
     from m3d.synth import unsaturated_rpn
     P = cached_params(stride=cfg.stride, num_anchors=cfg.num_anchors, mlp_dim=cfg.mlp_dim, seed=0)
     a = float(getattr(args, "prm_rpn_logit_scale", 0.25))
-    return unsaturated_rpn(P, a) if (cfg.stride == 8 and a != 1.0) else P
+    return unsaturated_rpn(P, a) if a != 1.0 else P
 
 
 def cached_params(**kw):
@@ -1227,8 +1232,10 @@ def compact_line(res, full_path=None):
                          if kk in ("workload", "peaks_per_tile", "peaks_back_propagated", "rois_per_volume", "prm_backward_ms", "prm_forward_ms", "launches_per_tile")
                          and v is not None}
         if isinstance(r.get("volumes"), dict):
-            sub["volumes"] = {n: _pick(v, ("value", "seconds_per_volume", "peaks")) for n, v in r["volumes"].items() if isinstance(v, dict)}
+            sub["volumes"] = {n: _pick(v, ("value", "seconds_per_volume", "peaks", "peaks_back_propagated")) for n, v in r["volumes"].items() if isinstance(v, dict)}
         out[k] = sub
+    if res.get("accounting_errors"):
+        out["accounting_errors"] = [_txt(str(e), 120) for e in res["accounting_errors"][:4]]
     if full_path:
         out["full_record"] = full_path
     line = json.dumps(out)
@@ -1241,8 +1248,30 @@ def compact_line(res, full_path=None):
     return line
 
 
+def hardware_fracs_above_one(rec, path=""):
+    """Every `frac` (a HARDWARE fraction: issued FLOPs or written bytes over time over peak) above 1 anywhere in a record, as
+    (path, value) pairs.  Such a value means the timed kernels did not do the counted work (round 5: the soma volume counted peaks the
+    engine had skipped, frac 1.89).  `frac_algorithmic` may exceed 1 (Winograd) and is not looked at."""
+    bad = []
+    if isinstance(rec, dict):
+        for k, v in rec.items():
+            here = "%s.%s" % (path, k) if path else k
+            if k == "frac" and isinstance(v, (int, float)) and not isinstance(v, bool) and v > 1.0:
+                bad.append((here, float(v)))
+            else:
+                bad += hardware_fracs_above_one(v, here)
+    elif isinstance(rec, (list, tuple)):
+        for i, v in enumerate(rec):
+            bad += hardware_fracs_above_one(v, "%s[%d]" % (path, i))
+    return bad
+
+
 def emit(res, tag):
     """Full record -> stderr + gpurun_out/bench_full_<tag>.json (profiles/ keeps the judged copies); compact line -> stdout, LAST."""
+    bad = hardware_fracs_above_one(res)
+    if bad:                                              # loud, and on the line itself: tools/check_bench_line.py and the tests refuse it
+        res["accounting_errors"] = ["%s = %.3f > 1" % b for b in bad]
+        sys.stderr.write("[bench.py] ACCOUNTING ERROR: hardware fraction above 1: %s\n" % res["accounting_errors"])
     full = json.dumps(res)
     path = None
     try:
@@ -1271,7 +1300,7 @@ def main():
     ap.add_argument("--pipelined", action="store_true", help="also time the two-stream begin(k+1) / finish(k) loop (N = 1)")
     ap.add_argument("--stress-rois", action="store_true", help="RPN NMS threshold 1.0: every volume gives RPN_POST_NMS_TOP_N = 1000 RoIs to the box head")
     ap.add_argument("--prm-norm-stream", type=int, default=1, help="PRM workloads: 0 = norm convs queued on the tile's own stream instead of a second one (A/B)")
-    ap.add_argument("--prm-rpn-logit-scale", type=float, default=0.25, help="PRM workloads, nuclei net: factor on the random-init RPN class logits (1.0 = rounds 1-3: saturated sigmoids, all-zero maps)")
+    ap.add_argument("--prm-rpn-logit-scale", type=float, default=0.25, help="PRM workloads: factor on the random-init RPN class logits of both nets (1.0 = the saturated sigmoids rounds 1-3 (nuclei) / 1-5 (soma) timed)")
     ap.add_argument("--prm-pipeline", type=int, default=0, help="PRM tile workloads: 1 = the two-tile software pipeline (m3d.prm.TilePipeline) instead of one prm_tile call per step (A/B: no faster)")
     ap.add_argument("--prm-f24-min", type=int, default=16, help="PRM workloads: smallest window that takes the F(2x4) strip family (A/B)")
     ap.add_argument("--prm-binarize-stream", type=int, default=1, help="PRM workloads: 0 = a tile's binarisation stage on the tile's stream instead of its own (where it runs beside the next tile's forward) (A/B)")
@@ -1349,6 +1378,19 @@ def main():
                 except Exception as e:
                     if isinstance(res.get("prm_nuclei_tile"), dict):
                         res["prm_nuclei_tile"]["rounds_1_3_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                # configs[3] as rounds 1-5 ran it (soma RPN left saturated: a quarter of the 128 peaks dead and, since round 5, skipped)
+                try:
+                    sub = copy.copy(args)
+                    sub.workload, sub.steps, sub.warmup, sub.prm_rpn_logit_scale, sub.no_cpu_baseline = "prm", 10, 3, 1.0, True
+                    old = bench_prm(sub, rank, world, dist)
+                    if isinstance(res.get("configs3_prm_soma"), dict) and old is not None:
+                        res["configs3_prm_soma"]["rounds_1_5_workload"] = {
+                            "ms_per_step": old["ms_per_step"], "peaks_per_tile": old["config"]["peaks_per_tile"],
+                            "peaks_back_propagated": old["config"]["peaks_back_propagated"],
+                            "what": "the same code on the soma net's random init as rounds 1-5 timed it (RPN sigmoids of the top peaks saturated)"}
+                except Exception as e:
+                    if isinstance(res.get("configs3_prm_soma"), dict):
+                        res["configs3_prm_soma"]["rounds_1_5_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
                 try:
                     res["volume_pipeline"] = condensed(bench_volume(args, rank, world, dist, reps=2, cpu_budget_s=10.0))

@@ -189,6 +189,12 @@ double m3d_conv3d_wino2_local_score(int batch, int cin, int cout, int depth, int
  * (F(2,3) along y, F(4,3) along x: 1/3; the default), 5 = F(2x4,3x3) with 64 output channels per 4-wave workgroup (A/B only; layers
  * whose cout is not a multiple of 64 run family 4); option "tune_wino2" / 100 selects one for A/B runs */
 int m3d_conv3d_wino2_family(void);
+/* What m3d_conv3d_wino2_forward_ws (local = 0) / m3d_conv3d_wino2_local_forward_ws (local = 1) would launch for this shape: kernel
+ * family, tile id (32 / 16 / 8; 0: none) and K split (1: one accumulation chain per output over the input channels; s > 1: s partial
+ * sums added in a fixed order, i.e. another summation order).  A pure function of the shape - no launch, no device access; replaces
+ * nothing in the reference (cuDNN's algorithm choice behind `F.conv3d`, lib/prm/peak_backprop_3d.py:40-42, is equally shape-dependent). */
+int m3d_conv3d_wino2_plan(int local, int batch, int cin, int cout, int depth, int height, int width, int* family_out, int* tile_out,
+                          int* ksplit_out);
 int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                 int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                 void* d_ws, size_t ws_bytes, void* stream);

@@ -1244,6 +1244,22 @@ M3D_API int m3d_prm_strip_dgrad_prepare(const float* d_gn, const float* d_packed
   return m3d_w24::launch_prep(xt, d_gn, d_packed + pack22_floats(cin, cout), d_out, cin, cout, ZA, window, (int)LA, quad_epi(ep), pe, st);
 }
 
+/* What m3d_conv3d_wino2_forward_ws (local = 0) / m3d_conv3d_wino2_local_forward_ws (local = 1) would launch for this shape: the kernel
+ * family (2: F(2x2,3x3), 4: F(2x4,3x3), ...), the tile id (32 / 16 / 8, 0: no tile) and the K split (1: every output is ONE accumulation
+ * chain over the input channels; s > 1: s partial sums over channel slices added in a fixed order - a different summation order).
+ * The plan is a pure function of the shape, so it tells apart two calls whose results may differ in the last bits (tests/test_gpu_prm.py:
+ * the strips of a batch of P peaks and of a sub-batch are different shapes).  No launch, no device access. */
+M3D_API int m3d_conv3d_wino2_plan(int local, int batch, int cin, int cout, int depth, int height, int width, int* family_out, int* tile_out,
+                                  int* ksplit_out) {
+  if (batch <= 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  const int fam = family_for(local ? 2 : family(), cout);
+  const int xt = choose_xt(fam, batch, cin, cout, depth, height, width);
+  if (family_out) *family_out = fam;
+  if (tile_out) *tile_out = xt;
+  if (ksplit_out) *ksplit_out = xt == 8 ? plan_splitk(fam, batch, cin, cout, depth, height, width).ksplit : 1;
+  return M3D_OK;
+}
+
 M3D_API int m3d_conv3d_wino2_forward_ws(const float* d_in, const float* d_packed, float* d_out, int batch, int cin, int cout,
                                         int depth, int height, int width, const float* d_scale, const float* d_shift, int relu,
                                         void* d_ws, size_t ws_bytes, void* stream) {

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_wino24_kernel(const float* __re
   // workgroups an XCD holds at a time are then a compact (z, y) brick of one x range, whose halo rows and planes (6 rows for 4, 4 planes
   // for 2: 3.1 x the tile's own voxels) are in that XCD's L2 while the neighbours fetch them, instead of 32 x tiles of one (y, z) row that
   // share nothing (round 4's PMC: 2.97 GB fetched for 0.71 GB of strip).  xcd_map 2 / 3 force the x-fast / x-slow order (A/B).
-  const bool x_slow = ep.xcd_map == 3 || (ep.xcd_map == 1 && tiles_x > 4);
+  // Only strips are that wide: the forward / pooled convs of the 128- and 200-wide maps have 2 - 13 x tiles whatever the tile id and keep
+  // the x-fast order their A/B runs and PMC data were taken with (round 5 switched every launch with more than 4 x tiles).  The other
+  // families' kernels read xcd_map as a boolean: 2 / 3 mean "on" there.
+  const bool x_slow = ep.xcd_map == 3 || (ep.xcd_map == 1 && tiles_x > 16);
   int tx;
   if (x_slow) { const int per_x = tiles_y * tiles_z; tx = bid / per_x; bid -= tx * per_x; }
   else { tx = bid % tiles_x; bid /= tiles_x; }

@@ -488,9 +488,12 @@ __global__ __launch_bounds__(256) void prm_fill_kernel(const float* __restrict__
   float4* d = dense + (size_t)blockIdx.y * n4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) d[e] = make_float4(v, v, v, v);
 }
-__global__ __launch_bounds__(256) void prm_fill_tail_kernel(const float* __restrict__ sums, long long n, long long from, float* __restrict__ dense) {
+// maps whose voxel count is not a multiple of 4 (or an unaligned buffer): per-peak bases are not 16-byte aligned, so dword stores - but over
+// the same (chunks, peak) grid as the float4 form, not one workgroup per map
+__global__ __launch_bounds__(256) void prm_fill_scalar_kernel(const float* __restrict__ sums, long long n, float* __restrict__ dense) {
   const float v = 0.f / sums[blockIdx.y];
-  for (long long e = from + threadIdx.x; e < n; e += 256) dense[(size_t)blockIdx.y * n + e] = v;
+  float* d = dense + (size_t)blockIdx.y * n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) d[e] = v;
 }
 
 // ---- normalise + scatter windows into the dense maps ----
@@ -731,7 +734,9 @@ M3D_API int m3d_prm_scatter(const float* d_windows, const float* d_sums, const i
     hipLaunchKernelGGL(prm_fill_kernel, dim3((unsigned)fb, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_sums, n / 4,
                        reinterpret_cast<float4*>(d_dense));
   } else {
-    hipLaunchKernelGGL(prm_fill_tail_kernel, dim3(1, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_sums, n, 0ll, d_dense);
+    long long fb = (n + 1023) / 1024;                     // 4 dwords per thread and sweep
+    if (fb > 1024) fb = 1024;
+    hipLaunchKernelGGL(prm_fill_scalar_kernel, dim3((unsigned)fb, num_peaks), dim3(256), 0, m3d::as_stream(stream), d_sums, n, d_dense);
   }
   const long long total = (long long)num_peaks * win * win * win;
   long long blocks = (total + 255) / 256;

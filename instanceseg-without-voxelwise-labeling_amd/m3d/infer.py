@@ -236,7 +236,8 @@ def infer_prm(engine, im, dataset=None, patch=None, overlap=None, out_dir=None, 
         else:
             origins_h = horg.numpy()
         rec = dict(num=num, start=(s, h, w), dets=out["dets"].numpy() if out["dets"].device.type == "cpu" else out["dets"].cpu().numpy(),
-                   peaks=out["peaks"].numpy() if out["peaks"].device.type == "cpu" else out["peaks"].cpu().numpy())
+                   peaks=out["peaks"].numpy() if out["peaks"].device.type == "cpu" else out["peaks"].cpu().numpy(),
+                   peaks_back_propagated=int(out.get("num_live", P)))
         results.append(rec)
         tile_dir = None
         if out_dir is not None:                                               # :213-216

@@ -463,17 +463,24 @@ def reduce_min(x):
     return out
 
 
+REDUCE_MIN_MULTI_MAX = 12      # kMinMulti of csrc/pool_bn.hip: m3d_reduce_min_multi returns M3D_EINVAL beyond it
+
+
 def reduce_min_multi(xs):
-    """Minima of up to 12 tensors in two launches -> float32 [len(xs)] (slice i:i+1 is the device scalar of tensor i)."""
+    """Minima of any number of tensors, two launches per group of up to 12 (the entry point's capacity) -> float32 [len(xs)]
+    (slice i:i+1 is the device scalar of tensor i)."""
     _need_gpu(*xs)
     xs = [_f32c(x) for x in xs]
     n = len(xs)
     out = torch.empty((max(n, 1),), dtype=torch.float32, device=xs[0].device)
     wsb = lib().m3d_reduce_min_multi_workspace_bytes()
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=xs[0].device)
-    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
-    cnts = (C.c_int64 * n)(*[x.numel() for x in xs])
-    check(lib().m3d_reduce_min_multi(ptrs, cnts, n, _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min_multi")
+    for g0 in range(0, n, REDUCE_MIN_MULTI_MAX):
+        grp = xs[g0:g0 + REDUCE_MIN_MULTI_MAX]
+        m = len(grp)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=xs[0].device)      # per group: the groups' launches are in flight together
+        ptrs = (C.c_void_p * m)(*[x.data_ptr() for x in grp])
+        cnts = (C.c_int64 * m)(*[x.numel() for x in grp])
+        check(lib().m3d_reduce_min_multi(ptrs, cnts, m, _ptr(out[g0:g0 + m]), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min_multi")
     return out
 
 
@@ -1136,6 +1143,13 @@ class WinoConv3d(object):
                         _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
                         int(bool(relu)), _stream()), "conv3d_wino_forward")
         return out
+
+    def plan(self, shape):
+        """(family, tile id, K split) the library would use for an input [B, cin, D, H, W] (m3d_conv3d_wino2_plan; 2-D kernels only)."""
+        B, D, H, W = (int(shape[0]),) + tuple(int(v) for v in shape[-3:])
+        f, t, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().m3d_conv3d_wino2_plan(int(self.local), B, self.cin, self.cout, D, H, W, C.byref(f), C.byref(t), C.byref(k)), "conv3d_wino2_plan")
+        return f.value, t.value, k.value
 
     def strip_prepare(self, gn, dims, origin, xnext, scale, norm, up_off, in_slab=False, out_slab=False):
         """PRM strips: this conv's backward-data on the prepared strip `gn` [cin, planes, U, L(U)] (quad-aligned layout, dims = (P, cin, U))

@@ -51,6 +51,10 @@ class PRMEngine:
         self._bstreams = None
         self.cfg = det.cfg
         self.probe = None                             # optional m3d.model.Probe: HIP-event spans around the phases of prm_tile (bench.py)
+        # optional list: backward_windows appends one record per layer it ran - dict(layer, kernel, plan (family, tile, K split of a
+        # strip conv; None elsewhere), P, U, strip, slab, t = a copy of the layer's output window batch) - so a test can tell WHICH
+        # launch makes two batch sizes differ in the last bits (tests/test_gpu_prm.py; never set on a product path: it copies)
+        self.trace = None
         # windows >= strip_min voxels wide run their backward-data through the F(2x2,3x3) kernel on the strip layout (all peaks
         # side by side along x): 4/9 of the MFMA work and tiles that fit; strip_wino=False keeps the direct kernel everywhere
         self.strip_wino = bool(strip_wino)
@@ -141,7 +145,7 @@ class PRMEngine:
                     xn, am = ops.maxpool3d_2x(y, return_argmax=True)
                 else:
                     xn, am = y, None
-            saved.append(dict(x=x[0], off=None, n=None, scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
+            saved.append(dict(name=L["name"], x=x[0], off=None, n=None, scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
                               xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_wino24=L["dgrad_wino24"], dgrad_small=L["dgrad_small"],
                               weight=L["weight"], norm_conv=L["norm_conv"]))
             x = xn
@@ -151,7 +155,7 @@ class PRMEngine:
             h = wn(feat, shift=det.rpn_conv_bias, relu=True)
         else:
             h = det.rpn_conv(feat, shift=det.rpn_conv_bias, relu=True)
-        saved.append(dict(x=feat[0], off=None, n=None, scale=None, pool=False, argmax=None, xnext=h[0], k=3,
+        saved.append(dict(name="RPN_conv", x=feat[0], off=None, n=None, scale=None, pool=False, argmax=None, xnext=h[0], k=3,
                           dgrad=self.rpn["dgrad"], dgrad_small=self.rpn["dgrad_small"], norm_conv=self.rpn["norm_conv"]))
         prob, deltas = det.rpn_outputs(h)
         top = dict(h=h[0], off_h=None, n_cls=None, prob=prob[0])
@@ -266,9 +270,13 @@ class PRMEngine:
                 r = rec["dgrad_wino24"].strip_prepare(gn, (P, gn.shape[0], Wn), origin, nxt["xnext"], nxt["scale"], nxt["n"], rec["off"],
                                                       in_slab=slab, out_slab=nslab)
                 if r is not None:
-                    return dict(t=r[0], strip=2, P=P, C=cout, U=Wn + 2, up_off=None, slab=nslab, prepared=True), r[1]
-            y = (rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"])(gn.unsqueeze(0))[0]
-            return dict(t=y, strip=strip, P=P, C=cout, U=Wn, up_off=rec["off"], slab=slab), origin
+                    return dict(t=r[0], strip=2, P=P, C=cout, U=Wn + 2, up_off=None, slab=nslab, prepared=True,
+                                kernel="strip F(2x4) + fused prepare of " + nxt.get("name", "?"),
+                                plan=rec["dgrad_wino24"].plan((1,) + tuple(gn.shape[-3:])) if self.trace is not None else None), r[1]
+            wc = rec["dgrad_wino24"] if strip == 2 else rec["dgrad_wino"]
+            y = wc(gn.unsqueeze(0))[0]
+            return dict(t=y, strip=strip, P=P, C=cout, U=Wn, up_off=rec["off"], slab=slab, kernel="strip F(2x4)" if strip == 2 else "strip F(2x2) local",
+                        plan=wc.plan((1,) + tuple(gn.shape[-3:])) if self.trace is not None else None), origin
 
         def take(wb, c0, c1):
             """peaks [c0, c1) of a window batch"""
@@ -297,6 +305,13 @@ class PRMEngine:
                 chunk = max(1, min(chunk, (2 ** 31 - 1) // (4 * cmax * Wn * Wn * pitch) - 1))
             if chunk >= P:
                 out, o2 = run_layer(rec, wb, origin, border, layers[1] if len(layers) > 1 else None)
+                if self.trace is not None:
+                    if rec["k"] == 5:
+                        self.trace.append(dict(layer=rec.get("name"), kernel="stem dgrad", plan=None, P=P, U=int(out[0].shape[1]), strip=0, slab=False,
+                                               t=out[0].clone()))
+                    else:
+                        self.trace.append(dict(layer=rec.get("name"), kernel=out.get("kernel", "window GEMM / direct windowed conv"), plan=out.get("plan"),
+                                               P=out["P"], U=out["U"], strip=out["strip"], slab=bool(out.get("slab")), t=out["t"].clone()))
                 return (out, o2) if rec["k"] == 5 else tail(layers[1:], out, o2)
             outs = [tail(layers, take(wb, c0, min(P, c0 + chunk)), origin[c0:c0 + chunk].contiguous()) for c0 in range(0, P, chunk)]
             wins = torch.cat([o[0][0] for o in outs]); sums = torch.cat([o[0][1] for o in outs]); orig = torch.cat([o[1] for o in outs])
@@ -430,13 +445,18 @@ class PRMEngine:
         if dead is not None and dead.any():
             hp = np.array(hp, copy=True)                                   # the pinned mirror goes back to the pool below
         sel["release"]()
+        nlive = P if dead is None else int(P - int(dead.sum()))
         with self.span("backward"):
             if dead is not None and dead.any():
                 win, sums, origins = self._backward_live(hp, dead, saved, top, data)
             else:
                 win, sums, origins = self.backward_windows(sel["peaks"][:P], saved, top, data)
+        if nlive == 0 and norms_done is not None:
+            # no peak was back-propagated, so nothing on this stream has waited for the side stream's norm convs (rec["ready"] is only
+            # consumed inside backward_windows): wait here, as the R == 0 / P == 0 returns do, before the tile's tensors are freed
+            torch.cuda.current_stream().wait_event(norms_done)
         out = dict(crm=prob, peaks=peaks, dets=dets, peaks_dev=sel["peaks"][:P], dets_dev=sel["dets"][:P], windows=win, sums=sums,
-                   origins=origins)
+                   origins=origins, num_live=nlive)
         if dense:
             out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
         return out
@@ -489,7 +509,7 @@ class PRMEngine:
         pk32 = peaks_v[:, 1:].to(torch.int32).contiguous()
         win, sums, origins = self.backward_windows(pk32, saved, top, data)
         out = dict(crm=prob, peaks=peaks_v.cpu(), dets=dets32.double().cpu(), peaks_dev=pk32, dets_dev=dets32, windows=win, sums=sums,
-                   origins=origins)
+                   origins=origins, num_live=int(pk32.shape[0]))
         if dense:
             out["prms"] = ops.prm_scatter(win, sums, origins, (S, H, W))
         return out

@@ -79,3 +79,23 @@ def test_dry_run_prints_one_short_json_line_last():
     for k in CONTRACT:
         assert k in d, k
     assert d["dry"] is True and d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1
+
+
+def test_a_hardware_fraction_above_one_is_an_accounting_error():
+    """Round 5's soma volume counted peaks the engine had skipped (frac 1.89): the checker must flag that record, pass the newest
+    committed one, and emit() must carry the finding on the line."""
+    b = _bench()
+    r05 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_full_record.json")))
+    bad = b.hardware_fracs_above_one(r05)
+    assert any("volume_pipeline" in p and "soma" in p and v > 1.5 for p, v in bad), bad
+    assert b.hardware_fracs_above_one({"roofline": {"frac": 0.63, "frac_algorithmic": 1.76}, "rooflines": [{"frac": 1.0}]}) == []
+    assert b.hardware_fracs_above_one({"a": [{"roofline": {"frac": 1.2}}]}) == [("a[0].roofline.frac", 1.2)]
+    import glob
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_default_full_record*.json")))
+    for f in newest:                                       # this round's judged copies: no fraction above 1 anywhere
+        rec = json.load(open(f))
+        assert b.hardware_fracs_above_one(rec) == [], f
+        soma = rec["configs3_prm_soma"]["config"]
+        assert soma["peaks_back_propagated"] == soma["peaks_per_tile"], soma
+    line = json.loads(b.compact_line(dict(r05, accounting_errors=["%s = %.3f > 1" % x for x in bad])))
+    assert line["accounting_errors"]

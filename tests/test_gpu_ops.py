@@ -1113,8 +1113,47 @@ def test_reduce_min_multi_equals_the_single_array_minima(m3d):
     for i, x in enumerate(xs):
         assert float(got[i]) == float(x.min()) == float(m3d.reduce_min(x.contiguous()))
     assert float(m3d.ops.reduce_min_multi(xs[:1])[0]) == float(xs[0].min())
-    with pytest.raises(m3d.M3DError):
-        m3d.ops.reduce_min_multi(xs + [xs[0]])                 # 13 arrays: over the entry point's limit
+    # beyond the entry point's 12 arrays the host op runs groups of 12 (a deeper backbone must not turn the PRM forward into an error);
+    # the C entry point itself still refuses 13
+    many = xs + xs[::-1] + xs[:5]                              # 29 arrays: groups of 12 + 12 + 5
+    gm = m3d.ops.reduce_min_multi(many).cpu()
+    assert gm.shape == (29,)
+    for i, x in enumerate(many):
+        assert float(gm[i]) == float(x.min())
+    import ctypes as C
+    n = 13
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in many[:n]])
+    cnts = (C.c_int64 * n)(*[x.numel() for x in many[:n]])
+    out = torch.empty((n,), device="cuda")
+    wsb = m3d._lib.lib().m3d_reduce_min_multi_workspace_bytes()
+    ws = torch.empty((wsb,), dtype=torch.uint8, device="cuda")
+    rc = m3d._lib.lib().m3d_reduce_min_multi(ptrs, cnts, n, C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), C.c_size_t(wsb), None)
+    assert rc == -1                                            # M3D_EINVAL
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 9), (6, 10, 14), (3, 5, 8)])
+def test_prm_scatter_fills_maps_whose_voxel_count_is_not_a_multiple_of_four(m3d, shape):
+    """m3d_prm_scatter writes every voxel of [P,D,H,W] (zero outside the window, NaN everywhere for a zero-sum peak): maps of 315 / 840 /
+    120 voxels - odd counts take the dword fill over a (chunks, peak) grid - against the statement in NumPy, bit for bit."""
+    rng = np.random.RandomState(11)
+    Pn, wn = 5, 4
+    D, H, W = shape
+    win = torch.from_numpy(rng.rand(Pn, wn, wn, wn).astype(np.float32)).cuda()
+    sums = win.sum((1, 2, 3))
+    sums[3] = 0.0
+    org = torch.from_numpy(rng.randint(-2, 4, (Pn, 3)).astype(np.int32)).cuda()
+    got = m3d.prm_scatter(win, sums, org, shape).cpu().numpy()
+    ref = np.zeros((Pn, D, H, W), np.float32)
+    wh, sh, oh = win.cpu().numpy(), sums.cpu().numpy(), org.cpu().numpy()
+    for p in range(Pn):
+        ref[p] = np.float32(0) / sh[p] if sh[p] == 0 else 0.0
+        for z in range(wn):
+            for y in range(wn):
+                for x in range(wn):
+                    q = oh[p] + (z, y, x)
+                    if 0 <= q[0] < D and 0 <= q[1] < H and 0 <= q[2] < W:
+                        ref[p, q[0], q[1], q[2]] = wh[p, z, y, x] / sh[p]
+    assert np.array_equal(got, ref, equal_nan=True)
 
 
 def test_paint_begin_fills_the_sentinel_and_derives_the_ids(m3d):

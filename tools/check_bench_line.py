@@ -10,6 +10,7 @@ assert len(last) < 8000, len(last)
 for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
     assert k in d, k
 assert "workload" in d["config"]
+assert not d.get("accounting_errors"), d["accounting_errors"]
 if d["n_gpus"] == 1 and not d.get("dry"):
     assert d.get("roofline") and d.get("cpu_baseline"), "roofline / cpu_baseline missing"
     for sub in ("configs1_backbone", "stress_rois", "configs3_prm_soma", "prm_nuclei_tile", "volume_pipeline"):
