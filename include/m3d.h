@@ -86,6 +86,11 @@ int m3d_roi_align3d_backward(int aligned_slices, int aligned_height, int aligned
  * descending volume (by_volume=1), ties in descending input index.  d_keep receives the surviving INPUT
  * indices in ascending order (np.where(suppressed == 0)[0], pyx:96); *d_num_keep their count.
  * fp32 arithmetic, `ovr >= thresh`, bit-exact with the reference.
+ * n <= 16384: rank sort, N x N/64 IoU bitmask, one workgroup resolves it from LDS.  16384 < n <= 2^20 (round 6; the cross-tile NMS of
+ * a whole volume's detections - tools/binarization_nuclei.py:81, tools/binarization_soma.py:57, lib/core/test.py:159 - has no bound in
+ * the reference): the blocked form - chunks of 1024 sorted rows, a chunk's own 1024 x 1024 bitmask resolved by one workgroup against
+ * the global removed bitmap, its kept boxes then tested against every later live box by a wide launch; same result, O(kept x alive)
+ * IoUs, workspace n x 176 bytes.  n > 2^20: M3D_EUNSUPPORTED (the O(n^2) rank sort alone would take seconds).
  * ------------------------------------------------------------------------------------------------------- */
 size_t m3d_nms3d_workspace_bytes(int n);
 int m3d_nms3d(const float* d_dets, int n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep,

@@ -9,13 +9,24 @@
 // total order incl. the tie rule), (2) upper-triangular 64x64 IoU bitmask tiles, (3) one workgroup walks
 // the rows in 64-row chunks staged in LDS: a scalar 64-step loop resolves the diagonal tile, then all
 // lanes OR the surviving rows into the "removed" bitmap, (4) flags are mapped back to input order and
-// compacted with a block scan.  N <= 16384.
+// compacted with a block scan.  That form keeps the whole N x N/64 bitmask and a 64-row chunk of it in LDS: N <= 16384.
+//
+// Beyond 16384 boxes (cross-tile NMS of a whole volume's detections: tools/binarization_nuclei.py:81, tools/binarization_soma.py:57,
+// lib/core/test.py:159 call nms_3d on every tile's rows at once, unbounded) the same greedy rule runs BLOCKED, with no N x N mask:
+// the sorted rows are cut into chunks of 1024; (2') one launch computes every chunk's own 1024 x 1024 diagonal bitmask; then per
+// chunk (3a) one workgroup resolves the chunk against the global "removed" bitmap (visiting only rows that are still alive) and
+// writes the chunk's KEPT boxes, (3b) a wide launch tests every later, still-alive box against those kept boxes (IoU on the fly,
+// first hit wins) and ORs the hits into the bitmap.  A box is removed iff an earlier KEPT box overlaps it by >= thresh - the
+// reference's loop (pyx:67-95), bit for bit, in O(kept x alive) IoUs.  N <= 2^20.
 #include "box_common.h"
 
 namespace {
 using namespace m3dbox;
 
-constexpr int kMaxNms = 16384;
+constexpr int kMaxNms = 16384;          // the one-workgroup resolve (LDS: 64 rows x N / 64 words)
+constexpr int kMaxNmsBlocked = 1 << 20; // the blocked form (O(N^2) rank sort: ~0.1 s at the cap)
+constexpr int kNmsChunk = 1024;         // rows per chunk of the blocked form = 16 bitmask words
+constexpr int kNmsChunkWords = kNmsChunk / 64;
 
 // ---- (1) volumes + keys ------------------------------------------------------------------------------
 __global__ void nms_prepare_kernel(const float* __restrict__ dets, int n_max, const int* __restrict__ d_n, int by_volume,
@@ -172,9 +183,162 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long
   if (threadIdx.x == 0) *num_keep = (keep_limit > 0 && scan_base > keep_limit) ? keep_limit : scan_base;
 }
 
+// ================================ blocked greedy NMS (N > 16384) ==========================================================
+// (2') diagonal bitmasks: dmask[i * 16 + cw] bit t <=> sorted box (chunk(i) * 1024 + cw * 64 + t) is suppressed by sorted box i (t later than i)
+__global__ __launch_bounds__(64) void nms_diag_mask_kernel(const SBox* __restrict__ sboxes, int n_max, const int* __restrict__ d_n,
+                                                           float thresh, unsigned long long* __restrict__ dmask) {
+  const int n = d_n ? *d_n : n_max;
+  const int cw = blockIdx.x, rb = blockIdx.y;                 // column word inside the chunk, 64-row group (global)
+  const int cb = (rb / kNmsChunkWords) * kNmsChunkWords + cw; // global 64-column block
+  const int i = rb * 64 + threadIdx.x;
+  if (rb * 64 >= n) return;
+  if (cb < rb || cb * 64 >= n) {
+    if (i < n) dmask[(size_t)i * kNmsChunkWords + cw] = 0ull;
+    return;
+  }
+  __shared__ SBox cols[64];
+  const int jc = cb * 64 + threadIdx.x;
+  if (jc < n) cols[threadIdx.x] = sboxes[jc];
+  __syncthreads();
+  if (i >= n) return;
+  const SBox bi = sboxes[i];
+  unsigned long long bits = 0ull;
+  const int m = min(64, n - cb * 64);
+  for (int t = 0; t < m; ++t) {
+    if (cb * 64 + t <= i) continue;
+    if (nms_suppresses(bi, cols[t], thresh)) bits |= 1ull << t;
+  }
+  dmask[(size_t)i * kNmsChunkWords + cw] = bits;
+}
+
+__global__ void nms_blocked_init_kernel(unsigned long long* __restrict__ removed, int nwords) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < nwords) removed[w] = 0ull;
+}
+
+// (3a) chunk c: resolve rows [c * 1024, ...) against removed[]; kept boxes -> kept_boxes[0 .. *kept_count), flags in input order
+__global__ __launch_bounds__(1024) void nms_chunk_resolve_kernel(const unsigned long long* __restrict__ dmask, const SBox* __restrict__ sboxes,
+                                                                 const int* __restrict__ order, int n_max, const int* __restrict__ d_n,
+                                                                 int chunk, unsigned long long* __restrict__ removed,
+                                                                 SBox* __restrict__ kept_boxes, int* __restrict__ kept_count,
+                                                                 unsigned char* __restrict__ flag) {
+  extern __shared__ unsigned long long lds[];                 // [1024 rows][16 words]
+  __shared__ unsigned long long rem[kNmsChunkWords], keptw[kNmsChunkWords];
+  __shared__ int kept_prefix[kNmsChunkWords + 1];
+  const int n = d_n ? *d_n : n_max;
+  const int r0 = chunk * kNmsChunk;
+  if (r0 >= n) { if (threadIdx.x == 0) *kept_count = 0; return; }
+  const int rows = min(kNmsChunk, n - r0);
+  const int words = (rows + 63) / 64;
+  for (int e = threadIdx.x; e < rows * kNmsChunkWords; e += blockDim.x) lds[e] = dmask[(size_t)r0 * kNmsChunkWords + e];
+  if (threadIdx.x < kNmsChunkWords) {
+    rem[threadIdx.x] = threadIdx.x < words ? removed[chunk * kNmsChunkWords + threadIdx.x] : ~0ull;
+    keptw[threadIdx.x] = 0ull;
+  }
+  __syncthreads();
+  for (int g = 0; g < words; ++g) {
+    if (threadIdx.x == 0) {
+      const int grows = min(64, rows - g * 64);
+      const unsigned long long valid = grows == 64 ? ~0ull : ((1ull << grows) - 1ull);
+      unsigned long long rm = rem[g], kept = 0ull;
+      unsigned long long avail = ~rm & valid;
+      while (avail) {                                         // only rows that are still alive are visited
+        const int b = __ffsll((long long)avail) - 1;
+        kept |= 1ull << b;
+        rm |= lds[(size_t)(g * 64 + b) * kNmsChunkWords + g];
+        avail = ~rm & valid & ~((2ull << b) - 1ull);          // alive rows after b ((2 << 63) wraps to 0: mask ~(0 - 1) = 0)
+        if (b == 63) avail = 0ull;
+      }
+      rem[g] = rm;
+      keptw[g] = kept;
+    }
+    __syncthreads();
+    const unsigned long long kept = keptw[g];
+    if (threadIdx.x > g && threadIdx.x < words) {             // later words of the chunk: OR the kept rows' masks
+      unsigned long long acc = rem[threadIdx.x], kk = kept;
+      while (kk) {
+        const int b = __ffsll((long long)kk) - 1;
+        kk &= kk - 1;
+        acc |= lds[(size_t)(g * 64 + b) * kNmsChunkWords + threadIdx.x];
+      }
+      rem[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int g = 0; g < kNmsChunkWords; ++g) { kept_prefix[g] = acc; acc += g < words ? __popcll(keptw[g]) : 0; }
+    kept_prefix[kNmsChunkWords] = acc;
+    *kept_count = acc;
+  }
+  if (threadIdx.x < words) removed[chunk * kNmsChunkWords + threadIdx.x] = rem[threadIdx.x];
+  __syncthreads();
+  if ((int)threadIdx.x < rows) {
+    const int g = threadIdx.x >> 6, b = threadIdx.x & 63;
+    const unsigned long long kw = keptw[g];
+    const bool k = (kw >> b) & 1ull;
+    flag[order[r0 + threadIdx.x]] = k ? 1 : 0;
+    if (k) kept_boxes[kept_prefix[g] + __popcll(kw & ((1ull << b) - 1ull))] = sboxes[r0 + threadIdx.x];
+  }
+}
+
+// (3b) every alive box after chunk c against the chunk's kept boxes; one wave = one word of the bitmap
+__global__ __launch_bounds__(256) void nms_chunk_apply_kernel(const SBox* __restrict__ sboxes, int n_max, const int* __restrict__ d_n,
+                                                              int chunk, float thresh, const SBox* __restrict__ kept_boxes,
+                                                              const int* __restrict__ kept_count, unsigned long long* __restrict__ removed) {
+  __shared__ SBox kb[kNmsChunk];
+  const int n = d_n ? *d_n : n_max;
+  const int nk = *kept_count;
+  const int j0 = (chunk + 1) * kNmsChunk + blockIdx.x * 256;
+  if (nk == 0 || j0 >= n) return;
+  for (int e = threadIdx.x; e < nk; e += 256) kb[e] = kept_boxes[e];
+  __syncthreads();
+  const int j = j0 + threadIdx.x;
+  const int w = j >> 6;
+  const unsigned long long rm = (w * 64 < n) ? removed[w] : ~0ull;
+  bool hit = false;
+  if (j < n && !((rm >> (j & 63)) & 1ull)) {
+    const SBox bj = sboxes[j];
+    for (int e = 0; e < nk; ++e)
+      if (nms_suppresses(kb[e], bj, thresh)) { hit = true; break; }
+  }
+  const unsigned long long ball = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && ball && w * 64 < n) removed[w] = rm | ball;    // this wave is the only writer of word w in this launch
+}
+
+// (4) kept input indices in ascending order from the flags; ONE workgroup
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const unsigned char* __restrict__ flag, int n_max, const int* __restrict__ d_n,
+                                                           int64_t* __restrict__ keep, int32_t* __restrict__ num_keep, int keep_limit) {
+  __shared__ int wave_sum[16];
+  __shared__ int scan_base;
+  const int n = d_n ? *d_n : n_max;
+  if (threadIdx.x == 0) scan_base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const bool f = i < n && flag[i];
+    const unsigned long long ball = __ballot(f);
+    if (lane == 0) wave_sum[wv] = __popcll(ball);
+    __syncthreads();
+    int before = scan_base;
+    for (int k = 0; k < wv; ++k) before += wave_sum[k];
+    const int pos = before + __popcll(ball & ((1ull << lane) - 1ull));
+    if (f && (keep_limit <= 0 || pos < keep_limit)) keep[pos] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wave_sum[k]; scan_base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *num_keep = (keep_limit > 0 && scan_base > keep_limit) ? keep_limit : scan_base;
+}
+
 struct NmsWs {
   float* vol; float* key; int* order; SBox* sboxes; unsigned long long* mask; unsigned char* flag;
+  // blocked form: mask = the diagonal bitmasks [n][16]
+  unsigned long long* removed; SBox* kept_boxes; int* kept_count;
 };
+
+inline size_t nms_mask_words_per_row(int n) { return n > kMaxNms ? (size_t)kNmsChunkWords : (size_t)(n + 63) / 64; }
 
 size_t nms_ws_bytes(int n) {
   const size_t nblk = (n + 63) / 64;
@@ -182,28 +346,59 @@ size_t nms_ws_bytes(int n) {
   b += m3d::align_up(sizeof(float) * n, 256) * 2;
   b += m3d::align_up(sizeof(int) * n, 256);
   b += m3d::align_up(sizeof(SBox) * n, 256);
-  b += m3d::align_up(sizeof(unsigned long long) * n * nblk, 256);
+  b += m3d::align_up(sizeof(unsigned long long) * n * nms_mask_words_per_row(n), 256);
   b += m3d::align_up((size_t)n, 256);
+  if (n > kMaxNms) {
+    b += m3d::align_up(sizeof(unsigned long long) * (nblk + kNmsChunkWords), 256);
+    b += m3d::align_up(sizeof(SBox) * kNmsChunk, 256) + 256;
+  }
   return b + 256;
 }
 
 NmsWs nms_carve(void* ws, int n) {
   const size_t nblk = (n + 63) / 64;
   char* p = (char*)m3d::align_up((size_t)ws, 256);
-  NmsWs w;
+  NmsWs w{};
   w.vol = (float*)p; p += m3d::align_up(sizeof(float) * n, 256);
   w.key = (float*)p; p += m3d::align_up(sizeof(float) * n, 256);
   w.order = (int*)p; p += m3d::align_up(sizeof(int) * n, 256);
   w.sboxes = (SBox*)p; p += m3d::align_up(sizeof(SBox) * n, 256);
-  w.mask = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * n * nblk, 256);
-  w.flag = (unsigned char*)p;
+  w.mask = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * n * nms_mask_words_per_row(n), 256);
+  w.flag = (unsigned char*)p; p += m3d::align_up((size_t)n, 256);
+  if (n > kMaxNms) {
+    w.removed = (unsigned long long*)p; p += m3d::align_up(sizeof(unsigned long long) * (nblk + kNmsChunkWords), 256);
+    w.kept_boxes = (SBox*)p; p += m3d::align_up(sizeof(SBox) * kNmsChunk, 256);
+    w.kept_count = (int*)p;
+  }
   return w;
+}
+
+// the blocked form: 2 + 1 + 1 launches and two per chunk of 1024 sorted rows
+int nms_launch_blocked(const float* d_dets, int n_max, const int* d_n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep,
+                       const NmsWs& w, int keep_limit, hipStream_t st) {
+  const int nblk = (n_max + 63) / 64, nchunk = (n_max + kNmsChunk - 1) / kNmsChunk;
+  hipLaunchKernelGGL(nms_prepare_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, n_max, d_n, by_volume, w.vol, w.key);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, w.vol, w.key, n_max, d_n, w.order, w.sboxes);
+  hipLaunchKernelGGL(nms_diag_mask_kernel, dim3(kNmsChunkWords, nblk), dim3(64), 0, st, w.sboxes, n_max, d_n, thresh, w.mask);
+  hipLaunchKernelGGL(nms_blocked_init_kernel, dim3((nblk + kNmsChunkWords + 255) / 256), dim3(256), 0, st, w.removed, nblk + kNmsChunkWords);
+  const size_t lds = sizeof(unsigned long long) * kNmsChunk * kNmsChunkWords;      // 128 KB
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_chunk_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int c = 0; c < nchunk; ++c) {
+    hipLaunchKernelGGL(nms_chunk_resolve_kernel, dim3(1), dim3(1024), lds, st, w.mask, w.sboxes, w.order, n_max, d_n, c, w.removed,
+                       w.kept_boxes, w.kept_count, w.flag);
+    const int after = n_max - (c + 1) * kNmsChunk;
+    if (after > 0)
+      hipLaunchKernelGGL(nms_chunk_apply_kernel, dim3((after + 255) / 256), dim3(256), 0, st, w.sboxes, n_max, d_n, c, thresh, w.kept_boxes,
+                         w.kept_count, w.removed);
+  }
+  hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, st, w.flag, n_max, d_n, d_keep, d_num_keep, keep_limit);
+  return m3d::check_launch("nms3d(blocked)");
 }
 
 // n_max: capacity (host); d_n: optional device count (<= n_max).
 int nms_launch(const float* d_dets, int n_max, const int* d_n, float thresh, int by_volume, int64_t* d_keep, int32_t* d_num_keep,
                void* d_ws, size_t ws_bytes, int keep_limit, hipStream_t st) {
-  if (n_max < 0 || n_max > kMaxNms) return n_max < 0 ? M3D_EINVAL : M3D_EUNSUPPORTED;
+  if (n_max < 0 || n_max > kMaxNmsBlocked) return n_max < 0 ? M3D_EINVAL : M3D_EUNSUPPORTED;
   if (!d_num_keep) return M3D_EINVAL;
   if (n_max == 0) {
     (void)hipMemsetAsync(d_num_keep, 0, sizeof(int32_t), st);   // boxes_3d.py:366-367
@@ -212,6 +407,7 @@ int nms_launch(const float* d_dets, int n_max, const int* d_n, float thresh, int
   if (!d_dets || !d_keep || !d_ws) return M3D_EINVAL;
   if (ws_bytes < nms_ws_bytes(n_max)) return M3D_EWORKSPACE;
   const NmsWs w = nms_carve(d_ws, n_max);
+  if (n_max > kMaxNms) return nms_launch_blocked(d_dets, n_max, d_n, thresh, by_volume, d_keep, d_num_keep, w, keep_limit, st);
   const int nblk = (n_max + 63) / 64;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, n_max, d_n, by_volume, w.vol, w.key);
   hipLaunchKernelGGL(nms_rank_kernel, dim3((n_max + 255) / 256), dim3(256), 0, st, d_dets, w.vol, w.key, n_max, d_n, w.order,

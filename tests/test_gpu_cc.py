@@ -240,3 +240,51 @@ def test_prefilters_bit_exact_with_scipy(m3d, shape):
     assert np.array_equal(m.cpu().numpy(), ndimage.median_filter(ref_g, size=3))
     g2 = m3d.gaussian_filter_u16(dev(a), 2.0)                      # another sigma: radius 8
     assert np.array_equal(g2.cpu().numpy(), ndimage.gaussian_filter(a, sigma=2))
+
+
+def _many_tile_nuclei_set(rs, S=12, H=1000, W=800, per_tile=270, real_every=4):
+    """63 overlapping nuclei tiles (9 x 7 of 200 x 200, binarization_nuclei.py:50-56), 270 detections each = 17 010 rows in the
+    cross-tile NMS - above the 16 384 boxes one workgroup can resolve.  Every fourth tile carries ONE real detection (an anisotropic
+    blob in the tile centre, the largest box of its neighbourhood, score > 0.4); the other rows are low-score boxes >= 32 wide (they
+    pass :71-77, take part in the volume-ordered NMS and are dropped by the 0.4 score cut of :83-85).  All rows of a tile share one
+    uint8 map (a stride-0 view), so the set costs 0.5 MB per tile."""
+    from m3d.binarize import nuclei_tiles
+    grid = nuclei_tiles(H, W)
+    img = (rs.randn(S, H, W) * 12 + 110)
+    tiles = {}
+    zz, yy, xx = np.mgrid[0:S, 0:200, 0:200]
+    for num, ss, hs, ws in grid:
+        n = per_tile
+        c = rs.uniform(20, 180, (n, 2))                         # (x, y) centres inside the tile
+        wh = rs.uniform(32.5, 44, (n, 2))
+        z1 = rs.uniform(0, 3, n); z2 = rs.uniform(S - 4, S - 1.01, n)
+        dets = np.stack([c[:, 0] - wh[:, 0] / 2, c[:, 1] - wh[:, 1] / 2, z1, c[:, 0] + wh[:, 0] / 2, c[:, 1] + wh[:, 1] / 2, z2,
+                         np.round(rs.uniform(0.01, 0.4, n), 3)], 1)
+        dets[:, [0, 1]] = np.maximum(dets[:, [0, 1]], 0); dets[:, [3, 4]] = np.minimum(dets[:, [3, 4]], 199)
+        pmap = np.zeros((S, 200, 200), np.uint8)
+        if num % real_every == 0:
+            cz, cy, cx = (S - 1) / 2.0, 100.0 + rs.uniform(-3, 3), 100.0 + rs.uniform(-3, 3)
+            d2 = ((zz - cz) / 3.0) ** 2 + ((yy - cy) / 9.0) ** 2 + ((xx - cx) / 9.0) ** 2
+            blob = np.exp(-d2 / 2)
+            img[:, hs:hs + 200, ws:ws + 200] += rs.uniform(500, 900) * blob
+            p = blob * (rs.rand(S, 200, 200) * 0.3 + 0.7)
+            p[d2 > 9] = 0
+            pmap = (p / p.max() * 255).astype(np.uint8)
+            dets[0] = [cx - 26, cy - 26, 0.3, cx + 26, cy + 26, S - 1.2, rs.uniform(0.5, 1.0)]     # 53 x 53 x S: the biggest box around
+        tiles[num] = (dets.astype(np.float64), np.broadcast_to(pmap, (n, S, 200, 200)))
+    return img.clip(0, 65535).astype(np.uint16), tiles, grid
+
+
+def test_binarize_volume_with_more_detections_than_one_nms_workgroup_resolves(m3d):
+    """tools/binarization_nuclei.py:81 runs nms_3d_volume over EVERY tile's detections at once, with no bound.  63 tiles x 270 rows =
+    17 010 boxes go through the blocked form of m3d_nms3d (csrc/box_ops.hip: N > 16 384); labels and table against the oracle's
+    restatement of the script, bit for bit, and the NMS stage alone against the oracle's NMS on the same rows."""
+    from m3d.binarize import binarize_volume
+    rs = np.random.RandomState(63)
+    img, tiles, grid = _many_tile_nuclei_set(rs)
+    assert len(grid) >= 60 and sum(len(t[0]) for t in tiles.values()) > 16384
+    seg, table = binarize_volume(img, tiles, "nuclei", max_gray_range=4096)
+    seg_ref, table_ref = O.binarize_volume(img, tiles, "nuclei")
+    assert seg_ref.max() >= 5 and len(table_ref) >= 5
+    assert np.array_equal(seg, seg_ref)
+    assert table.shape == table_ref.shape and np.array_equal(table, table_ref.astype(np.float64))

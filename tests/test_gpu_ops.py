@@ -42,6 +42,46 @@ def test_nms_vs_oracle_random_and_ties(m3d, n):
     assert np.array_equal(m3d.nms3d(dev(dets), 0.3, by_volume=True).cpu().numpy(), O.nms_3d_volume(dets, 0.3))
 
 
+@pytest.mark.parametrize("n,ext,thr_vol", [(16385, 140, 0.3), (17408, 140, 0.3), (17409, 140, 0.3), (20000, 150, 0.3), (50000, 200, 0.3),
+                                           (100000, 250, 0.1)])
+def test_nms_beyond_one_workgroups_capacity_equals_the_oracle(m3d, n, ext, thr_vol):
+    """Cross-tile NMS has no bound on its row count (tools/binarization_nuclei.py:81, binarization_soma.py:57, lib/core/test.py:159):
+    above 16 384 boxes m3d_nms3d runs the blocked form (chunks of 1024 sorted rows, csrc/box_ops.hip).  Same tie rule, same fp32
+    IoU, bit-equal keep lists against the oracle in score order and in volume order; sizes on and around chunk edges."""
+    rs = np.random.RandomState(n)
+    c = rs.uniform(0, ext, (n, 3)); s = rs.uniform(4, 40, (n, 3))
+    b = np.hstack((c - s / 2, c + s / 2))
+    sc = np.round(rs.uniform(0, 1, n), 3)            # ~n / 1000 rows per distinct score: the tie rule decides thousands of visits
+    dets = np.hstack((b, sc[:, None])).astype(np.float32)
+    dets[rs.randint(0, n, 50)] = dets[rs.randint(0, n, 50)]          # exact duplicates (IoU 1, equal score: descending index wins)
+    k = m3d.nms3d(dev(dets), 0.15).cpu().numpy()
+    assert np.array_equal(k, O.nms_3d(dets, 0.15))
+    assert np.array_equal(m3d.nms3d(dev(dets), thr_vol, by_volume=True).cpu().numpy(), O.nms_3d_volume(dets, thr_vol))
+    k2 = m3d.nms3d(dev(dets[k]), 0.15).cpu().numpy()                 # idempotence: survivors do not suppress each other
+    assert np.array_equal(k2, np.arange(len(k)))
+
+
+def test_nms_blocked_form_extremes(m3d):
+    """20 000 identical boxes -> exactly one survivor (the last row: ties visit the highest index first); 20 000 disjoint boxes ->
+    all survive, in input order; the entry point refuses more than 2^20 rows instead of running for minutes."""
+    n = 20000
+    same = np.tile(np.array([[1, 2, 3, 11, 12, 13, 0.5]], np.float32), (n, 1))
+    assert np.array_equal(m3d.nms3d(dev(same), 0.5).cpu().numpy(), [n - 1])
+    assert np.array_equal(m3d.nms3d(dev(same), 0.5, by_volume=True).cpu().numpy(), [n - 1])
+    g = np.arange(n)
+    far = np.stack([(g % 100) * 20, (g // 100 % 100) * 20, (g // 10000) * 20], 1).astype(np.float32)
+    rs = np.random.RandomState(3)
+    dets = np.hstack((far, far + 9, rs.permutation(n)[:, None] / n)).astype(np.float32)
+    assert np.array_equal(m3d.nms3d(dev(dets), 0.01).cpu().numpy(), g)
+    import ctypes as C
+    L = m3d._lib.lib()
+    big = (1 << 20) + 1
+    keep = torch.empty((8,), dtype=torch.int64, device="cuda"); num = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    rc = L.m3d_nms3d(C.c_void_p(keep.data_ptr()), big, C.c_float(0.3), 0, C.c_void_p(keep.data_ptr()), C.c_void_p(num.data_ptr()),
+                     C.c_void_p(keep.data_ptr()), C.c_size_t(64), None)
+    assert rc == -4                                                   # M3D_EUNSUPPORTED, before anything is launched
+
+
 def test_nms_empty_and_idempotent(m3d):
     assert m3d.nms3d(torch.zeros((0, 7), device="cuda"), 0.3).numel() == 0
     rs = np.random.RandomState(5)

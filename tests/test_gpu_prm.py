@@ -241,9 +241,12 @@ def test_dead_peaks_are_skipped_and_the_result_is_the_full_batchs(capsys):
             print("    %-9s %-46s %-14s %-14s %s" % (ra["layer"], ra["kernel"], ra["plan"], rb["plan"], "" if same else "<- differs"))
     exact = True
     for ra, rb in zip(ta, tb):
-        assert ra["P"] == len(live) and rb["P"] == len(sums) and ra["U"] == rb["U"] and ra["strip"] == rb["strip"]
+        assert ra["P"] == len(live) and rb["P"] == len(sums) and ra["strip"] == rb["strip"]
         if ra["layer"] == first_diff:
             exact = False
+        if ra["U"] != rb["U"]:                          # one engine's conv wrote the NEXT layer's prepared strip from its epilogue (fused
+            assert not exact                            # prepare needs an un-split K), the other the bare gradient: not comparable here
+            continue
         la, lb = _live_windows_of(ra, range(len(live)), m3d), _live_windows_of(rb, live, m3d)
         for i, (xa, xb) in enumerate(zip(la, lb)):
             if exact:                                   # same kernels, same plans so far: the sub-batch is the batch's rows, bit for bit
@@ -256,6 +259,7 @@ def test_dead_peaks_are_skipped_and_the_result_is_the_full_batchs(capsys):
         # the named cause, not an unexplained tolerance: the first differing layer is a strip conv whose K split (or tile) changed
         ra, rb = next((x, y_) for x, y_ in zip(ta, tb) if x["layer"] == first_diff)
         assert ra["plan"] is not None and rb["plan"] is not None and ra["plan"] != rb["plan"], (first_diff, ra["plan"], rb["plan"])
+        assert ra["plan"][2] != rb["plan"][2], "tile changed but not the K split: tiles alone keep the summation order"
         for i in live:
             assert np.allclose(wa[i], wb[i], rtol=1e-5, atol=1e-7 * float(wb[i].max())), i
         assert np.allclose(a["sums"].cpu().numpy(), sums, rtol=1e-5)
