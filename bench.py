@@ -1026,7 +1026,27 @@ def bench_detect(args, rank, world, dist):
         M = int(round(rois_probed))
         Kf, Nf = 256 * 343, cfg.mlp_dim
         fl = 2.0 * M * Nf * Kf
-        if "fc1" in getattr(det, "fc_split", {}):
+        import m3d.ops as _ops
+        if isinstance(getattr(det, "fc_split", {}).get("fc1"), _ops.SplitLinearF16):
+            # f16x2 split (round 6): three f16 MFMAs per fp32 multiply-add (two scaled fp16 planes per operand) -> priced against the f16 / bf16 peak
+            r = {"bound": "mfma", "launch": "one launch over the RoIs of the rank's %d volumes (M = %d rows, mean of the probed steps)" % (nvol, M),
+                 "kernel": "fc_x3b_gemm_kernel<1> (Box_Head.fc1: [M,87808] x [1024,87808]^T on v_mfma_f32_32x32x16_f16: both operands scaled by a power "
+                           "of two and cut into two fp16 numbers (22 bits), 3 products per fp32 product, 256 x 256 tiles, split-K; + absmax of the "
+                           "feature map (the x scale) + fc_reduce_kernel in the same span)",
+                 "achieved": 3.0 * fl / (ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": 3.0 * fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
+                 "issued_gflop_per_launch": 3.0 * fl / 1e9, "algorithmic_gflop_per_launch": fl / 1e9,
+                 "algorithmic_equivalent_tflops": fl / (ms * 1e-3) / 1e12,
+                 "fp32_mfma_peak_multiple": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "ceiling_tflops": BF16_MFMA_PEAK_TFLOPS / 3.0,
+                 "frac_of_ceiling": fl / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3.0),
+                 "algorithmic_bytes_per_launch": M * Kf * 4.0 + Nf * Kf * 4.0 + M * Nf * 4.0,
+                 "note": "achieved/frac count the f16 MFMA FLOPs ISSUED (3 x 2MNK) against the dense f16 (= bf16) peak; "
+                         "algorithmic_equivalent_tflops = 2MNK / time.  Error vs fp64 on this shape equals the fp32-input kernel's "
+                         "(tests/test_gpu_ops.py: test_linear_f16x2_split_gemm_is_as_accurate_as_the_fp32_kernel); M3D_FC_SPLIT=bf16x3 selects "
+                         "round 2-5's exact 3-way bf16 cut (6 products)"}
+            r.update(pmc_traffic("fc_x3b_gemm_kernel<1>"))
+        elif "fc1" in getattr(det, "fc_split", {}):
             # bf16x3 split: six bf16 MFMAs per fp32 multiply-add (exact 3-way cut of both operands) -> priced against the bf16 peak
             r = {"bound": "mfma", "launch": "one launch over the RoIs of the rank's %d volumes (M = %d rows, mean of the probed steps)" % (nvol, M),
                  "kernel": "fc_x3_gemm_kernel (Box_Head.fc1: [M,87808] x [1024,87808]^T at fp32 accuracy on v_mfma_f32_32x32x16_bf16: "
@@ -1096,9 +1116,10 @@ def bench_detect(args, rank, world, dist):
                       "kernel_ms_per_launch_median": {k: round(v, 4) for k, v in sorted(kern_med.items(), key=lambda kv: -kv[1])}},
            "roofline": conv_family, "rooflines": roofs}
     if not backbone_only and getattr(det, "fc_split", None):
-        res["dtype_note"] = ("every operand, accumulator and result is fp32; fc1 / fc2 multiply on the bf16 matrix cores after an EXACT 3-way bf16 cut "
-                             "of both fp32 operands (6 MFMAs per product, fp32 accumulation; error vs fp64 = the fp32-input kernel's, "
-                             "tests/test_gpu_ops.py); M3D_FC_SPLIT=0 selects the fp32-input MFMA kernel")
+        res["dtype_note"] = ("every operand, accumulator and result is fp32; fc1 / fc2 multiply on the f16 matrix cores after both fp32 operands are scaled "
+                             "by a power of two and cut into two fp16 numbers (22 significand bits; 3 MFMAs per product, fp32 accumulation; error vs "
+                             "fp64 on the shipped shape = the fp32-input kernel's, tests/test_gpu_ops.py); M3D_FC_SPLIT=bf16x3 selects the exact "
+                             "3-way bf16 cut (6 MFMAs, rounds 2-5), M3D_FC_SPLIT=0 the fp32-input MFMA kernel")
     for k, v in (("resident", resident), ("warm_host_to_host", warm), ("sustained", sustained), ("pipelined", piped), ("interleaved", inter)):
         if v is not None:
             res[k] = v

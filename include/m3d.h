@@ -358,6 +358,24 @@ size_t m3d_linear_bf16x3_w32_workspace_bytes(int M, int N, int K);
 int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weight, const float* d_bias, float* d_out, int M, int N, int K,
                                   int relu, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Round 6 - the same layer with THREE products per fp32 product ("f16x2 split"; replaces the same cuBLAS SGEMMs,
+ * lib/modeling/fast_rcnn_heads.py:84-85,114-115): each operand is scaled by a power of two (its largest magnitude just under 2^15) and
+ * cut into two fp16 numbers, x s = xh + xl with |x s - xh - xl| <= 2^-22 |x s| (11 + 11 significand bits, round to nearest); three
+ * v_mfma_f32_32x32x16_f16 products (hh, hl, lh) accumulate in fp32, the scales are undone exactly in the epilogue.  Dropped:
+ * xl.wl and the cut residuals, each <= 2^-22 of the product and of random sign - below what the fp32 accumulation of K products
+ * rounds in this kernel and in an SGEMM alike; tests compare both with fp64 on the shipped shape.  Half the matrix-core time of
+ * m3d_linear_bf16x3_forward, 4 bytes per packed weight (packed_bytes also holds the weight's largest magnitude).
+ * d_x_bound: device pointer to ONE float >= max|x| (m3d_absmax of x or of whatever bounds x: a RoIAlign output is a convex
+ * combination of its feature map's values, so the map's largest magnitude does), or NULL: the call sweeps x itself first.
+ * A bound smaller than max|x| overflows fp16 (inf / NaN outputs); a bound up to 2^8 too large costs no accuracy.  Finite operands only.
+ * Workspace m3d_linear_f16x2_workspace_bytes (always >= 256, 16-byte aligned).  K % 32 == 0 else M3D_EUNSUPPORTED. */
+int m3d_absmax(const float* d_x, long long n, float* d_out, void* stream);
+size_t m3d_linear_f16x2_packed_bytes(int N, int K);
+int m3d_linear_f16x2_pack(const float* d_weight, int N, int K, void* d_packed, void* stream);
+size_t m3d_linear_f16x2_workspace_bytes(int M, int N, int K);
+int m3d_linear_f16x2_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
+                             int relu, const float* d_x_bound, void* d_ws, size_t ws_bytes, void* stream);
+
 /* f-1 A/B: the fc1 GEMM with the RoIAlign gather in its A-operand loader - the [M, C * 343] RoIAlign output is never
  * written.  m3d_roi_align3d_tap_tables: the RoIs' per-axis sample tables (7^3 bins, sampling grid 2 - the shipped geometry) -> d_tab
  * (16 bytes x 3 axes x 14 samples per RoI) and d_roi_batch [num_rois]; m3d_linear_bf16x3_roi_forward: out[M, N] = act(RoIAlign3D(features,

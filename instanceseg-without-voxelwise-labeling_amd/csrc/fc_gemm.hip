@@ -20,6 +20,8 @@
 //    b128 fragment feeds four MFMAs with no shuffles;
 //  * split-K partials go to a caller workspace and are summed in slice order by a second kernel (deterministic; fused with
 //    bias + ReLU).  slices == 1 stores directly.
+#include <type_traits>
+
 #include "m3d_common.h"
 
 namespace {
@@ -348,9 +350,79 @@ __global__ __launch_bounds__(256) void fc_x3_pack_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// "f16x2 split" (round 6): the same GEMM with THREE products per fp32 product instead of six.  fp16 carries an 11-bit significand, so
+//     x s = xh + xl + e,   xh = fp16(x s) (round to nearest),  xl = fp16(x s - xh),  |e| <= 2^-22 |x s|
+// (s = a power of two that puts the operand's largest magnitude just under 2^15: fp16 has 30 binades, values 2^18 below the largest keep
+// all 22 bits, smaller ones an absolute error of 2^-40 of the largest), and
+//     x.w = xh.wh + (xh.wl + xl.wh)  +  [xl.wl <= 2^-22 |x.w|, e-terms <= 2^-22 |x.w|: dropped]
+// The dropped terms are random-sign and four times the rounding of ONE fp32 product; the fp32 accumulation of K = 87 808 products that
+// both this kernel and an SGEMM perform rounds by 2^-24 of the running SUM at every step, which is what the error against fp64
+// consists of in both (tests/test_gpu_ops.py measures the two against fp64 on the shipped shape).  v_mfma_f32_32x32x16_f16 runs at
+// the bf16 form's rate, so the MFMA time halves; the packed weights are 4 bytes per element (two planes) instead of 6.
+// Scales: the weight's from its largest magnitude at pack time (kept beside the planes); x's from a caller-supplied bound of max|x|
+// (RoIAlign averages trilinear interpolations, convex combinations of feature-map values: max|feature map| bounds it and is 16 MB to
+// sweep instead of 440) or, without one, from a sweep of x itself.  Products are exact in fp32 (22 bits), sums stay below 2^47.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// scale 2^k with bound * 2^k in [2^14, 2^15) and its inverse, from the bound's exponent field (no host read of the bound)
+__device__ __forceinline__ void f16_scale_of(float bound, float& s, float& inv) {
+  int f = 268 - (int)((__float_as_uint(bound) >> 23) & 255u);
+  f = f < 2 ? 2 : (f > 252 ? 252 : f);
+  s = __uint_as_float((unsigned)f << 23);
+  inv = __uint_as_float((unsigned)(254 - f) << 23);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const long long n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    const f32x4 v = x4[e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const unsigned b = __float_as_uint(v[j]) & 0x7FFFFFFFu; m = b > m ? b : m; }
+  }
+  for (long long e = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(x[e]) & 0x7FFFFFFFu; m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);            // |x| as bits: non-negative floats order like their bit patterns
+}
+
+// packed[tn][c][plane h, l][row][32 k] (fp16, scaled) <- W[N][K] fp32; rows beyond N are zero.  One thread = 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void fc_f16_pack_kernel(const float* __restrict__ w, int N, int K, u32x4* __restrict__ packed,
+                                                          int nt, int chunks, const float* __restrict__ wamax) {
+  float sw, inv;
+  f16_scale_of(*wamax, sw, inv);
+  const long long total = (long long)nt * chunks * 128 * 4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int q = (int)(e & 3), row = (int)((e >> 2) & 127);
+    const long long tc = e >> 9;
+    const int c = (int)(tc % chunks), tn = (int)(tc / chunks);
+    const int n = tn * 128 + row;
+    u32x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x2 hh, ll;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float v = (n < N ? w[(size_t)n * K + (size_t)c * 32 + 8 * q + 2 * j + t] : 0.f) * sw;
+        const _Float16 h = (_Float16)v;
+        hh[t] = h; ll[t] = (_Float16)(v - (float)h);
+      }
+      ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+    }
+    u32x4* dst = packed + (size_t)tc * (2 * 128 * 4) + row * 4 + q;
+    dst[0] = ph; dst[512] = pl;
+  }
+}
+
 struct FcX3Args {
   const float* x; const u32x4* wp; const float* bias; float* out; float* part;
   int M, N, K, mt, nt, slices, chunks, relu, per_xcd;
+  const float* xbound; const float* wamax;     // F16 = 1: device scalars, a bound of max|x| and max|W| (the scales' sources)
   int x_alias;             // > 0 (tuning build only, option tune_fc_x_alias): row m of x is read from row m % x_alias - a cache-resident A
                            // operand: what the GEMM costs when its operand is free (WRONG results; the f-1 lower bound, tools/f1_ab.py)
   // XM = 1 (f-1 A/B): x[m][k] is not read but computed - the RoIAlign gather in the operand loader (taps: roi_tap_table_kernel)
@@ -395,11 +467,22 @@ __device__ inline float roi_gather_element(const float* __restrict__ fb /* featu
 //     read F1 | 24 MFMA(F0) | barrier A (the chunk's LDS image is free) | cut + LDS writes of chunk c+1 under 16 MFMA(F1) |
 //     barrier B | global loads of chunk c+2 -> registers | read F0 of chunk c+1 | 8 MFMA(F1)
 // so every LDS / barrier latency has MFMAs of the same wave to hide under, not only those of the other wave of the SIMD.
-template <int WR, int XM = 0>
+// F16 = 1: the f16x2 split (two planes per operand, three products; see above) - same tiles, staging and schedule.
+template <int WR, int XM = 0, int F16 = 0>
 __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(FcX3Args a) {
   constexpr int TBM = 64 * WR, NT = 128 * WR;                      // tile rows, threads
-  constexpr int XPL = TBM * X3_RSW, XOP = 3 * XPL;                 // dwords of an x plane / of the x operand; W planes: X3_PLANE
-  constexpr int NXI = TBM * 4 / NT, NWI = 3 * 128 * 4 / NT;        // rows of x (two float4 each) / 16-byte units of W per thread and chunk
+  constexpr int NPL = F16 ? 2 : 3;                                 // planes per operand
+  constexpr int CHUNK_U4 = NPL * 128 * 4;                          // 16-byte units of one packed (tile, chunk) weight block
+  constexpr int XPL = TBM * X3_RSW, XOP = NPL * XPL;               // dwords of an x plane / of the x operand; W planes: X3_PLANE
+  constexpr int NXI = TBM * 4 / NT, NWI = NPL * 128 * 4 / NT;      // rows of x (two float4 each) / 16-byte units of W per thread and chunk
+  using frag_t = std::conditional_t<F16 != 0, f16x8, bf16x8>;
+  float xs = 1.f, out_s0 = 1.f, out_s1 = 1.f;                      // F16: x scale; the two factors that undo the x and W scales
+  if constexpr (F16) {
+    float ws_, iw;
+    f16_scale_of(*a.xbound, xs, out_s0);
+    f16_scale_of(*a.wamax, ws_, iw);
+    out_s1 = iw;
+  }
   extern __shared__ float lds_f[];
   unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);        // [x planes h, m, l: TBM rows][W planes h, m, l: 128 rows] x 16 dwords
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -429,7 +512,7 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
       px[i] = a.x + (size_t)(a.x_alias > 0 ? mrow % a.x_alias : mrow) * a.K + 8 * oct;
     }
   }
-  const u32x4* pw = a.wp + (size_t)tn * a.chunks * X3_CHUNK_U4 + tid;
+  const u32x4* pw = a.wp + (size_t)tn * a.chunks * CHUNK_U4 + tid;
   const int swq = 4 * (oct ^ ((row0 >> 2) & 3));                   // NT/4 is a multiple of 16: every row of this thread swizzles alike
   f32x4 sx[NXI][2]; u32x4 sw[NWI];
   auto fetch = [&](int c) __attribute__((always_inline)) {
@@ -445,27 +528,40 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
       }
     }
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) sw[i] = pw[(size_t)c * X3_CHUNK_U4 + NT * i];
+    for (int i = 0; i < NWI; ++i) sw[i] = pw[(size_t)c * CHUNK_U4 + NT * i];
   };
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       u32x4 ph, pm, pl;
+      if constexpr (F16) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {                                // elements 2j, 2j+1 of this row's 8
-        const float v0 = sx[i][j >> 1][2 * (j & 1)], v1 = sx[i][j >> 1][2 * (j & 1) + 1];
-        const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
-        const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
-        const unsigned q0 = __float_as_uint(r0) & 0xFFFF0000u, q1 = __float_as_uint(r1) & 0xFFFF0000u;
-        const float t0 = r0 - __uint_as_float(q0), t1 = r1 - __uint_as_float(q1);
-        ph[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
-        pm[j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
-        pl[j] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = sx[i][j >> 1][2 * (j & 1)] * xs, v1 = sx[i][j >> 1][2 * (j & 1) + 1] * xs;
+          const f16x2 hh = {(_Float16)v0, (_Float16)v1};
+          const f16x2 ll = {(_Float16)(v0 - (float)hh[0]), (_Float16)(v1 - (float)hh[1])};
+          ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+        }
+        unsigned* d = lds + (row0 + (NT / 4) * i) * X3_RSW + swq;
+        *reinterpret_cast<u32x4*>(d) = ph;
+        *reinterpret_cast<u32x4*>(d + XPL) = pl;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                              // elements 2j, 2j+1 of this row's 8
+          const float v0 = sx[i][j >> 1][2 * (j & 1)], v1 = sx[i][j >> 1][2 * (j & 1) + 1];
+          const unsigned h0 = __float_as_uint(v0) & 0xFFFF0000u, h1 = __float_as_uint(v1) & 0xFFFF0000u;
+          const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+          const unsigned q0 = __float_as_uint(r0) & 0xFFFF0000u, q1 = __float_as_uint(r1) & 0xFFFF0000u;
+          const float t0 = r0 - __uint_as_float(q0), t1 = r1 - __uint_as_float(q1);
+          ph[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+          pm[j] = __builtin_amdgcn_perm(q1, q0, 0x07060302u);
+          pl[j] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
+        }
+        unsigned* d = lds + (row0 + (NT / 4) * i) * X3_RSW + swq;
+        *reinterpret_cast<u32x4*>(d) = ph;
+        *reinterpret_cast<u32x4*>(d + XPL) = pm;
+        *reinterpret_cast<u32x4*>(d + 2 * XPL) = pl;
       }
-      unsigned* d = lds + (row0 + (NT / 4) * i) * X3_RSW + swq;
-      *reinterpret_cast<u32x4*>(d) = ph;
-      *reinterpret_cast<u32x4*>(d + XPL) = pm;
-      *reinterpret_cast<u32x4*>(d + 2 * XPL) = pl;
     }
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -488,28 +584,31 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  struct Frags { bf16x8 a[2][3], b[2][3]; };
+  struct Frags { frag_t a[2][NPL], b[2][NPL]; };
   Frags f0, f1;
   auto read_frags = [&](Frags& f, int oa, int ob) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        f.a[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + oa + s * XPL + i * 32 * X3_RSW));
-        f.b[i][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + ob + s * X3_PLANE + i * 32 * X3_RSW));
+      for (int s = 0; s < NPL; ++s) {
+        f.a[i][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + oa + s * XPL + i * 32 * X3_RSW));
+        f.b[i][s] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + ob + s * X3_PLANE + i * 32 * X3_RSW));
       }
   };
-  // products p0..p1 of one k16 step, small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+  // products p0..p1 of one k16 step, small terms first: bf16x3 (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); f16x2 (l,h) (h,l) (h,h)
+  constexpr int NP = F16 ? 3 : 6, NP_MID = F16 ? 2 : 4;
   auto mfmas = [&](const Frags& f, int p0, int p1) __attribute__((always_inline)) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, PB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
+    for (int p = 0; p < NP; ++p) {
       if (p < p0 || p >= p1) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[p]], f.b[j][PB[p]], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i][PA[p]], f.b[j][PB[p]], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][PA[p]], f.b[j][PB[p]], acc[i][j], 0, 0, 0);
+        }
     }
   };
 
@@ -522,17 +621,17 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
   for (int c = c0; c < c1; ++c) {
     read_frags(f1, offA1, offB1);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f0, 0, 6);
+    mfmas(f0, 0, NP);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                              // A: everybody holds the chunk's fragments; its LDS image is free
     commit();                                                     // chunk c + 1 (after the last chunk: a re-write nobody reads) ...
-    mfmas(f1, 0, 4);                                              // ... the compiler interleaves these 16 MFMAs with the cut
+    mfmas(f1, 0, NP_MID);                                         // ... the compiler interleaves these 16 (8) MFMAs with the cut
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                              // B: the image of chunk c + 1 is complete
     fetch(min(c + 2, c1 - 1));
     read_frags(f0, offA0, offB0);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(f1, 4, 6);
+    mfmas(f1, NP_MID, NP);
   }
 
   const bool direct = a.slices == 1;
@@ -549,6 +648,7 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
         const int m = mb + KGmap(g);
         if (m < a.M && n < a.N) {
           float v = acc[i][j][g];
+          if constexpr (F16) v = (v * out_s0) * out_s1;            // undo the operand scales (powers of two: exact)
           if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
           dst[(size_t)m * a.N + n] = v;
         }
@@ -563,9 +663,21 @@ __global__ __launch_bounds__(128 * WR, WR == 2 ? 2 : 1) void fc_x3_gemm_kernel(F
 // 128 columns = 2 x 4 MFMA blocks (128 accumulator registers), one workgroup per CU; LDS [x: 3 planes x 256 rows][W: 3 x 256]
 // x 64 B = 96 KB, swizzled as above.  The fragments of a k16 step are read in two column halves so that 48 fragment registers
 // suffice beside the accumulators.
+// F16 = 1 (round 6): the f16x2 split on these tiles - x (fp32) cut in the kernel, W from the packed fp16 planes (two 128-row blocks per
+// 256-column tile): 32 + 32 KB of loads per chunk for 48 MFMAs per wave, LDS 64 KB.
+template <int F16 = 0>
 __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
   constexpr int TB = 256;                                          // 512 threads
-  constexpr int PL = TB * X3_RSW, OP = 3 * PL;                     // dwords of a plane / of an operand
+  constexpr int NPL = F16 ? 2 : 3;
+  constexpr int PL = TB * X3_RSW, OP = NPL * PL;                   // dwords of a plane / of an operand
+  using frag_t = std::conditional_t<F16 != 0, f16x8, bf16x8>;
+  float xs = 1.f, out_s0 = 1.f, out_s1 = 1.f;
+  if constexpr (F16) {
+    float ws_, iw;
+    f16_scale_of(*a.xbound, xs, out_s0);
+    f16_scale_of(*a.wamax, ws_, iw);
+    out_s1 = iw;
+  }
   extern __shared__ float lds_f[];
   unsigned* const lds = reinterpret_cast<unsigned*>(lds_f);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -588,13 +700,21 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
   }
   const int swq = 4 * (oct ^ ((row0 >> 2) & 3));
   f32x4 sx[2][2], sq[2][2];
+  // F16: unit tid of (128-row block 2 tn + b, plane s) = row tid / 4, 16-byte unit tid % 4 of the packed (block, chunk) image
+  const u32x4* pwq[2] = {a.wp + (size_t)(2 * tn) * a.chunks * (2 * 128 * 4) + tid,
+                         a.wp + (size_t)min(2 * tn + 1, (a.N + 127) / 128 - 1) * a.chunks * (2 * 128 * 4) + tid};
   auto fetch = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       sx[i][0] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32);
       sx[i][1] = *reinterpret_cast<const f32x4*>(px[i] + (size_t)c * 32 + 4);
-      sq[i][0] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32);
-      sq[i][1] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32 + 4);
+      if constexpr (F16) {
+        sq[i][0] = __builtin_bit_cast(f32x4, pwq[i][(size_t)c * (2 * 128 * 4)]);            // plane h of block i
+        sq[i][1] = __builtin_bit_cast(f32x4, pwq[i][(size_t)c * (2 * 128 * 4) + 512]);      // plane l
+      } else {
+        sq[i][0] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32);
+        sq[i][1] = *reinterpret_cast<const f32x4*>(pq[i] + (size_t)c * 32 + 4);
+      }
     }
   };
   auto cut_store = [&](const f32x4 (&v)[2], unsigned* d) __attribute__((always_inline)) {
@@ -617,8 +737,25 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
   auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      cut_store(sx[i], lds + (row0 + 128 * i) * X3_RSW + swq);
-      cut_store(sq[i], lds + OP + (row0 + 128 * i) * X3_RSW + swq);
+      if constexpr (F16) {
+        u32x4 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = sx[i][j >> 1][2 * (j & 1)] * xs, v1 = sx[i][j >> 1][2 * (j & 1) + 1] * xs;
+          const f16x2 hh = {(_Float16)v0, (_Float16)v1};
+          const f16x2 ll = {(_Float16)(v0 - (float)hh[0]), (_Float16)(v1 - (float)hh[1])};
+          ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+        }
+        unsigned* d = lds + (row0 + 128 * i) * X3_RSW + swq;
+        *reinterpret_cast<u32x4*>(d) = ph;
+        *reinterpret_cast<u32x4*>(d + PL) = pl;
+        unsigned* dw = lds + OP + (row0 + 128 * i) * X3_RSW + swq;
+        *reinterpret_cast<u32x4*>(dw) = __builtin_bit_cast(u32x4, sq[i][0]);
+        *reinterpret_cast<u32x4*>(dw + PL) = __builtin_bit_cast(u32x4, sq[i][1]);
+      } else {
+        cut_store(sx[i], lds + (row0 + 128 * i) * X3_RSW + swq);
+        cut_store(sq[i], lds + OP + (row0 + 128 * i) * X3_RSW + swq);
+      }
     }
   };
 
@@ -635,30 +772,34 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  bf16x8 fa[2][3], fb[2][3];
+  frag_t fa[2][NPL], fb[2][NPL];
   auto read_a = [&](int oa) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3)
-        fa[i][s3] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + oa + s3 * PL + i * 32 * X3_RSW));
+      for (int s3 = 0; s3 < NPL; ++s3)
+        fa[i][s3] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + oa + s3 * PL + i * 32 * X3_RSW));
   };
   auto read_b = [&](int ob, int jh) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3)
-        fb[j][s3] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds + ob + s3 * PL + (2 * jh + j) * 32 * X3_RSW));
+      for (int s3 = 0; s3 < NPL; ++s3)
+        fb[j][s3] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + ob + s3 * PL + (2 * jh + j) * 32 * X3_RSW));
   };
   auto mfmas = [&](int jh) __attribute__((always_inline)) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, PB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-    for (int p = 0; p < 6; ++p)
+    for (int p = 0; p < (F16 ? 3 : 6); ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (F16)
+            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][PA[p]], fb[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
+          else
+            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[p]], fb[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
+        }
   };
 
   if (c0 < c1) {
@@ -698,6 +839,7 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
         const int m = mb + KGmap(g);
         if (m < a.M && n < a.N) {
           float v = acc[i][j][g];
+          if constexpr (F16) v = (v * out_s0) * out_s1;
           if (direct) { v += b; if (a.relu) v = fmaxf(v, 0.f); }
           dst[(size_t)m * a.N + n] = v;
         }
@@ -871,6 +1013,104 @@ M3D_API int m3d_linear_bf16x3_forward(const float* d_x, const void* d_packed, co
   return m3d::check_launch("linear_bf16x3_forward");
 }
 
+/* ---- f16x2 split variant (round 6; see the kernel's header comment): two fp16 planes per operand, three products per fp32 product ---- */
+M3D_API int m3d_absmax(const float* d_x, long long n, float* d_out, void* stream) {
+  if (n < 0 || !d_out || (n > 0 && !d_x)) return M3D_EINVAL;
+  hipStream_t st = m3d::as_stream(stream);
+  if (hipMemsetAsync(d_out, 0, sizeof(float), st) != hipSuccess) return M3D_ELAUNCH;
+  if (n > 0) {
+    long long blocks = (n / 4 + 255) / 256 + 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_x, n, reinterpret_cast<unsigned*>(d_out));
+  }
+  return m3d::check_launch("absmax");
+}
+
+namespace {
+inline size_t f16x2_plane_bytes(int N, int K) { return (size_t)((N + BN - 1) / BN) * (K / 32) * (2 * 128 * 4) * 16; }
+}
+
+M3D_API size_t m3d_linear_f16x2_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  return f16x2_plane_bytes(N, K) + 256;                            // + the weight's largest magnitude (one float) behind the planes
+}
+
+M3D_API int m3d_linear_f16x2_pack(const float* d_weight, int N, int K, void* d_packed, void* stream) {
+  if (!d_weight || !d_packed || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (K % 32 != 0 || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
+  const int nt = (N + BN - 1) / BN, chunks = K / 32;
+  float* wamax = reinterpret_cast<float*>(static_cast<char*>(d_packed) + f16x2_plane_bytes(N, K));
+  if (const int rc = m3d_absmax(d_weight, (long long)N * K, wamax, stream)) return rc;
+  hipLaunchKernelGGL(fc_f16_pack_kernel, dim3(4096), dim3(256), 0, m3d::as_stream(stream), d_weight, N, K, (u32x4*)d_packed, nt, chunks,
+                     (const float*)wamax);
+  return m3d::check_launch("linear_f16x2_pack");
+}
+
+namespace {
+// 256 x 256 tiles (fc_x3b_gemm_kernel<1>) from 384 rows and 256 columns on: 64 KB of loads per chunk and workgroup for 48 MFMAs per wave,
+// against 48 KB for 24 on 256 x 128 - the f16x2 GEMM has half the matrix work of bf16x3 per byte, so the bytes per MFMA decide earlier.
+// Option tune_fc_x3_rows (tuning build): 128 / 256 force the 128-column kernels, 512 the 256 x 256 tiles.
+inline bool f16x2_big_tiles(int M, int N) {
+  const int w = m3d::opt(m3d::OPT_TUNE_FC_X3_ROWS);
+  if (w == 128 || w == 256) return false;
+  if (w == 512) return true;
+  return M >= 384 && N >= 256;
+}
+inline int f16x2_slices(int M, int N, int K) { return f16x2_big_tiles(M, N) ? x3b_slices(M, N, K) : x3_plan(M, N, K).slices; }
+}
+
+M3D_API size_t m3d_linear_f16x2_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+  const int s = f16x2_slices(M, N, K);
+  return (s > 1 ? (size_t)s * M * N * sizeof(float) : 0) + 256;    // split-K partials + the bound of |x| when the caller gives none
+}
+
+M3D_API int m3d_linear_f16x2_forward(const float* d_x, const void* d_packed, const float* d_bias, float* d_out, int M, int N, int K,
+                                     int relu, const float* d_x_bound, void* d_ws, size_t ws_bytes, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return M3D_EINVAL;
+  if (M == 0) return M3D_OK;
+  if (!d_x || !d_packed || !d_out || !d_ws) return M3D_EINVAL;
+  if (K % 32 != 0 || ((uintptr_t)d_x & 15) || ((uintptr_t)d_packed & 15) || ((uintptr_t)d_ws & 15)) return M3D_EUNSUPPORTED;
+  const bool big = f16x2_big_tiles(M, N);
+  X3Plan p = x3_plan(M, N, K);
+  if (big) { p.wr = 8; p.mt = (M + 255) / 256; p.nt = (N + 255) / 256; p.slices = x3b_slices(M, N, K); p.per_xcd = (p.mt * p.nt * p.slices + 7) / 8; }
+  const int s = p.slices;
+  const size_t part_bytes = s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  if (ws_bytes < part_bytes + 256) return M3D_EWORKSPACE;
+  hipStream_t st = m3d::as_stream(stream);
+  if (!d_x_bound) {                                               // no bound from the producer: sweep x itself
+    float* b = reinterpret_cast<float*>(static_cast<char*>(d_ws) + part_bytes);
+    if (const int rc = m3d_absmax(d_x, (long long)M * K, b, stream)) return rc;
+    d_x_bound = b;
+  }
+  FcX3Args a{d_x, (const u32x4*)d_packed, d_bias, d_out, (float*)d_ws, M, N, K, p.mt, p.nt, s, K / 32, relu, p.per_xcd};
+  a.xbound = d_x_bound;
+  a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + f16x2_plane_bytes(N, K));
+  a.x_alias = 0;
+  a.feat = nullptr; a.taps = nullptr; a.roi_batch = nullptr; a.fC = a.fS = a.fH = a.fW = 0;
+  const size_t lds = big ? sizeof(unsigned) * 4 * 256 * X3_RSW : sizeof(unsigned) * (2 * (64 * p.wr) * X3_RSW + 2 * X3_PLANE);
+  if (big) {
+    auto kern = fc_x3b_gemm_kernel<1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  } else if (p.wr == 2) {
+    auto kern = fc_x3_gemm_kernel<2, 0, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(8 * a.per_xcd), dim3(256), lds, st, a);
+  } else {
+    auto kern = fc_x3_gemm_kernel<4, 0, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  }
+  if (s > 1) {
+    const long long MN = (long long)M * N;
+    long long blocks = (MN + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_ws, d_bias, d_out, MN, N, s, s, MN, relu);
+  }
+  return m3d::check_launch("linear_f16x2_forward");
+}
+
 /* f-1 A/B ("hand-written MFMA GEMM whose A-operand loader performs the RoIAlign gather"): out[M, N] = act(x W^T + b) where
  * x[m, :] = RoIAlign3D(features, roi m) (7^3 bins, sampling grid 2, the reference's memory order) is COMPUTED by the loader from the
  * feature maps and the tap tables of m3d_roi_align3d_tap_tables - the [M, C*343] intermediate never exists.  Same tiles, cut, MFMA loop
@@ -943,8 +1183,8 @@ M3D_API int m3d_linear_bf16x3_w32_forward(const float* d_x, const float* d_weigh
   a.x_alias = 0; a.feat = nullptr; a.taps = nullptr; a.roi_batch = nullptr; a.fC = a.fS = a.fH = a.fW = 0;
   hipStream_t st = m3d::as_stream(stream);
   const size_t lds = sizeof(unsigned) * 6 * 256 * X3_RSW;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3b_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(fc_x3b_gemm_kernel, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc_x3b_gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fc_x3b_gemm_kernel<0>, dim3(8 * a.per_xcd), dim3(512), lds, st, a);
   if (s > 1) {
     const long long MN = (long long)M * N;
     long long blocks = (MN + 255) / 256;

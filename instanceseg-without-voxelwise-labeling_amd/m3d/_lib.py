@@ -11,7 +11,7 @@ _lib = None
 SYMBOLS = [
     "m3d_version", "m3d_error_string", "m3d_last_hip_error", "m3d_set_option", "m3d_get_option", "m3d_tuning_build",
     "m3d_conv3d_stem5_prepare_dgrad_weights", "m3d_conv3d_stem5_dgrad", "m3d_norm1_workspace_bytes", "m3d_norm1", "m3d_norm1_batched",
-    "m3d_linear_workspace_bytes", "m3d_linear_forward", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_pack",
+    "m3d_linear_workspace_bytes", "m3d_linear_forward", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_pack", "m3d_absmax", "m3d_linear_f16x2_packed_bytes", "m3d_linear_f16x2_pack", "m3d_linear_f16x2_workspace_bytes", "m3d_linear_f16x2_forward",
     "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward", "m3d_roi_align3d_tap_tables", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_linear_bf16x3_roi_forward",
     "m3d_fused_max_boxes", "m3d_compact_rows", "m3d_compact_rows2", "m3d_box_head_outputs", "m3d_conv3d_forward_split_sigmoid", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
     "m3d_box_results3d_batched_workspace_bytes", "m3d_box_results3d_batched", "m3d_nms3d_batched_workspace_bytes", "m3d_nms3d_batched",
@@ -55,7 +55,7 @@ def _load(path):
     L.m3d_prm_strip_geometry.restype = C.c_int64
     L.m3d_conv3d_x3_launch_units.restype = C.c_longlong
     for n in ("m3d_roi_align3d_workspace_bytes", "m3d_nms3d_workspace_bytes", "m3d_generate_proposals3d_workspace_bytes",
-              "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_x3_packed_bytes", "m3d_conv3d_x3_workspace_bytes", "m3d_reduce_min_workspace_bytes", "m3d_reduce_min_multi_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
+              "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_x3_packed_bytes", "m3d_conv3d_x3_workspace_bytes", "m3d_reduce_min_workspace_bytes", "m3d_reduce_min_multi_workspace_bytes", "m3d_norm1_workspace_bytes", "m3d_prm_small_dgrad_packed_bytes", "m3d_linear_workspace_bytes", "m3d_linear_bf16x3_packed_bytes", "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_f16x2_packed_bytes", "m3d_linear_f16x2_workspace_bytes", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_mask_paste3d_workspace_bytes", "m3d_generate_proposals3d_batched_workspace_bytes",
               "m3d_box_results3d_batched_workspace_bytes", "m3d_nms3d_batched_workspace_bytes", "m3d_otsu2d_workspace_bytes",
               "m3d_cc_workspace_bytes", "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_stem_wino_packed_weight_bytes"):
         getattr(L, n).restype = C.c_size_t

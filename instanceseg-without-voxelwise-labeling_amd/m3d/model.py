@@ -114,14 +114,17 @@ class DetectorM3D:
         if self.has_head:
             self.outs_w = torch.cat([params["Box_Outs.cls_score.weight"], params["Box_Outs.bbox_pred.weight"]], 0).contiguous()
             self.outs_b = torch.cat([params["Box_Outs.cls_score.bias"], params["Box_Outs.bbox_pred.bias"]]).contiguous()
-            # fc1 / fc2 on the bf16 matrix cores at fp32 accuracy (exact 3-way bf16 cut, csrc/fc_gemm.hip): weights are cut once
-            # here.  M3D_FC_SPLIT=0 keeps the fp32-input MFMA kernel (A/B tooling).
+            # fc1 / fc2 on the 16-bit matrix cores at fp32 accuracy (csrc/fc_gemm.hip): weights are cut once here.  Round 6 default: the
+            # f16x2 split (two scaled fp16 planes per operand, three products per fp32 product); M3D_FC_SPLIT=bf16x3 keeps the exact 3-way
+            # bf16 cut (six products), M3D_FC_SPLIT=0 the fp32-input MFMA kernel (A/B tooling).
             self.fc_split = {}
-            if os.environ.get("M3D_FC_SPLIT", "1") != "0":
+            mode = os.environ.get("M3D_FC_SPLIT", "f16x2")
+            if mode != "0":
+                cls = ops.SplitLinear if mode in ("bf16x3", "1") else ops.SplitLinearF16
                 for name in ("fc1", "fc2"):
                     w = params["Box_Head.%s.weight" % name]
-                    if ops.SplitLinear.supported(w):
-                        self.fc_split[name] = ops.SplitLinear(w, params["Box_Head.%s.bias" % name])
+                    if cls.supported(w):
+                        self.fc_split[name] = cls(w, params["Box_Head.%s.bias" % name])
 
     # ---- lib/modeling/DSN.py:57-68
     def body_layer(self, li, x):
@@ -255,7 +258,13 @@ class DetectorM3D:
         for name in ("fc1", "fc2"):                                                                 # :114-115
             with self.span(name):
                 if name in self.fc_split:
-                    x = self.fc_split[name](x, relu=True)
+                    lin = self.fc_split[name]
+                    if isinstance(lin, ops.SplitLinearF16):
+                        # fc1's operand scale from the feature map (16 MB) instead of the RoIAlign output (440 MB): every RoIAlign value is a
+                        # convex combination of feature-map values; fc2's input is small and swept by the call itself
+                        x = lin(x, relu=True, x_bound=ops.absmax(feat) if name == "fc1" else None)
+                    else:
+                        x = lin(x, relu=True)
                 else:
                     x = ops.linear(x, P["Box_Head.%s.weight" % name], P["Box_Head.%s.bias" % name], relu=True)
         o = ops.linear(x, self.outs_w, self.outs_b)              # cls_score and bbox_pred share their input: one GEMM (:42,45)

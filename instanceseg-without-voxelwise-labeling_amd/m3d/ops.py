@@ -564,6 +564,60 @@ class SplitLinear:
         return out
 
 
+def absmax(x):
+    """max |x| of a float32 CUDA tensor as a 1-element device tensor (m3d_absmax; no host read).  Used as the bound of |RoIAlign
+    output| that sets the f16x2 GEMM's operand scale: the RoIAlign output is a convex combination of the feature map's values."""
+    _need_gpu(x)
+    x = _f32c(x)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib().m3d_absmax(_ptr(x), C.c_longlong(x.numel()), _ptr(out), _stream()), "absmax")
+    return out
+
+
+class SplitLinearF16:
+    """nn.Linear on the f16 matrix cores at fp32 accuracy with THREE products per fp32 product (csrc/fc_gemm.hip, "f16x2 split": both
+    operands scaled by a power of two and cut into two fp16 numbers, 22 bits; the dropped terms are below the rounding of the fp32
+    accumulation).  Weights cut once (4 bytes per element).  __call__(x, relu, out, x_bound): x_bound = a 1-element device tensor
+    >= max|x| (e.g. ops.absmax of the feature map the RoIAlign read); None: the library sweeps x itself."""
+
+    @staticmethod
+    def supported(weight):
+        return SplitLinear.supported(weight)
+
+    def __init__(self, weight, bias=None):
+        _need_gpu(weight, bias)
+        weight = _f32c(weight)
+        self.N, self.K = int(weight.shape[0]), int(weight.shape[1])
+        nb = lib().m3d_linear_f16x2_packed_bytes(self.N, self.K)
+        if nb == 0:
+            raise ValueError("SplitLinearF16: K = %d is not a multiple of 32" % self.K)
+        self.packed = torch.empty((nb,), dtype=torch.uint8, device=weight.device)
+        check(lib().m3d_linear_f16x2_pack(_ptr(weight), self.N, self.K, _ptr(self.packed), _stream()), "linear_f16x2_pack")
+        self.bias = None if bias is None else _f32c(bias)
+        self.weight = weight
+
+    def __call__(self, x, relu=False, out=None, x_bound=None):
+        _need_gpu(x)
+        x = _f32c(x)
+        M, K = x.shape
+        if K != self.K:
+            raise ValueError("SplitLinearF16: x is [%d,%d] but the weight is [%d,%d]" % (M, K, self.N, self.K))
+        if out is None:
+            out = torch.empty((M, self.N), dtype=torch.float32, device=x.device)
+        if M == 0:
+            return out
+        if M <= 32:                                       # a handful of rows: the fp32-input kernel's ragged-tile path
+            return linear(x, self.weight, self.bias, relu=relu, out=out)
+        if x_bound is not None:
+            _need_gpu(x_bound)
+            assert x_bound.dtype == torch.float32 and x_bound.numel() == 1
+        wsb = lib().m3d_linear_f16x2_workspace_bytes(M, self.N, K)
+        ws = torch.empty((wsb // 4,), dtype=torch.float32, device=x.device)
+        check(lib().m3d_linear_f16x2_forward(_ptr(x), _ptr(self.packed), _ptr(self.bias), _ptr(out), M, self.N, K, int(bool(relu)),
+                                             _ptr(x_bound), _ptr(ws), C.c_size_t(wsb), _stream()), "linear_f16x2_forward")
+        return out
+
+
 def linear_roi_fused(split, features, rois, spatial_scale, relu=False):
     """f-1 A/B: act(RoIAlign3D(features, rois).view(R, -1) @ W.T + b) with the gather inside the GEMM's operand loader
     (m3d_linear_bf16x3_roi_forward; 7^3 bins, sampling grid 2): the [R, C*343] intermediate is never written.  split: SplitLinear of the

@@ -858,6 +858,52 @@ def test_linear_bf16x3_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K
         assert torch.equal(torch.isfinite(got_i), torch.isfinite(ref_i)), variant
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(33, 64, 32, False), (37, 64, 5504, True), (130, 128, 43904, True), (320, 1024, 87808, True),
+                                         (1283, 1024, 1024, True), (257, 100, 1024, False), (1253, 1024, 87808, True), (520, 128, 1024, False)])
+def test_linear_f16x2_split_gemm_is_as_accurate_as_the_fp32_kernel(m3d, M, N, K, relu):
+    """Three f16 MFMAs on the scaled two-way fp16 cut (22 bits) of both operands, against fp64 - on operands shaped like the layer's
+    (x >= 0 with a heavy tail like a ReLU output and rows of different scale, kaiming weights), values down to 2^-17 of the largest
+    and exact zeros mixed in, the bound given exactly, loosely (as the box head does: the feature map's) and swept from x.
+    What is asserted: (a) the fp32 MFMA kernel's own acceptance bound (2e-6 of max|out| per sqrt(K / 1024)); (b) rms error <= 6e-7 of
+    the product's rms - the cut leaves <= 3 x 2^-22 = 7e-7 per product with random sign, 2.5e-7 rms - or, where the fp32 accumulation
+    itself rounds more than that (K = 87 808: 8e-7 in all three kernels), <= 1.25 x the fp32 kernel's rms error; (c) within 8 x the fp32 kernel's
+    measured maximum: that kernel fuses every product into the accumulate (no product rounding) and, with K split over up to 64
+    workgroups, adds short chains, so it beats BOTH this kernel and a sequential SGEMM (whose accumulation alone rounds by ~4e-6 of
+    the result at K = 87 808); the claim here is "inside an SGEMM's error", not "as good as the split-K fp32 MFMA kernel"."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.relu(torch.randn(M, K, generator=g)) * torch.exp(torch.randn(M, 1, generator=g))
+    x[0, :8] = torch.tensor([37.5, 1e-4, 3.0, 0.0, 1.0000001, 0.99999994, 255.5, 1 / 3])
+    x = x.cuda()
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    w[0, :8] = torch.tensor([1 / 3, 1 / 7, 1.0, 1.0, 1e-4, -2e-5, 5.0, -1.0]).cuda() * float(w.abs().max())
+    b = torch.randn(N, generator=g).cuda()
+    lin = m3d.ops.SplitLinearF16(w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = torch.relu(ref)
+    scale = ref.abs().max().item()
+    prod_rms = (x.double() @ w.double().t()).pow(2).mean().sqrt().item()
+    bound = 2e-6 * scale * max(1.0, np.sqrt(K / 1024.0))
+    g32 = m3d.linear(x, w, b, relu=relu)
+    err32 = (g32.double() - ref).abs().max().item()
+    rms32 = (g32.double() - ref).pow(2).mean().sqrt().item()
+    xb = m3d.ops.absmax(x)
+    assert float(xb) == float(x.abs().max())
+    for xbound in (xb, xb * 200.0, None):                                # exact bound, a loose one (a feature map's), swept inside the call
+        got = lin(x, relu=relu, x_bound=xbound)
+        err = (got.double() - ref).abs().max().item()
+        rms = (got.double() - ref).pow(2).mean().sqrt().item()
+        assert got.shape == (M, N) and err <= bound and err <= 8.0 * err32 + 1e-7 * scale, (err, err32, bound)
+        assert rms <= max(6e-7 * prod_rms, 1.25 * rms32), (rms, prod_rms, rms32)   # long K: the accumulation's rounding, as the fp32 kernel's
+        assert torch.equal(got, lin(x, relu=relu, x_bound=xbound))       # deterministic
+    assert lin(x[:0]).shape == (0, N)
+    with pytest.raises(ValueError):
+        m3d.ops.SplitLinearF16(w[:, :K - 4].contiguous())                # K % 32 != 0: the fp32 kernel's job
+    # all-zero x (no RoI feature survives the ReLU): the bias, exactly
+    z = lin(torch.zeros_like(x), relu=False)
+    assert torch.equal(z, b.expand(M, N))
+
+
 # ------------------------------------------------------------------ batched, fused box stages (csrc/box_fused.hip)
 def test_fused_proposals_without_nms_keep_every_valid_box(m3d):
     """RPN_NMS_THRESH <= 0: the reference applies post_nms_topN only inside `if nms_thresh > 0`

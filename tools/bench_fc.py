@@ -26,6 +26,7 @@ def main():
     w = (torch.randn(N, K) / np.sqrt(K)).cuda()
     b = torch.randn(N).cuda()
     lin = m3d.SplitLinear(w, b)
+    F16 = [m3d.SplitLinearF16(w, b)]
     for M in Ms:
         x = torch.randn(M, K).cuda()
         t32 = timed(lambda: m3d.linear(x, w, b, relu=True))
@@ -43,6 +44,22 @@ def main():
         eall = (lin(x, relu=True)[-64:].double() - torch.relu(x[-64:].double() @ w.double().t() + b.double())).abs().max().item() / ref.abs().max().item()
         print("         bf16x3 as the model calls it (variant by shape): %.3f ms (%.1f TF fp32-equivalent, err %.2e / last rows %.2e)"
               % (t3, fl / t3 / 1e9, e3, eall), flush=True)
+        # f16x2 split (round 6): three products per fp32 product; x = relu-like data as the RoIAlign output is, bound from a sweep / given
+        _lib.set_option("tune_fc_x3_rows", -1)
+        lf = F16[0]
+        xb = m3d.absmax(x)
+        rms = lambda a_: float((a_.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        for rows in (-1, 128, 256, 512):
+            _lib.set_option("tune_fc_x3_rows", rows)
+            tf = timed(lambda: lf(x, relu=True, x_bound=xb))
+            got = lf(x, relu=True, x_bound=xb)[:64]
+            ef = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+            print("         f16x2 rows %4s, bound given: %.3f ms (%.1f TF fp32-equivalent, %.0f TF f16 issued, err %.2e; rms err %.2e, fp32 kernel %.2e, bf16x3 %.2e)"
+                  % (rows if rows > 0 else "auto", tf, fl / tf / 1e9, 3 * fl / tf / 1e9, ef, rms(got), rms(m3d.linear(x, w, b, relu=True)[:64]),
+                     rms(lin(x, relu=True)[:64])), flush=True)
+        _lib.set_option("tune_fc_x3_rows", -1)
+        tf = timed(lambda: lf(x, relu=True))
+        print("         f16x2 auto, bound swept from x inside the call: %.3f ms" % tf, flush=True)
         for rows in (128, 256):
             _lib.set_option("tune_fc_x3_rows", rows)
             t3 = timed(lambda: lin(x, relu=True, variant="packed"))

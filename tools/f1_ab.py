@@ -46,7 +46,7 @@ def phase(which):
         R = int(sum(counts))
         rois = st["rois_packed"][:R].contiguous()
         feat = st["feat"]
-        lin = det.fc_split["fc1"]
+        lin = m3d.SplitLinear(det.P["Box_Head.fc1.weight"], det.P["Box_Head.fc1.bias"])     # the f-1 A/B was run on the bf16x3 planes
         rec = {"rois": R, "rois_per_volume": R / 4.0}
         ra = lambda: m3d.roi_align3d_forward(feat, rois, 7, 7, 7, 0.125, 2)          # noqa: E731
         xin = ra().view(R, -1)
