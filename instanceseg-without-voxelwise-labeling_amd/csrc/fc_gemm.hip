@@ -388,7 +388,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);            // |x| as bits: non-negative floats order like their bit patterns
+  __shared__ unsigned wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {                                         // ONE atomic per workgroup (per-wave atomics on one word serialise: 8192 of
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));                // them made a 16 MB sweep take 50-150 us)
+    if (m) atomicMax(out, m);                                     // |x| as bits: non-negative floats order like their bit patterns
+  }
 }
 
 // packed[tn][c][plane h, l][row][32 k] (fp16, scaled) <- W[N][K] fp32; rows beyond N are zero.  One thread = 8 consecutive k of one row.
@@ -802,6 +808,68 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
         }
   };
 
+  if constexpr (F16) {
+    // f16x2: half the MFMAs per fragment, so a fragment read in front of the MFMAs that need it is no longer hidden by the SIMD's other
+    // wave (both run the same program between the same barriers).  Two sets of A and B fragments: every read is issued one MFMA group
+    // (12 MFMAs) ahead of its use; the first fragments of the next chunk are read behind barrier B under the chunk's last 4 MFMAs.
+    frag_t ga[2][NPL], gb[2][NPL];
+    auto rd_a = [&](frag_t (&f)[2][NPL], int oa) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s3 = 0; s3 < NPL; ++s3)
+          f[i][s3] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + oa + s3 * PL + i * 32 * X3_RSW));
+    };
+    auto rd_b = [&](frag_t (&f)[2][NPL], int ob, int jh) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s3 = 0; s3 < NPL; ++s3)
+          f[j][s3] = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(lds + ob + s3 * PL + (2 * jh + j) * 32 * X3_RSW));
+    };
+    auto mm = [&](const frag_t (&A)[2][NPL], const frag_t (&Bf)[2][NPL], int jh, int p0, int p1) __attribute__((always_inline)) {
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                  // (l,h) (h,l) (h,h)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if (p < p0 || p >= p1) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][PA[p]], Bf[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
+      }
+    };
+    if (c0 < c1) {
+      fetch(c0); commit();
+      __syncthreads();
+      fetch(min(c0 + 1, c1 - 1));
+      rd_a(fa, offA0); rd_b(fb, offB0, 0);
+    }
+    for (int c = c0; c < c1; ++c) {
+      rd_b(gb, offB0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa, fb, 0, 0, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_a(ga, offA1); rd_b(fb, offB1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa, gb, 1, 0, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_b(gb, offB1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ga, fb, 0, 0, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                            // A: every fragment of the chunk is in registers; the image is free
+      commit();                                                   // chunk c + 1, under 8 of the last 12 MFMAs
+      mm(ga, gb, 1, 0, 2);                                        // (waves 4-7 taking the two in the other order - a stagger of the SIMD's two waves -
+      __builtin_amdgcn_sched_barrier(0);                          // measured no different: 0.672 ms both ways at M = 1253)
+      __syncthreads();                                            // B: the image of chunk c + 1 is complete
+      fetch(min(c + 2, c1 - 1));
+      rd_a(fa, offA0); rd_b(fb, offB0, 0);                        // (after the last chunk: a read nobody uses)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ga, gb, 1, 2, 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
   if (c0 < c1) {
     fetch(c0); commit();
     __syncthreads();
@@ -823,6 +891,7 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
     __syncthreads();                                              // B
     fetch(min(c + 2, c1 - 1));
     __builtin_amdgcn_sched_barrier(0);                            // or the scheduler sinks the loads to just before their use
+  }
   }
 
   const bool direct = a.slices == 1;
@@ -1020,7 +1089,7 @@ M3D_API int m3d_absmax(const float* d_x, long long n, float* d_out, void* stream
   if (hipMemsetAsync(d_out, 0, sizeof(float), st) != hipSuccess) return M3D_ELAUNCH;
   if (n > 0) {
     long long blocks = (n / 4 + 255) / 256 + 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_x, n, reinterpret_cast<unsigned*>(d_out));
   }
   return m3d::check_launch("absmax");
