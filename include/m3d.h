@@ -39,7 +39,9 @@ const char* m3d_last_hip_error(void);
  * "tune_fc_slices_tail" (split-K factors of m3d_linear_forward), "tune_fc_x3_rows" (128 / 256: tile height of m3d_linear_bf16x3_forward),
  * "tune_fc_x_alias" (> 0: m3d_linear_bf16x3_forward reads row m of x from row m % value - a cache-resident operand, WRONG results:
  * the GEMM's cost with a free operand, tools/f1_ab.py), "tune_stem" (1: the round-2 one-row stem kernel; 4 / 8: the rows kernel with that many planes per workgroup; -1: rows kernel, planes by
- * grid size).  Unknown name -> M3D_EINVAL. */
+ * grid size), "tune_fc_x3_rows" = 512 (the 256 x 256 tiles of m3d_linear_f16x2_forward), "tune_roi_xcd" (1: RoIAlign3D's XCD-aware
+ * channel split - every XCD one eighth of every RoI's channels; an A/B that removed the L2 misses and not the time, round 6).
+ * Unknown name -> M3D_EINVAL. */
 int m3d_set_option(const char* name, int value);
 int m3d_get_option(const char* name, int* value);
 int m3d_tuning_build(void);

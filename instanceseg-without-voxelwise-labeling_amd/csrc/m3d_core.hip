@@ -9,13 +9,13 @@ thread_local char g_last_hip_error[256] = "";
 // refuses.  Only the tuning build (libm3d_tune.so = the same objects + this file with -DM3D_TUNING; A/B tools and the kernel-family
 // tests load it beside the release library) keeps a mutable table.
 namespace m3d {
-[[maybe_unused]] static const int kOptDefaults[OPT_COUNT] = {1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-static const char* const kOptNames[OPT_COUNT] = {"xcd_map", "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt", "tune_fc_slices", "tune_fc_slices_tail", "tune_fc_x3_rows", "tune_stem", "tune_fc_x_alias"};
+[[maybe_unused]] static const int kOptDefaults[OPT_COUNT] = {1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0};
+static const char* const kOptNames[OPT_COUNT] = {"xcd_map", "tune_k3", "tune_wino", "tune_wino2", "tune_wino2_xt", "tune_fc_slices", "tune_fc_slices_tail", "tune_fc_x3_rows", "tune_stem", "tune_fc_x_alias", "tune_roi_xcd"};
 }  // namespace m3d
 #ifdef M3D_TUNING
 #include <atomic>
 namespace m3d {
-static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}};
+static std::atomic<int> g_opt[OPT_COUNT] = {{1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {-1}, {0}};
 int opt(Opt o) { return g_opt[o].load(std::memory_order_relaxed); }
 }  // namespace m3d
 #else

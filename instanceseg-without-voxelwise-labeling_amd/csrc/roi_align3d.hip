@@ -540,13 +540,39 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __
                                                                  const int* __restrict__ tabs) {
   __shared__ V3Shared sh;
   extern __shared__ float dyn[];
-  const int n = order ? order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;   // launch order: heavy RoIs first (roi_class_kernel)
-  int c0 = blockIdx.y * ch_per_block, c1 = min(C, c0 + ch_per_block);
-  if (marks) {
-    const unsigned int m = __float_as_uint(out[((size_t)n * C + 8 * blockIdx.y) * 343]);
-    if (m == kMedBits) { c0 = 8 * blockIdx.y; c1 = min(C, c0 + 8); }
-    else if (m == kSmallBits && blockIdx.y == 0) { c0 = 0; c1 = C; }
+  const int tid = threadIdx.x;
+  int n, c0, c1;
+  if (marks == 2) {
+    // XCD-aware split (round 6; C a multiple of 64, 1-D grid of R * C / 8 workgroups): workgroups are dealt to the 8 XCDs round-robin by
+    // their linear id, so id & 7 IS the XCD, and XCD g owns the channels [g C / 8, (g + 1) C / 8) of EVERY RoI: the part of the feature
+    // maps an XCD's L2 (4 MB) has to hold is 1/8 of them (4 x 128^3 volumes: 2.1 MB instead of 16.8 MB).  The first 8 R workgroups are
+    // (RoI rank, XCD): a small RoI's C / 8 channels, or the first octet of a medium one; the remaining (C / 64 - 1) 8 R are the other
+    // octets of the medium RoIs.  (Working workgroups FIRST in dispatch order: with them spread through the grid, one in 32, the
+    // launch is bound by the dispatch of the 41 000 that exit at once - 0.53 instead of 0.22 ms at R = 1281.)
+    const int per = C >> 6;                                   // channel octets per XCD
+    const int R8 = 8 * (int)(gridDim.x / (unsigned)(8 * per));
+    int xcd, r, sub;
+    if ((int)blockIdx.x < R8) { xcd = blockIdx.x & 7; r = blockIdx.x >> 3; sub = 0; }
+    else {
+      if (per == 1) return;
+      const int id2 = (int)blockIdx.x - R8, k = id2 >> 3;
+      xcd = id2 & 7; r = k / (per - 1); sub = 1 + k - r * (per - 1);
+    }
+    const int oct = xcd * per + sub;
+    n = order ? order[r] : r;                                 // launch order: heavy RoIs first (roi_class_kernel)
+    const unsigned int m = __float_as_uint(out[((size_t)n * C + 8 * oct) * 343]);
+    if (m == kMedBits) { c0 = 8 * oct; c1 = c0 + 8; }
+    else if (m == kSmallBits && sub == 0) { c0 = 8 * xcd * per; c1 = c0 + 8 * per; }
     else return;
+  } else {
+    n = order ? order[blockIdx.x] : (int)blockIdx.x;
+    c0 = blockIdx.y * ch_per_block; c1 = min(C, c0 + ch_per_block);
+    if (marks) {
+      const unsigned int m = __float_as_uint(out[((size_t)n * C + 8 * blockIdx.y) * 343]);
+      if (m == kMedBits) { c0 = 8 * blockIdx.y; c1 = min(C, c0 + 8); }
+      else if (m == kSmallBits && blockIdx.y == 0) { c0 = 0; c1 = C; }
+      else return;
+    }
   }
   const V3Dims d = tabs ? v3_load_tab(tabs + (size_t)n * kV3TabWords, sh) : v3_setup(rois, n, scale, B, S, H, W, sh);
   if (!sh.s_ok) return;                                     // roi_align3d_fwd_sep_kernel (skip_v3 mode) does this RoI
@@ -851,8 +877,16 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
       int* order = (ws && ws_bytes >= sizeof(int) * (size_t)R * (1 + kV3TabWords)) ? reinterpret_cast<int*>(ws) : nullptr;
       int* tabs = order ? order + R : nullptr;
       hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale, R, order, tabs);
-      hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, scale,
-                         8, 1, (const int*)order, (const int*)tabs);
+      // option tune_roi_xcd = 1 (tuning build; A/B and the PMC passes of profiles/r06_roi_xcd_ab.txt): the XCD-aware channel split
+      // described in the kernel.  It removes the sub-volume reads' L2 misses and leaves the time where it was (0.237 vs 0.225 ms at
+      // R = 1281: 8 set-ups per small RoI instead of one) - the launch is bound by LDS array cycles, not by those fetches - so the
+      // release library keeps one workgroup per small RoI.
+      if (m3d::opt(m3d::OPT_TUNE_ROI_XCD) == 1 && C % 64 == 0 && (long long)R * (C / 8) < 0x7FFFFFFFll)
+        hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3((unsigned)(R * (C / 8))), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S,
+                           H, W, scale, 8, 2, (const int*)order, (const int*)tabs);
+      else
+        hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, C / 8), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S, H, W, scale,
+                           8, 1, (const int*)order, (const int*)tabs);
     } else if (v3) {                // 32 channels per workgroup
       const int cpb3 = 32;
       hipLaunchKernelGGL(roi_align3d_fwd_v3_kernel, dim3(R, (C + cpb3 - 1) / cpb3), block, lds, m3d::as_stream(stream), a, rois, o, B, C, S,

@@ -38,7 +38,7 @@ class M3DError(RuntimeError):
 
 _TUNE_ENV = (("M3D_XCD_MAP", "xcd_map"), ("M3D_TUNE_K3", "tune_k3"), ("M3D_TUNE_WINO", "tune_wino"),
              ("M3D_TUNE_WINO2", "tune_wino2"), ("M3D_TUNE_WINO2_XT", "tune_wino2_xt"), ("M3D_TUNE_FC_SLICES", "tune_fc_slices"),
-             ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem"), ("M3D_TUNE_FC_X_ALIAS", "tune_fc_x_alias"))
+             ("M3D_TUNE_FC_SLICES_TAIL", "tune_fc_slices_tail"), ("M3D_TUNE_FC_X3_ROWS", "tune_fc_x3_rows"), ("M3D_TUNE_STEM", "tune_stem"), ("M3D_TUNE_FC_X_ALIAS", "tune_fc_x_alias"), ("M3D_TUNE_ROI_XCD", "tune_roi_xcd"))
 TUNE_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libm3d_tune.so")
 _tune = None
 

@@ -34,7 +34,7 @@ def main():
            "fetch_factor_16B_loads": f_vec, "write_size_over_known": w_chk,
            "kernels": {"dword": k_min[0][:80], "vec": k_cpy[0][:80] if k_cpy else None}}, "kernels": []}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k]) / len(fetch[k])):
-        if not any(t in k[0] for t in ("conv3d", "wino24", "fc_gemm", "fc_x3_gemm", "fc_reduce", "roi_align3d", "proposals_stage", "nms_mask_tiles", "norm1", "prm_", "window_sums")) or "pack" in k[0]:
+        if not any(t in k[0] for t in ("conv3d", "wino24", "fc_gemm", "fc_x3_gemm", "fc_x3b_gemm", "absmax", "fc_reduce", "roi_align3d", "proposals_stage", "nms_mask_tiles", "norm1", "prm_", "window_sums")) or "pack" in k[0]:
             continue
         fr = sum(fetch[k]) / len(fetch[k])
         wr = sum(write[k]) / len(write[k]) if k in write else None
