@@ -7,6 +7,7 @@ cd /root/repo
 P=/root/repo/gpurun_out/prof; mkdir -p $P
 if [[ $PHASE == *A* ]]; then
 python bench.py > $P/${R}_bench_default_line.json 2> $P/bench_detect.err          # the driver's command: headline + every sub-record
+cp gpurun_out/bench_full_detect_n1.json $P/${R}_bench_default_full_record.json     # (the later --no-subrecords runs overwrite that file)
 python bench.py --workload prm 2>/dev/null | tail -1 > $P/${R}_bench_prm_soma.json
 python bench.py --workload prm-nuclei 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei.json
 python bench.py --workload prm-nuclei --prm-rpn-logit-scale 1.0 --no-cpu-baseline 2>/dev/null | tail -1 > $P/${R}_bench_prm_nuclei_saturated_init.json   # rounds 1-3 workload
