@@ -564,6 +564,19 @@ int m3d_prm_small_dgrad_pack(const float* d_weight, int cout_fwd, int cin_fwd, f
 int m3d_prm_small_dgrad(const float* d_gn, const float* d_packed, int num_peaks, int cout_fwd, int cin_fwd, int win,
                         const float* d_full, const float* d_full_offset, const int32_t* d_origins, int depth, int height, int width,
                         float* d_out, void* stream);
+/* Round 6 - the same operation on the f16 matrix cores ("f16x2 split", see m3d_linear_f16x2_forward): both operands scaled by a power of
+ * two and cut into two fp16 numbers (22 bits), three v_mfma_f32_32x32x16_f16 products per fp32 product.  The gradient windows are
+ * scaled PER PEAK (every peak's [cout_fwd, win^3] block is swept once for its largest magnitude into the workspace; peaks differ by
+ * orders of magnitude), relu(W) per layer at pack time.  A column's result depends on its own peak only: a sub-batch gives the batch's
+ * rows bit for bit.  cout_fwd must be a multiple of 16 (m3d_prm_small_dgrad_f16_supported), win in {3, 5, 7}; workspace
+ * m3d_prm_small_dgrad_f16_workspace_bytes(num_peaks).  Agreement with m3d_prm_small_dgrad: ~1e-6 of the layer's largest value. */
+int m3d_prm_small_dgrad_f16_supported(int cout_fwd, int cin_fwd);
+size_t m3d_prm_small_dgrad_f16_packed_bytes(int cout_fwd, int cin_fwd);
+int m3d_prm_small_dgrad_f16_pack(const float* d_weight, int cout_fwd, int cin_fwd, void* d_packed, void* stream);
+size_t m3d_prm_small_dgrad_f16_workspace_bytes(int num_peaks);
+int m3d_prm_small_dgrad_f16(const float* d_gn, const void* d_packed, int num_peaks, int cout_fwd, int cin_fwd, int win,
+                            const float* d_full, const float* d_full_offset, const int32_t* d_origins, int depth, int height, int width,
+                            float* d_out, void* d_ws, size_t ws_bytes, void* stream);
 /* Backward-data of the 5^3 / Cin = 1 stem conv for autograd (what cuDNN dgrad computes for conv1a when the input requires
  * grad: the reference's PRM mode, lib/prm/peak_response_mapping_3d.py:88 + lib/prm/peak_backprop_3d.py:37-44, lib/modeling/DSN.py:19).
  *   m3d_conv3d_stem5_prepare_dgrad_weights  d_weight [C,1,5,5,5] -> d_wf [C,125], taps flipped (no ReLU: the caller passes

@@ -366,13 +366,7 @@ __global__ __launch_bounds__(256) void fc_x3_pack_kernel(const float* __restrict
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// scale 2^k with bound * 2^k in [2^14, 2^15) and its inverse, from the bound's exponent field (no host read of the bound)
-__device__ __forceinline__ void f16_scale_of(float bound, float& s, float& inv) {
-  int f = 268 - (int)((__float_as_uint(bound) >> 23) & 255u);
-  f = f < 2 ? 2 : (f > 252 ? 252 : f);
-  s = __uint_as_float((unsigned)f << 23);
-  inv = __uint_as_float((unsigned)(254 - f) << 23);
-}
+using m3d::f16_scale_of;      // scale 2^k with bound * 2^k in [2^14, 2^15) and its inverse (m3d_common.h; no host read of the bound)
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
   unsigned m = 0;

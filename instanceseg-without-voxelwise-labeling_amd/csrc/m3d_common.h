@@ -46,4 +46,12 @@ __host__ __device__ inline void strip_geom(int n, int mode, int num_peaks, int* 
   *pitch = bp; *lead = br; *L = (long long)num_peaks * bp + (br ? 4 : 0);
 }
 int window_sums(const float* d_win, long long w3, int num_peaks, float* d_sums, hipStream_t st);
+// f16x2 split (fc_gemm.hip, prm_small_f16.hip): the power of two s with bound * s in [2^14, 2^15) - an operand whose largest magnitude is
+// `bound` then fits fp16 with headroom - and its inverse, from the bound's exponent field
+__device__ __forceinline__ void f16_scale_of(float bound, float& s, float& inv) {
+  int f = 268 - (int)((__float_as_uint(bound) >> 23) & 255u);
+  f = f < 2 ? 2 : (f > 252 ? 252 : f);
+  s = __uint_as_float((unsigned)f << 23);
+  inv = __uint_as_float((unsigned)(254 - f) << 23);
+}
 }  // namespace m3d

@@ -750,11 +750,19 @@ class SmallWindowDgrad:
     (csrc/prm_small.hip); weight = the forward conv's [cout, cin, 3, 3, 3], packed once."""
     SIZES = (3, 5, 7)
 
-    def __init__(self, weight):
+    def __init__(self, weight, f16=True):
+        """f16 (round 6, default where the forward conv's cout is a multiple of 16): the f16x2 split on v_mfma_f32_32x32x16_f16 (csrc/
+        prm_small_f16.hip: two scaled fp16 pieces per operand, three products, per-peak gradient scales) instead of the fp32 MFMA GEMM."""
         _need_gpu(weight)
         w = _f32c(weight)
         assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
         self.cout_fwd, self.cin_fwd = int(w.shape[0]), int(w.shape[1])
+        self.f16 = bool(f16) and bool(lib().m3d_prm_small_dgrad_f16_supported(self.cout_fwd, self.cin_fwd))
+        if self.f16:
+            nbytes = lib().m3d_prm_small_dgrad_f16_packed_bytes(self.cout_fwd, self.cin_fwd)
+            self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
+            check(lib().m3d_prm_small_dgrad_f16_pack(_ptr(w), self.cout_fwd, self.cin_fwd, _ptr(self.packed), _stream()), "prm_small_dgrad_f16_pack")
+            return
         nbytes = lib().m3d_prm_small_dgrad_packed_bytes(self.cout_fwd, self.cin_fwd)
         self.packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=w.device)
         check(lib().m3d_prm_small_dgrad_pack(_ptr(w), self.cout_fwd, self.cin_fwd, _ptr(self.packed), _stream()), "prm_small_dgrad_pack")
@@ -766,6 +774,13 @@ class SmallWindowDgrad:
         P, Cc, n = gn.shape[0], gn.shape[1], gn.shape[2]
         assert Cc == self.cout_fwd and n in self.SIZES and full.shape[0] == self.cin_fwd
         out = torch.empty((P, self.cin_fwd, n, n, n), dtype=torch.float32, device=gn.device)
+        if self.f16:
+            wsb = lib().m3d_prm_small_dgrad_f16_workspace_bytes(P)
+            ws = torch.empty((wsb // 4,), dtype=torch.float32, device=gn.device)
+            check(lib().m3d_prm_small_dgrad_f16(_ptr(gn), _ptr(self.packed), P, self.cout_fwd, self.cin_fwd, n, _ptr(_f32c(full)), _ptr(full_off),
+                                                _ptr(origins), full.shape[1], full.shape[2], full.shape[3], _ptr(out), _ptr(ws), C.c_size_t(wsb),
+                                                _stream()), "prm_small_dgrad_f16")
+            return out
         check(lib().m3d_prm_small_dgrad(_ptr(gn), _ptr(self.packed), P, self.cout_fwd, self.cin_fwd, n, _ptr(_f32c(full)), _ptr(full_off),
                                         _ptr(origins), full.shape[1], full.shape[2], full.shape[3], _ptr(out), _stream()),
               "prm_small_dgrad")

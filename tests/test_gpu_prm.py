@@ -410,9 +410,28 @@ def test_small_window_gemm_equals_the_direct_windowed_kernel(win, cout_f, cin_f,
     origins = torch.stack([torch.randint(-win, D, (P,), generator=g), torch.randint(-win, H, (P,), generator=g),
                            torch.randint(-win, W, (P,), generator=g)], 1).to(torch.int32).cuda()
     ref = m3d.conv3d_windowed(m3d.PackedConv3d(w, m3d.W_DGRAD_RELU), gn, full, off, origins)
-    out = m3d.SmallWindowDgrad(w)(gn, full, off, origins)
+    out = m3d.SmallWindowDgrad(w, f16=False)(gn, full, off, origins)
     assert out.shape == ref.shape
     assert np.allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+    op16 = m3d.SmallWindowDgrad(w)                                       # round 6 default: the f16x2 split where cout_fwd % 16 == 0
+    assert op16.f16 == (cout_f % 16 == 0)
+    if op16.f16:
+        # peaks whose gradients differ by ten orders of magnitude (each starts from its own (1 - y) y): per-peak scales keep every peak
+        # at 22 bits - each peak's window within 3e-6 of ITS OWN largest value of the fp32 GEMM's result
+        mag = torch.pow(10.0, torch.linspace(-7, 3, P)).cuda().reshape(P, 1, 1, 1, 1)
+        gm = (gn * mag).contiguous()
+        a = op16(gm, full, off, origins).cpu().numpy()
+        b = m3d.SmallWindowDgrad(w, f16=False)(gm, full, off, origins).cpu().numpy()
+        for i in range(P):
+            assert np.abs(a[i] - b[i]).max() <= 3e-6 * np.abs(b[i]).max() + 1e-37, (i, np.abs(a[i] - b[i]).max(), np.abs(b[i]).max())
+        # a sub-batch is the batch's rows, bit for bit (columns never see another peak's data or scale)
+        sel = torch.arange(P - 1, -1, -2).cuda()
+        sub = op16(gm.index_select(0, sel).contiguous(), full, off, origins.index_select(0, sel).contiguous())
+        assert torch.equal(sub.cpu(), torch.from_numpy(a).index_select(0, sel.cpu()))
+        out = op16(gn, full, off, origins)
+        assert np.allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+        z = op16(torch.zeros_like(gn), full, off, origins)
+        assert not z.any()
     # fp64 spot check of one peak (dgrad of a zero-padded 'same' conv with relu(W), times (X - off) inside the volume)
     gx = torch.nn.functional.conv_transpose3d(gn[:1].double().cpu(), torch.relu(w).double().cpu(), padding=1)[0]
     o = origins[0].cpu().tolist()

@@ -26,8 +26,12 @@ for name, P, cout_f, cin_f, n, dims in [("nuclei rpn", 67, 256, 256, 3, (8, 25, 
     off = full.min().reshape(1)
     org = torch.zeros((P, 3), dtype=torch.int32, device="cuda")
     d = m3d.PackedConv3d(w, m3d.W_DGRAD_RELU)
-    s = m3d.SmallWindowDgrad(w)
+    s = m3d.SmallWindowDgrad(w, f16=False)
+    s16 = m3d.SmallWindowDgrad(w)
     gf = 2.0 * P * n ** 3 * cout_f * cin_f * 27 / 1e9
     td = t(lambda: m3d.conv3d_windowed(d, gn, full, off, org))
     ts = t(lambda: s(gn, full, off, org))
-    print("%-11s P=%3d %3d->%3d %d^3: direct %.3f ms (%5.1f TF)   dense GEMM %.3f ms (%5.1f TF)" % (name, P, cout_f, cin_f, n, td, gf / td, ts, gf / ts), flush=True)
+    t16 = t(lambda: s16(gn, full, off, org))
+    a, b = s16(gn, full, off, org), s(gn, full, off, org)
+    print("%-11s P=%3d %3d->%3d %d^3: direct %.3f ms (%5.1f TF)   dense GEMM fp32 %.3f ms (%5.1f TF)   f16x2 %.3f ms (%5.1f TF fp32-equivalent; max diff %.1e of max)"
+          % (name, P, cout_f, cin_f, n, td, gf / td, ts, gf / ts, t16, gf / t16, float((a - b).abs().max() / b.abs().max())), flush=True)
