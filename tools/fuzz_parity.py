@@ -27,6 +27,8 @@ def rand_boxes(rs, n, span=100, smax=40, grid=None):
 
 def f_nms(rs):
     n = int(rs.choice([1, 2, 3, 63, 64, 65, 127, 300, 1000, 2500]))
+    if rs.rand() < 0.01:                         # round 6: the blocked form above 16 384 rows (chunk edges at multiples of 1024)
+        n = int(rs.choice([16385, 17408, 17409, 20000, 33000]))
     b = rand_boxes(rs, n, span=rs.choice([30, 100, 300]), grid=rs.choice([None, None, 1.0, 4.0]))
     mode = rs.randint(4)
     sc = rs.uniform(0, 1, n) if mode == 0 else np.round(rs.uniform(0, 1, n), 1) if mode == 1 else \
@@ -256,6 +258,20 @@ def f_linear(rs):
     y3 = m3d.SplitLinear(wd, bd)(xd, relu=relu)
     assert ((y32.double() - ref).abs() / rows).max().item() < tol, ("linear fp32", M, N, K)
     assert ((y3.double() - ref).abs() / rows).max().item() < tol, ("linear bf16x3", M, N, K)
+    # round 6: the f16x2 split (two scaled fp16 pieces per operand, one scale per TENSOR): operands of bounded dynamic range - ReLU-like
+    # x whose rows differ by 10^+-2, weights whose rows differ by 10^+-1 - exact bound, a 100 x loose bound, and the bound swept inside
+    x2 = np.maximum(rs.randn(M, K), 0).astype(np.float32) * np.float32(10.0) ** rs.uniform(-2, 2, (M, 1)).astype(np.float32)
+    w2 = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32) * np.float32(10.0) ** rs.uniform(-1, 1, (N, 1)).astype(np.float32)
+    xd2, wd2 = dev(x2), dev(w2)
+    ref2 = xd2.double() @ wd2.double().t() + bd.double()
+    if relu:
+        ref2 = torch.relu(ref2)
+    rows2 = (xd2.double().abs() @ wd2.double().abs().t()).max(dim=1, keepdim=True).values + bd.double().abs().max()
+    lin16 = m3d.ops.SplitLinearF16(wd2, bd)
+    xb = m3d.ops.absmax(xd2)
+    for bound in (xb, xb * 100.0, None):
+        y16 = lin16(xd2, relu=relu, x_bound=bound)
+        assert ((y16.double() - ref2).abs() / rows2).max().item() < tol, ("linear f16x2", M, N, K)
 
 
 def f_mask_paste(rs):
@@ -404,7 +420,7 @@ def f_x3conv(rs):
 
 
 ops = [("quantise/segment", f_quant_segment), ("segment_tile vs oracle", f_segment_oracle), ("conv3d bf16x3", f_x3conv), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
-       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3", f_linear), ("mask paste", f_mask_paste), ("prm tile", f_prm)]
+       ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3 / f16x2", f_linear), ("mask paste", f_mask_paste), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
     ops = [o for o in ops if any(t in o[0] for t in only.split(","))]
