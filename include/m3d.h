@@ -275,6 +275,11 @@ int m3d_reduce_min(const float* d_in, int64_t n, float* d_out, void* d_ws, size_
 size_t m3d_reduce_min_multi_workspace_bytes(void);
 int m3d_reduce_min_multi(const float* const* d_ins, const int64_t* counts, int count, float* d_out, void* d_ws, size_t ws_bytes,
                          void* stream);
+/* Round 6: minima AND maxima of the same arrays in the same two launches (d_mins / d_maxs [count]); workspace
+ * m3d_reduce_minmax_multi_workspace_bytes().  The f16x2 norm convolutions (m3d_conv3d_x3f_forward_ws) scale X - min X by max X - min X. */
+size_t m3d_reduce_minmax_multi_workspace_bytes(void);
+int m3d_reduce_minmax_multi(const float* const* d_ins, const int64_t* counts, int count, float* d_mins, float* d_maxs, void* d_ws,
+                            size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Batched, fused box post-processing: ONE launch per stage for a whole batch of tiles, one workgroup per tile, no host
@@ -540,6 +545,17 @@ int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, 
 size_t m3d_conv3d_x3_workspace_bytes(int batch, int cin, int cout, int depth, int height, int width);
 int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                              int width, const float* d_in_offset, void* d_workspace, size_t workspace_bytes, void* stream);
+/* Round 6 - the same convolution with the "f16x2 split" of m3d_linear_f16x2_forward: both operands scaled by a power of two and cut into
+ * two fp16 numbers (22 bits), three v_mfma_f32_32x32x16_f16 products per fp32 product (replaces the same F.conv3d call,
+ * lib/prm/peak_backprop_3d.py:37-44).  d_in_max: device pointer to max(x) when d_in_offset is given (the operand x - offset is bounded by
+ * max - offset), to max |x| when it is not (m3d_reduce_minmax_multi / m3d_absmax).  For the norm convolutions every operand is >= 0 and
+ * every PRODUCT TRIPLE hh + hl + lh is >= 0: a result is zero exactly when every x w is, as with the fp32 and bf16x3 kernels.  Pack with
+ * m3d_conv3d_x3f_pack (4 bytes per weight + the weight's largest magnitude); workspace / launch units as m3d_conv3d_x3_*. */
+size_t m3d_conv3d_x3f_packed_bytes(int cin, int cout);
+int m3d_conv3d_x3f_pack(const float* d_weight, int cin, int cout, int relu_weights, void* d_packed, void* stream);
+int m3d_conv3d_x3f_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                              int width, const float* d_in_offset, const float* d_in_max, void* d_workspace, size_t workspace_bytes,
+                              void* stream);
 /* Workgroups m3d_conv3d_x3_forward_ws launches for this shape when given its workspace (spatial x cout tiles, times the K ranges): the
  * library's own decision, for callers that choose between this kernel and m3d_conv3d_forward by how well a launch fills the chip. */
 long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int depth, int height, int width);

@@ -18,6 +18,8 @@
 // one ds_read_b128 per lane at consecutive units - the lane -> voxel map below follows the lane groups ds_read_b128 is served in
 // ({0-3,12-15,20-27} / {4-11,16-19,28-31}, fc_gemm.hip), 16 consecutive x per group: no bank conflicts.  80.6 KB: two workgroups per CU.
 // Roofline: MFMA (bf16, 2.5 PFLOP/s dense): 6 x 2 x 27 x Cin x Cout issued FLOP per voxel.
+#include <type_traits>
+
 #include "m3d_common.h"
 
 // timing-only ablation builds (make x3_ablate, tools/bench_x3.py; WRONG results): 1 = no MFMAs, 2 = no fragment reads, 4 = no weight
@@ -29,16 +31,23 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TX = 16, TY = 4, TZ = 4, HX = TX + 2, HY = TY + 2, HZ = TZ + 2, NHV = HX * HY * HZ;   // 648 halo voxels
 constexpr int TM = 64;                                  // output channels per workgroup
 constexpr int NT = 256;
-constexpr int IN_UNITS = 6 * NHV;                       // [piece 3][k half 2][halo voxel]
-constexpr int W_UNITS = 6 * TM;                         // one tap: [piece 3][k half 2][row 64]
+// NPL = pieces per operand: 3 (bf16x3: exact three-way bf16 cut, six products) or 2 (round 6, "f16x2": both operands scaled by a power of
+// two and cut into two fp16 numbers, 22 bits, three products - fc_gemm.hip; conv3d_x3_kernel<.., 1>)
+constexpr int in_units(int npl) { return 2 * npl * NHV; }                 // [piece][k half 2][halo voxel]
+constexpr int w_units(int npl) { return 2 * npl * TM; }                  // one tap: [piece][k half 2][row 64]
+constexpr int IN_UNITS = in_units(3);
+constexpr int W_UNITS = w_units(3);
 constexpr int W_SLOTS = 3;
-constexpr int LDS_BYTES = (IN_UNITS + W_SLOTS * W_UNITS) * 16;        // 80 640 B: two workgroups per CU (161 280 of 163 840)
+constexpr int lds_bytes(int npl) { return (in_units(npl) + W_SLOTS * w_units(npl)) * 16; }
+constexpr int LDS_BYTES = lds_bytes(3);                                   // 80 640 B: two workgroups per CU (161 280 of 163 840); f16x2: 53 760 B
 constexpr int NTASK = (2 * NHV + NT - 1) / NT;          // staging tasks per thread and chunk: (halo voxel, 8-channel group)
 constexpr int acc_row(int g) { return (g & 3) + 8 * (g >> 2); }      // accumulator register g -> row of its 32 x 32 block (+ 4 * (lane >> 5))
 
@@ -74,8 +83,58 @@ __global__ __launch_bounds__(256) void conv3d_x3_pack_kernel(const float* __rest
   }
 }
 
+// f16x2: packed[cout tile][step][piece 2][k half][row 64] units of 8 fp16 <- weight * s (s from the largest |W| / relu(W): *wamax)
+__global__ __launch_bounds__(256) void conv3d_x3f_pack_kernel(const float* __restrict__ w, int cin, int cout, int relu, u32x4* __restrict__ packed,
+                                                              const float* __restrict__ wamax) {
+  float sw, inv;
+  m3d::f16_scale_of(*wamax, sw, inv);
+  const int chunks = cin / 16, ntile = (cout + TM - 1) / TM;
+  const long long total = (long long)ntile * chunks * 27 * 2 * TM;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int row = (int)(e % TM);
+    long long r = e / TM;
+    const int kh = (int)(r & 1); r >>= 1;
+    const int tap = (int)(r % 27); r /= 27;
+    const int ch = (int)(r % chunks), ct = (int)(r / chunks);
+    const int co = ct * TM + row;
+    u32x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x2 hh, ll;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float v = co < cout ? w[((size_t)co * cin + ch * 16 + 8 * kh + 2 * j + u) * 27 + tap] : 0.f;
+        if (relu && !(v > 0.f)) v = 0.f;
+        v *= sw;
+        const _Float16 h = (_Float16)v;
+        hh[u] = h; ll[u] = (_Float16)(v - (float)h);
+      }
+      ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+    }
+    u32x4* dst = packed + ((size_t)(ct * chunks + ch) * 27 + tap) * w_units(2) + kh * TM + row;
+    dst[0] = ph; dst[2 * TM] = pl;
+  }
+}
+
+// max |w| (relu: max of the positive entries) of a weight tensor; one workgroup, once per model
+__global__ __launch_bounds__(1024) void x3f_wamax_kernel(const float* __restrict__ w, long long n, int relu, float* __restrict__ out) {
+  unsigned m = 0;
+  for (long long e = threadIdx.x; e < n; e += 1024) {
+    const float v = w[e];
+    const unsigned b = relu ? (v > 0.f ? __float_as_uint(v) : 0u) : (__float_as_uint(v) & 0x7FFFFFFFu);
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+  __shared__ unsigned wm[16];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m; *out = __uint_as_float(m); }
+}
+
 struct X3Args {
   const float* x; const u32x4* wp; float* out; const float* in_off;
+  const float* in_max; const float* wamax;   // F16: max x (with in_off: the bound of x - off is *in_max - *in_off; without: max |x|), max |W|
   int B, cin, cout, D, H, W;
   int tx, ty, tz, ntile, per_xcd, units;
   int ksplit;              // > 1: the input channels are cut into `ksplit` ranges of whole chunk pairs, one workgroup each; range k writes its
@@ -93,8 +152,11 @@ __device__ __forceinline__ void col_xy(int c, int* x, int* y) {
 }
 
 // SPLIT: the launch cuts K into a.ksplit ranges (small maps); the unsplit instantiation keeps its compile-time zero range start
-template <bool SPLIT>
+template <bool SPLIT, int F16 = 0>
 __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
+  constexpr int NPL = F16 ? 2 : 3;
+  constexpr int IN_UNITS = in_units(NPL), W_UNITS = w_units(NPL);         // (shadow the bf16x3 constants of the file scope)
+  using frag_t = std::conditional_t<F16 != 0, f16x8, bf16x8>;
   extern __shared__ float lds_f[];
   u32x4* const lds = reinterpret_cast<u32x4*>(lds_f);              // [input: 6 * NHV][weights: 2 * 6 * TM] units
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,6 +178,12 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   const int chunks = SPLIT ? min(a.cin / 16, 2 * (int)((long long)(ks + 1) * pairs / a.ksplit)) : a.cin / 16;
   const int steps = chunks * 27;                                   // (names as in the unsplit kernel: `chunks` / `steps` = END of this range)
   const float off = a.in_off ? *a.in_off : 0.f;
+  float xs = 1.f, inv_x = 1.f, inv_w = 1.f;                        // F16: operand scales (powers of two) and what undoes them at the flush
+  if constexpr (F16) {
+    float sw_;
+    m3d::f16_scale_of(*a.in_max - off, xs, inv_x);
+    m3d::f16_scale_of(*a.wamax, sw_, inv_w);
+  }
 
   // ---- staging tasks of this thread: task = tid + NT * i -> (8-channel group g = task / NHV, halo voxel hv = task % NHV)
   int t_src[NTASK];                                               // offset of the voxel inside one channel map, or -1 (outside the volume)
@@ -151,6 +219,18 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
       if (t_dst[i] < 0) continue;
       const bool in = t_src[i] >= 0;                                // outside the volume: the zero padding of the SHIFTED input
       u32x4 ph, pm, pl;
+      if constexpr (F16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = in ? (sx[i][2 * j] - off) * xs : 0.f, v1 = in ? (sx[i][2 * j + 1] - off) * xs : 0.f;
+          const f16x2 hh = {(_Float16)v0, (_Float16)v1};
+          const f16x2 ll = {(_Float16)(v0 - (float)hh[0]), (_Float16)(v1 - (float)hh[1])};
+          ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+        }
+        lds[t_dst[i]] = ph;
+        lds[t_dst[i] + 2 * NHV] = pl;
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float v0 = in ? sx[i][2 * j] - off : 0.f, v1 = in ? sx[i][2 * j + 1] - off : 0.f;
@@ -175,12 +255,12 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   auto fetch_w = [&](int s, int set) __attribute__((always_inline)) {
     const u32x4* p = wsrc + (size_t)s * W_UNITS;
     sw[set][0] = p[tid];
-    if (tid < W_UNITS - NT) sw[set][1] = p[NT + tid];
+    if constexpr (W_UNITS > NT) { if (tid < W_UNITS - NT) sw[set][1] = p[NT + tid]; }
   };
   auto commit_w = [&](int set, int slot) __attribute__((always_inline)) {
     u32x4* d = lds + IN_UNITS + slot * W_UNITS;
     d[tid] = sw[set][0];
-    if (tid < W_UNITS - NT) d[NT + tid] = sw[set][1];
+    if constexpr (W_UNITS > NT) { if (tid < W_UNITS - NT) d[NT + tid] = sw[set][1]; }
   };
 
   // ---- fragments
@@ -227,7 +307,11 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const bool ok = vok & (ct * TM + 32 * rb + 4 * fh + acc_row(g) < a.cout);
-          if (ok) o[(size_t)(32 * rb + acc_row(g)) * DHW] = first ? acc[rb][cb][g] : v[rb][g] + acc[rb][cb][g];
+          if (ok) {
+            float av = acc[rb][cb][g];
+            if constexpr (F16) av = (av * inv_x) * inv_w;            // powers of two: exact
+            o[(size_t)(32 * rb + acc_row(g)) * DHW] = first ? av : v[rb][g] + av;
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -239,14 +323,15 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
         for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   };
 
-  struct Frags { bf16x8 a[2][3], b[2][3]; };
+  struct Frags { frag_t a[2][NPL], b[2][NPL]; };
   Frags F0, F1;                                                    // fragments of the even / odd steps
-  // fragment read i of 12: i = 4 * piece + {a[0], a[1], b[0], b[1]}
+  constexpr int NFR = 4 * NPL;                                     // fragment reads per step
+  // fragment read i of NFR: i = 4 * piece + {a[0], a[1], b[0], b[1]}
   auto read_frag = [&](Frags& f, int i, int t, int slot) __attribute__((always_inline)) {
     const int p = i >> 2, k = i & 3;
     const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-    if (k < 2) f.a[k][p] = __builtin_bit_cast(bf16x8, lds[(X3_EXP & 2) ? rowA : rowA + slot * W_UNITS + p * 2 * TM + 32 * k]);
-    else f.b[k - 2][p] = __builtin_bit_cast(bf16x8, lds[(X3_EXP & 2) ? hvB : hvB + (dz * HY + 2 * (k - 2) + dy) * HX + dx + p * 2 * NHV]);
+    if (k < 2) f.a[k][p] = __builtin_bit_cast(frag_t, lds[(X3_EXP & 2) ? rowA : rowA + slot * W_UNITS + p * 2 * TM + 32 * k]);
+    else f.b[k - 2][p] = __builtin_bit_cast(frag_t, lds[(X3_EXP & 2) ? hvB : hvB + (dz * HY + 2 * (k - 2) + dy) * HX + dx + p * 2 * NHV]);
   };
 
   const int sb0 = cb0 * 27;                                        // first step of the range (even: register set 0, LDS slot 0)
@@ -261,7 +346,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
   if (sb0 + 3 < steps) fetch_w(sb0 + 3, 1);
   if (cb0 + 1 < chunks) fetch_in(cb0 + 1);
 #pragma unroll
-  for (int i = 0; i < 12; ++i) read_frag(F0, i, 0, 0);
+  for (int i = 0; i < NFR; ++i) read_frag(F0, i, 0, 0);
 
   // one chunk = 27 steps; `par` = parity of its first step (27 is odd: the parity of the chunk index), a literal at both call sites so that
   // register-set choices fold to constants in the unrolled taps.  During the 24 MFMAs of a step the 12 fragments of the NEXT step are read,
@@ -274,22 +359,38 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
       const int ps = (par + t) & 1, s = s0 + t;
       Frags& cur = ps ? F1 : F0;
       Frags& nxt = ps ? F0 : F1;
-      // small products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      // small products first: bf16x3 (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); f16x2 (l,h) (h,l) (h,h)
+      constexpr int NPR = F16 ? 3 : 6;
+      constexpr int PA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, PB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
+      constexpr int RD0[7] = {0, F16 ? 3 : 2, F16 ? 6 : 4, F16 ? 8 : 6, 8, 10, 12};      // reads [RD0[q], RD0[q + 1]) of the next step ride on product q
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        if (t < 26) { read_frag(nxt, 2 * q, t + 1, (t + 1) % 3); read_frag(nxt, 2 * q + 1, t + 1, (t + 1) % 3); }
+      for (int q = 0; q < NPR; ++q) {
+        if (t < 26) {
+#pragma unroll
+          for (int i = RD0[q]; i < RD0[q + 1]; ++i) read_frag(nxt, i, t + 1, (t + 1) % 3);
+        }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-            if (!(X3_EXP & 1)) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb][PA[q]], cur.b[cb][PB[q]], acc[rb][cb], 0, 0, 0);
+          for (int cb = 0; cb < 2; ++cb) {
+            if constexpr (F16) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[rb][PA[q]], cur.b[cb][PB[q]], acc[rb][cb], 0, 0, 0);
+            else if (!(X3_EXP & 1)) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[rb][PA[q]], cur.b[cb][PB[q]], acc[rb][cb], 0, 0, 0);
             else acc[rb][cb][q] += (float)cur.a[rb][PA[q]][0] * (float)cur.b[cb][PB[q]][0];
+          }
       }
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {                                 // pin the interleaving: 2 LDS reads, 4 MFMAs
+      if constexpr (F16) {                                          // pin the interleaving: 3 / 3 / 2 LDS reads, 4 MFMAs each
+        if (t < 26) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (t < 26) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         if (t < 26) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NPR; ++q) {                             // pin the interleaving: 2 LDS reads, 4 MFMAs
+          if (t < 26) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
       }
       if (!(X3_EXP & 4) && s + 2 < steps) commit_w(ps, (t + 2) % 3); // the slot step s - 1 used: its fragments were read during step s - 2
       if (!(X3_EXP & 8)) __syncthreads();
@@ -305,7 +406,7 @@ __global__ __launch_bounds__(NT, 2) void conv3d_x3_kernel(X3Args a) {
     if (c + 1 < chunks) {
       Frags& first = par ? F0 : F1;                                 // parity of the next chunk's first step
 #pragma unroll
-      for (int i = 0; i < 12; ++i) read_frag(first, i, 0, 0);
+      for (int i = 0; i < NFR; ++i) read_frag(first, i, 0, 0);
     }
   };
 #pragma unroll 1
@@ -373,6 +474,70 @@ M3D_API long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int d
   return units * x3_ksplit(units, cin, (size_t)batch * cout * depth * height * width);
 }
 
+/* ---- f16x2 variant (round 6): two scaled fp16 pieces per operand, three products; see the kernel's template parameter ---- */
+namespace {
+inline size_t x3f_plane_bytes(int cin, int cout) { return (size_t)((cout + TM - 1) / TM) * (cin / 16) * 27 * w_units(2) * 16; }
+}
+
+M3D_API size_t m3d_conv3d_x3f_packed_bytes(int cin, int cout) {
+  if (cin <= 0 || cout <= 0 || cin % 16) return 0;
+  return x3f_plane_bytes(cin, cout) + 256;                        // + the largest |W| behind the planes
+}
+
+M3D_API int m3d_conv3d_x3f_pack(const float* d_weight, int cin, int cout, int relu_weights, void* d_packed, void* stream) {
+  if (!d_weight || !d_packed || cin <= 0 || cout <= 0) return M3D_EINVAL;
+  if (cin % 16 || ((uintptr_t)d_packed & 15)) return M3D_EUNSUPPORTED;
+  hipStream_t st = m3d::as_stream(stream);
+  float* wamax = reinterpret_cast<float*>(static_cast<char*>(d_packed) + x3f_plane_bytes(cin, cout));
+  hipLaunchKernelGGL(x3f_wamax_kernel, dim3(1), dim3(1024), 0, st, d_weight, (long long)cout * cin * 27, relu_weights ? 1 : 0, wamax);
+  const long long total = (long long)((cout + TM - 1) / TM) * (cin / 16) * 27 * 2 * TM;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(conv3d_x3f_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_weight, cin, cout, relu_weights ? 1 : 0,
+                     reinterpret_cast<u32x4*>(d_packed), (const float*)wamax);
+  return m3d::check_launch("conv3d_x3f_pack");
+}
+
+/* d_in_max: device pointer to max(x) when d_in_offset is given (the operand x - offset is then bounded by max - offset), to max |x| when it
+ * is not.  A bound that is too small overflows fp16 (inf / NaN); one up to 2^8 too large costs no accuracy.  Workspace, K split and launch
+ * geometry as m3d_conv3d_x3_forward_ws (m3d_conv3d_x3_workspace_bytes / _launch_units). */
+M3D_API int m3d_conv3d_x3f_forward_ws(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                                      int width, const float* d_in_offset, const float* d_in_max, void* d_workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (batch < 0 || cin <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (batch == 0) return M3D_OK;
+  if (!d_x || !d_packed || !d_out || !d_in_max) return M3D_EINVAL;
+  if (cin % 16) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * depth * height * width >= 0x7FFFFFFFull / 4) return M3D_EUNSUPPORTED;       // 32-bit offsets inside one item
+  X3Args a;
+  a.x = d_x; a.wp = reinterpret_cast<const u32x4*>(d_packed); a.out = d_out; a.in_off = d_in_offset; a.in_max = d_in_max;
+  a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + x3f_plane_bytes(cin, cout));
+  a.B = batch; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width;
+  a.tx = (width + TX - 1) / TX; a.ty = (height + TY - 1) / TY; a.tz = (depth + TZ - 1) / TZ; a.ntile = (cout + TM - 1) / TM;
+  long long units = (long long)batch * a.tx * a.ty * a.tz * a.ntile;
+  const size_t elems = (size_t)batch * cout * depth * height * width;
+  a.ksplit = x3_ksplit(units, cin, elems);
+  if (a.ksplit > 1 && (!d_workspace || workspace_bytes < (size_t)a.ksplit * elems * sizeof(float))) a.ksplit = 1;
+  a.part = a.ksplit > 1 ? reinterpret_cast<float*>(d_workspace) : nullptr;
+  units *= a.ksplit;
+  if (units > 0x3FFFFFFFll) return M3D_EUNSUPPORTED;
+  a.units = (int)units; a.per_xcd = (int)((units + 7) / 8);
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * a.per_xcd)), dim3(NT), lds_bytes(2), m3d::as_stream(stream), a);
+  };
+  if (a.ksplit > 1) launch(conv3d_x3_kernel<true, 1>);
+  else launch(conv3d_x3_kernel<false, 1>);
+  if (a.ksplit > 1) {
+    const long long n4 = (long long)(elems / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv3d_x3_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, m3d::as_stream(stream),
+                       reinterpret_cast<const float4*>(a.part), reinterpret_cast<float4*>(d_out), n4, a.ksplit);
+  }
+  return m3d::check_launch("conv3d_x3f_forward");
+}
+
 M3D_API int m3d_conv3d_x3_forward(const float* d_x, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                                   int width, const float* d_in_offset, void* stream) {
   return m3d_conv3d_x3_forward_ws(d_x, d_packed, d_out, batch, cin, cout, depth, height, width, d_in_offset, nullptr, 0, stream);
@@ -388,7 +553,7 @@ M3D_API int m3d_conv3d_x3_forward_ws(const float* d_x, const void* d_packed, flo
   if (cin % 16) return M3D_EUNSUPPORTED;
   if ((size_t)cin * depth * height * width >= 0x7FFFFFFFull / 4) return M3D_EUNSUPPORTED;       // 32-bit offsets inside one item
   X3Args a;
-  a.x = d_x; a.wp = reinterpret_cast<const u32x4*>(d_packed); a.out = d_out; a.in_off = d_in_offset;
+  a.x = d_x; a.wp = reinterpret_cast<const u32x4*>(d_packed); a.out = d_out; a.in_off = d_in_offset; a.in_max = nullptr; a.wamax = nullptr;
   a.B = batch; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width;
   a.tx = (width + TX - 1) / TX; a.ty = (height + TY - 1) / TY; a.tz = (depth + TZ - 1) / TZ; a.ntile = (cout + TM - 1) / TM;
   long long units = (long long)batch * a.tx * a.ty * a.tz * a.ntile;

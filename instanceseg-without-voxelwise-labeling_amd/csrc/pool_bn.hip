@@ -106,6 +106,41 @@ __global__ __launch_bounds__(64) void min_final_multi_kernel(const float* __rest
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
+// minima AND maxima of up to 12 arrays in the same two launches (round 6: the f16x2 norm convolutions scale their operand X - min X by its
+// largest value, max X - min X)
+__global__ __launch_bounds__(256) void minmax_partial_multi_kernel(MinMultiArgs a, float* __restrict__ partial) {
+  __shared__ float smn[4], smx[4];
+  const float* in = a.in[blockIdx.y];
+  const long long n = a.n[blockIdx.y];
+  float v = INFINITY, u = -INFINITY;
+  if ((n & 3) == 0 && ((uintptr_t)in & 15) == 0) {
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (n >> 2); e += (long long)gridDim.x * 256) {
+      const float4 q = in4[e];
+      v = fminf(fminf(v, fminf(q.x, q.y)), fminf(q.z, q.w));
+      u = fmaxf(fmaxf(u, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) { v = fminf(v, in[e]); u = fmaxf(u, in[e]); }
+  }
+  v = wave_min(v);
+  u = -wave_min(-u);
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = v; smx[threadIdx.x >> 6] = u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[(2 * blockIdx.y) * kMinBlocks + blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    partial[(2 * blockIdx.y + 1) * kMinBlocks + blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+__global__ __launch_bounds__(64) void minmax_final_multi_kernel(const float* __restrict__ partial, float* __restrict__ mins, float* __restrict__ maxs) {
+  const float* pm = partial + (2 * blockIdx.x) * kMinBlocks;
+  float v = fminf(pm[threadIdx.x], pm[64 + threadIdx.x]);
+  float u = fmaxf(pm[kMinBlocks + threadIdx.x], pm[kMinBlocks + 64 + threadIdx.x]);
+  v = wave_min(v);
+  u = -wave_min(-u);
+  if (threadIdx.x == 0) { mins[blockIdx.x] = v; maxs[blockIdx.x] = u; }
+}
+
 inline unsigned grid_for(long long total) {
   long long b = (total + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -165,4 +200,24 @@ M3D_API int m3d_reduce_min_multi(const float* const* d_ins, const int64_t* count
   hipLaunchKernelGGL(min_partial_multi_kernel, dim3(kMinBlocks, count), dim3(256), 0, m3d::as_stream(stream), a, (float*)d_ws);
   hipLaunchKernelGGL(min_final_multi_kernel, dim3(count), dim3(64), 0, m3d::as_stream(stream), (const float*)d_ws, d_out);
   return m3d::check_launch("reduce_min_multi");
+}
+
+/* Minima and maxima of `count` (<= 12) device fp32 arrays in two launches (m3d_reduce_min_multi's contract; d_mins / d_maxs [count]). */
+M3D_API size_t m3d_reduce_minmax_multi_workspace_bytes(void) { return sizeof(float) * 2 * kMinMulti * kMinBlocks; }
+
+M3D_API int m3d_reduce_minmax_multi(const float* const* d_ins, const int64_t* counts, int count, float* d_mins, float* d_maxs, void* d_ws,
+                                    size_t ws_bytes, void* stream) {
+  if (count < 0 || count > kMinMulti) return M3D_EINVAL;
+  if (count == 0) return M3D_OK;
+  if (!d_ins || !counts || !d_mins || !d_maxs || !d_ws) return M3D_EINVAL;
+  if (ws_bytes < sizeof(float) * 2 * kMinMulti * kMinBlocks) return M3D_EWORKSPACE;
+  MinMultiArgs a;
+  for (int i = 0; i < kMinMulti; ++i) {
+    const int k = i < count ? i : 0;
+    if (!d_ins[k] || counts[k] <= 0) return M3D_EINVAL;
+    a.in[i] = d_ins[k]; a.n[i] = counts[k];
+  }
+  hipLaunchKernelGGL(minmax_partial_multi_kernel, dim3(kMinBlocks, count), dim3(256), 0, m3d::as_stream(stream), a, (float*)d_ws);
+  hipLaunchKernelGGL(minmax_final_multi_kernel, dim3(count), dim3(64), 0, m3d::as_stream(stream), (const float*)d_ws, d_mins, d_maxs);
+  return m3d::check_launch("reduce_minmax_multi");
 }

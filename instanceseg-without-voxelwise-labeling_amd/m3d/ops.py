@@ -397,11 +397,19 @@ class X3Conv3d:
     def supported(weight):
         return weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3) and bool(lib().m3d_conv3d_x3_supported(weight.shape[1], weight.shape[0]))
 
-    def __init__(self, weight, mode=W_PLAIN):
+    def __init__(self, weight, mode=W_PLAIN, f16=False):
+        """f16 (round 6): the f16x2 split - two scaled fp16 pieces per operand, three products per fp32 product (m3d_conv3d_x3f_*); the call then
+        needs `in_max` (a device scalar: max x with in_offset, max |x| without)."""
         _need_gpu(weight)
         weight = _f32c(weight)
         assert mode in (W_PLAIN, W_RELU) and X3Conv3d.supported(weight)
         self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.f16 = bool(f16)
+        if self.f16:
+            nbytes = lib().m3d_conv3d_x3f_packed_bytes(self.cin, self.cout)
+            self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
+            check(lib().m3d_conv3d_x3f_pack(_ptr(weight), self.cin, self.cout, int(mode == W_RELU), _ptr(self.packed), _stream()), "conv3d_x3f_pack")
+            return
         nbytes = lib().m3d_conv3d_x3_packed_bytes(self.cin, self.cout)
         self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=weight.device)
         check(lib().m3d_conv3d_x3_pack(_ptr(weight), self.cin, self.cout, int(mode == W_RELU), _ptr(self.packed), _stream()), "conv3d_x3_pack")
@@ -412,12 +420,14 @@ class X3Conv3d:
         B, _, D, H, W = shape
         return int(lib().m3d_conv3d_x3_launch_units(int(B), self.cin, self.cout, int(D), int(H), int(W)))
 
-    def __call__(self, x, in_offset=None, out=None):
+    def __call__(self, x, in_offset=None, out=None, in_max=None):
         _need_gpu(x)
         x = _f32c(x)
         B, Cin, D, H, W = x.shape
         if Cin != self.cin:
             raise ValueError("expected %d input channels, got %d" % (self.cin, Cin))
+        if self.f16 and in_max is None:
+            raise ValueError("X3Conv3d(f16=True) needs in_max (ops.reduce_minmax_multi / ops.absmax)")
         if out is None:
             out = torch.empty((B, self.cout, D, H, W), dtype=torch.float32, device=x.device)
         wsb = lib().m3d_conv3d_x3_workspace_bytes(B, Cin, self.cout, D, H, W)
@@ -428,6 +438,11 @@ class X3Conv3d:
             ws = cache.get(key)
             if ws is None or ws.numel() < wsb:
                 ws = cache[key] = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+        if self.f16:
+            _need_gpu(in_max)
+            check(lib().m3d_conv3d_x3f_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, _ptr(in_offset), _ptr(in_max),
+                                                  _ptr(ws), C.c_size_t(wsb), _stream()), "conv3d_x3f_forward")
+            return out
         check(lib().m3d_conv3d_x3_forward_ws(_ptr(x), _ptr(self.packed), _ptr(out), B, Cin, self.cout, D, H, W, _ptr(in_offset), _ptr(ws),
                                              C.c_size_t(wsb), _stream()), "conv3d_x3_forward")
         return out
@@ -482,6 +497,24 @@ def reduce_min_multi(xs):
         cnts = (C.c_int64 * m)(*[x.numel() for x in grp])
         check(lib().m3d_reduce_min_multi(ptrs, cnts, m, _ptr(out[g0:g0 + m]), _ptr(ws), C.c_size_t(wsb), _stream()), "reduce_min_multi")
     return out
+
+
+def reduce_minmax_multi(xs):
+    """(minima, maxima) of any number of tensors, two launches per group of up to 12 -> two float32 [len(xs)] device tensors."""
+    _need_gpu(*xs)
+    xs = [_f32c(x) for x in xs]
+    n = len(xs)
+    out = torch.empty((2, max(n, 1)), dtype=torch.float32, device=xs[0].device)
+    wsb = lib().m3d_reduce_minmax_multi_workspace_bytes()
+    for g0 in range(0, n, REDUCE_MIN_MULTI_MAX):
+        grp = xs[g0:g0 + REDUCE_MIN_MULTI_MAX]
+        m = len(grp)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=xs[0].device)
+        ptrs = (C.c_void_p * m)(*[x.data_ptr() for x in grp])
+        cnts = (C.c_int64 * m)(*[x.numel() for x in grp])
+        check(lib().m3d_reduce_minmax_multi(ptrs, cnts, m, _ptr(out[0, g0:g0 + m]), _ptr(out[1, g0:g0 + m]), _ptr(ws), C.c_size_t(wsb), _stream()),
+              "reduce_minmax_multi")
+    return out[0], out[1]
 
 
 def linear(x, weight, bias=None, relu=False, out=None):

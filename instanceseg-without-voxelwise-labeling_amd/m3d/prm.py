@@ -16,7 +16,7 @@ from .model import DetectorM3D, _NOSPAN
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
                  strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True,
-                 fused_prepare=True, skip_dead_peaks=True):
+                 fused_prepare=True, skip_dead_peaks=True, x3_f16=True):
         self.det = det
         # skip_dead_peaks: a kept peak whose RPN sigmoid is exactly 1.0f has the derivative (1 - y) y == 0: its seed, every layer of its
         # back-propagation and its map are exactly zero (the reference then returns 0 / 0 = NaN for it, peak_response_mapping_3d.py:170-171).
@@ -41,6 +41,10 @@ class PRMEngine:
         # x3_norm: the 3^3 norm convs on the bf16 matrix cores at fp32 accuracy (ops.X3Conv3d: exact bf16x3 cut, six products) instead of
         # the fp32-MFMA direct kernel; sums of non-negative products either way, so the exact zeros are the same
         self.x3_norm = bool(x3_norm)
+        # x3_f16 (round 6): those norm convs with the f16x2 split (two scaled fp16 pieces per operand, three products instead of bf16x3's
+        # six; ops.X3Conv3d(f16=True)): the operand X - min X is scaled by its largest value max X - min X, which the forward's two-launch
+        # sweep now delivers beside the minima (ops.reduce_minmax_multi); the exact zeros are the same (tests/test_gpu_ops.py)
+        self.x3_f16 = bool(x3_f16)
         # backward_streams = 2: the tile's peaks are back-propagated as two halves on two HIP streams - while one half's element-wise
         # `prepare` pass streams through HBM the other half's window convolution holds the matrix cores, and each launch's last,
         # partly filled round of workgroups is filled from the other chain.  A half's launches are the ones the one-stream engine issues
@@ -102,12 +106,14 @@ class PRMEngine:
         direct = ops.PackedConv3d(w, ops.W_RELU)
         if not (self.x3_norm and ops.X3Conv3d.supported(w)):
             return direct
-        x3 = ops.X3Conv3d(w, ops.W_RELU)
+        x3 = ops.X3Conv3d(w, ops.W_RELU, f16=self.x3_f16)
 
-        def conv(x, in_offset=None):
-            # the bf16x3 kernel's 64-channel x 16 x 4 x 4-voxel workgroups need about a round of the chip to pay (8 x 25 x 25 maps of the
+        def conv(x, in_offset=None, in_max=None):
+            # the 16-bit kernel's 64-channel x 16 x 4 x 4-voxel workgroups need about a round of the chip to pay (8 x 25 x 25 maps of the
             # nuclei net: 112 workgroups, slower than the fp32 kernel's small tiles; 16 x 40 x 40 and up: 1.3-1.7 x faster)
-            return (x3 if x3.workgroups(x.shape) >= 192 else direct)(x, in_offset=in_offset)
+            if x3.workgroups(x.shape) >= 192:
+                return x3(x, in_offset=in_offset, in_max=in_max) if x3.f16 else x3(x, in_offset=in_offset)
+            return direct(x, in_offset=in_offset)
         return conv
 
     @staticmethod
@@ -171,9 +177,10 @@ class PRMEngine:
         # every `input.min()` of this call (peak_backprop_3d.py:38) in TWO launches, not two per layer
         xs = [saved[i]["x"] for i in idx] + ([top["h"]] if need_cls else [])
         if xs:
-            mins = ops.reduce_min_multi(xs)
+            mins, maxs = ops.reduce_minmax_multi(xs)
             for k, i in enumerate(idx):
                 saved[i]["off"] = mins[k:k + 1]
+                saved[i]["max"] = maxs[k:k + 1]
             if need_cls:
                 top["off_h"] = mins[len(idx):len(idx) + 1]
 
@@ -190,7 +197,8 @@ class PRMEngine:
         for i in (reversed(idx) if top_first else idx):
             rec = saved[i]
             x = rec["x"].unsqueeze(0)
-            rec["n"] = rec["norm_conv"](x, in_offset=rec["off"])[0]
+            nc = rec["norm_conv"]
+            rec["n"] = (nc(x, in_offset=rec["off"]) if isinstance(nc, ops.PackedConv3d) else nc(x, in_offset=rec["off"], in_max=rec["max"]))[0]
             if rec["k"] == 5 and rec["pool"] and self.fused_stem:
                 rec["den"] = ops.prm_den_pool(rec["argmax"], rec["xnext"], rec["n"])      # peak-independent part of the prepare step
             if top_first:

@@ -1185,6 +1185,25 @@ def test_bf16x3_direct_conv_has_fp32_accuracy_and_the_fp32_kernels_exact_zeros(c
     plain = ops.X3Conv3d(wc, ops.W_PLAIN)(xc).cpu()                          # signed weights, no offset
     ref2 = torch.nn.functional.conv3d(x.double(), w.double(), padding=1)
     assert float((plain.double() - ref2).abs().max()) / float(ref2.abs().max()) < 2e-6
+    # round 6: the f16x2 split (two scaled fp16 pieces per operand, three products): the same exact zeros (every product triple of a
+    # non-negative pair is >= 0 and zero only when x w is), error against fp64 within 3e-6 of the largest output, minima / maxima from the
+    # two-launch sweep, with and without the K split
+    mn, mx = ops.reduce_minmax_multi([xc, xc[:, :1].contiguous()])
+    assert float(mn[0]) == float(x.min()) == 0.25 and float(mx[0]) == float(x.max()) and float(mx[1]) == float(x[:, :1].max())
+    c16 = ops.X3Conv3d(wc, ops.W_RELU, f16=True)
+    got16 = c16(xc, in_offset=off, in_max=mx[0:1]).cpu()
+    e16 = float((got16.double() - ref).abs().max()) / scale
+    assert e16 < 3e-6, (e16, e_f32)
+    assert torch.equal(got16 == 0, zero) and bool((got16 >= 0).all())
+    whole16 = torch.empty_like(got, device="cuda")
+    check(lib().m3d_conv3d_x3f_forward_ws(C.c_void_p(xc.data_ptr()), C.c_void_p(c16.packed.data_ptr()), C.c_void_p(whole16.data_ptr()), batch, cin, cout,
+                                          shape[0], shape[1], shape[2], C.c_void_p(off.data_ptr()), C.c_void_p(mx.data_ptr()), None, C.c_size_t(0),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "x3f")
+    assert float((whole16.cpu().double() - ref).abs().max()) / scale < 3e-6 and torch.equal(whole16.cpu() == 0, zero)
+    p16 = ops.X3Conv3d(wc, ops.W_PLAIN, f16=True)(xc, in_max=ops.absmax(xc)).cpu()      # signed weights, no offset: bound = max |x|
+    assert float((p16.double() - ref2).abs().max()) / float(ref2.abs().max()) < 3e-6
+    with pytest.raises(ValueError):
+        c16(xc, in_offset=off)                                               # the f16 form needs the operand's bound
 
 
 def test_reduce_min_multi_equals_the_single_array_minima(m3d):

@@ -30,7 +30,9 @@ for name, cin, cout, shape in [("soma 2a", 32, 64, (32, 80, 80)), ("soma 2b", 64
     w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.1).cuda()
     off = ops.reduce_min(x)
     res = []
-    for conv in (ops.X3Conv3d(w, ops.W_RELU), ops.PackedConv3d(w, ops.W_RELU)):
+    mx = ops.reduce_minmax_multi([x])[1]
+    c16 = ops.X3Conv3d(w, ops.W_RELU, f16=True)
+    for conv in (ops.X3Conv3d(w, ops.W_RELU), ops.PackedConv3d(w, ops.W_RELU), lambda x_, in_offset: c16(x_, in_offset=in_offset, in_max=mx)):
         for _ in range(3): conv(x, in_offset=off)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,4 +41,4 @@ for name, cin, cout, shape in [("soma 2a", 32, 64, (32, 80, 80)), ("soma 2b", 64
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20)
     gf = 2.0 * 27 * cin * cout * shape[0] * shape[1] * shape[2] / 1e9
-    print("%-12s %4d->%4d %-14s x3 %.3f ms (%.0f TF alg)   fp32 %.3f ms (%.0f TF)" % (name, cin, cout, shape, res[0], gf / res[0], res[1], gf / res[1]))
+    print("%-12s %4d->%4d %-14s bf16x3 %.3f ms (%.0f TF alg)   fp32 %.3f ms (%.0f TF)   f16x2 %.3f ms (%.0f TF)" % (name, cin, cout, shape, res[0], gf / res[0], res[1], gf / res[1], res[2], gf / res[2]))
