@@ -76,6 +76,15 @@ int m3d_roi_align3d_forward_ws(int aligned_slices, int aligned_height, int align
                                int sampling_ratio, const float* d_features, int batch, int channels, int slices,
                                int height, int width, const float* d_rois, int num_rois, int roi_cols,
                                float* d_output, void* d_workspace, size_t workspace_bytes, void* stream);
+/* Round 6: the same with d_feat_absmax, a device pointer to ONE float >= max |d_features| (m3d_absmax), or NULL (then exactly _ws): RoIs
+ * whose sub-volume has <= 128 voxels run as ONE GEMM per RoI on the f16 matrix cores - out[c][bin] = sum_k f[c][k] M[k][bin], M the
+ * separable interpolation operator of the RoI, both operands scaled and cut into two fp16 numbers, three products - the others through
+ * the separable kernels as before.  Within 1e-6 max |f| of m3d_roi_align3d_forward_ws (the fast mode's contract is 1e-5 max |f|;
+ * m3d_roi_align3d_forward_exact stays the reference-order, bit-exact form). */
+int m3d_roi_align3d_forward_ws2(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
+                                int sampling_ratio, const float* d_features, int batch, int channels, int slices,
+                                int height, int width, const float* d_rois, int num_rois, int roi_cols,
+                                float* d_output, void* d_workspace, size_t workspace_bytes, const float* d_feat_absmax, void* stream);
 int m3d_roi_align3d_backward(int aligned_slices, int aligned_height, int aligned_width, float spatial_scale,
                              int sampling_ratio, const float* d_top_grad, const float* d_rois, int num_rois,
                              int roi_cols, float* d_bottom_grad, int batch, int channels, int slices, int height,

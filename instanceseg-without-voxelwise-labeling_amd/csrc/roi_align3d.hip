@@ -488,6 +488,9 @@ __device__ inline int v3_waves(const V3Dims& d) {
 //   declined (bins wider than 4 voxels / sub-volume beyond the LDS): the complement pass (roi_align3d_fwd_sep_kernel) does it.
 // Every other workgroup of the (RoI, C/8) grid leaves after one load.
 constexpr unsigned int kSmallBits = 0x7FC05A11u, kMedBits = 0x7FC03ED0u;
+// round 6: RoIs whose sub-volume has <= 64 / <= 128 voxels go to the matrix-core form (roi_align3d_fwd_gemm_kernel<4> / <8>) when the caller
+// supplied the feature maps' largest magnitude (the f16x2 split needs an operand scale)
+constexpr unsigned int kGemm4Bits = 0x7FC06E34u, kGemm8Bits = 0x7FC06E38u;
 
 // LDS floats one channel of RoI m needs in the v3 kernel, estimated from its corners alone (extent of the sample positions per axis):
 // the launch order's sort key - heavy RoIs first.  Any deterministic function of the RoI gives a valid order; this one tracks v3_dims.
@@ -509,12 +512,13 @@ __device__ inline int roi_cost(const float* __restrict__ r, float scale, int S, 
 // index), so that the few long RoIs start first instead of forming the launch's tail (measured on the bench's RoIs: 0.269 -> 0.214 ms).
 // Every workgroup ranks its own RoI against all R (R / 256 cost evaluations per thread): no second launch, no atomics.
 __global__ __launch_bounds__(256) void roi_class_kernel(const float* __restrict__ rois, float* __restrict__ out, int B, int C, int S, int H,
-                                                        int W, float scale, int R, int* __restrict__ order, int* __restrict__ tabs) {
+                                                        int W, float scale, int R, int* __restrict__ order, int* __restrict__ tabs, int gemm) {
   __shared__ V3Shared sh;
   __shared__ int s_rank[4];
   const int n = blockIdx.x, tid = threadIdx.x;
   const V3Dims d = v3_setup(rois, n, scale, B, S, H, W, sh);
-  const unsigned int cls = !sh.s_ok ? kDeclinedBits : (v3_waves(d) == 4 ? kSmallBits : kMedBits);
+  unsigned int cls = !sh.s_ok ? kDeclinedBits : (v3_waves(d) == 4 ? kSmallBits : kMedBits);
+  if (gemm && sh.s_ok && d.sub <= 128 && d.ez <= 16 && d.ey <= 16 && d.ex <= 16) cls = d.sub <= 64 ? kGemm4Bits : kGemm8Bits;
   for (int k = tid; 8 * k < C; k += 256) out[((size_t)n * C + 8 * k) * 343] = __uint_as_float(cls);
   if (tabs) v3_store_tab(sh, tabs + (size_t)n * kV3TabWords);
   if (order) {
@@ -590,6 +594,167 @@ __global__ __launch_bounds__(256) void roi_align3d_fwd_v3_kernel(const float* __
   float* wl = dyn + (size_t)wave * slice;
   if (2 * d.per_ch <= slice) v3_run<true>(fbase, cs, obase, wl, sh.fz, sh.fy, sh.fx, d, HW, W, gofs, c0 + wave, c1, nw);
   else v3_run<false>(fbase, cs, obase, wl, sh.fz, sh.fy, sh.fx, d, HW, W, gofs, c0 + wave, c1, nw);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Round 6: the matrix-core form for SMALL sub-volumes.  With the folds, the whole RoIAlign of one RoI is ONE linear map from its
+// sub-volume (K = ez ey ex voxels, the same for every channel) to its 343 bins:
+//     out[c][bin] = sum_k f[c][k] * M[k][bin],      M[k = (z, y, x)][bin = (ph, pw, ps)] = Wz[ps][z] * Wy[ph][y] * Wx[pw][x]
+// (W?[p][t] = the fold's four weights spread over the axis; Wy carries the 1 / 8 of the sample mean) - a [C x K] x [K x 343] GEMM per RoI.
+// On the fp32 matrix pipe that was slower than the three LDS passes (round 5: 0.71 ms); with the f16x2 split of fc_gemm.hip (both
+// operands scaled and cut into two fp16 numbers, three v_mfma_f32_32x32x16_f16 products per fp32 product: 16 / 3 of the fp32 MFMA
+// rate) K <= 128 costs 264 - 528 MFMAs of 32 cycles per wave and RoI, and no LDS pass at all.  Error: <= 7e-7 of max |f| per product
+// (the fast mode's contract is 1e-5 max |f|; the exact-order kernel stays the bit-exact one).
+//   M dimension = channels (A = features: lane (channel, k half) gathers its 8 voxels of a k16 step straight from the L2-resident map and
+//                 cuts them once per RoI; 16 KS registers per wave), N dimension = bins in blocks of 32 (B = the operator, built per bin
+//                 block into LDS by the four waves together, double-buffered, one barrier per block), K = voxels in steps of 16.
+//   A wave owns C / 128 channel blocks of 32 and walks the 11 bin blocks; an accumulator register holds 32 consecutive bins of one
+//   channel across lanes 0 - 31 (and of channel + 4 across lanes 32 - 63): every store instruction writes two 128-byte runs.
+// KS = k16 steps (4: sub-volumes <= 64 voxels, 8: <= 128).  Grid: one workgroup per RoI rank; the RoI's class marker decides.
+template <int KS>
+__global__ __launch_bounds__(256) void roi_align3d_fwd_gemm_kernel(const float* __restrict__ feat, float* __restrict__ out, int B, int C, int S,
+                                                                   int H, int W, const int* __restrict__ order, const int* __restrict__ tabs,
+                                                                   const float* __restrict__ feat_absmax) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int K = 16 * KS;
+  constexpr int NCB = 2;                                     // channel blocks of 32 per wave and pass (C = 256: one pass)
+  __shared__ V3Shared sh;
+  __shared__ float wtab[3][7][16];                           // [axis z, y, x][bin][position]: the folds as dense rows
+  __shared__ int koff[K];                                    // voxel k -> offset inside one channel map (relative to the sub-volume origin)
+  __shared__ unsigned kzyx[K];                               // voxel k -> z | y << 8 | x << 16 (k >= sub: a position whose weights are zero)
+  __shared__ u32x4 bimg[2][KS * 2 * 64];                     // operator image of one bin block: [k16 step][hi / lo][lane]
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, h = l >> 5, nl = l & 31;
+  const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
+  const unsigned int cls = __float_as_uint(out[(size_t)n * C * 343]);
+  if (cls != (KS == 4 ? kGemm4Bits : kGemm8Bits)) return;
+  const V3Dims d = v3_load_tab(tabs + (size_t)n * kV3TabWords, sh);
+  const RoiGeom g = sh.sg;
+  const int HW = H * W;
+  // ---- per-RoI tables
+  for (int e = tid; e < 3 * 7 * 16; e += 256) (&wtab[0][0][0])[e] = 0.f;
+  __syncthreads();
+  if (tid < 21) {                                            // one thread per (axis, bin): its four taps (clamped duplicates carry weight 0)
+    const int ax = tid / 7, pb = tid % 7;
+    const Fold f = ax == 0 ? sh.fz[pb] : (ax == 1 ? sh.fy[pb] : sh.fx[pb]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wtab[ax][pb][f.k[i]] += f.w[i];
+  }
+  for (int k = tid; k < K; k += 256) {
+    const bool in = k < d.sub;
+    const int x = in ? k % d.ex : 0, r = in ? k / d.ex : 0;
+    const int y = r % d.ey, z = r / d.ey;
+    koff[k] = z * HW + y * W + x;
+    kzyx[k] = (unsigned)(z | (y << 8) | (x << 16));                            // (k >= sub: never used, the operator is zero there)
+  }
+  __syncthreads();
+  float fs, inv_f;
+  m3d::f16_scale_of(*feat_absmax, fs, inv_f);
+  constexpr float kMs = 16384.f, kInvMs = 1.f / 16384.f;     // operator scale 2^14: an axis weight is <= 2 (two samples on one voxel), the
+                                                             // y row carries 1 / 8: M <= 2 * 2 * 0.25 = 1 -> <= 2^14 in fp16
+  const float* fbase = feat + (size_t)g.batch * C * S * HW + (size_t)sh.rng[0] * HW + sh.rng[2] * W + sh.rng[4];
+  const size_t cs = (size_t)S * HW;
+  float* obase = out + (size_t)n * C * 343;
+
+  // B image of bin block `blk` into bimg[buf]: wave w builds the k16 steps s = w, w + 4 (KS = 8); lane (bin n, k half h)
+  auto build_b = [&](int blk, int buf) __attribute__((always_inline)) {
+    const int bin = 32 * blk + nl;
+    const bool bok = bin < 343;
+    const int ph = bok ? bin / 49 : 0, pw = bok ? (bin / 7) % 7 : 0, ps = bok ? bin % 7 : 0;
+    const float* wz = wtab[0][ps]; const float* wy = wtab[1][ph]; const float* wx = wtab[2][pw];
+#pragma unroll
+    for (int s = 0; s < KS / 4; ++s) {
+      const int st = wave + 4 * s;
+      u32x4 ph4, pl4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f16x2 hh, ll;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = 16 * st + 8 * h + 2 * j + u;
+          const unsigned c = kzyx[k];
+          float m = (wz[c & 255] * wy[(c >> 8) & 255]) * wx[(c >> 16) & 255];
+          m *= (k < d.sub && bok) ? kMs : 0.f;                                 // (a select, not a branch around the table reads)
+          const _Float16 hv = (_Float16)m;
+          hh[u] = hv; ll[u] = (_Float16)(m - (float)hv);
+        }
+        ph4[j] = __builtin_bit_cast(unsigned, hh); pl4[j] = __builtin_bit_cast(unsigned, ll);
+      }
+      bimg[buf][(st * 2 + 0) * 64 + l] = ph4;
+      bimg[buf][(st * 2 + 1) * 64 + l] = pl4;
+    }
+  };
+
+  // every wave runs every pass (the operator image is built by all four and barriers are workgroup-wide); a wave's channel blocks in
+  // a pass: `per` = 1 (C <= 128: all four waves have one) or 2; blocks beyond C / 32 only skip their MFMAs and stores
+  const int ncb_total = C / 32;
+  const int per = ncb_total <= 4 ? 1 : NCB;
+  for (int pass0 = 0; pass0 < ncb_total; pass0 += 4 * per) {
+    const int cb0 = pass0 + wave * per;
+    // ---- A fragments of this wave's channel blocks: gathered and cut once per RoI
+    f16x8 ah[NCB][KS], al[NCB][KS];
+#pragma unroll
+    for (int q = 0; q < NCB; ++q) {
+      const int ch = 32 * (cb0 + (q < per ? q : 0)) + nl;
+      const float* fc = fbase + (size_t)min(ch, C - 1) * cs;
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fc[koff[16 * st + 8 * h + j]];      // unconditional (k >= sub reads voxel 0: the operator is zero
+                                                                                // there): a guarded load waits for its data at the join
+        f16x8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = v[j] * fs;
+          const _Float16 hv = (_Float16)t;
+          vh[j] = hv; vl[j] = (_Float16)(t - (float)hv);
+        }
+        ah[q][st] = vh; al[q][st] = vl;
+      }
+    }
+    build_b(0, 0);
+    __syncthreads();
+    for (int blk = 0; blk < 11; ++blk) {
+      if (blk + 1 < 11) build_b(blk + 1, (blk + 1) & 1);              // the next block's operator, under this block's MFMAs
+      f32x16 acc[NCB];
+#pragma unroll
+      for (int q = 0; q < NCB; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+      const u32x4* bi = bimg[blk & 1];
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, bi[(st * 2 + 0) * 64 + l]);
+        const f16x8 bl = __builtin_bit_cast(f16x8, bi[(st * 2 + 1) * 64 + l]);
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) {
+          if (q < per && cb0 + q < ncb_total) {
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q][st], bh, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][st], bl, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][st], bh, acc[q], 0, 0, 0);
+          }
+        }
+      }
+      // accumulator register e: channel row 8 (e / 4) + 4 h + e % 4 of the block, bin 32 blk + nl: 32 consecutive floats per half wave
+      const int bin = 32 * blk + nl;
+      if (bin < 343) {
+#pragma unroll
+        for (int q = 0; q < NCB; ++q) {
+          if (q < per && cb0 + q < ncb_total) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int ch = 32 * (cb0 + q) + 8 * (e >> 2) + 4 * h + (e & 3);
+              obase[(size_t)ch * 343 + bin] = (acc[q][e] * inv_f) * kInvMs;
+            }
+          }
+        }
+      }
+      __syncthreads();                                                // block blk's image is free, block blk + 1's is complete
+    }
+  }
 }
 
 struct AxisTaps { int lo, hi, n; };        // sub-volume range [lo, hi] and number of taps per bin
@@ -846,7 +1011,8 @@ __global__ __launch_bounds__(64) void roi_tap_table_kernel(const float* __restri
 }
 
 int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int AW, float scale, int ratio, const float* a, const float* rois, float* o, int B,
-           int C, int S, int H, int W, int R, int roi_cols, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
+           int C, int S, int H, int W, int R, int roi_cols, void* stream, void* ws = nullptr, size_t ws_bytes = 0,
+           const float* feat_absmax = nullptr) {
   if (roi_cols != 7) return M3D_EINVAL;   // roi_align_cuda_3d.c:19-22
   if (R < 0 || B <= 0 || C <= 0 || S <= 0 || H <= 0 || W <= 0 || AS <= 0 || AH <= 0 || AW <= 0) return M3D_EINVAL;
   if (R == 0) return M3D_OK;
@@ -876,7 +1042,15 @@ int launch(int mode /*0 fast fwd, 1 exact fwd, 2 backward*/, int AS, int AH, int
       // workspace: [R] launch order (heaviest RoI first) + [R][kV3TabWords] set-up records (see v3_store_tab)
       int* order = (ws && ws_bytes >= sizeof(int) * (size_t)R * (1 + kV3TabWords)) ? reinterpret_cast<int*>(ws) : nullptr;
       int* tabs = order ? order + R : nullptr;
-      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale, R, order, tabs);
+      // with the feature maps' largest magnitude (and the set-up records): small sub-volumes take the matrix-core form
+      const int gemm = (feat_absmax && tabs) ? 1 : 0;
+      hipLaunchKernelGGL(roi_class_kernel, dim3(R), block, 0, m3d::as_stream(stream), rois, o, B, C, S, H, W, scale, R, order, tabs, gemm);
+      if (gemm) {
+        hipLaunchKernelGGL(roi_align3d_fwd_gemm_kernel<4>, dim3(R), block, 0, m3d::as_stream(stream), a, o, B, C, S, H, W, (const int*)order,
+                           (const int*)tabs, feat_absmax);
+        hipLaunchKernelGGL(roi_align3d_fwd_gemm_kernel<8>, dim3(R), block, 0, m3d::as_stream(stream), a, o, B, C, S, H, W, (const int*)order,
+                           (const int*)tabs, feat_absmax);
+      }
       // option tune_roi_xcd = 1 (tuning build; A/B and the PMC passes of profiles/r06_roi_xcd_ab.txt): the XCD-aware channel split
       // described in the kernel.  It removes the sub-volume reads' L2 misses and leaves the time where it was (0.237 vs 0.225 ms at
       // R = 1281: 8 set-ups per small RoI instead of one) - the launch is bound by LDS array cycles, not by those fetches - so the
@@ -922,6 +1096,17 @@ M3D_API int m3d_roi_align3d_forward_ws(int AS, int AH, int AW, float spatial_sca
                                        int num_rois, int roi_cols, float* d_output, void* d_ws, size_t ws_bytes, void* stream) {
   return launch(0, AS, AH, AW, spatial_scale, sampling_ratio, d_features, d_rois, d_output, batch, channels, slices, height,
                 width, num_rois, roi_cols, stream, d_ws, ws_bytes);
+}
+
+/* Round 6: ... and with d_feat_absmax, a device pointer to ONE float >= max |d_features| (m3d_absmax): RoIs whose sub-volume has <= 128
+ * voxels then run as one [channels x K] x [K x 343] GEMM on the f16 matrix cores (two scaled fp16 pieces per operand, three products;
+ * <= 7e-7 max |f| from the separable kernel's result, inside the fast mode's 1e-5 max |f|); the others as before.  NULL: as _ws. */
+M3D_API int m3d_roi_align3d_forward_ws2(int AS, int AH, int AW, float spatial_scale, int sampling_ratio, const float* d_features,
+                                        int batch, int channels, int slices, int height, int width, const float* d_rois,
+                                        int num_rois, int roi_cols, float* d_output, void* d_ws, size_t ws_bytes,
+                                        const float* d_feat_absmax, void* stream) {
+  return launch(0, AS, AH, AW, spatial_scale, sampling_ratio, d_features, d_rois, d_output, batch, channels, slices, height,
+                width, num_rois, roi_cols, stream, d_ws, ws_bytes, d_feat_absmax);
 }
 
 M3D_API int m3d_roi_align3d_backward(int AS, int AH, int AW, float spatial_scale, int sampling_ratio, const float* d_top_grad,

@@ -15,7 +15,7 @@ SYMBOLS = [
     "m3d_linear_bf16x3_workspace_bytes", "m3d_linear_bf16x3_forward", "m3d_mask_paste3d_workspace_bytes", "m3d_mask_paste3d", "m3d_linear_bf16x3_w32_workspace_bytes", "m3d_linear_bf16x3_w32_forward", "m3d_roi_align3d_tap_tables", "m3d_linear_bf16x3_roi_workspace_bytes", "m3d_linear_bf16x3_roi_forward",
     "m3d_fused_max_boxes", "m3d_compact_rows", "m3d_compact_rows2", "m3d_box_head_outputs", "m3d_conv3d_forward_split_sigmoid", "m3d_generate_proposals3d_batched_workspace_bytes", "m3d_generate_proposals3d_batched",
     "m3d_box_results3d_batched_workspace_bytes", "m3d_box_results3d_batched", "m3d_nms3d_batched_workspace_bytes", "m3d_nms3d_batched",
-    "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward", "m3d_roi_align3d_workspace_bytes", "m3d_roi_align3d_forward_ws",
+    "m3d_roi_align3d_forward", "m3d_roi_align3d_forward_exact", "m3d_roi_align3d_backward", "m3d_roi_align3d_workspace_bytes", "m3d_roi_align3d_forward_ws", "m3d_roi_align3d_forward_ws2",
     "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
     "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
     "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_pack_weights", "m3d_conv3d_forward", "m3d_conv3d_forward_dilated", "m3d_conv3d_forward_windowed", "m3d_conv3d_forward_pool2",

@@ -111,6 +111,10 @@ class DetectorM3D:
         self.rpn_heads = ops.PackedConv3d(w)
         self.rpn_heads_bias = torch.cat([params["RPN.RPN_cls_score.bias"], params["RPN.RPN_bbox_pred.bias"]]).contiguous()
         self.has_head = "Box_Head.fc1.weight" in params
+        # RoIAlign3D's matrix-core form for sub-volumes of <= 128 voxels (round 6 A/B, M3D_ROI_GEMM=1).  NOT the product path: correct
+        # (tests/test_gpu_ops.py) and slower - 0.49 instead of 0.23 ms at R = 1281: its two launches take 0.16 ms each (1 408 dword stores
+        # per RoI from two waves per SIMD) and run AFTER the separable launch, whose time is set by its heavy RoIs either way
+        self.roi_gemm = os.environ.get("M3D_ROI_GEMM", "0") == "1"
         if self.has_head:
             self.outs_w = torch.cat([params["Box_Outs.cls_score.weight"], params["Box_Outs.bbox_pred.weight"]], 0).contiguous()
             self.outs_b = torch.cat([params["Box_Outs.cls_score.bias"], params["Box_Outs.bbox_pred.bias"]]).contiguous()
@@ -253,7 +257,11 @@ class DetectorM3D:
         (cls [R,nc], bbox [R,6nc], pred_boxes [R,6nc]).  rois [R,7]."""
         c, P = self.cfg, self.P
         with self.span("roi_align3d"):
-            x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio)
+            # the feature maps' largest magnitude (16 MB sweep, once): the operand scale of the f16x2 kernels - RoIAlign3D's matrix-core form
+            # for small sub-volumes and, since every RoIAlign value is a convex combination of feature-map values, fc1's x scale
+            fmax = ops.absmax(feat) if self.roi_gemm or any(isinstance(v, ops.SplitLinearF16) for v in self.fc_split.values()) else None
+            x = ops.roi_align3d_forward(feat, rois, c.roi_res, c.roi_res, c.roi_res, 1.0 / c.stride, c.sampling_ratio,
+                                        feat_absmax=fmax if self.roi_gemm else None)
         x = x.view(x.shape[0], -1)
         for name in ("fc1", "fc2"):                                                                 # :114-115
             with self.span(name):
@@ -262,7 +270,7 @@ class DetectorM3D:
                     if isinstance(lin, ops.SplitLinearF16):
                         # fc1's operand scale from the feature map (16 MB) instead of the RoIAlign output (440 MB): every RoIAlign value is a
                         # convex combination of feature-map values; fc2's input is small and swept by the call itself
-                        x = lin(x, relu=True, x_bound=ops.absmax(feat) if name == "fc1" else None)
+                        x = lin(x, relu=True, x_bound=fmax if name == "fc1" else None)
                     else:
                         x = lin(x, relu=True)
                 else:

@@ -37,9 +37,11 @@ def _f32c(t):
 
 
 # ------------------------------------------------------------------ RoIAlign3D
-def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio, exact=False, ordered=True):
+def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_ratio, exact=False, ordered=True, feat_absmax=None):
     """exact=True: the reference kernel's fp32 operation order (bit-identical to the oracle); default: the
-    separable fast form (same samples and weights, different summation order).  ordered=False: RoIs launched in index order (A/B)."""
+    separable fast form (same samples and weights, different summation order).  ordered=False: RoIs launched in index order (A/B).
+    feat_absmax (round 6; a 1-element device tensor >= max |features|, ops.absmax): RoIs with sub-volumes of <= 128 voxels run as one GEMM
+    per RoI on the f16 matrix cores (m3d_roi_align3d_forward_ws2); None keeps every RoI on the separable kernels."""
     _need_gpu(features, rois)
     features, rois = _f32c(features), _f32c(rois)
     B, Cc, S, H, W = features.shape
@@ -54,6 +56,12 @@ def roi_align3d_forward(features, rois, AS, AH, AW, spatial_scale, sampling_rati
         return out
     wsb = int(lib().m3d_roi_align3d_workspace_bytes(R)) if ordered else 0          # launch order (heaviest RoI first) + per-RoI set-up records
     ws = torch.empty((max(wsb, 4),), dtype=torch.uint8, device=features.device) if ordered else None
+    if feat_absmax is not None and ordered:
+        _need_gpu(feat_absmax)
+        check(lib().m3d_roi_align3d_forward_ws2(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
+                                                _ptr(rois), R, cols, _ptr(out), _ptr(ws), C.c_size_t(wsb), _ptr(feat_absmax), _stream()),
+              "roi_align3d_forward")
+        return out
     check(lib().m3d_roi_align3d_forward_ws(int(AS), int(AH), int(AW), C.c_float(spatial_scale), int(sampling_ratio), _ptr(features), B, Cc, S, H, W,
                                            _ptr(rois), R, cols, _ptr(out), _ptr(ws), C.c_size_t(wsb), _stream()), "roi_align3d_forward")
     return out

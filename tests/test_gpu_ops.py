@@ -169,6 +169,46 @@ def test_roi_align_forward_bit_exact(m3d, shape, R, res, ratio):
     assert np.array_equal(fast == 0, ref == 0) or np.abs(fast[ref == 0]).max() < 1e-6
 
 
+@pytest.mark.parametrize("B,C,dims,R", [(4, 256, (16, 16, 16), 400), (1, 128, (16, 40, 40), 300), (2, 64, (8, 25, 25), 150), (1, 96, (12, 14, 16), 80)])
+def test_roi_align_matrix_core_form_for_small_sub_volumes(m3d, B, C, dims, R):
+    """Round 6: with the feature maps' largest magnitude, RoIs whose sub-volume has <= 128 voxels run as ONE GEMM per RoI on the f16 matrix
+    cores (out[c][bin] = sum_k f[c][k] M[k][bin], f16x2 split: csrc/roi_align3d.hip roi_align3d_fwd_gemm_kernel); the others through the
+    separable kernels.  Against the oracle (reference operation order) within the fast mode's 1e-5 max |f|, against the separable form
+    within 2e-6 max |f|; RoIs of every class in one call (tiny, <= 64, <= 128, larger, wide-bin, malformed, outside), channel counts
+    that give a wave two, one or no channel block; a loose bound; no NaN marker left behind."""
+    rs = np.random.RandomState(C + R)
+    S, H, W = dims
+    f = (rs.randn(B, C, S, H, W) * np.exp(rs.randn(B, C, 1, 1, 1))).astype(np.float32)
+    ext = 8.0 * np.array([W, H, S])
+    c = rs.uniform(0, 1, (R, 3)) * ext
+    kind = rs.randint(0, 5, (R, 1))
+    s = np.where(kind == 0, rs.uniform(2, 16, (R, 3)), np.where(kind == 1, rs.uniform(12, 30, (R, 3)), np.where(kind == 2, rs.uniform(20, 45, (R, 3)),
+        np.where(kind == 3, rs.uniform(40, 90, (R, 3)), rs.uniform(200, 400, (R, 3))))))
+    rois = np.hstack((rs.randint(0, B, (R, 1)), c - s / 2, c + s / 2)).astype(np.float32)
+    rois[0, 4:] = rois[0, 1:4] - 3          # malformed (x2 < x1)
+    rois[1, 1:] = 4000.                     # fully outside
+    rois[2, 1:] = [-30, -30, -30, 6, 6, 6]  # mostly outside: samples below -1 contribute 0
+    fd, rd = dev(f), dev(rois)
+    ref = O.roi_align_3d_forward(f, rois, 7, 7, 7, 0.125, 2)
+    sep = m3d.roi_align3d_forward(fd, rd, 7, 7, 7, 0.125, 2).cpu().numpy()
+    fmax = np.abs(f).max()
+    for bound in (m3d.ops.absmax(fd), m3d.ops.absmax(fd) * 64.0):
+        got = m3d.roi_align3d_forward(fd, rd, 7, 7, 7, 0.125, 2, feat_absmax=bound).cpu().numpy()
+        assert not np.isnan(got).any()
+        assert np.abs(got - ref).max() <= 1e-5 * fmax
+        assert np.abs(got - sep).max() <= 2e-6 * fmax, np.abs(got - sep).max() / fmax
+        assert np.abs(got[ref == 0]).max() <= 1e-6 * fmax
+    # per batch item the error is relative to the whole tensor's largest value (one scale for the operand): a quiet item next to a loud one
+    # keeps 22 bits down to 2^-18 of the largest - checked on the item with the smallest values
+    q = int(np.argmin([np.abs(f[b]).max() for b in range(B)]))
+    sel = rois[:, 0] == q
+    if sel.sum() > 3:
+        assert np.abs(got[sel] - ref[sel]).max() <= 1e-5 * fmax
+    # some RoIs must really have gone each way (the marker classes are the kernel's business; here: sub-volume sizes on both sides of 128)
+    from_small = (s.max(1) < 30).sum(); from_large = (s.min(1) > 45).sum()
+    assert from_small > 5 and from_large > 5
+
+
 @pytest.mark.parametrize("C", [64, 96, 40])
 def test_roi_align_fast_and_complement_kernels_share_the_rois(m3d, C):
     """ratio 2, 7^3 bins: RoIs with bins wider than 4 voxels are declined by the fast kernel and done by the complement pass

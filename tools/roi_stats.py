@@ -46,6 +46,12 @@ def timeit(f, n=10):
 t = timeit(lambda: m3d.roi_align3d_forward(feat, ro, 7, 7, 7, 0.125, 2))
 by = len(rois) * 256 * 343 * 4
 print("roi_align3d on these %d rois: %.3f ms  (%.0f MB written, %.2f TB/s = %.1f%% of 8 TB/s)" % (len(rois), t, by / 1e6, by / t / 1e9, by / t / 1e9 / 8 * 100))
+fb = m3d.ops.absmax(feat)
+tg = timeit(lambda: m3d.roi_align3d_forward(feat, ro, 7, 7, 7, 0.125, 2, feat_absmax=fb))
+print("   with the matrix-core form for sub-volumes <= 128 voxels (%d of them <= 64, %d <= 128): %.3f ms  (%.2f TB/s = %.1f%% of 8 TB/s)"
+      % ((sub <= 64).sum(), (sub <= 128).sum(), tg, by / tg / 1e9, by / tg / 1e9 / 8 * 100))
+ta = timeit(lambda: m3d.ops.absmax(feat))
+print("   (absmax of the feature maps: %.3f ms)" % ta)
 for name, sel in (("small", 4 * per <= 6144), ("medium", (4 * per > 6144) & (per <= 6144)), ("huge", per > 6144)):
     if sel.sum():
         rr = torch.from_numpy(rois[sel]).cuda()
