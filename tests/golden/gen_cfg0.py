@@ -86,6 +86,10 @@ def main():
     out.update(crm=crm.numpy().astype(np.float32), p_peaks=vpl.numpy().astype(np.int64), p_dets=dets.numpy().astype(np.float64),
                p_prm_sum=prms.sum((1, 2, 3)), p_prm_z=prms.sum((2, 3)), p_prm_y=prms.sum((1, 3)), p_prm_x=prms.sum((1, 2)),
                p_prm_max=prms.reshape(len(prms), -1).max(1), p_prm_argmax=prms.reshape(len(prms), -1).argmax(1).astype(np.int64),
+               # round 6: per-voxel values - every map's 2048 largest voxels (flat index ascending among equal values) and a strided sample
+               p_prm_top_idx=np.stack([np.argsort(-m.ravel(), kind="stable")[:2048] for m in prms]).astype(np.int32),
+               p_prm_top_val=np.stack([m.ravel()[np.argsort(-m.ravel(), kind="stable")[:2048]] for m in prms]).astype(np.float32),
+               p_prm_stride_val=np.stack([m.ravel()[::257] for m in prms]).astype(np.float32),
                distinct_scores=np.int64(len(np.unique(crm.numpy())) == crm.numel()),
                seed_params=np.int64(SEED_P), seed_volume=np.int64(SEED_V), size=np.int64(SIZE))
     p = os.path.join(HERE, "cfg0_64.npz")

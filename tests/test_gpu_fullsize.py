@@ -367,3 +367,13 @@ def test_config0_64_cubed_equals_the_reference_run(golden):
     assert (pr.reshape(len(pr), -1).argmax(1) == g["p_prm_argmax"]).mean() >= 0.9          # ties between neighbouring voxels may flip
     for ax, key in (((2, 3), "p_prm_z"), ((1, 3), "p_prm_y"), ((1, 2), "p_prm_x")):
         assert np.allclose(pr.sum(ax), g[key], rtol=3e-3, atol=3e-6)
+    # round 6: PER VOXEL against the reference run - every map's 2048 largest voxels and a strided sample of all of it, relative to the
+    # map's maximum: the 1e-4 contract at every sampled voxel of every one of the 21 maps (measured: top voxels median 4.4e-7, worst
+    # 5.7e-5; strided sample worst 1.1e-5)
+    flat = pr.reshape(len(pr), -1)
+    mx = g["p_prm_max"].astype(np.float64)
+    e_top = np.array([np.abs(flat[i, g["p_prm_top_idx"][i]] - g["p_prm_top_val"][i]).max() for i in range(len(pr))]) / mx
+    e_str = np.abs(flat[:, ::257] - g["p_prm_stride_val"]).max(1) / mx
+    print("cfg0 per-voxel error / map maximum: top-2048 voxels median %.2e worst %.2e; strided sample median %.2e worst %.2e (%d maps)"
+          % (np.median(e_top), e_top.max(), np.median(e_str), e_str.max(), len(pr)))
+    assert e_top.max() <= 1e-4 and e_str.max() <= 1e-4 and np.median(e_top) <= 5e-6, (e_top.max(), e_str.max(), np.median(e_top))
