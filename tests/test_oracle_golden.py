@@ -218,6 +218,10 @@ def test_config0_64_cubed_reference_run(golden):
         assert abs(prm.sum() - g["p_prm_sum"][i]) < 1e-4 and int(prm.argmax()) == int(g["p_prm_argmax"][i])
         for ax, key in (((1, 2), "p_prm_z"), ((0, 2), "p_prm_y"), ((0, 1), "p_prm_x")):
             assert np.allclose(prm.sum(ax), g[key][i], rtol=2e-3, atol=2e-6)
+        # round 6 keys: per voxel - the map's 2048 largest voxels and a strided sample, against the reference run's values
+        mx = float(g["p_prm_max"][i])
+        assert np.abs(prm.ravel()[g["p_prm_top_idx"][i]] - g["p_prm_top_val"][i]).max() <= 1e-4 * mx
+        assert np.abs(prm.ravel()[::257] - g["p_prm_stride_val"][i]).max() <= 1e-4 * mx
 
 
 def test_skimage_resize_restatement_known_answers():
