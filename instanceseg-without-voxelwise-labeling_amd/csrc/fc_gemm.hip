@@ -734,7 +734,7 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
     *reinterpret_cast<u32x4*>(d + PL) = pm;
     *reinterpret_cast<u32x4*>(d + 2 * PL) = pl;
   };
-  auto commit = [&]() __attribute__((always_inline)) {
+  auto commit = [&](int base = 0) __attribute__((always_inline)) {      // base: dword offset of the LDS image (F16: two images)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if constexpr (F16) {
@@ -746,10 +746,10 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
           const f16x2 ll = {(_Float16)(v0 - (float)hh[0]), (_Float16)(v1 - (float)hh[1])};
           ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
         }
-        unsigned* d = lds + (row0 + 128 * i) * X3_RSW + swq;
+        unsigned* d = lds + base + (row0 + 128 * i) * X3_RSW + swq;
         *reinterpret_cast<u32x4*>(d) = ph;
         *reinterpret_cast<u32x4*>(d + PL) = pl;
-        unsigned* dw = lds + OP + (row0 + 128 * i) * X3_RSW + swq;
+        unsigned* dw = lds + base + OP + (row0 + 128 * i) * X3_RSW + swq;
         *reinterpret_cast<u32x4*>(dw) = __builtin_bit_cast(u32x4, sq[i][0]);
         *reinterpret_cast<u32x4*>(dw + PL) = __builtin_bit_cast(u32x4, sq[i][1]);
       } else {
@@ -833,32 +833,34 @@ __global__ __launch_bounds__(512, 1) void fc_x3b_gemm_kernel(FcX3Args a) {
             acc[i][2 * jh + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][PA[p]], Bf[j][PB[p]], acc[i][2 * jh + j], 0, 0, 0);
       }
     };
+    // Two LDS images (2 x 64 KB): chunk c + 1 is cut and written into the OTHER image at any time during chunk c, so a chunk has ONE
+    // barrier (the image of c + 1 is complete, nobody reads the image of c any more) instead of two with the cut squeezed between them.
+    constexpr int IMG = 2 * OP;
     if (c0 < c1) {
-      fetch(c0); commit();
+      fetch(c0); commit(0);
       __syncthreads();
       fetch(min(c0 + 1, c1 - 1));
       rd_a(fa, offA0); rd_b(fb, offB0, 0);
     }
     for (int c = c0; c < c1; ++c) {
-      rd_b(gb, offB0, 1);
+      const int bo = ((c - c0) & 1) * IMG, bn = IMG - bo;
+      rd_b(gb, bo + offB0, 1);
       __builtin_amdgcn_sched_barrier(0);
       mm(fa, fb, 0, 0, 3);
       __builtin_amdgcn_sched_barrier(0);
-      rd_a(ga, offA1); rd_b(fb, offB1, 0);
+      rd_a(ga, bo + offA1); rd_b(fb, bo + offB1, 0);
+      commit(bn);                                                 // chunk c + 1 (after the last chunk: a write nobody reads) ...
+      mm(fa, gb, 1, 0, 3);                                        // ... the compiler interleaves the cut with these 12 MFMAs
       __builtin_amdgcn_sched_barrier(0);
-      mm(fa, gb, 1, 0, 3);
-      __builtin_amdgcn_sched_barrier(0);
-      rd_b(gb, offB1, 1);
+      rd_b(gb, bo + offB1, 1);
+      fetch(min(c + 2, c1 - 1));
       __builtin_amdgcn_sched_barrier(0);
       mm(ga, fb, 0, 0, 3);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();                                            // A: every fragment of the chunk is in registers; the image is free
-      commit();                                                   // chunk c + 1, under 8 of the last 12 MFMAs
-      mm(ga, gb, 1, 0, 2);                                        // (waves 4-7 taking the two in the other order - a stagger of the SIMD's two waves -
-      __builtin_amdgcn_sched_barrier(0);                          // measured no different: 0.672 ms both ways at M = 1253)
-      __syncthreads();                                            // B: the image of chunk c + 1 is complete
-      fetch(min(c + 2, c1 - 1));
-      rd_a(fa, offA0); rd_b(fb, offB0, 0);                        // (after the last chunk: a read nobody uses)
+      mm(ga, gb, 1, 0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                            // the image of chunk c + 1 is complete; the image of chunk c is free
+      rd_a(fa, bn + offA0); rd_b(fb, bn + offB0, 0);              // first fragments of chunk c + 1, under the chunk's last 4 MFMAs
       __builtin_amdgcn_sched_barrier(0);
       mm(ga, gb, 1, 2, 3);
       __builtin_amdgcn_sched_barrier(0);
@@ -1151,7 +1153,7 @@ M3D_API int m3d_linear_f16x2_forward(const float* d_x, const void* d_packed, con
   a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + f16x2_plane_bytes(N, K));
   a.x_alias = 0;
   a.feat = nullptr; a.taps = nullptr; a.roi_batch = nullptr; a.fC = a.fS = a.fH = a.fW = 0;
-  const size_t lds = big ? sizeof(unsigned) * 4 * 256 * X3_RSW : sizeof(unsigned) * (2 * (64 * p.wr) * X3_RSW + 2 * X3_PLANE);
+  const size_t lds = big ? sizeof(unsigned) * 2 * 4 * 256 * X3_RSW : sizeof(unsigned) * (2 * (64 * p.wr) * X3_RSW + 2 * X3_PLANE);   // big: two images
   if (big) {
     auto kern = fc_x3b_gemm_kernel<1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
