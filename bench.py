@@ -625,15 +625,19 @@ def bench_detect(args, rank, world, dist):
         rdev = [h.cuda() for h in rhost]
         xb = torch.empty((nv, 1, VOL, VOL, VOL), dtype=torch.float32, device="cuda")
 
-        def batch(raw):
+        def batch(raw, between=None):
             """The rank's batch of volumes -> packed detections [nv, cap+1, 7] on the device (m3d.shard block: rows = detections,
             trailer row = count).  norm1 per volume; ONE batched pass for the convolutions, RoIAlign and the box-head GEMMs; ONE
             launch each for the proposals, the per-class NMS + cap and the cross-tile NMS + packing of all volumes; one host read
-            (the proposal counts that size the GEMM)."""
+            (the proposal counts that size the GEMM).  `between` (host-to-host loop): called when the backbone, RPN and proposal launches
+            are queued and before the host waits for the proposal counts - where the next step's upload is issued."""
             if backbone_only:                                                           # configs[1]: the 3D-conv forward alone (xb was
                 return det.conv_body(xb)                                                # normalised once, outside the timed steps)
             m3d.norm1_batched(raw, f32_arith=True, out=xb)                              # blob.py:179-184, per volume statistics
-            r = det.detect_batch(xb, im_info, as_dicts=False)                           # core/test.py:106-114 per volume
+            st_ = det.detect_batch_begin(xb, im_info)                                   # core/test.py:106-114 per volume
+            if between is not None:
+                between()
+            r = det.detect_batch_finish(st_, as_dicts=False)
             last["num_rois"] = r["num_rois"]
             rois_seen.append(float(sum(r["num_rois"])))
             if "cls_boxes" not in r:
@@ -705,12 +709,20 @@ def bench_detect(args, rank, world, dist):
             b = i & 1
             state["i"] += 1
             torch.cuda.current_stream().wait_event(ready[b])
-            packed = batch(bufs[b])
-            freed[b].record()
-            # the NEXT step's volumes (the next of the rotating batches) cross PCIe under this step's box head.  The upload is issued
-            # after this step's launches: on this stack the 16.8 MB pinned hipMemcpyAsync holds the calling thread for ~0.5 ms, and
-            # issued first it kept the GPU waiting for the step's kernels
-            upload(b ^ 1, i + 1)
+            # the NEXT step's volumes (the next of the rotating batches) cross PCIe during this step.  On this stack the 16.8 MB pinned
+            # hipMemcpyAsync holds the calling thread for ~0.5 ms: issued before the step's launches it kept the GPU waiting for them.
+            # --upload-at end (rounds 4-5): after ALL of the step's launches - the copy then runs beside the box head (fc1 streams 0.8 GB)
+            # and the next step's first kernels; --upload-at mid (round 6): once backbone / RPN / proposals are queued, before the host
+            # waits for the proposal counts - the held thread is hidden behind 2.7 ms of queued convolutions and the copy runs beside them.
+            # Measured equal (3.944 vs 3.940 ms per step, two runs each on one box): the 0.15 ms between this loop and `resident` is not a
+            # matter of WHICH kernels the copy runs beside
+            if args.upload_at == "mid":
+                packed = batch(bufs[b], between=lambda: upload(b ^ 1, i + 1))
+                freed[b].record()
+            else:
+                packed = batch(bufs[b])
+                freed[b].record()
+                upload(b ^ 1, i + 1)
             g = exchange(packed)
             last["packed"] = g
             if rank == 0:
@@ -1331,6 +1343,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="launcher + exchange rehearsal without a GPU (stub step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--upload-at", default="end", choices=["mid", "end"], help="host-to-host loop: where the next step's pinned upload is issued (A/B, measured equal: 3.944 / 3.940 ms; see step_host)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.workload == "backbone" else 20     # a timed region of ~0.1-0.2 s either way
