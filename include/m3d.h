@@ -569,6 +569,23 @@ int m3d_conv3d_x3f_forward_ws(const float* d_x, const void* d_packed, float* d_o
  * library's own decision, for callers that choose between this kernel and m3d_conv3d_forward by how well a launch fills the chip. */
 long long m3d_conv3d_x3_launch_units(int batch, int cin, int cout, int depth, int height, int width);
 
+/* Round 6 - the FORWARD 3x3x3 convolution + eval-BN + ReLU [+ MaxPool3d(2,2)] of lib/modeling/DSN.py:57-68 (and rpn_heads.py:94-96) on the
+ * f16 matrix cores at fp32 accuracy: the f16x2 split (three fp16 products per fp32 product) with Winograd F(2,3) along z (36 instead of 54
+ * products per output pair): csrc/conv3d_zw.hip.  cin must be a multiple of 16; depth >= 2, height >= 4, width >= 12 (pool: even extents,
+ * width >= 24) - m3d_conv3d_zw_supported.  d_in_max: device array of m3d_conv3d_zw_slots() (= 32) non-negative floats whose LARGEST is
+ * >= max |d_in| (the operand scale; an input beyond the bound overflows fp16); d_out_max (or NULL): the same kind of array for d_out,
+ * updated with atomic maxima - the caller zeroes it before the launch and hands it to the next layer as its d_in_max, so that a chain of
+ * layers needs one sweep (m3d_conv3d_zw_bound_of) for its first input only.  relu / d_scale / d_shift as m3d_conv3d_forward; pool = 1:
+ * d_out is [batch, cout, depth/2, height/2, width/2].  Differences to the fp32 kernels: ~1e-6 of the largest output. */
+int m3d_conv3d_zw_supported(int cin, int cout, int depth, int height, int width, int pool);
+size_t m3d_conv3d_zw_packed_bytes(int cin, int cout);
+int m3d_conv3d_zw_pack(const float* d_weight, int cin, int cout, void* d_packed, void* stream);
+int m3d_conv3d_zw_slots(void);
+int m3d_conv3d_zw_bound_of(const float* d_x, long long n, float* d_slots, void* stream);
+int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                          int width, const float* d_scale, const float* d_shift, int relu, int pool, const float* d_in_max,
+                          float* d_out_max, void* stream);
+
 /* Round 5: backward-data of a 3^3 conv on the quad-aligned strip FUSED with the prepare step of the layer below (no pooling between them):
  * d_gn [cin, in_planes, window, L(window)] (m3d_prm_prepare_ex2's out_strip = 2 layout; in_slab: the map's planes), d_packed =
  * m3d_conv3d_wino2_pack_weights of the backward-data weights -> d_out [cout, out_planes, window + 2, L(window + 2)], the strip

@@ -1,0 +1,444 @@
+// 3x3x3 forward convolution (stride 1, pad 1) + eval-BN + ReLU [+ MaxPool3d(2,2)] of lib/modeling/DSN.py:57-68 on the f16 matrix cores at
+// fp32 accuracy: the "f16x2" cut of fc_gemm.hip (both operands scaled by a power of two and cut into two fp16 numbers, 22 bits; three
+// v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulation) combined with Winograd F(2,3) ALONG Z:
+//
+//   per output z pair (z0, z0 + 1) and input planes d0..d3 = in[z0 - 1 .. z0 + 2]:
+//     V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3                  (input side: two-plane sums, formed while staging)
+//     U0 = g0,  U1 = (g0 + g1 + g2) / 2,  U2 = (g0 - g1 + g2) / 2,  U3 = g2      (weights g_dz, transformed in double at pack time)
+//     M_k = sum over (ci, dy, dx) of U_k * V_k   (four direct 3 x 3 convolutions on the (y, x) plane: the matrix-core work)
+//     out[z0] = M0 + M1 + M2,  out[z0 + 1] = M1 - M2 - M3
+//   36 products per output pair and (ci, co) instead of 54: 2/3 of the direct convolution's matrix work, x 3 for the f16x2 cut = 2 f16
+//   products per algorithmic multiply-add, at 16 x the fp32 MFMA's rate (the F(2x4,3x3) fp32 kernel of conv3d_wino24.hip issues 1/3 of
+//   the direct products at the fp32 rate: 2.7 x the matrix-pipe time of this form).
+//
+// Decomposition: a workgroup (8 waves) owns 64 output channels x a tile of XB x 4*RY x 2 outputs (XB = 32, RY = 1 or XB = 16, RY = 2);
+// wave = (z point k, 32-channel block): its four accumulator blocks are the tile's four 32-voxel column blocks (XB x RY voxels each) of
+// M_k.  GEMM view per (dy, dx) tap and 16-channel chunk: A = U (32 co x 16 ci, packed fragment-ready in global memory, read straight
+// into registers two taps ahead - every wave has its own (k, block), nothing to share through LDS), B = V_k (16 ci x 32 voxels: one
+// ds_read_b128 per fragment from the channel-contiguous LDS image [hi / lo][k half][point][row][x]).  The halo tile of the next chunk
+// is loaded to registers at the start of a chunk, cut (z transform, scale, hi / lo) and written to the other LDS buffer in its middle:
+// ONE barrier per chunk.  The four M_k meet in an LDS exchange at the end; every wave then finishes one column block (or, with the
+// fused pool, one row pair of half the channels).
+//
+// Operand scales: the input's largest magnitude comes from the PRODUCER (a 32-slot device array of non-negative floats, the largest is
+// the bound; this kernel's epilogue fills the array for the next layer: `d_out_max`), so no sweep of the activations is ever needed.
+// The f16 MFMA truncates when it adds into the accumulator (conv3d_x3.hip): with signed weights the bias is ~3e-9 of the running sum
+// per MFMA, 5e-6 at 256 input channels - below the fp32 Winograd kernels' error; the accumulators run over all of K.
+#include <type_traits>
+
+#include "m3d_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ZW_NT = 512;
+constexpr int ZW_SLOTS = 32;                       // slots of an absmax array
+constexpr int ZW_STEP_UNITS = 4 * 2 * 128;         // packed weights of one (chunk, tap): [point 4][block 2][hi / lo][k half][row 32] 16-byte units
+constexpr int acc_row(int g) { return (g & 3) + 8 * (g >> 2); }
+
+template <int XB>
+struct ZwCfg {
+  static constexpr int RY = 32 / XB;
+  static constexpr int TX = XB, TY = 4 * RY, TZ = 2;
+  static constexpr int HXN = XB + 2, HYN = TY + 2;
+  static constexpr int HXP = HXN;                  // row pitch in units
+  static constexpr int PLANE = HYN * HXP;
+  static constexpr int BUF_UNITS = 16 * PLANE;     // [hi / lo][k half][point]
+  static constexpr int ITEMS = 2 * HYN * HXN;      // staging items of a chunk: (8-channel half, halo row, halo column)
+  static constexpr int XCH_BYTES = 2 * 4 * 4 * 4 * 64 * 16;      // exchange: [block][point][column block][g / 4][lane] x 16 bytes
+  static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16 > XCH_BYTES ? 2 * BUF_UNITS * 16 : XCH_BYTES;
+  static_assert(ITEMS <= ZW_NT, "one staging item per thread");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// column (lane % 32) of a 16 x 2 column block -> (x, y): the lane groups ds_read_b128 is served in ({0-3,12-15,20-27} / {4-11,16-19,28-31},
+// conv3d_x3.hip) each read 16 consecutive units of ONE row
+__device__ __forceinline__ void col_xy16(int c, int* x, int* y) {
+  if (c < 4) { *x = c; *y = 0; }
+  else if (c < 12) { *x = c - 4; *y = 1; }
+  else if (c < 16) { *x = c - 8; *y = 0; }
+  else if (c < 20) { *x = c - 8; *y = 1; }
+  else if (c < 28) { *x = c - 12; *y = 0; }
+  else { *x = c - 16; *y = 1; }
+}
+
+// packed[cout group 64][step = chunk * 9 + dy * 3 + dx][point][block][hi / lo][k half][row 32] <- weight [cout][cin][3][3][3] fp32
+__global__ __launch_bounds__(256) void zw_pack_kernel(const float* __restrict__ w, int cin, int cout, u32x4* __restrict__ packed,
+                                                      const float* __restrict__ wamax) {
+  float sw, inv;
+  m3d::f16_scale_of(1.5f * *wamax, sw, inv);        // |U1|, |U2| <= 1.5 max |g|
+  const int chunks = cin / 16, ncg = (cout + 63) / 64;
+  const long long total = (long long)ncg * chunks * 9 * 4 * 2 * 64;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int row = (int)(e & 31), kh = (int)((e >> 5) & 1), cb = (int)((e >> 6) & 1), point = (int)((e >> 7) & 3);
+    long long r = e >> 9;
+    const int tap = (int)(r % 9); r /= 9;
+    const int ch = (int)(r % chunks), cg = (int)(r / chunks);
+    const int co = cg * 64 + cb * 32 + row;
+    u32x4 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x2 hh, ll;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float v = 0.f;
+        if (co < cout) {
+          const float* g = w + ((size_t)co * cin + ch * 16 + 8 * kh + 2 * j + u) * 27 + tap;
+          const double g0 = g[0], g1 = g[9], g2 = g[18];
+          const double t = point == 0 ? g0 : point == 1 ? 0.5 * (g0 + g1 + g2) : point == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+          v = (float)t * sw;
+        }
+        const _Float16 h = (_Float16)v;
+        hh[u] = h; ll[u] = (_Float16)(v - (float)h);
+      }
+      ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
+    }
+    u32x4* dst = packed + ((size_t)(cg * chunks + ch) * 9 + tap) * ZW_STEP_UNITS + (point * 2 + cb) * 128 + kh * 32 + row;
+    dst[0] = ph; dst[64] = pl;
+  }
+}
+
+struct ZwArgs {
+  const float* x; const u32x4* wp; float* out; const float* scale; const float* shift;
+  const float* in_max; unsigned* out_max; const float* wamax;
+  int B, cin, cout, D, H, W, relu;
+  int tiles_x, tiles_y, tiles_z, ncg;
+};
+
+__device__ __forceinline__ int zw_xcd_contiguous(int bid, int n) {
+  const int per = n >> 3, rem = n & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return xcd * per + (xcd < rem ? xcd : rem) + idx;
+}
+
+template <int XB, bool POOL>
+__global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
+  using C = ZwCfg<XB>;
+  static_assert(!POOL || XB == 32, "fused pool: 32-wide column blocks (a row pair = two blocks of the finishing wave)");
+  extern __shared__ float lds_f[];
+  u32x4* const lds = reinterpret_cast<u32x4*>(lds_f);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int point = wave & 3, cb = wave >> 2;
+
+  int l = zw_xcd_contiguous(blockIdx.x, gridDim.x);
+  const int cg = l % a.ncg; l /= a.ncg;
+  const int tx = l % a.tiles_x; l /= a.tiles_x;
+  const int ty = l % a.tiles_y; l /= a.tiles_y;
+  const int tz = l % a.tiles_z;
+  const int b = l / a.tiles_z;
+  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
+  const size_t HW = (size_t)a.H * a.W, DHW = HW * a.D;
+  const int chunks = a.cin / 16;
+
+  // ---- operand scales (powers of two): input bound = the largest slot x 2 (a V is a sum of two planes), weights as packed
+  float xs, inv_x, inv_w;
+  {
+    float im = a.in_max[lane & (ZW_SLOTS - 1)];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) im = fmaxf(im, __shfl_xor(im, o));
+    float sw_;
+    m3d::f16_scale_of(2.f * im, xs, inv_x);
+    m3d::f16_scale_of(1.5f * *a.wamax, sw_, inv_w);
+  }
+
+  // ---- staging item of this thread: (8-channel half g, halo row hy, halo column hx); the four planes z0 - 1 .. z0 + 2
+  const bool has = tid < C::ITEMS;
+  const int sg = has ? tid / (C::HYN * C::HXN) : 0;
+  const int sr = has ? tid % (C::HYN * C::HXN) : 0;
+  const int shy = sr / C::HXN, shx = sr % C::HXN;
+  const int sy = y0 - 1 + shy, sx = x0 - 1 + shx;
+  const bool okyx = has & (sy >= 0) & (sy < a.H) & (sx >= 0) & (sx < a.W);
+  bool okz[4];
+  int zoff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int z = z0 - 1 + k;
+    okz[k] = okyx & (z >= 0) & (z < a.D);
+    zoff[k] = okz[k] ? (int)((size_t)z * HW + (size_t)sy * a.W + sx) : 0;      // (host: one channel map < 2^31 elements)
+  }
+  // 32-bit buffer offsets (host: cin * D * H * W * 4 < 2^31): four per-plane byte offsets in registers, channel and chunk in the scalar offset
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (size_t)b * a.cin * DHW), 0, (unsigned)((size_t)a.cin * DHW * sizeof(float)), 0x00020000);
+  int voff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) voff[k] = (zoff[k] + 8 * sg * (int)DHW) * 4;
+  const int ch_bytes = (int)(DHW * sizeof(float));
+  float raw[4][8];
+  auto fetch_in = [&](int c) __attribute__((always_inline)) {
+    const int cbase = c * 16 * ch_bytes;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        raw[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[k], cbase + j * ch_bytes, 0));
+  };
+  const int st_unit = (sg * 4) * C::PLANE + shy * C::HXP + shx;               // + point * PLANE + hilo * 8 * PLANE + buf * BUF_UNITS
+  auto commit_in = [&](int buf) __attribute__((always_inline)) {
+    if (!has) return;
+    u32x4 ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x2 hh[4], ll[4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ch = 2 * j + u;
+        const float d0 = okz[0] ? raw[0][ch] : 0.f, d1 = okz[1] ? raw[1][ch] : 0.f, d2 = okz[2] ? raw[2][ch] : 0.f, d3 = okz[3] ? raw[3][ch] : 0.f;
+        const float v[4] = {(d0 - d2) * xs, (d1 + d2) * xs, (d2 - d1) * xs, (d1 - d3) * xs};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const _Float16 h = (_Float16)v[k];
+          hh[k][u] = h; ll[k][u] = (_Float16)(v[k] - (float)h);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ph[k][j] = __builtin_bit_cast(unsigned, hh[k]); pl[k][j] = __builtin_bit_cast(unsigned, ll[k]); }
+    }
+    u32x4* d = lds + buf * C::BUF_UNITS + st_unit;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { d[k * C::PLANE] = ph[k]; d[k * C::PLANE + 8 * C::PLANE] = pl[k]; }
+  };
+
+  // ---- fragments
+  const int fr = lane & 31, fh = lane >> 5;
+  int cx, cy;
+  if constexpr (XB == 32) { cx = fr; cy = 0; } else { col_xy16(fr, &cx, &cy); }
+  const int bB = (fh * 4 + point) * C::PLANE + cy * C::HXP + cx;              // + (RY * j + dy) * HXP + dx + piece * 8 * PLANE + buf * BUF_UNITS
+  const u32x4* const wsrc = a.wp + (size_t)cg * chunks * 9 * ZW_STEP_UNITS + (point * 2 + cb) * 128 + lane;
+  const int steps = chunks * 9;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+
+  struct BF { f16x8 b[4][2]; };
+  BF F0, F1;
+  f16x8 A[3][2];                                                             // A of step s: set s % 3 (9 taps per chunk: the tap's index % 3)
+  auto read_b = [&](BF& f, int i, int t, int buf) __attribute__((always_inline)) {     // read i of 8: column block i >> 1, piece i & 1
+    const int j = i >> 1, p = i & 1, dy = t / 3, dx = t % 3;
+    f.b[j][p] = __builtin_bit_cast(f16x8, lds[buf * C::BUF_UNITS + bB + (C::RY * j + dy) * C::HXP + dx + p * 8 * C::PLANE]);
+  };
+  auto fetch_a = [&](int s, int set) __attribute__((always_inline)) {
+    const u32x4* p = wsrc + (size_t)s * ZW_STEP_UNITS;
+    A[set][0] = __builtin_bit_cast(f16x8, p[0]);
+    A[set][1] = __builtin_bit_cast(f16x8, p[64]);
+  };
+
+  // ---- prologue
+  fetch_in(0);
+  fetch_a(0, 0);
+  fetch_a(1, 1);
+  commit_in(0);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) read_b(F0, i, 0, 0);
+
+  // one chunk = 9 taps on LDS buffer `buf`; `par` = parity of its first step (9 is odd: the chunk's parity), a literal at both call sites.
+  // During the 12 MFMAs of a tap the 8 B fragments of the next tap are read (3 / 3 / 2 per four MFMAs) and the A fragments of the tap after
+  // it are requested.  The next chunk's tile: loads at tap 0, cut + LDS writes after tap 4, barrier before tap 8 (whose prefetch reads it).
+  auto run_chunk = [&](int c, const int par) __attribute__((always_inline)) {
+    const int buf = par;                                                      // chunk parity = buffer
+    const int cn = min(c + 1, chunks - 1);                                    // branch-free: the last chunk stages itself again (unused)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int s = c * 9 + t;
+      BF& cur = ((par + t) & 1) ? F1 : F0;
+      BF& nxt = ((par + t) & 1) ? F0 : F1;
+      if (t == 0) fetch_in(cn);
+      if (t == 8) __syncthreads();
+      fetch_a(min(s + 2, steps - 1), (t + 2) % 3);
+      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                     // small products first: (lo, hi) (hi, lo) (hi, hi)
+      constexpr int RD0[4] = {0, 3, 6, 8};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = RD0[q]; i < RD0[q + 1]; ++i) read_b(nxt, i, t < 8 ? t + 1 : 0, t < 8 ? buf : buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t % 3][PA[q]], cur.b[j][PB[q]], acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (t == 4) commit_in(buf ^ 1);
+    }
+  };
+#pragma unroll 1
+  for (int c = 0; c < chunks; c += 2) {
+    run_chunk(c, 0);
+    if (c + 1 < chunks) run_chunk(c + 1, 1);
+  }
+
+  // ---- the four M_k meet: [block][point][column block][g / 4][lane] x 16 bytes
+  __syncthreads();
+  f32x4* const xch = reinterpret_cast<f32x4*>(lds_f);
+  {
+    f32x4* xw = xch + ((size_t)((cb * 4 + point) * 4) * 4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        xw[(j * 4 + gq) * 64] = f32x4{acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]};
+  }
+  __syncthreads();
+  const float un = inv_x * inv_w;
+  const int cobase = cg * 64 + cb * 32 + 4 * fh;
+  float vmax = 0.f;
+  float* const ob = a.out + (size_t)b * a.cout * (POOL ? DHW / 8 : DHW);
+  if constexpr (!POOL) {
+    // wave (point p, block) finishes column block j = p: both planes, 16 channels per lane
+    const int j = point;
+    const int x = x0 + cx, y = y0 + C::RY * j + cy;
+    const bool vok = (x < a.W) & (y < a.H);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
+      const f32x4 o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = cobase + acc_row(4 * gq + e);
+        if (!(vok && co < a.cout)) continue;
+        const float sc = (a.scale ? a.scale[co] : 1.f) * un, sh = a.shift ? a.shift[co] : 0.f;
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+          if (z0 + zz >= a.D) continue;
+          float v = (zz ? o1[e] : o0[e]) * sc + sh;
+          if (a.relu) v = fmaxf(v, 0.f);
+          vmax = fmaxf(vmax, fabsf(v));
+          ob[(size_t)co * DHW + (size_t)(z0 + zz) * HW + (size_t)y * a.W + x] = v;
+        }
+      }
+    }
+  } else {
+    // fused MaxPool3d(2,2): wave (point p, block) finishes row pair p & 1 (column blocks 2 rp, 2 rp + 1) for channel quads 2 (p >> 1) + {0, 1};
+    // z pair and y pair in the lane, x pair in lanes x, x ^ 1
+    const int rp = point & 1, gh = point >> 1;
+    const int PD = a.D / 2, PH = a.H / 2, PW = a.W / 2;
+    const int x = x0 + cx, yp = (y0 >> 1) + rp, zp = z0 >> 1, xp = x >> 1;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int gq = 2 * gh + gi;
+      f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = min(cobase + acc_row(4 * gq + e), a.cout - 1);
+        sc[e] = (a.scale ? a.scale[co] : 1.f) * un; sh[e] = a.shift ? a.shift[co] : 0.f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * rp + jj;
+        f32x4 m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
+        const f32x4 o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0 = o0[e] * sc[e] + sh[e], v1 = o1[e] * sc[e] + sh[e];
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          best[e] = fmaxf(best[e], fmaxf(v0, v1));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float other = __shfl_xor(best[e], 1);
+        const float v = fmaxf(best[e], other);
+        const int co = cobase + acc_row(4 * gq + e);
+        if ((lane & 1) == 0 && co < a.cout && xp < PW && yp < PH && zp < PD) {
+          vmax = fmaxf(vmax, fabsf(v));
+          ob[(size_t)co * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = v;
+        }
+      }
+    }
+  }
+  // ---- the next layer's operand bound: one atomic per workgroup into slot (block % 32)
+  if (a.out_max) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    __shared__ float wm[8];
+    if (lane == 0) wm[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = wm[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) m = fmaxf(m, wm[k]);
+      if (m > 0.f) atomicMax(a.out_max + (blockIdx.x & (ZW_SLOTS - 1)), __float_as_uint(m));
+    }
+  }
+}
+
+template <int XB, bool POOL>
+int launch_zw(ZwArgs a, hipStream_t st) {
+  using C = ZwCfg<XB>;
+  a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
+  a.ncg = (a.cout + 63) / 64;
+  const long long blocks = (long long)a.ncg * a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  if (blocks > 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
+  auto kern = conv3d_zw_kernel<XB, POOL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ZW_NT), C::LDS_BYTES, st, a);
+  return m3d::check_launch("conv3d_zw");
+}
+
+inline size_t zw_plane_bytes(int cin, int cout) { return (size_t)((cout + 63) / 64) * (cin / 16) * 9 * ZW_STEP_UNITS * 16; }
+
+}  // namespace
+
+M3D_API int m3d_conv3d_zw_supported(int cin, int cout, int depth, int height, int width, int pool) {
+  if (cin <= 0 || cout <= 0 || cin % 16 != 0 || depth < 2 || height < 4 || width < 12) return 0;
+  if ((size_t)depth * height * width >= 0x7FFFFFFFull) return 0;
+  if (pool && ((depth | height | width) & 1)) return 0;
+  if (pool && width < 24) return 0;                  // the fused pool exists for the 32-wide column blocks
+  return 1;
+}
+
+M3D_API size_t m3d_conv3d_zw_packed_bytes(int cin, int cout) {
+  if (cin <= 0 || cout <= 0 || cin % 16 != 0) return 0;
+  return zw_plane_bytes(cin, cout) + 256;            // + the weight's largest magnitude (one float) behind the fragments
+}
+
+M3D_API int m3d_conv3d_zw_pack(const float* d_weight, int cin, int cout, void* d_packed, void* stream) {
+  if (!d_weight || !d_packed || cin <= 0 || cout <= 0 || cin % 16 != 0) return M3D_EINVAL;
+  float* wamax = reinterpret_cast<float*>(static_cast<char*>(d_packed) + zw_plane_bytes(cin, cout));
+  if (const int rc = m3d_absmax(d_weight, (long long)cout * cin * 27, wamax, stream)) return rc;
+  hipLaunchKernelGGL(zw_pack_kernel, dim3(1024), dim3(256), 0, m3d::as_stream(stream), d_weight, cin, cout, (u32x4*)d_packed, (const float*)wamax);
+  return m3d::check_launch("conv3d_zw_pack");
+}
+
+M3D_API int m3d_conv3d_zw_slots(void) { return ZW_SLOTS; }
+
+/* d_slots[0] = max |x|, the other 31 slots 0: an operand bound for m3d_conv3d_zw_forward from a sweep of x (the first layer of a chain) */
+M3D_API int m3d_conv3d_zw_bound_of(const float* d_x, long long n, float* d_slots, void* stream) {
+  if (!d_slots) return M3D_EINVAL;
+  hipStream_t st = m3d::as_stream(stream);
+  if (hipMemsetAsync(d_slots, 0, ZW_SLOTS * sizeof(float), st) != hipSuccess) return M3D_ELAUNCH;
+  return m3d_absmax(d_x, n, d_slots, stream);
+}
+
+M3D_API int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
+                                  int width, const float* d_scale, const float* d_shift, int relu, int pool, const float* d_in_max,
+                                  float* d_out_max, void* stream) {
+  if (!d_in || !d_packed || !d_out || !d_in_max || batch <= 0) return M3D_EINVAL;
+  if (!m3d_conv3d_zw_supported(cin, cout, depth, height, width, pool)) return M3D_EUNSUPPORTED;
+  ZwArgs a{};
+  a.x = d_in; a.wp = static_cast<const u32x4*>(d_packed); a.out = d_out; a.scale = d_scale; a.shift = d_shift;
+  a.in_max = d_in_max; a.out_max = reinterpret_cast<unsigned*>(d_out_max);
+  a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + zw_plane_bytes(cin, cout));
+  a.B = batch; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width; a.relu = relu;
+  hipStream_t st = m3d::as_stream(stream);
+  if (pool) return launch_zw<32, true>(a, st);
+  if (width >= 24) return launch_zw<32, false>(a, st);
+  return launch_zw<16, false>(a, st);
+}

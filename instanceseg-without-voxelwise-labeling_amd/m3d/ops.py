@@ -13,7 +13,7 @@ BBOX_XFORM_CLIP = float(np.log(1000. / 16.))   # lib/core/config.py:947
 
 __all__ = ["compact_rows", "compact_rows2", "box_head_outputs", "roi_align3d_forward", "roi_align3d_backward", "nms3d", "bbox_overlaps3d", "bbox_transform3d",
            "generate_proposals3d", "generate_proposals3d_batched", "box_results3d_batched", "nms3d_batched", "fused_max_boxes", "PackedConv3d", "maxpool3d_2x", "maxpool3d_2x_backward", "reduce_min", "reduce_min_multi", "norm1", "norm1_batched", "linear", "SplitLinear", "linear_roi_fused", "mask_paste3d",
-           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "X3Conv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "paint_begin", "crop_offsets", "upload_packed", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
+           "otsu2d_batch", "prm_quantize_u8", "prm_quantize_windows_u8", "prm_quantize_windows_compact_u8", "roi_normalize", "conv3d_wgrad", "conv3d_bias_grad", "WinoConv3d", "ZwConv3d", "X3Conv3d", "StemWinoConv3d", "gaussian_filter_u16", "median_filter3_u16", "cc_largest_batch", "binary_closing6_batch", "paint_instances", "paint_instances_into", "paint_finish", "paint_begin", "crop_offsets", "upload_packed", "conv3d_windowed", "prm_seed", "strip_geometry", "prm_select_peaks", "PinnedPool", "upload", "prm_prepare", "prm_stem_dgrad", "prm_stem_prepare_weights", "SmallWindowDgrad", "prm_den_pool", "prm_stem_mfma_weights", "prm_stem_dgrad_fused", "prm_stem_dgrad_fused_supported", "prm_scatter", "conv3d_stem5_dgrad", "conv3d_stem5_dgrad_weights", "M3DError", "BBOX_XFORM_CLIP", "W_PLAIN", "W_RELU", "W_DGRAD", "W_DGRAD_RELU"]
 
 W_PLAIN, W_RELU, W_DGRAD, W_DGRAD_RELU = 0, 1, 2, 3
 
@@ -1191,6 +1191,65 @@ def roi_normalize(image_u16, prm_u8, boxes, mode, boxes_host=None, map_index=Non
 
 
 # ------------------------------------------------------------------ Winograd-x 3x3x3 forward
+class ZwConv3d(object):
+    """3x3x3 forward conv (stride 1, pad 1) + scale/shift + ReLU [+ MaxPool3d(2,2)] on the f16 matrix cores at fp32 accuracy
+    (csrc/conv3d_zw.hip: f16x2 split, Winograd F(2,3) along z).  The operand scale comes from a BOUND of the input's largest magnitude
+    that travels with the activations: `in_max` is a device array of SLOTS floats (its largest entry is the bound; `bound_of(x)` sweeps a
+    tensor), and every call returns the same kind of array for its OUTPUT (filled by the kernel's epilogue), so a chain of layers sweeps
+    only its first input.  __call__ -> (out, out_max)."""
+    SLOTS = 32
+
+    @staticmethod
+    def supported(weight, shape=None, pool=False):
+        """weight [cout, cin, 3, 3, 3] with cin % 16 == 0; shape = (D, H, W) of the input (None: any supported map)."""
+        if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or int(weight.shape[1]) % 16 != 0:
+            return False
+        if shape is None:
+            return True
+        D, H, W = (int(v) for v in shape)
+        return bool(lib().m3d_conv3d_zw_supported(int(weight.shape[1]), int(weight.shape[0]), D, H, W, int(bool(pool))))
+
+    def __init__(self, weight):
+        _need_gpu(weight)
+        w = _f32c(weight)
+        assert ZwConv3d.supported(w)
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        nbytes = lib().m3d_conv3d_zw_packed_bytes(self.cin, self.cout)
+        self.packed = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+        check(lib().m3d_conv3d_zw_pack(_ptr(w), self.cin, self.cout, _ptr(self.packed), _stream()), "conv3d_zw_pack")
+
+    def supports(self, shape, pool=False):
+        D, H, W = (int(v) for v in shape[-3:])
+        return bool(lib().m3d_conv3d_zw_supported(self.cin, self.cout, D, H, W, int(bool(pool))))
+
+    @staticmethod
+    def bound_of(x):
+        """[SLOTS] device floats, slot 0 = max |x| (one sweep of x)."""
+        _need_gpu(x)
+        x = _f32c(x)
+        out = torch.empty((ZwConv3d.SLOTS,), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_zw_bound_of(_ptr(x), C.c_longlong(x.numel()), _ptr(out), _stream()), "conv3d_zw_bound_of")
+        return out
+
+    def __call__(self, x, in_max, scale=None, shift=None, relu=False, pool=False, out=None, out_max=None):
+        """out_max: a ZEROED [SLOTS] float tensor to receive the output's bound (None: a fresh one)."""
+        _need_gpu(x, in_max)
+        x = _f32c(x)
+        B, cin, D, H, W = x.shape
+        assert cin == self.cin and in_max.numel() == self.SLOTS and in_max.dtype == torch.float32
+        assert x[0].numel() * 4 < 0x7FFFFFFF                  # one batch item is addressed with 32-bit buffer offsets
+        oshape = (B, self.cout, D // 2, H // 2, W // 2) if pool else (B, self.cout, D, H, W)
+        if out is None:
+            out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        assert tuple(out.shape) == oshape and out.is_contiguous()
+        if out_max is None:
+            out_max = torch.zeros((self.SLOTS,), dtype=torch.float32, device=x.device)
+        check(lib().m3d_conv3d_zw_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
+                                          _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
+                                          int(bool(relu)), int(bool(pool)), _ptr(in_max), _ptr(out_max), _stream()), "conv3d_zw_forward")
+        return out, out_max
+
+
 class WinoConv3d(object):
     """3x3x3 forward conv (stride 1, pad 1) through a Winograd MFMA kernel; weights transformed and packed once.
     two_d=False: F(2,3) along x (2/3 of the MFMA work); two_d=True: F(2x2,3x3) on the (y,x) plane (4/9).

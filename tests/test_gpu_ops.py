@@ -419,6 +419,47 @@ def test_conv3d_winograd_2d_pool_argmax(m3d, B, cin, cout, D, H, W):
     assert int(allzero.sum()) > 0 and int(am[allzero].max()) == 0
 
 
+@pytest.mark.parametrize("B,cin,cout,D,H,W", [
+    (1, 32, 64, 6, 8, 64), (2, 64, 64, 4, 12, 32), (1, 16, 96, 7, 13, 129), (1, 64, 128, 6, 11, 37), (1, 128, 128, 4, 6, 24),
+    (1, 256, 256, 4, 16, 16), (1, 128, 40, 3, 9, 17), (1, 48, 70, 2, 4, 12), (1, 256, 245, 8, 25, 23)])
+def test_conv3d_f16x2_z_winograd_vs_fp64(m3d, B, cin, cout, D, H, W):
+    """csrc/conv3d_zw.hip (f16x2 split, F(2,3) along z): conv + scale/shift + ReLU (+ fused pool) against torch's fp64 conv, both column-block
+    widths, ragged tiles, odd depths, channel counts that are not multiples of 64; the output bound the epilogue leaves for the next layer."""
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + W)
+    x = torch.relu(torch.randn(B, cin, D, H, W, generator=g)) * 3.0          # activations as the layers see them: >= 0
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), None, 1, 1)
+    conv = m3d.ZwConv3d(w.cuda())
+    assert conv.supports((D, H, W))
+    xm = m3d.ZwConv3d.bound_of(x.cuda())
+    assert float(xm[0]) == float(x.abs().max()) and float(xm[1:].abs().max()) == 0.0
+    y, ym = conv(x.cuda(), xm)
+    y = y.cpu().double()
+    err = (y - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-4, err                                   # north_star tolerance
+    assert err < 3e-6, err                                   # what 22-bit operands and fp32 accumulation deliver
+    assert abs(float(ym.max()) - float(y.abs().max())) == 0.0
+    ref2 = torch.relu(ref * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1))
+    y2, ym2 = conv(x.cuda(), xm, scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    assert (y2.cpu().double() - ref2).abs().max().item() / ref2.abs().max().item() < 3e-6
+    assert float(ym2.max()) == float(y2.max())
+    # signed input (no ReLU in front), and a bound larger than the data (a producer's bound is allowed to be loose)
+    xs = torch.randn(B, cin, D, H, W, generator=g)
+    refs = torch.nn.functional.conv3d(xs.double(), w.double(), None, 1, 1)
+    loose = m3d.ZwConv3d.bound_of(xs.cuda()) * 7.0
+    ys, _ = conv(xs.cuda(), loose)
+    assert (ys.cpu().double() - refs).abs().max().item() / refs.abs().max().item() < 3e-6
+    if conv.supports((D, H, W), pool=True):
+        yp, ymp = conv(x.cuda(), xm, scale=sc.cuda(), shift=sh.cuda(), relu=True, pool=True)
+        refp = torch.nn.functional.max_pool3d(ref2, 2, 2)
+        assert yp.shape == refp.shape
+        assert (yp.cpu().double() - refp).abs().max().item() / refp.abs().max().item() < 3e-6
+        assert float(ymp.max()) == float(yp.max())
+        assert torch.equal(yp, torch.nn.functional.max_pool3d(y2, 2, 2))        # the fused pool is the un-pooled kernel's output, pooled
+
+
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 128, 256, 16, 16, 16), (1, 256, 256, 8, 25, 23), (2, 20, 40, 3, 13, 12),
                                                 (1, 256, 70, 5, 9, 17), (1, 6, 33, 2, 30, 21)])
 def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
