@@ -558,36 +558,50 @@ def cached_params(**kw):
 
 
 def conv_family_roofline(det, work, kern_ms, nvol, what_batch):
-    """`roofline` of the 3D-convolution family from live HIP-event spans: frac = ISSUED fp32 MFMA FLOPs / time / peak (the hardware
-    fraction), frac_algorithmic = direct-convolution FLOPs / time / peak (may exceed 1: Winograd)."""
+    """`roofline` of the 3D-convolution family from live HIP-event spans.  Per launch: frac = matrix-core FLOPs ISSUED / time / the peak of
+    the launch's operand type (fp32 MFMA 157.3 TF for the fp32 Winograd kernels, f16 MFMA 2 500 TF for the f16x2 kernels of round 6);
+    frac_algorithmic = direct-convolution FLOPs / time / the fp32 peak (may exceed 1: Winograd, 16-bit matrix cores).  Family: the launches'
+    matrix-pipe time at peak (sum of issued / peak) over their summed duration."""
     roofs = {}
-    fam_issued = fam_alg = fam_ms = 0.0
+    fam_pipe_s = fam_alg = fam_ms = fam_f16_issued = fam_f32_issued = 0.0
     for name, wk in work.items():
         if name not in kern_ms:
             continue
         ms = kern_ms[name]
-        fam_issued += wk["issued_flop"]; fam_alg += wk["algorithmic_flop"]; fam_ms += ms
+        f16 = wk.get("dtype") == "f16"
+        peak = BF16_MFMA_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
+        fam_pipe_s += wk["issued_flop"] / (peak * 1e12); fam_alg += wk["algorithmic_flop"]; fam_ms += ms
+        if f16:
+            fam_f16_issued += wk["issued_flop"]
+        else:
+            fam_f32_issued += wk["issued_flop"]
         ach = wk["issued_flop"] / (ms * 1e-3) / 1e12
         alg = wk["algorithmic_flop"] / (ms * 1e-3) / 1e12
         roofs[name] = {"bound": "mfma", "kernel": wk["kernel"], "shape": wk["shape"], "launch": "one launch over %s" % what_batch,
-                       "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                       "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "operands": "f16" if f16 else "f32",
                        "frac_algorithmic": alg / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": ms,
                        "issued_gflop_per_launch": wk["issued_flop"] / 1e9, "algorithmic_gflop_per_launch": wk["algorithmic_flop"] / 1e9,
                        "algorithmic_tflops": alg}
     fam = None
     if fam_ms > 0:
-        ach = fam_issued / (fam_ms * 1e-3) / 1e12
+        frac = fam_pipe_s / (fam_ms * 1e-3)
         alg = fam_alg / (fam_ms * 1e-3) / 1e12
+        mixed = fam_f16_issued > 0
+        peak = BF16_MFMA_PEAK_TFLOPS if mixed else FP32_MFMA_PEAK_TFLOPS
         fam = {"bound": "mfma",
                "kernel": "3D-convolution family: dsn_body conv1a..conv4b (+BN+ReLU+MaxPool fused)%s, %d launches over %s"
                          % (" and the RPN convs" if "rpn" in kern_ms else "", len([n for n in work if n in kern_ms]), what_batch),
-               "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+               "achieved": frac * peak, "peak": peak, "unit": "TFLOP/s", "frac": frac,
                "frac_algorithmic": alg / FP32_MFMA_PEAK_TFLOPS, "algorithmic_tflops": alg, "kernel_ms": fam_ms,
-               "issued_gflop_per_step": fam_issued / 1e9, "algorithmic_gflop_per_step": fam_alg / 1e9,
-               "frac_definition": "frac = fp32 MFMA FLOPs ISSUED (Winograd F(2x4,3x3) issues 1/3, the stem's F(2,5) 78/125 of the direct "
-                                  "convolution's multiply-adds) / summed live duration of the launches / 157.3 TF: the hardware fraction.  "
-                                  "frac_algorithmic = direct-convolution FLOPs (2*Cin*Cout*k^3 per voxel) over the same time and peak: "
-                                  "work delivered per peak-FLOP, > 1 is possible and is not a hardware fraction"}
+               "issued_gflop_per_step": (fam_f16_issued + fam_f32_issued) / 1e9, "issued_f16_gflop_per_step": fam_f16_issued / 1e9,
+               "issued_f32_gflop_per_step": fam_f32_issued / 1e9, "algorithmic_gflop_per_step": fam_alg / 1e9,
+               "frac_definition": "frac = the launches' matrix-pipe time at peak / their summed live duration: sum over launches of (FLOPs ISSUED / "
+                                  "peak of the launch's operand type) - fp32 MFMA 157.3 TF for the stem (F(2,5) along x: 78/125 of the direct "
+                                  "multiply-adds) and any fp32 Winograd launch (F(2x4,3x3): 1/3), f16 MFMA 2 500 TF for the f16x2 launches "
+                                  "(csrc/conv3d_zw.hip: F(2,3) along z, 2/3 of the direct products, each cut into three fp16 products = 2 issued "
+                                  "per algorithmic multiply-add).  achieved = frac x the f16 peak (f16-equivalent TFLOP/s).  "
+                                  "frac_algorithmic = direct-convolution FLOPs (2*Cin*Cout*k^3 per voxel) over the same time / the fp32 "
+                                  "peak: work delivered per fp32-peak-FLOP, > 1 is possible and is not a hardware fraction"}
     return fam, roofs
 
 
@@ -1127,8 +1141,9 @@ def bench_detect(args, rank, world, dist):
                                             "`warm_host_to_host` is the same loop on a chip that holds its clock, `sustained` the steady state of the resident steps",
                       "kernel_ms_per_launch_median": {k: round(v, 4) for k, v in sorted(kern_med.items(), key=lambda kv: -kv[1])}},
            "roofline": conv_family, "rooflines": roofs}
-    if not backbone_only and getattr(det, "fc_split", None):
-        res["dtype_note"] = ("every operand, accumulator and result is fp32; fc1 / fc2 multiply on the f16 matrix cores after both fp32 operands are scaled "
+    if getattr(det, "conv_f16", False) or (not backbone_only and getattr(det, "fc_split", None)):
+        res["dtype_note"] = ("every operand, accumulator and result is fp32; " + ("the 3^3 conv layers with 16 | cin (conv2a .. conv4b, the RPN conv) and " if getattr(det, "conv_f16", False) else "") +
+                             "fc1 / fc2 multiply on the f16 matrix cores after both fp32 operands are scaled "
                              "by a power of two and cut into two fp16 numbers (22 significand bits; 3 MFMAs per product, fp32 accumulation; error vs "
                              "fp64 on the shipped shape = the fp32-input kernel's, tests/test_gpu_ops.py); M3D_FC_SPLIT=bf16x3 selects the exact "
                              "3-way bf16 cut (6 MFMAs, rounds 2-5), M3D_FC_SPLIT=0 the fp32-input MFMA kernel")

@@ -102,6 +102,15 @@ class DetectorM3D:
         w1 = params["Conv_Body.conv1a.weight"]
         if self.use_wino and tuple(w1.shape[1:]) == (1, 5, 5, 5):
             self.stem_wino = ops.StemWinoConv3d(w1)
+        # Round 6: the 3^3 layers with cin % 16 == 0 on the f16 matrix cores at fp32 accuracy (csrc/conv3d_zw.hip: f16x2 split + F(2,3)
+        # along z; 1.5 x the fp32 F(2x4,3x3) kernel on the step's layers).  The operand bound travels with the activations (tensor
+        # attribute `_m3d_bound`, filled by the producing launch's epilogue); M3D_CONV_F16=0 keeps the fp32 Winograd kernels (A/B).
+        self.conv_f16 = self.use_wino and os.environ.get("M3D_CONV_F16", "1") == "1"
+        self.body_zw = [ops.ZwConv3d(params["Conv_Body." + cname + ".weight"])
+                        if (self.conv_f16 and ops.ZwConv3d.supported(params["Conv_Body." + cname + ".weight"])) else None
+                        for cname, _, _ in dsn_layers(cfg.stride)]
+        self.rpn_conv_zw = ops.ZwConv3d(params["RPN.RPN_conv.weight"]) \
+            if (self.conv_f16 and ops.ZwConv3d.supported(params["RPN.RPN_conv.weight"])) else None
         self.rpn_conv = ops.PackedConv3d(params["RPN.RPN_conv.weight"])
         self.rpn_conv_wino = ops.WinoConv3d(params["RPN.RPN_conv.weight"], two_d=(self.wino_mode == 2)) if self.use_wino else None
         self.rpn_conv_bias = params["RPN.RPN_conv.bias"].contiguous()
@@ -143,6 +152,14 @@ class DetectorM3D:
         if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(width):
             return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True) if pool else \
                 self.stem_wino(x, scale=scale, shift=shift, relu=True)
+        zw = self.body_zw[li]
+        if zw is not None and small and self._zw_ok(zw, x):
+            fused = pool and zw.supports(x.shape, pool=True)
+            y, ym = zw(x, self._bound(x), scale=scale, shift=shift, relu=True, pool=fused)
+            if pool and not fused:
+                y = ops.maxpool3d_2x(y)
+            y._m3d_bound = ym                                 # (a pooled map's bound is its un-pooled map's)
+            return y
         if wino is not None and wino.supports(width, (x.shape[0],) + tuple(x.shape[2:])):
             if pool and wino.supports_pool(width):
                 return wino.pooled(x, scale=scale, shift=shift, relu=True)
@@ -153,13 +170,29 @@ class DetectorM3D:
         x = conv(x, scale=scale, shift=shift, relu=True)
         return ops.maxpool3d_2x(x) if pool else x
 
+    @staticmethod
+    def _bound(x):
+        """The operand bound of an activation tensor for the f16x2 conv kernels: left on the tensor by the launch that produced it, else
+        one sweep of it (the chain's first layer, or a tensor that came from somewhere else)."""
+        b = getattr(x, "_m3d_bound", None)
+        return b if b is not None else ops.ZwConv3d.bound_of(x)
+
+    @staticmethod
+    def _zw_ok(zw, x):
+        """the f16x2 kernel runs one workgroup per (64 channels, 32 x 4 x 2 voxels): maps that give it less than ~0.8 of a round of the
+        chip's 256 CUs stay with the fp32 Winograd kernels (split-K over workgroups)"""
+        return zw.supports(x.shape) and zw.units(x.shape) >= 200
+
     def span(self, name):
         return self.probe(name) if self.probe is not None else _NOSPAN
 
     # MFMA multiply-adds a kernel family ISSUES per algorithmic multiply-add: Winograd F(2x2,3x3) 16/36, F(2x4,3x3) 24/72, F(2,3) along x 4/6,
     # the stem's F(2,5) along x 78/125 (13 row pairs x 6 xi per output pair against 125 taps per output)
+    # "f16x2 F(2,3)z" (csrc/conv3d_zw.hip): 36/54 of the direct products, each cut into three fp16 products - 2 f16 multiply-adds issued
+    # per algorithmic one, priced against the f16 peak (dtype "f16" in conv_work's records)
     ISSUED_FRACTION = {"winograd F(2x2,3x3)": 4.0 / 9.0, "winograd F(2x4,3x3)": 1.0 / 3.0, "winograd F(2,3)x": 2.0 / 3.0,
-                       "winograd F(2,5)x stem": 78.0 / 125.0, "direct": 1.0}
+                       "winograd F(2,5)x stem": 78.0 / 125.0, "direct": 1.0, "f16x2 F(2,3)z": 2.0}
+    F16_KINDS = ("f16x2 F(2,3)z",)
 
     def conv_work(self, batch, size):
         """Per probe span of the convolution family (conv1a .. conv4b, rpn): algorithmic FLOPs (2*Cin*Cout*k^3 per output voxel), the
@@ -172,6 +205,9 @@ class DetectorM3D:
 
         def pad32(c):
             return (c + 31) // 32 * 32 / float(c)
+
+        def pad64(c):
+            return (c + 63) // 64 * 64 / float(c)
         for li, (cname, _, pool) in enumerate(names):
             w = self.P["Conv_Body." + cname + ".weight"]
             cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[-1])
@@ -179,22 +215,28 @@ class DetectorM3D:
             kind = "direct"
             if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(W):
                 kind = "winograd F(2,5)x stem"
+            elif small and self.body_zw[li] is not None and self.body_zw[li].supports((S, H, W)) and self.body_zw[li].units((batch, cin, S, H, W)) >= 200:
+                kind = "f16x2 F(2,3)z"
             elif small and self.body_wino[li] is not None and self.body_wino[li].supports(W, (batch, S, H, W)):
                 kind = two_d if self.wino_mode == 2 else "winograd F(2,3)x"
             alg = 2.0 * cin * cout * k ** 3 * S * H * W * batch
-            out[cname] = dict(algorithmic_flop=alg, issued_flop=alg * self.ISSUED_FRACTION[kind] * pad32(cout), kernel=kind,
-                              shape="%d->%d k%d @ %dx%dx%d" % (cin, cout, k, S, H, W))
+            out[cname] = dict(algorithmic_flop=alg, issued_flop=alg * self.ISSUED_FRACTION[kind] * (pad64(cout) if kind in self.F16_KINDS else pad32(cout)),
+                              kernel=kind, shape="%d->%d k%d @ %dx%dx%d" % (cin, cout, k, S, H, W), dtype="f16" if kind in self.F16_KINDS else "f32")
             if pool:
                 S, H, W = S // 2, H // 2, W // 2
         w = self.P["RPN.RPN_conv.weight"]
         cout, cin = int(w.shape[0]), int(w.shape[1])
         kind = "direct"
-        if self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(W, (batch, S, H, W)) and cin * S * H * W * 4 < 0x7FFFFFFF:
+        if self.rpn_conv_zw is not None and cin * S * H * W * 4 < 0x7FFFFFFF and self.rpn_conv_zw.supports((S, H, W)) \
+                and self.rpn_conv_zw.units((batch, cin, S, H, W)) >= 200:
+            kind = "f16x2 F(2,3)z"
+        elif self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(W, (batch, S, H, W)) and cin * S * H * W * 4 < 0x7FFFFFFF:
             kind = two_d if self.wino_mode == 2 else "winograd F(2,3)x"
         alg = 2.0 * cin * cout * 27 * S * H * W * batch
         nh = 7 * self.A
         alg_h = 2.0 * cout * nh * S * H * W * batch
         out["rpn"] = dict(algorithmic_flop=alg + alg_h, issued_flop=alg * self.ISSUED_FRACTION[kind] * pad32(cout) + alg_h * pad32(nh),
+                          dtype="f16" if kind in self.F16_KINDS else "f32",
                           kernel=kind + " (3^3 conv) + direct (the two 1^3 heads as one conv)",
                           shape="%d->%d k3, %d->%d k1 @ %dx%dx%d" % (cin, cout, cout, nh, S, H, W))
         return out
@@ -226,7 +268,11 @@ class DetectorM3D:
     def rpn(self, feat):
         rc = self.rpn_conv_wino if (self.rpn_conv_wino is not None and self.rpn_conv_wino.supports(feat.shape[-1], (feat.shape[0],) + tuple(feat.shape[2:]))
                                     and feat[0].numel() * 4 < 0x7FFFFFFF) else self.rpn_conv
-        h = rc(feat, shift=self.rpn_conv_bias, relu=True)
+        zw = self.rpn_conv_zw
+        if zw is not None and feat[0].numel() * 4 < 0x7FFFFFFF and self._zw_ok(zw, feat):
+            h, _ = zw(feat, self._bound(feat), shift=self.rpn_conv_bias, relu=True)
+        else:
+            h = rc(feat, shift=self.rpn_conv_bias, relu=True)
         return self.rpn_outputs(h)
 
     def rpn_outputs(self, h):

@@ -1222,6 +1222,13 @@ class ZwConv3d(object):
         D, H, W = (int(v) for v in shape[-3:])
         return bool(lib().m3d_conv3d_zw_supported(self.cin, self.cout, D, H, W, int(bool(pool))))
 
+    def units(self, shape):
+        """workgroups of a launch on an input [B, cin, D, H, W] (or (D, H, W): one item): (64 channels) x (32 x 4 x 2 or 16 x 8 x 2 voxels)"""
+        B = int(shape[0]) if len(shape) == 5 else 1
+        D, H, W = (int(v) for v in shape[-3:])
+        xb, ty = (32, 4) if W >= 24 else (16, 8)
+        return B * ((self.cout + 63) // 64) * ((W + xb - 1) // xb) * ((H + ty - 1) // ty) * ((D + 1) // 2)
+
     @staticmethod
     def bound_of(x):
         """[SLOTS] device floats, slot 0 = max |x| (one sweep of x)."""
