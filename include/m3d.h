@@ -238,6 +238,11 @@ int m3d_conv3d_stem_wino_pack_weights(const float* d_weight /*[cout,1,5,5,5]*/, 
 int m3d_conv3d_stem_wino_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
                                  int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
                                  void* stream);
+/* Round 6: the same launch also leaves the largest |output| in d_out_max (32 floats, zeroed by the caller, atomic maxima; NULL: exactly
+ * the call above) - the operand bound m3d_conv3d_zw_forward takes as d_in_max, so that the layer behind the stem needs no sweep. */
+int m3d_conv3d_stem_wino_forward_bound(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
+                                       int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
+                                       float* d_out_max, void* stream);
 
 /* Backward-weights and bias gradient of the same stride-1 "same" convolution (what autograd computes for the
  * F.conv3d calls of lib/prm/peak_backprop_3d.py:40-42 and every nn.Conv3d of lib/modeling/DSN.py:19-36 in training):

@@ -59,6 +59,7 @@ struct SEpi {
   const float* scale;
   const float* shift;
   int relu;
+  unsigned* out_max;     // or null: 32 slots that receive the largest |output| (atomic maxima; the operand bound of the f16x2 conv that follows)
 #ifdef M3D_W2_STAMPS
   unsigned long long* stamps;
 #endif
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* 
   const size_t DHW = (size_t)D * H * W;
   const float* in_b = in + (size_t)b * DHW;
 
+  float vmaxt = 0.f;                                   // largest |stored value| of this thread (ep.out_max)
   // ---- the wave's 78 weight fragments -> registers (the block's pack is L2-resident: every workgroup reads the same 20 KB)
   f32x4 aw[20];
   {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* 
             for (int j = 0; j < 4; ++j) {
               float v = cur[4 * q + j] + sh[j];
               if (ep.relu) v = fmaxf(v, 0.f);
-              if (all8 || co0 + 8 * q + j < cout) ob[(size_t)(8 * q + j) * PDHW] = v;
+              if (all8 || co0 + 8 * q + j < cout) { ob[(size_t)(8 * q + j) * PDHW] = v; vmaxt = fmaxf(vmaxt, fabsf(v)); }
             }
           }
         }
@@ -487,17 +489,24 @@ __global__ __launch_bounds__(256, 2) void conv3d_stem_wino4_kernel(const float* 
             if (ep.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
             if (!(all8 || co0 + 8 * q + j < cout)) continue;
             float* o = ob + (size_t)(8 * q + j) * DHW;
+            vmaxt = fmaxf(vmaxt, fabsf(v0));
             if (pair_ok) {
               *reinterpret_cast<f32x2*>(o) = f32x2{v0, v1};
+              vmaxt = fmaxf(vmaxt, fabsf(v1));
             } else {
               o[0] = v0;
-              if (x + 1 < W) o[1] = v1;
+              if (x + 1 < W) { o[1] = v1; vmaxt = fmaxf(vmaxt, fabsf(v1)); }
             }
           }
         }
       }
     }
     STEM_STAMP(rr < 4 ? 3 + 2 * rr : 11);
+  }
+  if (ep.out_max) {                                      // one atomic per wave, spread over the 32 slots
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmaxt = fmaxf(vmaxt, __shfl_xor(vmaxt, o));
+    if (lane == 0 && vmaxt > 0.f) atomicMax(ep.out_max + ((blockIdx.x * 4 + wave) & 31), __float_as_uint(vmaxt));
   }
   STEM_STAMP(13);
 }
@@ -549,14 +558,24 @@ M3D_API int m3d_conv3d_stem_wino_pack_weights(const float* d_weight /*[cout,1,5,
   return m3d::check_launch("stem_wino_pack");
 }
 
+M3D_API int m3d_conv3d_stem_wino_forward_bound(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
+                                               int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
+                                               float* d_out_max, void* stream);
 M3D_API int m3d_conv3d_stem_wino_forward(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
                                          int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
                                          void* stream) {
+  return m3d_conv3d_stem_wino_forward_bound(d_in, d_packed, d_out, batch, cout, depth, height, width, d_scale, d_shift, relu, pool, nullptr, stream);
+}
+
+M3D_API int m3d_conv3d_stem_wino_forward_bound(const float* d_in, const float* d_packed, float* d_out, int batch, int cout, int depth,
+                                               int height, int width, const float* d_scale, const float* d_shift, int relu, int pool,
+                                               float* d_out_max, void* stream) {
   if (!d_in || !d_packed || !d_out || batch <= 0 || cout <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
   if ((size_t)depth * height * width * sizeof(float) >= 0x7FFFFFFFull) return M3D_EUNSUPPORTED;
   if (width < 32) return M3D_EUNSUPPORTED;           // 64-wide tiles: narrower maps use the direct stem kernel
   if (pool && (depth < 2 || height < 2 || width < 2)) return M3D_EINVAL;
-  SEpi ep{d_scale, d_shift, relu};
+  if (d_out_max && m3d::opt(m3d::OPT_TUNE_STEM) == 1) return M3D_EUNSUPPORTED;      // the one-row kernel of round 2 (A/B builds) has no bound output
+  SEpi ep{d_scale, d_shift, relu, reinterpret_cast<unsigned*>(d_out_max)};
 #ifdef M3D_W2_STAMPS
   ep.stamps = g_stem_stamps;
 #endif

@@ -125,16 +125,9 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int point = wave & 3, cb = wave >> 2;
-
-  int l = zw_xcd_contiguous(blockIdx.x, gridDim.x);
-  const int cg = l % a.ncg; l /= a.ncg;
-  const int tx = l % a.tiles_x; l /= a.tiles_x;
-  const int ty = l % a.tiles_y; l /= a.tiles_y;
-  const int tz = l % a.tiles_z;
-  const int b = l / a.tiles_z;
-  const int x0 = tx * C::TX, y0 = ty * C::TY, z0 = tz * C::TZ;
   const size_t HW = (size_t)a.H * a.W, DHW = HW * a.D;
-  const int chunks = a.cin / 16;
+  const int chunks = a.cin / 16, steps = chunks * 9;
+  const int ch_bytes = (int)(DHW * sizeof(float));
 
   // ---- operand scales (powers of two): input bound = the largest slot x 2 (a V is a sum of two planes), weights as packed
   float xs, inv_x, inv_w;
@@ -146,40 +139,58 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     m3d::f16_scale_of(2.f * im, xs, inv_x);
     m3d::f16_scale_of(1.5f * *a.wamax, sw_, inv_w);
   }
+  const float un = inv_x * inv_w;
 
-  // ---- staging item of this thread: (8-channel half g, halo row hy, halo column hx); the four planes z0 - 1 .. z0 + 2
+  // ---- units: (cout group fastest, x, y, z, batch item); a workgroup walks units l0, l0 + grid, ... (persistent: the next unit's first
+  // halo tile and weight fragments are requested during the current unit's last chunk, so that only the first unit of a workgroup waits
+  // for a global load).  Neighbouring workgroups of an XCD hold neighbouring units: shared halos and weights in that XCD's L2.
+  const int units = a.ncg * a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  struct Unit { int cg, x0, y0, z0, b; };
+  auto decode = [&](int u) __attribute__((always_inline)) {
+    Unit r;
+    r.cg = u % a.ncg; u /= a.ncg;
+    r.x0 = (u % a.tiles_x) * C::TX; u /= a.tiles_x;
+    r.y0 = (u % a.tiles_y) * C::TY; u /= a.tiles_y;
+    r.z0 = (u % a.tiles_z) * C::TZ;
+    r.b = u / a.tiles_z;
+    return r;
+  };
+
+  // ---- staging item of this thread: (8-channel half g, halo row hy, halo column hx); the four planes z0 - 1 .. z0 + 2.
+  // 32-bit buffer offsets inside one batch item (host: cin * D * H * W * 4 < 2^31): four per-plane byte offsets, channel and chunk scalar.
   const bool has = tid < C::ITEMS;
   const int sg = has ? tid / (C::HYN * C::HXN) : 0;
   const int sr = has ? tid % (C::HYN * C::HXN) : 0;
   const int shy = sr / C::HXN, shx = sr % C::HXN;
-  const int sy = y0 - 1 + shy, sx = x0 - 1 + shx;
-  const bool okyx = has & (sy >= 0) & (sy < a.H) & (sx >= 0) & (sx < a.W);
-  bool okz[4];
-  int zoff[4];
+  struct Stage { int voff[4]; int okm; const float* base; };
+  auto stage_of = [&](const Unit& q) __attribute__((always_inline)) {
+    Stage st;
+    const int sy = q.y0 - 1 + shy, sx = q.x0 - 1 + shx;
+    const bool okyx = has & (sy >= 0) & (sy < a.H) & (sx >= 0) & (sx < a.W);
+    st.okm = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int z = z0 - 1 + k;
-    okz[k] = okyx & (z >= 0) & (z < a.D);
-    zoff[k] = okz[k] ? (int)((size_t)z * HW + (size_t)sy * a.W + sx) : 0;      // (host: one channel map < 2^31 elements)
-  }
-  // 32-bit buffer offsets (host: cin * D * H * W * 4 < 2^31): four per-plane byte offsets in registers, channel and chunk in the scalar offset
-  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x + (size_t)b * a.cin * DHW), 0, (unsigned)((size_t)a.cin * DHW * sizeof(float)), 0x00020000);
-  int voff[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) voff[k] = (zoff[k] + 8 * sg * (int)DHW) * 4;
-  const int ch_bytes = (int)(DHW * sizeof(float));
+    for (int k = 0; k < 4; ++k) {
+      const int z = q.z0 - 1 + k;
+      const bool ok = okyx & (z >= 0) & (z < a.D);
+      st.okm |= ok ? (1 << k) : 0;
+      st.voff[k] = ok ? (int)(((size_t)z * HW + (size_t)sy * a.W + sx + (size_t)8 * sg * DHW) * 4) : 0;
+    }
+    st.base = a.x + (size_t)q.b * a.cin * DHW;
+    return st;
+  };
   float raw[4][8];
-  auto fetch_in = [&](int c) __attribute__((always_inline)) {
+  auto fetch_in = [&](const Stage& st, int c) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.base), 0,
+                                                                        (unsigned)((size_t)a.cin * DHW * sizeof(float)), 0x00020000);
     const int cbase = c * 16 * ch_bytes;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        raw[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[k], cbase + j * ch_bytes, 0));
+        raw[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, st.voff[k], cbase + j * ch_bytes, 0));
   };
   const int st_unit = (sg * 4) * C::PLANE + shy * C::HXP + shx;               // + point * PLANE + hilo * 8 * PLANE + buf * BUF_UNITS
-  auto commit_in = [&](int buf) __attribute__((always_inline)) {
+  auto commit_in = [&](int buf, int okm) __attribute__((always_inline)) {
     if (!has) return;
     u32x4 ph[4], pl[4];
 #pragma unroll
@@ -188,7 +199,8 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ch = 2 * j + u;
-        const float d0 = okz[0] ? raw[0][ch] : 0.f, d1 = okz[1] ? raw[1][ch] : 0.f, d2 = okz[2] ? raw[2][ch] : 0.f, d3 = okz[3] ? raw[3][ch] : 0.f;
+        const float d0 = (okm & 1) ? raw[0][ch] : 0.f, d1 = (okm & 2) ? raw[1][ch] : 0.f, d2 = (okm & 4) ? raw[2][ch] : 0.f,
+                    d3 = (okm & 8) ? raw[3][ch] : 0.f;
         const float v[4] = {(d0 - d2) * xs, (d1 + d2) * xs, (d2 - d1) * xs, (d1 - d3) * xs};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -209,14 +221,9 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   int cx, cy;
   if constexpr (XB == 32) { cx = fr; cy = 0; } else { col_xy16(fr, &cx, &cy); }
   const int bB = (fh * 4 + point) * C::PLANE + cy * C::HXP + cx;              // + (RY * j + dy) * HXP + dx + piece * 8 * PLANE + buf * BUF_UNITS
-  const u32x4* const wsrc = a.wp + (size_t)cg * chunks * 9 * ZW_STEP_UNITS + (point * 2 + cb) * 128 + lane;
-  const int steps = chunks * 9;
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+  auto wsrc_of = [&](int cg) __attribute__((always_inline)) {
+    return a.wp + (size_t)cg * chunks * 9 * ZW_STEP_UNITS + (point * 2 + cb) * 128 + lane;
+  };
 
   struct BF { f16x8 b[4][2]; };
   BF F0, F1;
@@ -225,143 +232,176 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     const int j = i >> 1, p = i & 1, dy = t / 3, dx = t % 3;
     f.b[j][p] = __builtin_bit_cast(f16x8, lds[buf * C::BUF_UNITS + bB + (C::RY * j + dy) * C::HXP + dx + p * 8 * C::PLANE]);
   };
-  auto fetch_a = [&](int s, int set) __attribute__((always_inline)) {
-    const u32x4* p = wsrc + (size_t)s * ZW_STEP_UNITS;
+  auto fetch_a = [&](const u32x4* p, int set) __attribute__((always_inline)) {
     A[set][0] = __builtin_bit_cast(f16x8, p[0]);
     A[set][1] = __builtin_bit_cast(f16x8, p[64]);
   };
 
-  // ---- prologue
-  fetch_in(0);
-  fetch_a(0, 0);
-  fetch_a(1, 1);
-  commit_in(0);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) read_b(F0, i, 0, 0);
-
-  // one chunk = 9 taps on LDS buffer `buf`; `par` = parity of its first step (9 is odd: the chunk's parity), a literal at both call sites.
-  // During the 12 MFMAs of a tap the 8 B fragments of the next tap are read (3 / 3 / 2 per four MFMAs) and the A fragments of the tap after
-  // it are requested.  The next chunk's tile: loads at tap 0, cut + LDS writes after tap 4, barrier before tap 8 (whose prefetch reads it).
-  auto run_chunk = [&](int c, const int par) __attribute__((always_inline)) {
-    const int buf = par;                                                      // chunk parity = buffer
-    const int cn = min(c + 1, chunks - 1);                                    // branch-free: the last chunk stages itself again (unused)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int s = c * 9 + t;
-      BF& cur = ((par + t) & 1) ? F1 : F0;
-      BF& nxt = ((par + t) & 1) ? F0 : F1;
-      if (t == 0) fetch_in(cn);
-      if (t == 8) __syncthreads();
-      fetch_a(min(s + 2, steps - 1), (t + 2) % 3);
-      constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                     // small products first: (lo, hi) (hi, lo) (hi, hi)
-      constexpr int RD0[4] = {0, 3, 6, 8};
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-#pragma unroll
-        for (int i = RD0[q]; i < RD0[q + 1]; ++i) read_b(nxt, i, t < 8 ? t + 1 : 0, t < 8 ? buf : buf ^ 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t % 3][PA[q]], cur.b[j][PB[q]], acc[j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      if (t == 4) commit_in(buf ^ 1);
-    }
-  };
-#pragma unroll 1
-  for (int c = 0; c < chunks; c += 2) {
-    run_chunk(c, 0);
-    if (c + 1 < chunks) run_chunk(c + 1, 1);
-  }
-
-  // ---- the four M_k meet: [block][point][column block][g / 4][lane] x 16 bytes
-  __syncthreads();
+  const int l0 = zw_xcd_contiguous(blockIdx.x, gridDim.x);
+  int u = l0;
+  Unit cur = decode(u);
+  Stage S = stage_of(cur);
+  const u32x4* wsrc = wsrc_of(cur.cg);
+  fetch_in(S, 0);
+  fetch_a(wsrc, 0);
+  fetch_a(wsrc + (steps > 1 ? ZW_STEP_UNITS : 0), 1);
+  float vmax = 0.f;
   f32x4* const xch = reinterpret_cast<f32x4*>(lds_f);
-  {
-    f32x4* xw = xch + ((size_t)((cb * 4 + point) * 4) * 4) * 64 + lane;
+
+  for (;;) {
+    const int un_ = u + (int)gridDim.x;
+    const bool hasn = un_ < units;
+    const Unit nxtu = decode(hasn ? un_ : u);
+    const Stage SN = stage_of(nxtu);
+    const u32x4* const wsrcN = wsrc_of(nxtu.cg);
+
+    commit_in(0, S.okm);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_b(F0, i, 0, 0);
+
+    f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        xw[(j * 4 + gq) * 64] = f32x4{acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]};
-  }
-  __syncthreads();
-  const float un = inv_x * inv_w;
-  const int cobase = cg * 64 + cb * 32 + 4 * fh;
-  float vmax = 0.f;
-  float* const ob = a.out + (size_t)b * a.cout * (POOL ? DHW / 8 : DHW);
-  if constexpr (!POOL) {
-    // wave (point p, block) finishes column block j = p: both planes, 16 channels per lane
-    const int j = point;
-    const int x = x0 + cx, y = y0 + C::RY * j + cy;
-    const bool vok = (x < a.W) & (y < a.H);
+      for (int g = 0; g < 16; ++g) acc[j][g] = 0.f;
+
+    // one chunk = 9 taps on LDS buffer `par` (9 is odd: the chunk's parity = the parity of its first step), a literal at both call sites.
+    // During the 12 MFMAs of a tap the 8 B fragments of the next tap are read (3 / 3 / 2 per four MFMAs) and the A fragments of the tap
+    // after it are requested (beyond the unit's last step: the NEXT unit's first two).  The next chunk's tile: loads at tap 0 (last chunk:
+    // the next unit's chunk 0, which stays in registers through the epilogue), cut + LDS writes after tap 4, barrier before tap 8.
+    auto run_chunk = [&](int c, const int par) __attribute__((always_inline)) {
+      const int buf = par;
+      const bool last = c + 1 >= chunks;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      f32x4 m[4];
+      for (int t = 0; t < 9; ++t) {
+        const int s = c * 9 + t;
+        BF& curf = ((par + t) & 1) ? F1 : F0;
+        BF& nxtf = ((par + t) & 1) ? F0 : F1;
+        if (t == 0) {
+          Stage q;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
-      const f32x4 o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = cobase + acc_row(4 * gq + e);
-        if (!(vok && co < a.cout)) continue;
-        const float sc = (a.scale ? a.scale[co] : 1.f) * un, sh = a.shift ? a.shift[co] : 0.f;
-#pragma unroll
-        for (int zz = 0; zz < 2; ++zz) {
-          if (z0 + zz >= a.D) continue;
-          float v = (zz ? o1[e] : o0[e]) * sc + sh;
-          if (a.relu) v = fmaxf(v, 0.f);
-          vmax = fmaxf(vmax, fabsf(v));
-          ob[(size_t)co * DHW + (size_t)(z0 + zz) * HW + (size_t)y * a.W + x] = v;
+          for (int k = 0; k < 4; ++k) q.voff[k] = last ? SN.voff[k] : S.voff[k];
+          q.base = last ? SN.base : S.base; q.okm = 0;
+          fetch_in(q, last ? 0 : c + 1);
         }
+        if (t == 8) __syncthreads();
+        {
+          const int idx = s + 2;
+          const bool over = idx >= steps;
+          fetch_a((over ? wsrcN : wsrc) + (size_t)(over ? idx - steps : idx) * ZW_STEP_UNITS, (t + 2) % 3);
+        }
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                   // small products first: (lo, hi) (hi, lo) (hi, hi)
+        constexpr int RD0[4] = {0, 3, 6, 8};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int i = RD0[q]; i < RD0[q + 1]; ++i) read_b(nxtf, i, t < 8 ? t + 1 : 0, t < 8 ? buf : buf ^ 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t % 3][PA[q]], curf.b[j][PB[q]], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (t == 4 && !last) commit_in(buf ^ 1, S.okm);
       }
+    };
+#pragma unroll 1
+    for (int c = 0; c < chunks; c += 2) {
+      run_chunk(c, 0);
+      if (c + 1 < chunks) run_chunk(c + 1, 1);
     }
-  } else {
-    // fused MaxPool3d(2,2): wave (point p, block) finishes row pair p & 1 (column blocks 2 rp, 2 rp + 1) for channel quads 2 (p >> 1) + {0, 1};
-    // z pair and y pair in the lane, x pair in lanes x, x ^ 1
-    const int rp = point & 1, gh = point >> 1;
-    const int PD = a.D / 2, PH = a.H / 2, PW = a.W / 2;
-    const int x = x0 + cx, yp = (y0 >> 1) + rp, zp = z0 >> 1, xp = x >> 1;
+
+    // ---- the four M_k meet: [block][point][column block][g / 4][lane] x 16 bytes
+    __syncthreads();
+    {
+      f32x4* xw = xch + ((size_t)((cb * 4 + point) * 4) * 4) * 64 + lane;
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      const int gq = 2 * gh + gi;
-      f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      float sc[4], sh[4];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = min(cobase + acc_row(4 * gq + e), a.cout - 1);
-        sc[e] = (a.scale ? a.scale[co] : 1.f) * un; sh[e] = a.shift ? a.shift[co] : 0.f;
-      }
+        for (int gq = 0; gq < 4; ++gq)
+          xw[(j * 4 + gq) * 64] = f32x4{acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]};
+    }
+    __syncthreads();
+    const int cobase = cur.cg * 64 + cb * 32 + 4 * fh;
+    const int x0 = cur.x0, y0 = cur.y0, z0 = cur.z0;
+    float* const ob = a.out + (size_t)cur.b * a.cout * (POOL ? DHW / 8 : DHW);
+    if constexpr (!POOL) {
+      // wave (point p, block) finishes column block j = p: both planes, 16 channels per lane
+      const int j = point;
+      const int x = x0 + cx, y = y0 + C::RY * j + cy;
+      const bool vok = (x < a.W) & (y < a.H);
+      f32x4 o0[4], o1[4];
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * rp + jj;
+      for (int gq = 0; gq < 4; ++gq) {
         f32x4 m[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
-        const f32x4 o0 = (m[0] + m[1]) + m[2], o1 = (m[1] - m[2]) - m[3];
+        o0[gq] = (m[0] + m[1]) + m[2]; o1[gq] = (m[1] - m[2]) - m[3];
+      }
+      if (hasn) __syncthreads();                       // every wave has its sums: the staging buffers are free for the next unit
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v0 = o0[e] * sc[e] + sh[e], v1 = o1[e] * sc[e] + sh[e];
-          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          best[e] = fmaxf(best[e], fmaxf(v0, v1));
-        }
-      }
+          const int co = cobase + acc_row(4 * gq + e);
+          if (!(vok && co < a.cout)) continue;
+          const float sc = (a.scale ? a.scale[co] : 1.f) * un, sh = a.shift ? a.shift[co] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float other = __shfl_xor(best[e], 1);
-        const float v = fmaxf(best[e], other);
-        const int co = cobase + acc_row(4 * gq + e);
-        if ((lane & 1) == 0 && co < a.cout && xp < PW && yp < PH && zp < PD) {
-          vmax = fmaxf(vmax, fabsf(v));
-          ob[(size_t)co * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = v;
+          for (int zz = 0; zz < 2; ++zz) {
+            if (z0 + zz >= a.D) continue;
+            float v = (zz ? o1[gq][e] : o0[gq][e]) * sc + sh;
+            if (a.relu) v = fmaxf(v, 0.f);
+            vmax = fmaxf(vmax, fabsf(v));
+            ob[(size_t)co * DHW + (size_t)(z0 + zz) * HW + (size_t)y * a.W + x] = v;
+          }
+        }
+    } else {
+      // fused MaxPool3d(2,2): wave (point p, block) finishes row pair p & 1 (column blocks 2 rp, 2 rp + 1) for channel quads 2 (p >> 1) + {0, 1};
+      // z pair and y pair in the lane, x pair in lanes x, x ^ 1
+      const int rp = point & 1, gh = point >> 1;
+      const int PD = a.D / 2, PH = a.H / 2, PW = a.W / 2;
+      const int x = x0 + cx, yp = (y0 >> 1) + rp, zp = z0 >> 1, xp = x >> 1;
+      f32x4 o0[2][2], o1[2][2];
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int gq = 2 * gh + gi, j = 2 * rp + jj;
+          f32x4 m[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
+          o0[gi][jj] = (m[0] + m[1]) + m[2]; o1[gi][jj] = (m[1] - m[2]) - m[3];
+        }
+      if (hasn) __syncthreads();
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        const int gq = 2 * gh + gi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = cobase + acc_row(4 * gq + e), coc = min(co, a.cout - 1);
+          const float sc = (a.scale ? a.scale[coc] : 1.f) * un, sh = a.shift ? a.shift[coc] : 0.f;
+          float best = -INFINITY;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            float v0 = o0[gi][jj][e] * sc + sh, v1 = o1[gi][jj][e] * sc + sh;
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            best = fmaxf(best, fmaxf(v0, v1));
+          }
+          const float v = fmaxf(best, __shfl_xor(best, 1));
+          if ((lane & 1) == 0 && co < a.cout && xp < PW && yp < PH && zp < PD) {
+            vmax = fmaxf(vmax, fabsf(v));
+            ob[(size_t)co * ((size_t)PD * PH * PW) + ((size_t)zp * PH + yp) * PW + xp] = v;
+          }
         }
       }
     }
+    if (!hasn) break;
+    u = un_; cur = nxtu; S = SN; wsrc = wsrcN;
   }
   // ---- the next layer's operand bound: one atomic per workgroup into slot (block % 32)
   if (a.out_max) {
@@ -384,8 +424,17 @@ int launch_zw(ZwArgs a, hipStream_t st) {
   using C = ZwCfg<XB>;
   a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
   a.ncg = (a.cout + 63) / 64;
-  const long long blocks = (long long)a.ncg * a.tiles_x * a.tiles_y * a.tiles_z * a.B;
-  if (blocks > 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
+  const long long units = (long long)a.ncg * a.tiles_x * a.tiles_y * a.tiles_z * a.B;
+  if (units > 0x7FFFFFFFll) return M3D_EUNSUPPORTED;
+  // persistent workgroups, one per CU (131 KB of LDS each): every workgroup the same number of units where the count allows it
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const long long rounds = (units + cus - 1) / cus;
+  const long long blocks = (units + rounds - 1) / rounds;
   auto kern = conv3d_zw_kernel<XB, POOL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ZW_NT), C::LDS_BYTES, st, a);

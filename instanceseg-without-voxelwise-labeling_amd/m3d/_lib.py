@@ -26,7 +26,7 @@ SYMBOLS = [
     "m3d_conv3d_wgrad_workspace_bytes", "m3d_conv3d_wgrad", "m3d_conv3d_bias_grad",
     "m3d_conv3d_wino_packed_weight_bytes", "m3d_conv3d_wino_pack_weights", "m3d_conv3d_wino_forward", "m3d_conv3d_wino_forward_pool2",
     "m3d_conv3d_wino2_packed_weight_bytes", "m3d_conv3d_wino2_pack_weights", "m3d_conv3d_wino2_forward", "m3d_conv3d_wino2_forward_pool2", "m3d_conv3d_wino2_forward_pool2_argmax", "m3d_conv3d_wino2_workspace_bytes", "m3d_conv3d_wino2_forward_ws", "m3d_conv3d_wino2_score", "m3d_conv3d_wino2_local_score", "m3d_conv3d_wino2_family", "m3d_conv3d_wino2_plan", "m3d_conv3d_wino2_local_workspace_bytes", "m3d_conv3d_wino2_local_forward_ws",
-    "m3d_conv3d_stem_wino_packed_weight_bytes", "m3d_conv3d_stem_wino_pack_weights", "m3d_conv3d_stem_wino_forward",
+    "m3d_conv3d_stem_wino_packed_weight_bytes", "m3d_conv3d_stem_wino_pack_weights", "m3d_conv3d_stem_wino_forward", "m3d_conv3d_stem_wino_forward_bound",
     "m3d_gaussian_filter_u16", "m3d_median_filter3_u16",
     "m3d_cc_workspace_bytes", "m3d_cc_largest_batch", "m3d_binary_closing6_batch", "m3d_paint_instances", "m3d_paint_finish", "m3d_paint_begin",
 ]

@@ -150,8 +150,8 @@ class DetectorM3D:
         if not small:
             wino = None
         if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(width):
-            return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True) if pool else \
-                self.stem_wino(x, scale=scale, shift=shift, relu=True)
+            return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True, bound=self.conv_f16) if pool else \
+                self.stem_wino(x, scale=scale, shift=shift, relu=True, bound=self.conv_f16)
         zw = self.body_zw[li]
         if zw is not None and small and self._zw_ok(zw, x):
             fused = pool and zw.supports(x.shape, pool=True)

@@ -1392,7 +1392,7 @@ class StemWinoConv3d(object):
     def supports(width):
         return width >= 32
 
-    def _run(self, x, scale, shift, relu, pool, out):
+    def _run(self, x, scale, shift, relu, pool, out, bound=False):
         _need_gpu(x)
         x = _f32c(x)
         B, cin, D, H, W = x.shape
@@ -1400,17 +1400,20 @@ class StemWinoConv3d(object):
         if out is None:
             shp = (B, self.cout, D // 2, H // 2, W // 2) if pool else (B, self.cout, D, H, W)
             out = torch.empty(shp, dtype=torch.float32, device=x.device)
-        check(lib().m3d_conv3d_stem_wino_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, self.cout, D, H, W,
-                                                 _ptr(scale) if scale is not None else None,
-                                                 _ptr(shift) if shift is not None else None, int(bool(relu)), int(bool(pool)),
-                                                 _stream()), "conv3d_stem_wino_forward")
+        om = torch.zeros((ZwConv3d.SLOTS,), dtype=torch.float32, device=x.device) if bound else None
+        check(lib().m3d_conv3d_stem_wino_forward_bound(_ptr(x), _ptr(self.packed), _ptr(out), B, self.cout, D, H, W,
+                                                       _ptr(scale) if scale is not None else None,
+                                                       _ptr(shift) if shift is not None else None, int(bool(relu)), int(bool(pool)),
+                                                       _ptr(om) if bound else None, _stream()), "conv3d_stem_wino_forward")
+        if bound:
+            out._m3d_bound = om                            # the operand bound of the f16x2 conv that reads `out` (ZwConv3d)
         return out
 
-    def __call__(self, x, scale=None, shift=None, relu=False, out=None):
-        return self._run(x, scale, shift, relu, False, out)
+    def __call__(self, x, scale=None, shift=None, relu=False, out=None, bound=False):
+        return self._run(x, scale, shift, relu, False, out, bound)
 
-    def pooled(self, x, scale=None, shift=None, relu=False):
-        return self._run(x, scale, shift, relu, True, None)
+    def pooled(self, x, scale=None, shift=None, relu=False, bound=False):
+        return self._run(x, scale, shift, relu, True, None, bound)
 
 
 # ------------------------------------------------------------------ conv backward-weights / bias gradient
