@@ -51,7 +51,8 @@ struct ZwCfg {
   static constexpr int BUF_UNITS = 16 * PLANE;     // [hi / lo][k half][point]
   static constexpr int ITEMS = 2 * HYN * HXN;      // staging items of a chunk: (8-channel half, halo row, halo column)
   static constexpr int XCH_BYTES = 2 * 4 * 4 * 4 * 64 * 16;      // exchange: [block][point][column block][g / 4][lane] x 16 bytes
-  static constexpr int LDS_BYTES = 2 * BUF_UNITS * 16 > XCH_BYTES ? 2 * BUF_UNITS * 16 : XCH_BYTES;
+  static constexpr int AFF_OFF = 2 * BUF_UNITS * 16 > XCH_BYTES ? 2 * BUF_UNITS * 16 : XCH_BYTES;   // [unit parity][scale 64 | shift 64] floats
+  static constexpr int LDS_BYTES = AFF_OFF + 2 * 128 * 4;
   static_assert(ITEMS <= ZW_NT, "one staging item per thread");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -179,41 +180,47 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     return st;
   };
   float raw[4][8];
-  auto fetch_in = [&](const Stage& st, int c) __attribute__((always_inline)) {
+  // plane k of the staged item's four (8 dword loads).  The K loop requests one plane per tap, BEHIND that tap's weight-fragment request:
+  // loads complete in order, so a wait for weight fragments is a wait for every plane requested before them
+  auto fetch_plane = [&](const Stage& st, int c, const int k) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.base), 0,
                                                                         (unsigned)((size_t)a.cin * DHW * sizeof(float)), 0x00020000);
     const int cbase = c * 16 * ch_bytes;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 8; ++j)
+      raw[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, st.voff[k], cbase + j * ch_bytes, 0));
+  };
+  auto fetch_in = [&](const Stage& st, int c) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        raw[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, st.voff[k], cbase + j * ch_bytes, 0));
+    for (int k = 0; k < 4; ++k) fetch_plane(st, c, k);
   };
   const int st_unit = (sg * 4) * C::PLANE + shy * C::HXP + shx;               // + point * PLANE + hilo * 8 * PLANE + buf * BUF_UNITS
-  auto commit_in = [&](int buf, int okm) __attribute__((always_inline)) {
+  // one z point k of the staged item: V_k of its 8 channels, scaled and cut -> two 16-byte units.  Called point by point from different
+  // taps (40 VALU each ride in the MFMAs' shadow; all four at once stalled both waves of a SIMD at the same tap)
+  auto commit_point = [&](int buf, int okm, const int k) __attribute__((always_inline)) {
     if (!has) return;
-    u32x4 ph[4], pl[4];
+    constexpr int PA_[4] = {0, 1, 2, 1}, PB_[4] = {2, 2, 1, 3};               // V_k = d[PA] -+ d[PB]: d0 - d2, d1 + d2, d2 - d1, d1 - d3
+    const bool oka = (okm >> PA_[k]) & 1, okb = (okm >> PB_[k]) & 1;
+    u32x4 ph, pl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f16x2 hh[4], ll[4];
+      f16x2 hh, ll;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ch = 2 * j + u;
-        const float d0 = (okm & 1) ? raw[0][ch] : 0.f, d1 = (okm & 2) ? raw[1][ch] : 0.f, d2 = (okm & 4) ? raw[2][ch] : 0.f,
-                    d3 = (okm & 8) ? raw[3][ch] : 0.f;
-        const float v[4] = {(d0 - d2) * xs, (d1 + d2) * xs, (d2 - d1) * xs, (d1 - d3) * xs};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const _Float16 h = (_Float16)v[k];
-          hh[k][u] = h; ll[k][u] = (_Float16)(v[k] - (float)h);
-        }
+        const float da = oka ? raw[PA_[k]][ch] : 0.f, db = okb ? raw[PB_[k]][ch] : 0.f;
+        const float v = (k == 1 ? da + db : da - db) * xs;
+        const _Float16 h = (_Float16)v;
+        hh[u] = h; ll[u] = (_Float16)(v - (float)h);
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { ph[k][j] = __builtin_bit_cast(unsigned, hh[k]); pl[k][j] = __builtin_bit_cast(unsigned, ll[k]); }
+      ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
     }
-    u32x4* d = lds + buf * C::BUF_UNITS + st_unit;
+    u32x4* d = lds + buf * C::BUF_UNITS + st_unit + k * C::PLANE;
+    d[0] = ph; d[8 * C::PLANE] = pl;
+  };
+  auto commit_in = [&](int buf, int okm) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { d[k * C::PLANE] = ph[k]; d[k * C::PLANE + 8 * C::PLANE] = pl[k]; }
+    for (int k = 0; k < 4; ++k) commit_point(buf, okm, k);
   };
 
   // ---- fragments
@@ -244,11 +251,11 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   const u32x4* wsrc = wsrc_of(cur.cg);
   fetch_in(S, 0);
   fetch_a(wsrc, 0);
-  fetch_a(wsrc + (steps > 1 ? ZW_STEP_UNITS : 0), 1);
+  fetch_a(wsrc + ZW_STEP_UNITS, 1);
   float vmax = 0.f;
   f32x4* const xch = reinterpret_cast<f32x4*>(lds_f);
 
-  for (;;) {
+  for (int it = 0;; ++it) {
     const int un_ = u + (int)gridDim.x;
     const bool hasn = un_ < units;
     const Unit nxtu = decode(hasn ? un_ : u);
@@ -256,6 +263,12 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     const u32x4* const wsrcN = wsrc_of(nxtu.cg);
 
     commit_in(0, S.okm);
+    float* const aff = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_f) + C::AFF_OFF) + (it & 1) * 128;
+    if (tid < 64) {                                      // the unit's 64 channels: scale x the operand scales' inverse, shift
+      const int co = min(cur.cg * 64 + tid, a.cout - 1);
+      aff[tid] = (a.scale ? a.scale[co] : 1.f) * un;
+      aff[64 + tid] = a.shift ? a.shift[co] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) read_b(F0, i, 0, 0);
@@ -268,8 +281,8 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
 
     // one chunk = 9 taps on LDS buffer `par` (9 is odd: the chunk's parity = the parity of its first step), a literal at both call sites.
     // During the 12 MFMAs of a tap the 8 B fragments of the next tap are read (3 / 3 / 2 per four MFMAs) and the A fragments of the tap
-    // after it are requested (beyond the unit's last step: the NEXT unit's first two).  The next chunk's tile: loads at tap 0 (last chunk:
-    // the next unit's chunk 0, which stays in registers through the epilogue), cut + LDS writes after tap 4, barrier before tap 8.
+    // after it are requested (beyond the unit's last step: the NEXT unit's first two).  The next chunk's tile: loads at tap 0 (last
+    // chunk: the next unit's chunk 0, which stays in registers through the epilogue), cut + LDS writes at taps 4..7, barrier before tap 8.
     auto run_chunk = [&](int c, const int par) __attribute__((always_inline)) {
       const int buf = par;
       const bool last = c + 1 >= chunks;
@@ -278,15 +291,8 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         const int s = c * 9 + t;
         BF& curf = ((par + t) & 1) ? F1 : F0;
         BF& nxtf = ((par + t) & 1) ? F0 : F1;
-        if (t == 0) {
-          Stage q;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) q.voff[k] = last ? SN.voff[k] : S.voff[k];
-          q.base = last ? SN.base : S.base; q.okm = 0;
-          fetch_in(q, last ? 0 : c + 1);
-        }
         if (t == 8) __syncthreads();
-        {
+        {                                                // weight fragments two taps ahead (set (t + 2) % 3 was consumed by tap t - 1)
           const int idx = s + 2;
           const bool over = idx >= steps;
           fetch_a((over ? wsrcN : wsrc) + (size_t)(over ? idx - steps : idx) * ZW_STEP_UNITS, (t + 2) % 3);
@@ -301,13 +307,23 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
           for (int j = 0; j < 4; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t % 3][PA[q]], curf.b[j][PB[q]], acc[j], 0, 0, 0);
         }
+        if (t < 4) {                                     // planes 2, 0, 1, 3 at taps 0..3, each behind its tap's weight request (loads complete in order)
+          constexpr int PL[4] = {2, 0, 1, 3};
+          Stage q;
+          q.voff[PL[t]] = last ? SN.voff[PL[t]] : S.voff[PL[t]];
+          q.base = last ? SN.base : S.base; q.okm = 0;
+          fetch_plane(q, last ? 0 : c + 1, PL[t]);
+        }
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        if (t == 4 && !last) commit_in(buf ^ 1, S.okm);
+        if (t >= 4 && t <= 7 && !last) {                 // points 0 (planes 0, 2), 2 (2, 1), 1 (1, 2), 3 (1, 3)
+          constexpr int PT[4] = {0, 2, 1, 3};
+          commit_point(buf ^ 1, S.okm, PT[t - 4]);
+        }
       }
     };
 #pragma unroll 1
@@ -327,7 +343,6 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
           xw[(j * 4 + gq) * 64] = f32x4{acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]};
     }
     __syncthreads();
-    const int cobase = cur.cg * 64 + cb * 32 + 4 * fh;
     const int x0 = cur.x0, y0 = cur.y0, z0 = cur.z0;
     float* const ob = a.out + (size_t)cur.b * a.cout * (POOL ? DHW / 8 : DHW);
     if constexpr (!POOL) {
@@ -348,9 +363,9 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int co = cobase + acc_row(4 * gq + e);
+          const int cl = cb * 32 + 4 * fh + acc_row(4 * gq + e), co = cur.cg * 64 + cl;
           if (!(vok && co < a.cout)) continue;
-          const float sc = (a.scale ? a.scale[co] : 1.f) * un, sh = a.shift ? a.shift[co] : 0.f;
+          const float sc = aff[cl], sh = aff[64 + cl];
 #pragma unroll
           for (int zz = 0; zz < 2; ++zz) {
             if (z0 + zz >= a.D) continue;
@@ -383,8 +398,8 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         const int gq = 2 * gh + gi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int co = cobase + acc_row(4 * gq + e), coc = min(co, a.cout - 1);
-          const float sc = (a.scale ? a.scale[coc] : 1.f) * un, sh = a.shift ? a.shift[coc] : 0.f;
+          const int cl = cb * 32 + 4 * fh + acc_row(4 * gq + e), co = cur.cg * 64 + cl;
+          const float sc = aff[cl], sh = aff[64 + cl];
           float best = -INFINITY;
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {

@@ -398,6 +398,41 @@ def f_segment_oracle(rs):
     assert np.array_equal(p1.cpu().numpy().astype(bool), painted), ("painted", shape, mode)
 
 
+def f_zwconv(rs):
+    """m3d_conv3d_zw_forward (f16x2 split + Winograd F(2,3) along z on the f16 matrix cores) against float64: conv + scale/shift + ReLU
+    [+ MaxPool3d(2,2)], ragged shapes, both column-block widths, batches, loose / exact operand bounds, and a two-layer chain whose second
+    layer takes the bound the first one's epilogue left (never a sweep)."""
+    from m3d import ops as mops
+    cin = int(16 * rs.randint(1, 9)); cout = int(rs.choice([8, 32, 64, 96, 128, 200]))
+    D, H, W = int(rs.randint(2, 12)), int(rs.randint(4, 20)), int(rs.randint(12, 70))
+    B = int(rs.randint(1, 3))
+    mag = float(10.0 ** rs.uniform(-6, 6))                                  # the scale follows the data: any magnitude
+    x = (np.maximum(rs.randn(B, cin, D, H, W), 0) * mag).astype(np.float32) if rs.rand() < 0.7 else (rs.randn(B, cin, D, H, W) * mag).astype(np.float32)
+    w = (rs.randn(cout, cin, 3, 3, 3) * (2.0 / (cin * 27)) ** 0.5).astype(np.float32)
+    sc = (rs.rand(cout) + 0.5).astype(np.float32); sh = (rs.randn(cout) * mag).astype(np.float32)
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    conv = mops.ZwConv3d(wt.cuda())
+    if not conv.supports((D, H, W)):
+        return
+    bound = mops.ZwConv3d.bound_of(xt.cuda()) * float(rs.choice([1.0, 1.0, 3.0, 100.0]))
+    ref = torch.relu(torch.nn.functional.conv3d(xt.double(), wt.double(), padding=1) * torch.from_numpy(sc).double().view(1, -1, 1, 1, 1)
+                     + torch.from_numpy(sh).double().view(1, -1, 1, 1, 1))
+    pool = bool(rs.randint(2)) and conv.supports((D, H, W), pool=True)
+    got, gm = conv(xt.cuda(), bound, scale=torch.from_numpy(sc).cuda(), shift=torch.from_numpy(sh).cuda(), relu=True, pool=pool)
+    want = torch.nn.functional.max_pool3d(ref, 2, 2) if pool else ref
+    scale = float(want.abs().max()) or 1.0
+    assert got.shape == want.shape and float((got.cpu().double() - want).abs().max()) <= 5e-6 * max(scale, float(ref.abs().max())), \
+        ("zw conv error", cin, cout, (B, D, H, W), pool, float((got.cpu().double() - want).abs().max()) / scale)
+    assert float(gm.max()) == float(got.abs().max()), ("zw conv bound", cin, cout, (B, D, H, W), pool)
+    if cout % 16 == 0 and conv.supports(tuple(got.shape[-3:])) and mops.ZwConv3d.supported(torch.empty(8, cout, 3, 3, 3)):
+        w2 = (rs.randn(24, cout, 3, 3, 3) * (2.0 / (cout * 27)) ** 0.5).astype(np.float32)
+        c2 = mops.ZwConv3d(torch.from_numpy(w2).cuda())
+        if c2.supports(tuple(got.shape[-3:])):
+            y2, _ = c2(got, gm)
+            r2 = torch.nn.functional.conv3d(want, torch.from_numpy(w2).double(), padding=1)
+            assert float((y2.cpu().double() - r2).abs().max()) <= 1e-5 * (float(r2.abs().max()) or 1.0), ("zw conv chain", cin, cout, (B, D, H, W), pool)
+
+
 def f_x3conv(rs):
     """m3d_conv3d_x3_forward (bf16x3 cut on the bf16 matrix cores) as conv3d(x - min x, relu(W), padding 1) against float64: fp32-level
     error, exact zeros where the inputs under every positive weight are zero; ragged shapes, odd chunk counts, batches."""
@@ -419,7 +454,7 @@ def f_x3conv(rs):
     assert torch.equal(got == 0, ref == 0), ("x3 conv zeros", cin, cout, (D, H, W))
 
 
-ops = [("quantise/segment", f_quant_segment), ("segment_tile vs oracle", f_segment_oracle), ("conv3d bf16x3", f_x3conv), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
+ops = [("quantise/segment", f_quant_segment), ("segment_tile vs oracle", f_segment_oracle), ("conv3d bf16x3", f_x3conv), ("conv3d f16x2 F(2,3)z", f_zwconv), ("nms3d", f_nms), ("bbox_overlaps3d", f_overlaps), ("bbox_transform3d", f_transform), ("generate_proposals3d", f_proposals),
        ("roi_align3d", f_roialign), ("otsu2d", f_otsu), ("cc/closing", f_cc), ("conv3d fwd/dgrad/wgrad/winograd", f_conv), ("linear fp32 / bf16x3 / f16x2", f_linear), ("mask paste", f_mask_paste), ("prm tile", f_prm)]
 only = os.environ.get("FUZZ_ONLY")
 if only:
