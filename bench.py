@@ -131,7 +131,7 @@ def pmc_traffic(symbol_prefix, which="largest", grid_div=None):
             d = json.load(open(f))
             k = [e for e in d["kernels"] if e["kernel"].replace(" ", "").startswith(symbol_prefix.replace(" ", ""))]
             if k:
-                k.sort(key=lambda e: e.get("grid", 0))
+                k.sort(key=lambda e: (e.get("grid", 0), e.get("traffic", 0)))
                 e = k[0] if which == "smallest" else k[-1]
                 return {"traffic": e["traffic"], "traffic_unit": "bytes/launch (FETCH_SIZE x%.2f gfx950 correction + WRITE_SIZE)" %
                         d["calibration"]["fetch_factor_dword_loads"], "traffic_source": os.path.relpath(f, ROOT), "traffic_grid": e.get("grid")}
@@ -1012,8 +1012,11 @@ def bench_detect(args, rank, world, dist):
         bp.spans.clear()
         fam_b, roofs_b = conv_family_roofline(det, det.conv_work(1, (VOL, VOL, VOL)), kmb, 1, "one 1x128^3 volume")
         if fam_b is not None and "conv2b" in roofs_b:
-            fam_b.update(pmc_traffic("conv3d_wino24_kernel<4, 16, 2, 1, true", grid_div=nvol))
-            fam_b["traffic_what"] = "HBM bytes per launch of the largest member (conv2b + pool) at this batch size, PMC"
+            if "f16x2" in roofs_b["conv2b"]["kernel"]:          # persistent launches: one grid for every layer and batch size - no per-batch-size record
+                fam_b["traffic"] = None
+            else:
+                fam_b.update(pmc_traffic("conv3d_wino24_kernel<4, 16, 2, 1, true", grid_div=nvol))
+                fam_b["traffic_what"] = "HBM bytes per launch of the largest member (conv2b + pool) at this batch size, PMC"
         bb1 = {"value": nsb * VOL ** 3 / dt_b, "unit": "voxels/s", "ms_per_step": dt_b / nsb * 1e3, "steps": nsb, "warmup": 20,
                "config": {"workload": "dsn_body forward (7 conv3d + BN + ReLU + 3 maxpool; the volume normalised beforehand), 1x1x128x128x128 [configs[1]]",
                           "backbone_gflop_per_volume": backbone_flops(VOL) / 1e9,
@@ -1041,7 +1044,8 @@ def bench_detect(args, rank, world, dist):
                                  "host-to-host loop that gives `value` carries no probe" % PROBE_STEPS) \
             if rkern else "HIP-event spans of the first %d timed steps" % PROBE_STEPS
     if "conv2b" in roofs:
-        w2 = "conv3d_wino24_kernel<4, 16, 2, 1, true" if "F(2x4" in work["conv2b"]["kernel"] else "conv3d_wino2e_kernel<4, 32, 2, 2, true>"
+        w2 = "conv3d_zw_kernel<32, true>" if "f16x2" in work["conv2b"]["kernel"] else \
+            "conv3d_wino24_kernel<4, 16, 2, 1, true" if "F(2x4" in work["conv2b"]["kernel"] else "conv3d_wino2e_kernel<4, 32, 2, 2, true>"
         roofs["conv2b"].update(pmc_traffic({2: w2, 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
                                             0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
     if conv_family is not None:

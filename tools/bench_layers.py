@@ -57,6 +57,23 @@ for name, cin, cout, k, s in L:
             frac = (1.0 / 3.0 if fam4 else 4.0 / 9.0) if two_d else 2.0 / 3.0
             line += "   %s %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% issued)" % (
                 ("F(2x4,3x3)" if fam4 else "F(2x2,3x3)") if two_d else "F(2,3)x", msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * frac)
+    if k == 3 and mode != 0 and os.environ.get("M3D_CONV_F16", "1") == "1" and m3d.ZwConv3d.supported(w, (s, s, s)):   # round 6: what the pipeline runs
+        zw = m3d.ZwConv3d(w)
+        xr = torch.relu(x)
+        xm = m3d.ZwConv3d.bound_of(xr)
+        om = torch.zeros(32, device="cuda")
+        fz = name.startswith(("conv2b", "conv3b")) and zw.supports((s, s, s), pool=True)
+        outz = torch.empty((BATCH, cout, s // 2, s // 2, s // 2) if fz else (BATCH, cout, s, s, s), device="cuda")
+        runz = lambda: zw(xr, xm, scale=sc, shift=sh, relu=True, pool=fz, out=outz, out_max=om)
+        for _ in range(3):
+            runz()
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps):
+            runz()
+        e1.record(); torch.cuda.synchronize()
+        msw = e0.elapsed_time(e1) / reps
+        line += "   f16x2 F(2,3)z%s %7.3f ms %6.2f TF alg. (%.0f TF f16 issued = %.0f%% of 2.5 PF)" % (
+            "+pool" if fz else "", msw, fl / msw / 1e9, 2 * fl / msw / 1e9, 2 * fl / msw / 1e9 / 2500 * 100)
     if k == 5 and mode != 0 and m3d.StemWinoConv3d.supports(s):
         sw = m3d.StemWinoConv3d(w)
         runw = (lambda: sw.pooled(x, scale=sc, shift=sh, relu=True)) if fused else (lambda: sw(x, scale=sc, shift=sh, relu=True, out=out))
@@ -70,5 +87,5 @@ for name, cin, cout, k, s in L:
         line += "   F(2,5)x %7.3f ms %6.2f TF alg. (%.0f%%; %.0f%% issued)" % (msw, fl / msw / 1e9, fl / msw / 1e9 / 157.3 * 100, fl / msw / 1e9 / 157.3 * 100 * 0.624)
     tot_w += msw
     print(line)
-print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (Winograd where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
+print("TOTAL direct %.3f ms (%.2f TFLOP/s)   as run (f16x2 / Winograd where supported) %.3f ms (%.2f TFLOP/s algorithmic)  %.2f GFLOP" %
       (tot_t, tot_f / tot_t / 1e9, tot_w, tot_f / tot_w / 1e9, tot_f / 1e9))

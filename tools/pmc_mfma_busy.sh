@@ -40,7 +40,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     cnt[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in cnt for c in cnt[k]})
-keep = [k for k in cnt if any(t in k for t in ("wino2e", "wino24", "stem_wino", "fc_x3", "roi_align3d_fwd_v3"))]
+keep = [k for k in cnt if any(t in k for t in ("wino2e", "wino24", "conv3d_zw", "stem_wino", "fc_x3", "roi_align3d_fwd_v3"))]
 print("%-60s " % "kernel" + " ".join("%22s" % n for n in names))
 for k in sorted(keep, key=lambda k: -sum(cnt[k].get("SQ_WAVE_CYCLES", [0]))):
     short = k.replace("(anonymous namespace)::", "").replace("void ", "")[:60]

@@ -36,11 +36,24 @@ def main():
     for k in sorted(fetch, key=lambda k: -sum(fetch[k]) / len(fetch[k])):
         if not any(t in k[0] for t in ("conv3d", "wino24", "fc_gemm", "fc_x3_gemm", "fc_x3b_gemm", "absmax", "fc_reduce", "roi_align3d", "proposals_stage", "nms_mask_tiles", "norm1", "prm_", "window_sums")) or "pack" in k[0]:
             continue
-        fr = sum(fetch[k]) / len(fetch[k])
-        wr = sum(write[k]) / len(write[k]) if k in write else None
-        res["kernels"].append({"kernel": k[0].split("(float")[0].split("((anonymous")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), "grid": k[1],
-                               "launches": len(fetch[k]), "fetch_raw": fr, "fetch_corrected": fr * f_dword, "write": wr,
-                               "traffic": fr * f_dword + (wr or 0)})
+        # A persistent kernel (conv3d_zw_kernel: one workgroup per CU whatever the layer) runs DIFFERENT layers under one (name, grid): its
+        # launches are split into groups of similar FETCH_SIZE (within 25 %), one entry per group, the write counters matched by launch index
+        idx = sorted(range(len(fetch[k])), key=lambda i: -fetch[k][i])
+        groups = []
+        for i in idx:
+            if "conv3d_zw_kernel" in k[0] and groups and fetch[k][i] < 0.75 * fetch[k][groups[-1][0]]:
+                groups.append([i])
+            elif groups:
+                groups[-1].append(i)
+            else:
+                groups.append([i])
+        for g in groups:
+            fr = sum(fetch[k][i] for i in g) / len(g)
+            wv = [write[k][i] for i in g if k in write and i < len(write[k])]
+            wr = sum(wv) / len(wv) if wv else None
+            res["kernels"].append({"kernel": k[0].split("(float")[0].split("((anonymous")[0].split("(ZwArgs")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), "grid": k[1],
+                                   "launches": len(g), "fetch_raw": fr, "fetch_corrected": fr * f_dword, "write": wr,
+                                   "traffic": fr * f_dword + (wr or 0)})
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
