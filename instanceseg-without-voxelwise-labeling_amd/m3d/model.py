@@ -140,7 +140,7 @@ class DetectorM3D:
                         self.fc_split[name] = cls(w, params["Box_Head.%s.bias" % name])
 
     # ---- lib/modeling/DSN.py:57-68
-    def body_layer(self, li, x):
+    def body_layer(self, li, x, bound_slot=None):
         """conv + eval-BN + ReLU (+ MaxPool) of body layer li: Winograd-x kernel where it has a tile configuration,
         otherwise the direct MFMA kernel; the pool is fused into the conv launch when the map is large enough."""
         conv, scale, shift, pool = self.body[li]
@@ -150,12 +150,13 @@ class DetectorM3D:
         if not small:
             wino = None
         if li == 0 and small and self.stem_wino is not None and self.stem_wino.supports(width):
-            return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True, bound=self.conv_f16) if pool else \
-                self.stem_wino(x, scale=scale, shift=shift, relu=True, bound=self.conv_f16)
+            sb = (bound_slot if bound_slot is not None else True) if self.conv_f16 else False
+            return self.stem_wino.pooled(x, scale=scale, shift=shift, relu=True, bound=sb) if pool else \
+                self.stem_wino(x, scale=scale, shift=shift, relu=True, bound=sb)
         zw = self.body_zw[li]
         if zw is not None and small and self._zw_ok(zw, x):
             fused = pool and zw.supports(x.shape, pool=True)
-            y, ym = zw(x, self._bound(x), scale=scale, shift=shift, relu=True, pool=fused)
+            y, ym = zw(x, self._bound(x), scale=scale, shift=shift, relu=True, pool=fused, out_max=bound_slot)
             if pool and not fused:
                 y = ops.maxpool3d_2x(y)
             y._m3d_bound = ym                                 # (a pooled map's bound is its un-pooled map's)
@@ -243,9 +244,11 @@ class DetectorM3D:
 
     def conv_body(self, x, first=0, last=None):
         names = dsn_layers(self.cfg.stride)
+        # the f16x2 layers' operand bounds (one zeroed slot array per layer, filled by the producing launch): ONE fill for the whole body
+        slots = torch.zeros((len(self.body), ops.ZwConv3d.SLOTS), dtype=torch.float32, device=x.device) if self.conv_f16 else None
         for li in range(first, len(self.body) if last is None else last):
             with self.span(names[li][0]):
-                x = self.body_layer(li, x)
+                x = self.body_layer(li, x, slots[li] if slots is not None else None)
         return x
 
     def capture_body(self, x, first=0, last=None):
@@ -270,7 +273,7 @@ class DetectorM3D:
                                     and feat[0].numel() * 4 < 0x7FFFFFFF) else self.rpn_conv
         zw = self.rpn_conv_zw
         if zw is not None and feat[0].numel() * 4 < 0x7FFFFFFF and self._zw_ok(zw, feat):
-            h, _ = zw(feat, self._bound(feat), shift=self.rpn_conv_bias, relu=True)
+            h, _ = zw(feat, self._bound(feat), shift=self.rpn_conv_bias, relu=True, out_max=False)
         else:
             h = rc(feat, shift=self.rpn_conv_bias, relu=True)
         return self.rpn_outputs(h)

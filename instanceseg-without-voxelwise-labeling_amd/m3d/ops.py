@@ -1239,7 +1239,7 @@ class ZwConv3d(object):
         return out
 
     def __call__(self, x, in_max, scale=None, shift=None, relu=False, pool=False, out=None, out_max=None):
-        """out_max: a ZEROED [SLOTS] float tensor to receive the output's bound (None: a fresh one)."""
+        """out_max: a ZEROED [SLOTS] float tensor to receive the output's bound (None: a fresh one; False: no bound output)."""
         _need_gpu(x, in_max)
         x = _f32c(x)
         B, cin, D, H, W = x.shape
@@ -1251,9 +1251,12 @@ class ZwConv3d(object):
         assert tuple(out.shape) == oshape and out.is_contiguous()
         if out_max is None:
             out_max = torch.zeros((self.SLOTS,), dtype=torch.float32, device=x.device)
+        elif out_max is False:                             # nobody needs the output's bound (the last layer of a chain)
+            out_max = None
         check(lib().m3d_conv3d_zw_forward(_ptr(x), _ptr(self.packed), _ptr(out), B, cin, self.cout, D, H, W,
                                           _ptr(scale) if scale is not None else None, _ptr(shift) if shift is not None else None,
-                                          int(bool(relu)), int(bool(pool)), _ptr(in_max), _ptr(out_max), _stream()), "conv3d_zw_forward")
+                                          int(bool(relu)), int(bool(pool)), _ptr(in_max), _ptr(out_max) if out_max is not None else None,
+                                          _stream()), "conv3d_zw_forward")
         return out, out_max
 
 
@@ -1400,7 +1403,10 @@ class StemWinoConv3d(object):
         if out is None:
             shp = (B, self.cout, D // 2, H // 2, W // 2) if pool else (B, self.cout, D, H, W)
             out = torch.empty(shp, dtype=torch.float32, device=x.device)
-        om = torch.zeros((ZwConv3d.SLOTS,), dtype=torch.float32, device=x.device) if bound else None
+        # bound: True (a fresh zeroed slot array) or a ZEROED [SLOTS] float tensor of the caller's
+        om = None if bound is False or bound is None else \
+            (torch.zeros((ZwConv3d.SLOTS,), dtype=torch.float32, device=x.device) if bound is True else bound)
+        bound = om is not None
         check(lib().m3d_conv3d_stem_wino_forward_bound(_ptr(x), _ptr(self.packed), _ptr(out), B, self.cout, D, H, W,
                                                        _ptr(scale) if scale is not None else None,
                                                        _ptr(shift) if shift is not None else None, int(bool(relu)), int(bool(pool)),
