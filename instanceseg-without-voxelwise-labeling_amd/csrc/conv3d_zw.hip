@@ -332,49 +332,68 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       if (c + 1 < chunks) run_chunk(c + 1, 1);
     }
 
-    // ---- the four M_k meet: [block][point][column block][g / 4][lane] x 16 bytes
+    // ---- the four M_k meet in LDS
     __syncthreads();
-    {
+    const int x0 = cur.x0, y0 = cur.y0, z0 = cur.z0;
+    float* const ob = a.out + (size_t)cur.b * a.cout * (POOL ? DHW / 8 : DHW);
+    if constexpr (POOL) {                                // [block][point][column block][g / 4][lane] x 16 bytes: readers keep the writers' lanes
       f32x4* xw = xch + ((size_t)((cb * 4 + point) * 4) * 4) * 64 + lane;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
           xw[(j * 4 + gq) * 64] = f32x4{acc[j][4 * gq], acc[j][4 * gq + 1], acc[j][4 * gq + 2], acc[j][4 * gq + 3]};
+    } else {
+      // TRANSPOSED: [point][channel 64][row 4 RY][x XB] floats (128 per channel), so that a reader lane owns four consecutive x of one
+      // (channel, row) and stores 16 bytes per plane - the un-pooled epilogue was bound by the issue rate of its 256 dword wave-stores
+      // per unit.  The lanes of k half 1 (channel + 4) write 32 floats further (XOR 32 inside the channel's 128): no bank conflicts.
+      float* xt = lds_f + ((size_t)point * 64 + cb * 32 + 4 * fh) * 128 + (XB == 32 ? cx : 16 * cy + cx);     // + channel row, + 32 j (^ 32 for k half 1)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          xt[acc_row(g) * 128 + ((32 * j) ^ (fh << 5))] = acc[j][g];
     }
     __syncthreads();
-    const int x0 = cur.x0, y0 = cur.y0, z0 = cur.z0;
-    float* const ob = a.out + (size_t)cur.b * a.cout * (POOL ? DHW / 8 : DHW);
     if constexpr (!POOL) {
-      // wave (point p, block) finishes column block j = p: both planes, 16 channels per lane
-      const int j = point;
-      const int x = x0 + cx, y = y0 + C::RY * j + cy;
-      const bool vok = (x < a.W) & (y < a.H);
+      // thread -> items i = 0..3: channel 16 i + 2 wave + (lane >> 5), (row, x quad) from lane & 31; both planes
+      constexpr int QX = XB / 4;                        // x quads per row
+      const int ridx = lane & 31, rrow = ridx / QX, rxq = ridx % QX;
+      const int x = x0 + 4 * rxq, y = y0 + rrow;
       f32x4 o0[4], o1[4];
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
+      for (int i = 0; i < 4; ++i) {
+        const int cl = 16 * i + 2 * wave + (lane >> 5);
+        const float* src = lds_f + (size_t)cl * 128 + ((rrow * XB + 4 * rxq) ^ (((cl >> 2) & 1) << 5));
         f32x4 m[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = xch[((size_t)((cb * 4 + k) * 4 + j) * 4 + gq) * 64 + lane];
-        o0[gq] = (m[0] + m[1]) + m[2]; o1[gq] = (m[1] - m[2]) - m[3];
+        for (int k = 0; k < 4; ++k) m[k] = *reinterpret_cast<const f32x4*>(src + (size_t)k * 64 * 128);
+        o0[i] = (m[0] + m[1]) + m[2]; o1[i] = (m[1] - m[2]) - m[3];
       }
       if (hasn) __syncthreads();                       // every wave has its sums: the staging buffers are free for the next unit
+      const bool quad_ok = ((a.W & 3) == 0);
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
+      for (int i = 0; i < 4; ++i) {
+        const int cl = 16 * i + 2 * wave + (lane >> 5), co = cur.cg * 64 + cl;
+        if (!(y < a.H && x < a.W && co < a.cout)) continue;
+        const float sc = aff[cl], sh = aff[64 + cl];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int cl = cb * 32 + 4 * fh + acc_row(4 * gq + e), co = cur.cg * 64 + cl;
-          if (!(vok && co < a.cout)) continue;
-          const float sc = aff[cl], sh = aff[64 + cl];
+        for (int zz = 0; zz < 2; ++zz) {
+          if (z0 + zz >= a.D) continue;
+          f32x4 v = (zz ? o1[i] : o0[i]) * sc + sh;
 #pragma unroll
-          for (int zz = 0; zz < 2; ++zz) {
-            if (z0 + zz >= a.D) continue;
-            float v = (zz ? o1[gq][e] : o0[gq][e]) * sc + sh;
-            if (a.relu) v = fmaxf(v, 0.f);
-            vmax = fmaxf(vmax, fabsf(v));
-            ob[(size_t)co * DHW + (size_t)(z0 + zz) * HW + (size_t)y * a.W + x] = v;
+          for (int e = 0; e < 4; ++e) if (a.relu) v[e] = fmaxf(v[e], 0.f);
+          float* o = ob + (size_t)co * DHW + (size_t)(z0 + zz) * HW + (size_t)y * a.W + x;
+          if (quad_ok) {                                 // (x is a multiple of 4 and W is: the quad is inside the row)
+            *reinterpret_cast<f32x4*>(o) = v;
+            vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (x + e < a.W) { o[e] = v[e]; vmax = fmaxf(vmax, fabsf(v[e])); }
           }
         }
+      }
     } else {
       // fused MaxPool3d(2,2): wave (point p, block) finishes row pair p & 1 (column blocks 2 rp, 2 rp + 1) for channel quads 2 (p >> 1) + {0, 1};
       // z pair and y pair in the lane, x pair in lanes x, x ^ 1
