@@ -174,7 +174,9 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       const int z = q.z0 - 1 + k;
       const bool ok = okyx & (z >= 0) & (z < a.D);
       st.okm |= ok ? (1 << k) : 0;
-      st.voff[k] = ok ? (int)(((size_t)z * HW + (size_t)sy * a.W + sx + (size_t)8 * sg * DHW) * 4) : 0;
+      // outside the volume: an offset beyond the buffer's num_records (< 2^31; offset + any scalar part stays below 2^32) - the load returns 0,
+      // which is the zero padding: no per-value select when the tile is cut
+      st.voff[k] = ok ? (int)(((size_t)z * HW + (size_t)sy * a.W + sx + (size_t)8 * sg * DHW) * 4) : 0x7FFFFF00;
     }
     st.base = a.x + (size_t)q.b * a.cin * DHW;
     return st;
@@ -200,7 +202,6 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   auto commit_point = [&](int buf, int okm, const int k) __attribute__((always_inline)) {
     if (!has) return;
     constexpr int PA_[4] = {0, 1, 2, 1}, PB_[4] = {2, 2, 1, 3};               // V_k = d[PA] -+ d[PB]: d0 - d2, d1 + d2, d2 - d1, d1 - d3
-    const bool oka = (okm >> PA_[k]) & 1, okb = (okm >> PB_[k]) & 1;
     u32x4 ph, pl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ch = 2 * j + u;
-        const float da = oka ? raw[PA_[k]][ch] : 0.f, db = okb ? raw[PB_[k]][ch] : 0.f;
+        const float da = raw[PA_[k]][ch], db = raw[PB_[k]][ch];
         const float v = (k == 1 ? da + db : da - db) * xs;
         const _Float16 h = (_Float16)v;
         hh[u] = h; ll[u] = (_Float16)(v - (float)h);
