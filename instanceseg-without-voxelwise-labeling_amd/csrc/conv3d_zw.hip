@@ -229,9 +229,12 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   int cx, cy;
   if constexpr (XB == 32) { cx = fr; cy = 0; } else { col_xy16(fr, &cx, &cy); }
   const int bB = (fh * 4 + point) * C::PLANE + cy * C::HXP + cx;              // + (RY * j + dy) * HXP + dx + piece * 8 * PLANE + buf * BUF_UNITS
-  auto wsrc_of = [&](int cg) __attribute__((always_inline)) {
-    return a.wp + (size_t)cg * chunks * 9 * ZW_STEP_UNITS + (point * 2 + cb) * 128 + lane;
-  };
+  // weight fragments: buffer loads with the (cout group, step) part of the address in the scalar offset - no 64-bit vector address arithmetic
+  // in the K loop.  wsrc = byte offset of a cout group's first step.
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(a.wp), 0, (unsigned)((size_t)a.ncg * chunks * 9 * ZW_STEP_UNITS * 16), 0x00020000);
+  const int w_lane = ((point * 2 + cb) * 128 + lane) * 16;
+  auto wsrc_of = [&](int cg) __attribute__((always_inline)) { return cg * chunks * 9 * (ZW_STEP_UNITS * 16); };
 
   struct BF { f16x8 b[4][2]; };
   BF F0, F1;
@@ -240,19 +243,19 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     const int j = i >> 1, p = i & 1, dy = t / 3, dx = t % 3;
     f.b[j][p] = __builtin_bit_cast(f16x8, lds[buf * C::BUF_UNITS + bB + (C::RY * j + dy) * C::HXP + dx + p * 8 * C::PLANE]);
   };
-  auto fetch_a = [&](const u32x4* p, int set) __attribute__((always_inline)) {
-    A[set][0] = __builtin_bit_cast(f16x8, p[0]);
-    A[set][1] = __builtin_bit_cast(f16x8, p[64]);
+  auto fetch_a = [&](int step_bytes, int set) __attribute__((always_inline)) {
+    A[set][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, step_bytes, 0));
+    A[set][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + 1024, step_bytes, 0));
   };
 
   const int l0 = zw_xcd_contiguous(blockIdx.x, gridDim.x);
   int u = l0;
   Unit cur = decode(u);
   Stage S = stage_of(cur);
-  const u32x4* wsrc = wsrc_of(cur.cg);
+  int wsrc = wsrc_of(cur.cg);
   fetch_in(S, 0);
   fetch_a(wsrc, 0);
-  fetch_a(wsrc + ZW_STEP_UNITS, 1);
+  fetch_a(wsrc + ZW_STEP_UNITS * 16, 1);
   float vmax = 0.f;
   f32x4* const xch = reinterpret_cast<f32x4*>(lds_f);
 
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     const bool hasn = un_ < units;
     const Unit nxtu = decode(hasn ? un_ : u);
     const Stage SN = stage_of(nxtu);
-    const u32x4* const wsrcN = wsrc_of(nxtu.cg);
+    const int wsrcN = wsrc_of(nxtu.cg);
 
     commit_in(0, S.okm);
     float* const aff = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_f) + C::AFF_OFF) + (it & 1) * 128;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         {                                                // weight fragments two taps ahead (set (t + 2) % 3 was consumed by tap t - 1)
           const int idx = s + 2;
           const bool over = idx >= steps;
-          fetch_a((over ? wsrcN : wsrc) + (size_t)(over ? idx - steps : idx) * ZW_STEP_UNITS, (t + 2) % 3);
+          fetch_a((over ? wsrcN : wsrc) + (over ? idx - steps : idx) * (ZW_STEP_UNITS * 16), (t + 2) % 3);
         }
         constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                   // small products first: (lo, hi) (hi, lo) (hi, hi)
         constexpr int RD0[4] = {0, 3, 6, 8};
