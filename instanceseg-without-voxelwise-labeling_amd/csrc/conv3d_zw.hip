@@ -519,6 +519,7 @@ M3D_API int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float
                                   float* d_out_max, void* stream) {
   if (!d_in || !d_packed || !d_out || !d_in_max || batch <= 0) return M3D_EINVAL;
   if (!m3d_conv3d_zw_supported(cin, cout, depth, height, width, pool)) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * depth * height * width * sizeof(float) >= 0x7FFFFF00ull) return M3D_EUNSUPPORTED;      // 32-bit buffer offsets inside one batch item
   ZwArgs a{};
   a.x = d_in; a.wp = static_cast<const u32x4*>(d_packed); a.out = d_out; a.scale = d_scale; a.shift = d_shift;
   a.in_max = d_in_max; a.out_max = reinterpret_cast<unsigned*>(d_out_max);
