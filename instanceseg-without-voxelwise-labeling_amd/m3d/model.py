@@ -159,7 +159,7 @@ class DetectorM3D:
             y, ym = zw(x, self._bound(x), scale=scale, shift=shift, relu=True, pool=fused, out_max=bound_slot)
             if pool and not fused:
                 y = ops.maxpool3d_2x(y)
-            y._m3d_bound = ym                                 # (a pooled map's bound is its un-pooled map's)
+            y._m3d_bound = (ym, y._version)                   # (a pooled map's bound is its un-pooled map's)
             return y
         if wino is not None and wino.supports(width, (x.shape[0],) + tuple(x.shape[2:])):
             if pool and wino.supports_pool(width):
@@ -176,7 +176,9 @@ class DetectorM3D:
         """The operand bound of an activation tensor for the f16x2 conv kernels: left on the tensor by the launch that produced it, else
         one sweep of it (the chain's first layer, or a tensor that came from somewhere else)."""
         b = getattr(x, "_m3d_bound", None)
-        return b if b is not None else ops.ZwConv3d.bound_of(x)
+        if b is not None and b[1] == x._version:           # (an in-place write since the producing launch makes the bound stale: sweep again)
+            return b[0]
+        return ops.ZwConv3d.bound_of(x)
 
     @staticmethod
     def _zw_ok(zw, x):

@@ -1412,7 +1412,7 @@ class StemWinoConv3d(object):
                                                        _ptr(shift) if shift is not None else None, int(bool(relu)), int(bool(pool)),
                                                        _ptr(om) if bound else None, _stream()), "conv3d_stem_wino_forward")
         if bound:
-            out._m3d_bound = om                            # the operand bound of the f16x2 conv that reads `out` (ZwConv3d)
+            out._m3d_bound = (om, out._version)            # the operand bound of the f16x2 conv that reads `out` (ZwConv3d), valid for this version of `out`
         return out
 
     def __call__(self, x, scale=None, shift=None, relu=False, out=None, bound=False):

@@ -460,6 +460,26 @@ def test_conv3d_f16x2_z_winograd_vs_fp64(m3d, B, cin, cout, D, H, W):
         assert torch.equal(yp, torch.nn.functional.max_pool3d(y2, 2, 2))        # the fused pool is the un-pooled kernel's output, pooled
 
 
+def test_conv3d_f16x2_operand_bound_is_tied_to_the_tensor_version(m3d):
+    """The bound a producing launch leaves on its output tensor (`_m3d_bound`) is only used while the tensor is unchanged: after an in-place
+    write the model sweeps the tensor again (a stale bound would overflow fp16 silently)."""
+    from m3d.model import DetectorM3D
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(1, 16, 4, 8, 32, generator=g)).cuda()
+    w = (torch.randn(32, 16, 3, 3, 3, generator=g) * 0.05).cuda()
+    conv = m3d.ZwConv3d(w)
+    y, ym = conv(x, m3d.ZwConv3d.bound_of(x), relu=True)
+    y._m3d_bound = (ym, y._version)
+    assert DetectorM3D._bound(y) is ym
+    y.mul_(1000.0)                                           # in place: the recorded bound is 1000 x too small now
+    b2 = DetectorM3D._bound(y)
+    assert b2 is not ym and float(b2.max()) == float(y.abs().max())
+    w2 = (torch.randn(16, 32, 3, 3, 3, generator=g) * 0.05).cuda()
+    z, _ = m3d.ZwConv3d(w2)(y, b2)
+    ref = torch.nn.functional.conv3d(y.cpu().double(), w2.cpu().double(), padding=1)
+    assert (z.cpu().double() - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+
+
 @pytest.mark.parametrize("B,cin,cout,D,H,W", [(1, 128, 256, 16, 16, 16), (1, 256, 256, 8, 25, 23), (2, 20, 40, 3, 13, 12),
                                                 (1, 256, 70, 5, 9, 17), (1, 6, 33, 2, 30, 21)])
 def test_conv3d_winograd_2d_split_k_small_maps(m3d, B, cin, cout, D, H, W):
