@@ -536,6 +536,13 @@ int m3d_prm_prepare_ex2(const float* d_gup, const int32_t* d_origin_up, int num_
                         const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width, const float* d_scale,
                         const float* d_norm, int depth, int height, int width, int in_strip, int in_slab, int out_strip, int out_slab,
                         const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream);
+/* ... and d_peak_max [num_peaks x 32] (or NULL: exactly the call above): element 32 p = the largest |value| written for peak p (zeroed and
+ * filled by this call; one cache line per peak) - the per-window operand bound m3d_conv3d_zw_forward_strip takes, so that the strip is never swept for it. */
+int m3d_prm_prepare_ex3(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                        int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                        const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip, int in_slab,
+                        int out_strip, int out_slab, const float* d_up_offset, float* d_out, int32_t* d_origin_out,
+                        float* d_peak_max, void* stream);
 int m3d_prm_stem_dgrad_fused_ex2(const float* d_gup, int gup_strip, int gup_slab, const float* d_xnext, const float* d_up_offset,
                                  const int32_t* d_origin_up, int num_peaks, int channels, int up_size, const float* d_den,
                                  const uint8_t* d_argmax, const float* d_scale, int up_depth, int up_height, int up_width,
@@ -590,6 +597,15 @@ int m3d_conv3d_zw_bound_of(const float* d_x, long long n, float* d_slots, void* 
 int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,
                           int width, const float* d_scale, const float* d_shift, int relu, int pool, const float* d_in_max,
                           float* d_out_max, void* stream);
+/* The same convolution on a PRM window strip [cin, depth, height, width] (peak_backprop_3d.py:8-34 batched over peaks: the windows of all
+ * peaks side by side along x, cell p = columns [pitch p, pitch (p + 1)), pitch a multiple of 4 - m3d_prm_strip_geometry mode 2) with ONE
+ * OPERAND SCALE PER WINDOW: d_col_bound [num_peaks x 32], element 32 p = the largest |input| of window p (one cache line per window;
+ * m3d_prm_strip_absmax: one sweep, rows = cin x depth x height; or the d_peak_max of m3d_prm_prepare_ex3).  The gradients of different peaks differ by orders of magnitude: each keeps its own 22 bits, and a window's
+ * outputs do not depend on which other windows share the strip.  F(2,3) along z and the direct (y, x) taps are exactly local: a window's
+ * outputs read nothing beyond its own 3^3 supports.  No scale / shift / ReLU / pool; width >= 24. */
+int m3d_prm_strip_absmax(const float* d_strip, long long rows, int L, int pitch, int num_peaks, float* d_out, void* stream);
+int m3d_conv3d_zw_forward_strip(const float* d_in, const void* d_packed, float* d_out, int cin, int cout, int depth, int height,
+                                int width, const float* d_col_bound, int num_peaks, int pitch, void* stream);
 
 /* Round 5: backward-data of a 3^3 conv on the quad-aligned strip FUSED with the prepare step of the layer below (no pooling between them):
  * d_gn [cin, in_planes, window, L(window)] (m3d_prm_prepare_ex2's out_strip = 2 layout; in_slab: the map's planes), d_packed =

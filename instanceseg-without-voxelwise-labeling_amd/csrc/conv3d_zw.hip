@@ -109,6 +109,9 @@ struct ZwArgs {
   const float* in_max; unsigned* out_max; const float* wamax;
   int B, cin, cout, D, H, W, relu;
   int tiles_x, tiles_y, tiles_z, ncg;
+  // strip mode (PRM windows side by side along x, one scale per window): col_bound[p] = largest |input| of window p, cell p = columns
+  // [pitch p, pitch (p + 1)) (pitch a multiple of 4: a 16-byte output quad never straddles two cells); col_bound == null: one scale (in_max)
+  const float* col_bound; int pitch, npeaks;
 };
 
 __device__ __forceinline__ int zw_xcd_contiguous(int bid, int n) {
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   // ---- operand scales (powers of two): input bound = the largest slot x 2 (a V is a sum of two planes), weights as packed
   float xs, inv_x, inv_w;
   {
-    float im = a.in_max[lane & (ZW_SLOTS - 1)];
+    float im = a.col_bound ? 0.f : a.in_max[lane & (ZW_SLOTS - 1)];      // (strip mode: one scale per window, see Stage::xs)
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) im = fmaxf(im, __shfl_xor(im, o));
     float sw_;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   const int sg = has ? tid / (C::HYN * C::HXN) : 0;
   const int sr = has ? tid % (C::HYN * C::HXN) : 0;
   const int shy = sr / C::HXN, shx = sr % C::HXN;
-  struct Stage { int voff[4]; int okm; const float* base; };
+  struct Stage { int voff[4]; int okm; const float* base; float xs; };
   auto stage_of = [&](const Unit& q) __attribute__((always_inline)) {
     Stage st;
     const int sy = q.y0 - 1 + shy, sx = q.x0 - 1 + shx;
@@ -179,6 +182,12 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       st.voff[k] = ok ? (int)(((size_t)z * HW + (size_t)sy * a.W + sx + (size_t)8 * sg * DHW) * 4) : 0x7FFFFF00;
     }
     st.base = a.x + (size_t)q.b * a.cin * DHW;
+    st.xs = xs;
+    if (a.col_bound) {                                  // this halo column's window: its own power-of-two scale
+      const int p = min(max(sx, 0) / a.pitch, a.npeaks - 1);
+      float inv_;
+      m3d::f16_scale_of(2.f * a.col_bound[32 * p], st.xs, inv_);
+    }
     return st;
   };
   float raw[4][8];
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   const int st_unit = (sg * 4) * C::PLANE + shy * C::HXP + shx;               // + point * PLANE + hilo * 8 * PLANE + buf * BUF_UNITS
   // one z point k of the staged item: V_k of its 8 channels, scaled and cut -> two 16-byte units.  Called point by point from different
   // taps (40 VALU each ride in the MFMAs' shadow; all four at once stalled both waves of a SIMD at the same tap)
-  auto commit_point = [&](int buf, int okm, const int k) __attribute__((always_inline)) {
+  auto commit_point = [&](int buf, float xs_, const int k) __attribute__((always_inline)) {
     if (!has) return;
     constexpr int PA_[4] = {0, 1, 2, 1}, PB_[4] = {2, 2, 1, 3};               // V_k = d[PA] -+ d[PB]: d0 - d2, d1 + d2, d2 - d1, d1 - d3
     u32x4 ph, pl;
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       for (int u = 0; u < 2; ++u) {
         const int ch = 2 * j + u;
         const float da = raw[PA_[k]][ch], db = raw[PB_[k]][ch];
-        const float v = (k == 1 ? da + db : da - db) * xs;
+        const float v = (k == 1 ? da + db : da - db) * xs_;
         const _Float16 h = (_Float16)v;
         hh[u] = h; ll[u] = (_Float16)(v - (float)h);
       }
@@ -219,9 +228,9 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     u32x4* d = lds + buf * C::BUF_UNITS + st_unit + k * C::PLANE;
     d[0] = ph; d[8 * C::PLANE] = pl;
   };
-  auto commit_in = [&](int buf, int okm) __attribute__((always_inline)) {
+  auto commit_in = [&](int buf, float xs_) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) commit_point(buf, okm, k);
+    for (int k = 0; k < 4; ++k) commit_point(buf, xs_, k);
   };
 
   // ---- fragments
@@ -266,11 +275,17 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
     const Stage SN = stage_of(nxtu);
     const int wsrcN = wsrc_of(nxtu.cg);
 
-    commit_in(0, S.okm);
+    float inv_e = 1.f;                                   // strip mode: the inverse input scale of the window this lane's output quad lies in
+    if (a.col_bound) {
+      const int p = min((cur.x0 + 4 * ((lane & 31) % (XB / 4))) / a.pitch, a.npeaks - 1);
+      float s_;
+      m3d::f16_scale_of(2.f * a.col_bound[32 * p], s_, inv_e);
+    }
+    commit_in(0, S.xs);
     float* const aff = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_f) + C::AFF_OFF) + (it & 1) * 128;
     if (tid < 64) {                                      // the unit's 64 channels: scale x the operand scales' inverse, shift
       const int co = min(cur.cg * 64 + tid, a.cout - 1);
-      aff[tid] = (a.scale ? a.scale[co] : 1.f) * un;
+      aff[tid] = (a.scale ? a.scale[co] : 1.f) * (a.col_bound ? inv_w : un);
       aff[64 + tid] = a.shift ? a.shift[co] : 0.f;
     }
     __syncthreads();
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         if (t >= 4 && t <= 7 && !last) {                 // points 0 (planes 0, 2), 2 (2, 1), 1 (1, 2), 3 (1, 3)
           constexpr int PT[4] = {0, 2, 1, 3};
-          commit_point(buf ^ 1, S.okm, PT[t - 4]);
+          commit_point(buf ^ 1, S.xs, PT[t - 4]);
         }
       }
     };
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int cl = 16 * i + 2 * wave + (lane >> 5), co = cur.cg * 64 + cl;
         if (!(y < a.H && x < a.W && co < a.cout)) continue;
-        const float sc = aff[cl], sh = aff[64 + cl];
+        const float sc = aff[cl] * inv_e, sh = aff[64 + cl];        // (inv_e: a power of two, 1 outside strip mode)
 #pragma unroll
         for (int zz = 0; zz < 2; ++zz) {
           if (z0 + zz >= a.D) continue;
@@ -512,6 +527,58 @@ M3D_API int m3d_conv3d_zw_bound_of(const float* d_x, long long n, float* d_slots
   hipStream_t st = m3d::as_stream(stream);
   if (hipMemsetAsync(d_slots, 0, ZW_SLOTS * sizeof(float), st) != hipSuccess) return M3D_ELAUNCH;
   return m3d_absmax(d_x, n, d_slots, stream);
+}
+
+namespace {
+// largest |value| of every window of a strip [rows][L] (rows = channels x planes x window rows), cell p = columns [pitch p, pitch (p + 1)):
+// lanes walk a row (coalesced), maxima meet in an LDS array per workgroup, one global atomic per (workgroup, window)
+__global__ __launch_bounds__(256) void zw_strip_absmax_kernel(const float* __restrict__ x, long long rows, int L, int pitch, int P,
+                                                              unsigned* __restrict__ out) {
+  extern __shared__ unsigned pm[];
+  for (int i = threadIdx.x; i < P; i += 256) pm[i] = 0;
+  __syncthreads();
+  const int L4 = L / 4;                                  // (L is a multiple of 4 and pitch is: a quad lies in one cell)
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(x + r * L);
+    for (int q = threadIdx.x; q < L4; q += 256) {
+      const f32x4 v = row[q];
+      const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      if (m > 0.f) atomicMax(&pm[min(4 * q / pitch, P - 1)], __float_as_uint(m));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P; i += 256)
+    if (pm[i]) atomicMax(out + 32 * i, pm[i]);
+}
+}  // namespace
+
+/* d_out[32 p] (one cache line per window: the producers' atomic maxima do not queue on one line) = largest |x| inside cell p (columns [pitch p, pitch (p + 1))) of the strip d_strip [rows][L]; L and pitch multiples of 4 */
+M3D_API int m3d_prm_strip_absmax(const float* d_strip, long long rows, int L, int pitch, int num_peaks, float* d_out, void* stream) {
+  if (!d_strip || !d_out || rows <= 0 || L <= 0 || pitch <= 0 || num_peaks <= 0 || (L & 3) || (pitch & 3) || num_peaks > 12288) return M3D_EINVAL;
+  hipStream_t st = m3d::as_stream(stream);
+  if (hipMemsetAsync(d_out, 0, (size_t)num_peaks * 32 * sizeof(float), st) != hipSuccess) return M3D_ELAUNCH;
+  const long long blocks = rows < 2048 ? rows : 2048;
+  hipLaunchKernelGGL(zw_strip_absmax_kernel, dim3((unsigned)blocks), dim3(256), (size_t)num_peaks * 4, st, d_strip, rows, L, pitch, num_peaks,
+                     reinterpret_cast<unsigned*>(d_out));
+  return m3d::check_launch("prm_strip_absmax");
+}
+
+/* The convolution of m3d_conv3d_zw_forward on a PRM window strip [cin, depth, height, width] (windows side by side along x, cell p =
+ * columns [pitch p, pitch (p + 1)), pitch a multiple of 4) with ONE OPERAND SCALE PER WINDOW: d_col_bound [num_peaks x 32], element 32 p = the largest
+ * |input| of window p (m3d_prm_strip_absmax, or m3d_prm_prepare_ex3's d_peak_max).  Windows of very different magnitude keep their own 22 bits, and a window's outputs do not depend on
+ * which other windows share the strip (a sub-batch gives the batch's values bit for bit).  No scale / shift / ReLU / pool. */
+M3D_API int m3d_conv3d_zw_forward_strip(const float* d_in, const void* d_packed, float* d_out, int cin, int cout, int depth, int height,
+                                        int width, const float* d_col_bound, int num_peaks, int pitch, void* stream) {
+  if (!d_in || !d_packed || !d_out || !d_col_bound || num_peaks <= 0 || pitch <= 0 || (pitch & 3)) return M3D_EINVAL;
+  if (!m3d_conv3d_zw_supported(cin, cout, depth, height, width, 0) || width < 24) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * depth * height * width * sizeof(float) >= 0x7FFFFF00ull) return M3D_EUNSUPPORTED;
+  ZwArgs a{};
+  a.x = d_in; a.wp = static_cast<const u32x4*>(d_packed); a.out = d_out;
+  a.in_max = d_col_bound;                                // (read, not used: the per-window scales replace it)
+  a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + zw_plane_bytes(cin, cout));
+  a.B = 1; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width;
+  a.col_bound = d_col_bound; a.pitch = pitch; a.npeaks = num_peaks;
+  return launch_zw<32, false>(a, m3d::as_stream(stream));
 }
 
 M3D_API int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,

@@ -126,6 +126,8 @@ struct PrepParams {
   int out_sep;             // strip output: zero columns after each window (pitch - Wn), zero-filled here
   int out_lead, out_tail;  // strip output: zero columns before window 0 / after the last window's separator
   const float* xoff;       // non-null: gup is a bare backward-data result; the PreHook multiply by (X_{L+1} - *xoff) happens here
+  unsigned* peak_max;      // or null: [P] largest |value| written for each peak (atomic maxima of float bits, zeroed by the host entry): the
+                           // per-window operand scale of the f16x2 strip convolution that reads `out` (m3d_conv3d_zw_forward_strip)
   // Depth-clipped strips ("slab" strips, izn / ozn > 0): a strip [C, zn, n, L] stores the planes of the LAYER (plane k of every window =
   // plane k of the layer's map, zn = the layer's depth) instead of the n planes of each window.  Where the tile is thinner than the cone
   // (nuclei: 32 planes against 38 / 40-plane windows) the planes of a window that lie outside the volume - zero gradient in, results
@@ -136,6 +138,16 @@ struct PrepParams {
 // One thread per output voxel (no pooling between this layer and the upper one).  grid = (chunks, C, P): a workgroup walks
 // its share of the (p, c) window in strides of 256 voxels - a million 256-voxel workgroups were bound by the dispatch rate, not
 // by memory - and channel and peak come from the block index (no 64-bit div/mod chains).
+// largest |value| a wave stored for peak p -> q.peak_max[p] (one atomic per wave; every lane of the wave must call)
+__device__ __forceinline__ void prep_peak_max(const PrepParams& q, int p, float vm) {
+  if (!q.peak_max) return;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o));
+  // one 128-byte line per peak (stride 32 floats): thousands of waves add to a peak's maximum, and with the peaks' words side by side in
+  // two cache lines every atomic of the launch queued on the same L2 line (the pool kernel's time doubled)
+  if ((threadIdx.x & 63) == 0 && vm > 0.f) atomicMax(q.peak_max + 32 * p, __float_as_uint(vm));
+}
+
 __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   const int w3 = (q.ozn ? q.ozn : q.Wn) * q.Wn * q.Wn;
   const int c = blockIdx.y, p = blockIdx.z;
@@ -150,6 +162,7 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
   const float* norm = q.norm + (size_t)c * q.D * q.H * q.W;
   float* out = q.out + (size_t)p * q.ops + (size_t)c * q.ocs;
   const float inv_w = 1.0f / (float)q.Wn;
+  float vm = 0.f;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < w3; e += gridDim.x * 256) {
     const int r = (int)(((float)e + 0.5f) * inv_w), x = e - r * q.Wn;      // exact for e < 2^22 (Wn <= 100)
     const int zk = (int)(((float)r + 0.5f) * inv_w), y = r - zk * q.Wn;
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
     }
     float* o = out + (size_t)zk * q.ozs + (size_t)y * q.oys + x;
     o[0] = g;
+    vm = fmaxf(vm, fabsf(g));
     if (q.out_sep && x == q.Wn - 1) {
       const int nz = q.out_sep + (p == q.P - 1 ? q.out_tail : 0);
       for (int j = 1; j <= nz; ++j) o[j] = 0.f;
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(256) void prm_prepare_kernel(PrepParams q) {
     if (q.out_lead && p == 0 && x == 0)
       for (int j = 1; j <= q.out_lead; ++j) o[-j] = 0.f;
   }
+  prep_peak_max(q, p, vm);
 }
 
 // The same element rule for a QUAD-ALIGNED output strip (mode 2: pitch % 4 == 0, window p inside the cell [p pitch, (p + 1) pitch) at
@@ -201,8 +216,8 @@ __global__ __launch_bounds__(256) void prm_prepare_quad_kernel(PrepParams q, int
   float* out = q.out - lead + (size_t)p * pitch + (size_t)c * q.ocs;
   const int j = threadIdx.x % TX, ry = threadIdx.x / TX;
   const int nq = pitch / 4 + ((p == q.P - 1 && tail) ? tail / 4 : 0);       // quads of this cell (+ the strip's tail behind the last one)
-  if (j >= nq) return;
-  const int rows = (q.ozn ? q.ozn : q.Wn) * q.Wn;
+  const int rows = (j < nq) ? (q.ozn ? q.ozn : q.Wn) * q.Wn : 0;            // (lanes beyond the cell's quads idle; they join the wave's maximum below)
+  float vm = 0.f;
   const float inv_w = 1.0f / (float)q.Wn;
   const int x0 = 4 * j - lead;                                               // window column of the quad's first element
   const int ix0 = x0 - q.border, qx0 = ox + x0;
@@ -236,7 +251,9 @@ __global__ __launch_bounds__(256) void prm_prepare_quad_kernel(PrepParams q, int
       }
     }
     *reinterpret_cast<float4*>(out + (size_t)zk * q.ozs + (size_t)y * q.oys + 4 * j) = make_float4(g[0], g[1], g[2], g[3]);
+    vm = fmaxf(vm, fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
   }
+  prep_peak_max(q, p, vm);
 }
 
 // MaxPool3d(2,2) between this layer and the upper one: one thread per 2x2x2 output block, i.e. per UPPER voxel (plus a
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
   const float inv_u = 1.0f / (float)UB;
   // slab output: the z blocks are the pooling blocks of the LAYER (az = 0 .. ceil(ozn / 2)), so that every stored plane is written
   const int ub3 = (q.ozn ? (q.ozn + 1) / 2 : UB) * UB * UB;
+  float vm = 0.f;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < ub3; e += gridDim.x * 256) {
     // block b covers inner coordinates 2*(b-1) .. 2*(b-1)+1 shifted so that every window voxel belongs to one block:
     // window coordinate w = inner + border; blocks are aligned to the INNER grid (pooling windows).
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
       if ((wz >= 0) & (wz < (q.ozn ? q.ozn : q.Wn)) & (wy >= 0) & (wy < q.Wn) & (wx >= 0) & (wx < q.Wn)) {
         float* d = o + (size_t)wz * q.ozs + (size_t)wy * q.oys + wx;
         d[0] = vals[k];
+        vm = fmaxf(vm, fabsf(vals[k]));
         if (q.out_sep && wx == q.Wn - 1) {
           const int nz = q.out_sep + (p == q.P - 1 ? q.out_tail : 0);
           for (int j = 1; j <= nz; ++j) d[j] = 0.f;
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(256) void prm_prepare_pool_kernel(PrepParams q) {
       }
     }
   }
+  prep_peak_max(q, p, vm);
 }
 
 // ---- stem dgrad: conv1a is 1 -> 32 channels, 5^3; its backward-data has ONE output channel, so an MFMA tile
@@ -577,6 +597,19 @@ M3D_API int m3d_prm_prepare_ex2(const float* d_gup, const int32_t* d_origin_up, 
                                 int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
                                 const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip, int in_slab,
                                 int out_strip, int out_slab, const float* d_up_offset, float* d_out, int32_t* d_origin_out, void* stream) {
+  return m3d_prm_prepare_ex3(d_gup, d_origin_up, num_peaks, channels, up_size, pool, border, d_argmax, d_xnext, up_depth, up_height, up_width,
+                             d_scale, d_norm, depth, height, width, in_strip, in_slab, out_strip, out_slab, d_up_offset, d_out, d_origin_out,
+                             nullptr, stream);
+}
+
+/* ... and d_peak_max [num_peaks x 32] (or NULL; peak p's value at element 32 p: one cache line per peak): the largest |value| written for
+ * each peak, the per-window operand bound of
+ * m3d_conv3d_zw_forward_strip (zeroed here, filled by the launch: no sweep of the strip). */
+M3D_API int m3d_prm_prepare_ex3(const float* d_gup, const int32_t* d_origin_up, int num_peaks, int channels, int up_size, int pool,
+                                int border, const uint8_t* d_argmax, const float* d_xnext, int up_depth, int up_height, int up_width,
+                                const float* d_scale, const float* d_norm, int depth, int height, int width, int in_strip, int in_slab,
+                                int out_strip, int out_slab, const float* d_up_offset, float* d_out, int32_t* d_origin_out,
+                                float* d_peak_max, void* stream) {
   if (num_peaks < 0 || channels <= 0 || up_size <= 0 || border < 0) return M3D_EINVAL;
   if ((in_slab && !in_strip) || (out_slab && !out_strip) || depth <= 0 || up_depth <= 0) return M3D_EINVAL;
   if (!pool && (up_depth != depth || up_height != height || up_width != width)) return M3D_EINVAL;
@@ -589,6 +622,8 @@ M3D_API int m3d_prm_prepare_ex2(const float* d_gup, const int32_t* d_origin_up, 
   q.D = depth; q.H = height; q.W = width; q.UD = up_depth; q.UH = up_height; q.UW = up_width;
   q.xoff = d_up_offset; q.out_sep = 0; q.out_lead = 0; q.out_tail = 0;
   q.izn = in_slab ? up_depth : 0; q.ozn = out_slab ? depth : 0;
+  q.peak_max = reinterpret_cast<unsigned*>(d_peak_max);
+  if (d_peak_max && hipMemsetAsync(d_peak_max, 0, (size_t)num_peaks * 32 * sizeof(float), m3d::as_stream(stream)) != hipSuccess) return M3D_ELAUNCH;
   long long ibase = 0, obase = 0;
   auto strides = [&](int n, int zn, int strip, long long* ps, long long* cs, int* zs, int* ys, long long* base, bool is_out) {
     if (strip) {

@@ -984,7 +984,7 @@ def strip_geometry(n, mode, P):
 
 
 def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_strip=False, out_strip=False, up_off=None, dims=None,
-                in_slab=False, out_slab=False):
+                in_slab=False, out_slab=False, peak_max=False):
     """gup [P,C,U,U,U]; xnext [C,UD,UH,UW]; norm [C,D,H,W] -> (window [P,C,Wn,Wn,Wn], origin int32 [P,3]).
     Strip layout (in_strip / out_strip): the P windows side by side along x with one separator column after each,
     [C,n,n,P*(n+1)] - what the Winograd kernel convolves as one wide volume; dims = (P, C, U) is then required.
@@ -1001,10 +1001,15 @@ def prm_prepare(gup, origin_up, pool, border, argmax, xnext, scale, norm, in_str
     out = torch.empty((Cc, norm.shape[1] if out_slab else Wn, Wn, strip_geometry(Wn, out_strip, P)[2]) if out_strip else (P, Cc, Wn, Wn, Wn),
                       dtype=torch.float32, device=gup.device)
     oo = torch.empty((P, 3), dtype=torch.int32, device=gup.device)
-    check(lib().m3d_prm_prepare_ex2(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
+    # peak_max: the launch also leaves the largest |value| of every peak's window on the output tensor (`_m3d_peak_max` [P]): the per-window
+    # operand bounds of ZwConv3d.strip
+    pm = torch.empty((P, 32), dtype=torch.float32, device=gup.device) if peak_max else None      # (one cache line per peak, value in column 0)
+    check(lib().m3d_prm_prepare_ex3(_ptr(gup), _ptr(origin_up), P, Cc, U, int(bool(pool)), int(border), _ptr(argmax), _ptr(xnext),
                                     xnext.shape[1], xnext.shape[2], xnext.shape[3], _ptr(scale), _ptr(norm), norm.shape[1],
                                     norm.shape[2], norm.shape[3], in_strip, int(in_slab), out_strip, int(out_slab), _ptr(up_off), _ptr(out),
-                                    _ptr(oo), _stream()), "prm_prepare")
+                                    _ptr(oo), _ptr(pm) if pm is not None else None, _stream()), "prm_prepare")
+    if pm is not None:
+        out._m3d_peak_max = pm
     return out, oo
 
 
@@ -1221,6 +1226,26 @@ class ZwConv3d(object):
     def supports(self, shape, pool=False):
         D, H, W = (int(v) for v in shape[-3:])
         return bool(lib().m3d_conv3d_zw_supported(self.cin, self.cout, D, H, W, int(bool(pool))))
+
+    def strip(self, gn, pitch, P, out=None, bounds=None):
+        """PRM window strip gn [cin, planes, U, L] (windows side by side along x, cell p = columns [pitch p, pitch (p + 1)): strip_geometry
+        mode 2) -> [cout, planes, U, L], one operand scale per window (bounds [P, 32], column 0 = the largest |value| of each window, e.g. what
+        prm_prepare(peak_max=True) left on gn; None: swept here, m3d_prm_strip_absmax).  Returns None when the library has no
+        configuration for the shape."""
+        _need_gpu(gn)
+        assert gn.dim() == 4 and gn.shape[0] == self.cin and gn.is_contiguous() and gn.dtype == torch.float32
+        cin, D, H, L = (int(v) for v in gn.shape)
+        if L < 24 or not self.supports((D, H, L)) or gn.numel() * 4 >= 0x7FFFFF00 or pitch % 4 or L % 4:
+            return None
+        if bounds is None:                                  # (the producer did not leave them: one sweep of the strip)
+            bounds = torch.empty((P, 32), dtype=torch.float32, device=gn.device)
+            check(lib().m3d_prm_strip_absmax(_ptr(gn), C.c_longlong(cin * D * H), L, int(pitch), int(P), _ptr(bounds), _stream()), "prm_strip_absmax")
+        assert tuple(bounds.shape) == (P, 32) and bounds.dtype == torch.float32 and bounds.is_contiguous()
+        if out is None:
+            out = torch.empty((self.cout, D, H, L), dtype=torch.float32, device=gn.device)
+        check(lib().m3d_conv3d_zw_forward_strip(_ptr(gn), _ptr(self.packed), _ptr(out), cin, self.cout, D, H, L, _ptr(bounds), int(P), int(pitch),
+                                                _stream()), "conv3d_zw_forward_strip")
+        return out
 
     def units(self, shape):
         """workgroups of a launch on an input [B, cin, D, H, W] (or (D, H, W): one item): (64 channels) x (32 x 4 x 2 or 16 x 8 x 2 voxels)"""

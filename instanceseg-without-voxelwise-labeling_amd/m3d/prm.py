@@ -7,6 +7,7 @@ reference also computes (its Conv3d is patched too) is skipped: nothing back-pro
 Backward: ALL kept peaks of the tile at once, as batches of receptive-field windows (csrc/prm.hip).
 """
 import numpy as np
+import os
 import torch
 
 from . import ops
@@ -16,7 +17,7 @@ from .model import DetectorM3D, _NOSPAN
 class PRMEngine:
     def __init__(self, det: DetectorM3D, peak_chunk=None, window_budget=3 << 30, fused_stem=True, strip_wino=True, strip_min=16, wino_forward=True, small_gemm=True,
                  strip_f24=True, strip_f24_min=16, norm_stream=True, backward_streams=1, backward_split_min=8, slab_strips=True, x3_norm=True,
-                 fused_prepare=True, skip_dead_peaks=True, x3_f16=True):
+                 fused_prepare=True, skip_dead_peaks=True, x3_f16=True, strip_zw=None):
         self.det = det
         # skip_dead_peaks: a kept peak whose RPN sigmoid is exactly 1.0f has the derivative (1 - y) y == 0: its seed, every layer of its
         # back-propagation and its map are exactly zero (the reference then returns 0 / 0 = NaN for it, peak_response_mapping_3d.py:170-171).
@@ -25,6 +26,12 @@ class PRMEngine:
         # the full batch's up to summation order, as between any two batch sizes; tests/test_gpu_prm.py).  Trained detectors
         # saturate on their confident detections; rounds 1-3 of the nuclei bench were 67 dead peaks out of 67.
         self.skip_dead_peaks = bool(skip_dead_peaks)
+        # strip_zw (round 6, second half): the quad-aligned strips' backward-data convs on the f16 matrix cores (ops.ZwConv3d.strip: f16x2 cut +
+        # F(2,3) along z, one operand scale per window) where the conv has >= 64 output channels; such a layer runs conv + prepare as two
+        # launches (the fp32 kernel's fused prepare epilogue does not exist there; the prepare launch leaves every peak's largest value for
+        # the conv's per-window scales).  Nuclei tile 13.9 -> 12.4 ms, soma 4.67 -> 4.51.  None: environment M3D_PRM_STRIP_ZW (default on;
+        # 0 = the fp32 F(2x4,3x3) strips of rounds 4-5 everywhere).
+        self.strip_zw = (os.environ.get("M3D_PRM_STRIP_ZW", "1") == "1") if strip_zw is None else bool(strip_zw)
         # fused_prepare: where two consecutive layers both run on the quad-aligned strip with no pooling between them (conv3b -> conv3a,
         # conv2b -> conv2a), the upper conv's backward-data writes the lower layer's PREPARED strip from its epilogue
         # (ops.WinoConv3d.strip_prepare): the bare gradient strip is never stored and re-read, and the prepare launch disappears.
@@ -86,6 +93,7 @@ class PRMEngine:
                                     dgrad=None if w.shape[2] == 5 else ops.PackedConv3d(w, ops.W_DGRAD_RELU),
                                     dgrad_wino=self._dgrad_wino(w) if (strip_wino and w.shape[2] == 3) else None,
                                     dgrad_wino24=self._dgrad_wino(w, local=False) if (strip_wino and strip_f24 and w.shape[2] == 3) else None,
+                                    dgrad_zw=self._dgrad_zw(w) if (self.strip_zw and strip_wino and strip_f24 and w.shape[2] == 3) else None,
                                     dgrad_small=ops.SmallWindowDgrad(w) if (small_gemm and w.shape[2] == 3) else None, weight=w))
         w = P["RPN.RPN_conv.weight"]
         self.rpn = dict(norm_conv=self._norm_conv(w), dgrad=ops.PackedConv3d(w, ops.W_DGRAD_RELU),
@@ -124,6 +132,13 @@ class PRMEngine:
         wd = torch.relu(w).flip(2, 3, 4).transpose(0, 1).contiguous()
         return ops.WinoConv3d(wd, two_d=True, local=local)
 
+    @staticmethod
+    def _dgrad_zw(w):
+        """the same backward-data conv packed for the f16x2 F(2,3)z kernel; None where that kernel would idle (fewer than 64 output
+        channels = the forward conv's input channels) or has no configuration (its input channels = the forward conv's output channels % 16)"""
+        wd = torch.relu(w).flip(2, 3, 4).transpose(0, 1).contiguous()
+        return ops.ZwConv3d(wd) if (wd.shape[0] >= 64 and ops.ZwConv3d.supported(wd)) else None
+
     # ---------------------------------------------------------------- forward (peak_backprop_3d.py:37-44 per conv)
     # pr_conv3d computes two convolutions per layer: the response Y = conv(X, W, b) that feeds the next layer, and the norm conv
     # N = conv(X - min X, relu(W)) that only the backward hooks read.  Nothing of the detection path (RPN, proposals, box head, box
@@ -152,7 +167,7 @@ class PRMEngine:
                 else:
                     xn, am = y, None
             saved.append(dict(name=L["name"], x=x[0], off=None, n=None, scale=L["scale"], pool=L["pool"], argmax=None if am is None else am[0],
-                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_wino24=L["dgrad_wino24"], dgrad_small=L["dgrad_small"],
+                              xnext=xn[0], k=L["k"], dgrad=L["dgrad"], dgrad_wino=L["dgrad_wino"], dgrad_wino24=L["dgrad_wino24"], dgrad_zw=L["dgrad_zw"], dgrad_small=L["dgrad_small"],
                               weight=L["weight"], norm_conv=L["norm_conv"]))
             x = xn
         feat = x
@@ -253,7 +268,8 @@ class PRMEngine:
             slab = bool(strip) and self.slab_strips and rec["n"].shape[1] < Wn       # the layer's map is thinner than the window
             gn, origin = ops.prm_prepare(wb["t"], origin, rec["pool"], border, rec["argmax"], rec["xnext"], rec["scale"], rec["n"],
                                          in_strip=wb["strip"], out_strip=strip, up_off=wb["up_off"], dims=dims,
-                                         in_slab=wb.get("slab", False), out_slab=slab)
+                                         in_slab=wb.get("slab", False), out_slab=slab,
+                                         peak_max=(strip == 2 and rec.get("dgrad_zw") is not None))
             if rec["k"] == 5:                    # conv1a: 5^3, one input channel -> VALU stem dgrad
                 w, s = ops.prm_stem_dgrad(gn, self.stem_wf, data[0, 0], rec["off"], origin)
                 return (w, s), origin
@@ -271,6 +287,10 @@ class PRMEngine:
             """backward-data of `rec`'s conv on its prepared strip; with the next layer (`nxt`) on the quad-aligned strip too and no pool
             between them, that layer's prepare runs in this conv's epilogue"""
             cout = rec["x"].shape[0]
+            if strip == 2 and rec.get("dgrad_zw") is not None:
+                y = rec["dgrad_zw"].strip(gn, ops.strip_geometry(Wn, 2, P)[0], P, bounds=getattr(gn, "_m3d_peak_max", None))
+                if y is not None:
+                    return dict(t=y, strip=2, P=P, C=cout, U=Wn, up_off=rec["off"], slab=slab, kernel="strip f16x2 F(2,3)z", plan=None), origin
             if self.fused_prepare and strip == 2 and nxt is not None and nxt["k"] == 3 and not nxt["pool"] and wino(nxt, Wn + 2) == 2:
                 if nxt.get("ready") is not None:
                     torch.cuda.current_stream().wait_event(nxt["ready"])

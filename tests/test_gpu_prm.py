@@ -177,6 +177,14 @@ def test_quad_prepare_kernel_writes_the_element_kernels_strip_bit_for_bit(U, bor
                 if 0 <= z < Wn:
                     exp[:, zk, :, lead + p_ * pitch:lead + p_ * pitch + Wn] = ref[p_, :, z]
         assert torch.equal(got, exp), (U, slab, up_off is not None, int((got != exp).sum()))
+        # round 6: the same launch can leave every peak's largest |value| (the per-window operand bounds of ZwConv3d.strip): the same
+        # strip bit for bit, the maxima exactly those of the windows
+        got2, _ = ops.prm_prepare(gup, org, False, border, None, xnext, scale, norm, out_strip=2, up_off=up_off, dims=(P, Cc, U), out_slab=slab,
+                                  peak_max=True)
+        assert torch.equal(got2, got)
+        pm = got2._m3d_peak_max
+        want = torch.stack([got[..., p_ * pitch:(p_ + 1) * pitch].abs().max() for p_ in range(P)])
+        assert tuple(pm.shape) == (P, 32) and torch.equal(pm[:, 0], want), (pm[:, 0], want)
     assert int((ref != 0).sum()) > 0
 
 
@@ -1009,3 +1017,41 @@ def test_odd_tile_with_an_arg_max_near_tie_equals_the_oracle_once_the_tie_is_rou
         with torch.no_grad():
             ref = O.prm_backward(P, osaved, p, p2.shape)[0].numpy()
         _maps_close(dense[i], ref, None, "odd tile peak %d" % i)
+
+
+def test_strip_conv_on_the_f16_matrix_cores_has_one_scale_per_window_and_is_local():
+    """ops.ZwConv3d.strip (m3d_conv3d_zw_forward_strip): the backward-data conv of a quad-aligned window strip against float64 window by
+    window although the windows' magnitudes span ten orders; a sub-batch of the windows gives the batch's values bit for bit; outputs of a
+    window read nothing of its neighbours (a neighbour filled with huge values changes nothing)."""
+    from m3d import ops
+    g = torch.Generator().manual_seed(3)
+    cin, cout, n, P = 64, 64, 18, 9
+    pitch, lead, L = ops.strip_geometry(n, 2, P)
+    w = torch.relu(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05)
+    wins = torch.relu(torch.randn(P, cin, n, n, n, generator=g)) * (10.0 ** torch.linspace(-7, 3, P)).view(P, 1, 1, 1, 1)
+    strip = torch.zeros(cin, n, n, L)
+    for p in range(P):
+        strip[..., lead + p * pitch:lead + p * pitch + n] = wins[p]
+    conv = ops.ZwConv3d(w.cuda())
+    y = conv.strip(strip.cuda().contiguous(), pitch, P)
+    assert y is not None and tuple(y.shape) == (cout, n, n, L)
+    for p in range(P):
+        ref = torch.nn.functional.conv3d(wins[p:p + 1].double(), w.double(), padding=1)[0]
+        got = y[..., lead + p * pitch:lead + p * pitch + n].cpu().double()
+        assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item(), p
+    # a sub-batch (windows 2..5) on its own strip: the same bits
+    P2 = 4
+    pitch2, lead2, L2 = ops.strip_geometry(n, 2, P2)
+    assert (pitch2, lead2) == (pitch, lead)
+    s2 = torch.zeros(cin, n, n, L2)
+    for k in range(P2):
+        s2[..., lead + k * pitch:lead + k * pitch + n] = wins[2 + k]
+    y2 = conv.strip(s2.cuda().contiguous(), pitch, P2)
+    for k in range(P2):
+        assert torch.equal(y2[..., lead + k * pitch:lead + k * pitch + n], y[..., lead + (2 + k) * pitch:lead + (2 + k) * pitch + n])
+    # locality: window 4 replaced by huge values leaves windows 3 and 5 as they were
+    s3 = strip.clone()
+    s3[..., lead + 4 * pitch:lead + 4 * pitch + n] = 1e30
+    y3 = conv.strip(s3.cuda().contiguous(), pitch, P)
+    for p in (3, 5):
+        assert torch.equal(y3[..., lead + p * pitch:lead + p * pitch + n], y[..., lead + p * pitch:lead + p * pitch + n])
