@@ -606,6 +606,14 @@ int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out,
 int m3d_prm_strip_absmax(const float* d_strip, long long rows, int L, int pitch, int num_peaks, float* d_out, void* stream);
 int m3d_conv3d_zw_forward_strip(const float* d_in, const void* d_packed, float* d_out, int cin, int cout, int depth, int height,
                                 int width, const float* d_col_bound, int num_peaks, int pitch, void* stream);
+/* m3d_conv3d_zw_forward_strip FUSED with the prepare step of the layer below: the contract of m3d_prm_strip_dgrad_prepare (the fp32
+ * F(2x4,3x3) kernel's fused form), the same arguments plus d_col_bound (and d_packed from m3d_conv3d_zw_pack).  The strip it writes is the
+ * two launches' (m3d_conv3d_zw_forward_strip, then m3d_prm_prepare_ex2 with pool = 0, border = 1) bit for bit; the bare gradient strip is
+ * never stored.  M3D_EUNSUPPORTED where the kernel has no configuration (the caller takes the two launches). */
+int m3d_prm_strip_dgrad_prepare_zw(const float* d_gn, const void* d_packed, int cin, int cout, int num_peaks, int window, int in_slab,
+                                   const int32_t* d_origin, const float* d_xnext, const float* d_norm, const float* d_scale,
+                                   const float* d_up_offset, int depth, int height, int width, int out_slab,
+                                   const float* d_col_bound, float* d_out, int32_t* d_origin_out, void* stream);
 
 /* Round 5: backward-data of a 3^3 conv on the quad-aligned strip FUSED with the prepare step of the layer below (no pooling between them):
  * d_gn [cin, in_planes, window, L(window)] (m3d_prm_prepare_ex2's out_strip = 2 layout; in_slab: the map's planes), d_packed =

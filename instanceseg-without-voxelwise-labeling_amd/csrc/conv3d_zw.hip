@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "m3d_common.h"
+#include "conv3d_wino24.h"      // m3d_w24::PrepEpi: the fused `prepare` epilogue of the PRM strips (same contract as the fp32 kernel's)
 
 namespace {
 
@@ -112,6 +113,7 @@ struct ZwArgs {
   // strip mode (PRM windows side by side along x, one scale per window): col_bound[p] = largest |input| of window p, cell p = columns
   // [pitch p, pitch (p + 1)) (pitch a multiple of 4: a 16-byte output quad never straddles two cells); col_bound == null: one scale (in_max)
   const float* col_bound; int pitch, npeaks;
+  m3d_w24::PrepEpi pe;     // PREP instantiation only
 };
 
 __device__ __forceinline__ int zw_xcd_contiguous(int bid, int n) {
@@ -120,8 +122,9 @@ __device__ __forceinline__ int zw_xcd_contiguous(int bid, int n) {
   return xcd * per + (xcd < rem ? xcd : rem) + idx;
 }
 
-template <int XB, bool POOL>
+template <int XB, bool POOL, bool PREP = false>
 __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
+  static_assert(!PREP || (XB == 32 && !POOL), "fused prepare: the un-pooled 32-wide form");
   using C = ZwCfg<XB>;
   static_assert(!POOL || XB == 32, "fused pool: 32-wide column blocks (a row pair = two blocks of the finishing wave)");
   extern __shared__ float lds_f[];
@@ -390,6 +393,99 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         o0[i] = (m[0] + m[1]) + m[2]; o1[i] = (m[1] - m[2]) - m[3];
       }
       if (hasn) __syncthreads();                       // every wave has its sums: the staging buffers are free for the next unit
+      if constexpr (PREP) {
+        // ---- fused `prepare` of the layer below (m3d_w24::PrepEpi; the element rule of prm_prepare_kernel, evaluated in the same order on
+        // the value the un-fused launch would have stored: the two-launch path's strip bit for bit).  Strip column x -> (peak, window column).
+        const m3d_w24::PrepEpi& pe = a.pe;
+        constexpr float kEpsP = 1e-10f;                                    // peak_backprop_3d.py:29
+        const int p = (int)(((float)x + 0.5f) * pe.inv_pitchA);            // exact: x < 2^22
+        if (p < pe.P && y < a.H && x < a.W) {
+          const int cxw = x - p * pe.pitchA, ix0 = cxw - pe.leadA;
+          const int oz = pe.origin[3 * p], oy = pe.origin[3 * p + 1], ox = pe.origin[3 * p + 2];
+          const float xoff = *pe.xoff;
+          const long long colB = (long long)p * pe.pitchB + pe.leadB + ix0 + 1;       // B column of the quad's first element
+          const bool quadB = ((colB & 3) == 0) && colB >= 0 && colB + 3 < pe.LB;
+          const int MHW = pe.MH * pe.MW, MV = pe.MD * MHW;
+          const int qy = oy + y;
+          bool okx[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const int ix = ix0 + c, qx = ox + ix; okx[c] = (ix >= 0) & (ix < pe.U) & (qx >= 0) & (qx < pe.MW); }
+          const bool allx = okx[0] & okx[1] & okx[2] & okx[3], anyx = okx[0] | okx[1] | okx[2] | okx[3];
+          const bool wave_fast = __builtin_amdgcn_ballot_w64(anyx & !allx) == 0ull;
+          // per plane: validity and map row
+          bool okp[2]; int zB[2], rbase[2];
+#pragma unroll
+          for (int zz = 0; zz < 2; ++zz) {
+            const int z = z0 + zz;
+            if (z == 0 && y == 0 && cxw == 0 && cur.cg == 0 && wave == 0 && (lane >> 5) == 0 && zz == 0) {
+              pe.origin_out[3 * p] = oz - 1; pe.origin_out[3 * p + 1] = oy - 1; pe.origin_out[3 * p + 2] = ox - 1;
+            }
+            const int iz = pe.slabA ? z - oz : z;
+            const int qz = oz + iz;
+            bool ok = (z < a.D) & (iz >= 0) & (iz < pe.U);
+            if (pe.slabB) ok = ok & (qz >= 0) & (qz < pe.MD);               // B stores the map's planes only
+            okp[zz] = ok;
+            zB[zz] = pe.slabB ? qz : iz + 1;
+            const bool okr = ok & (qz >= 0) & (qz < pe.MD) & (qy >= 0) & (qy < pe.MH);
+            rbase[zz] = okr ? qz * MHW + qy * pe.MW : -1;
+          }
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+          f32x4 xn[4][2], nn[4][2];
+          float scv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int co = cur.cg * 64 + 16 * i + 2 * wave + (lane >> 5);
+            const bool okc = co < a.cout;
+            scv[i] = (pe.scale && okc) ? pe.scale[co] : 1.f;
+            const int cbm = okc ? co * MV : 0;                               // (host: cout * MV < 2^31)
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz) {
+              if (wave_fast) {
+                const int pos = cbm + ((rbase[zz] >= 0 && allx) ? rbase[zz] + ox + ix0 : 0);
+                xn[i][zz] = *reinterpret_cast<const f32x4u*>(pe.xnext + pos);
+                nn[i][zz] = *reinterpret_cast<const f32x4u*>(pe.norm + pos);
+              } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const int pos = cbm + ((rbase[zz] >= 0 && okx[c]) ? rbase[zz] + ox + ix0 + c : 0);
+                  xn[i][zz][c] = pe.xnext[pos];
+                  nn[i][zz][c] = pe.norm[pos];
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cl = 16 * i + 2 * wave + (lane >> 5), co = cur.cg * 64 + cl;
+            if (co >= a.cout) continue;
+            const float sc = aff[cl] * inv_e;
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz) {
+              if (!okp[zz]) continue;
+              float g[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                float v = (zz ? o1[i][c] : o0[i][c]) * sc;                  // what the un-fused launch stores (powers of two: exact)
+                v = (xn[i][zz][c] - xoff) * v;                              // PreHook of the layer just back-propagated (:16-18)
+                if (!(xn[i][zz][c] > 0.f)) v = 0.f;                         // ReLU backward
+                if (pe.scale) v = v * scv[i];                               // eval-BatchNorm backward
+                v = (nn[i][zz][c] < kEpsP) ? 0.f : v / (fabsf(nn[i][zz][c]) + kEpsP);   // PostHook (:30-33)
+                g[c] = (rbase[zz] >= 0 && okx[c]) ? v : 0.f;
+              }
+              float* dst = a.out + (size_t)co * pe.ocs + (size_t)zB[zz] * pe.ozs + (size_t)(y + 1) * pe.LB + colB;
+              if (quadB) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{g[0], g[1], g[2], g[3]};
+              } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                               // B window columns 0 .. U + 1 only (others belong to other cells)
+                  const int ix = ix0 + c;
+                  if (ix >= -1 && ix <= pe.U && colB + c >= 0 && colB + c < pe.LB) dst[c] = g[c];
+                }
+              }
+            }
+          }
+        }
+      } else {
       const bool quad_ok = ((a.W & 3) == 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -412,6 +508,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
               if (x + e < a.W) { o[e] = v[e]; vmax = fmaxf(vmax, fabsf(v[e])); }
           }
         }
+      }
       }
     } else {
       // fused MaxPool3d(2,2): wave (point p, block) finishes row pair p & 1 (column blocks 2 rp, 2 rp + 1) for channel quads 2 (p >> 1) + {0, 1};
@@ -472,7 +569,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   }
 }
 
-template <int XB, bool POOL>
+template <int XB, bool POOL, bool PREP = false>
 int launch_zw(ZwArgs a, hipStream_t st) {
   using C = ZwCfg<XB>;
   a.tiles_x = (a.W + C::TX - 1) / C::TX; a.tiles_y = (a.H + C::TY - 1) / C::TY; a.tiles_z = (a.D + C::TZ - 1) / C::TZ;
@@ -488,7 +585,7 @@ int launch_zw(ZwArgs a, hipStream_t st) {
   }
   const long long rounds = (units + cus - 1) / cus;
   const long long blocks = (units + rounds - 1) / rounds;
-  auto kern = conv3d_zw_kernel<XB, POOL>;
+  auto kern = conv3d_zw_kernel<XB, POOL, PREP>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ZW_NT), C::LDS_BYTES, st, a);
   return m3d::check_launch("conv3d_zw");
@@ -579,6 +676,44 @@ M3D_API int m3d_conv3d_zw_forward_strip(const float* d_in, const void* d_packed,
   a.B = 1; a.cin = cin; a.cout = cout; a.D = depth; a.H = height; a.W = width;
   a.col_bound = d_col_bound; a.pitch = pitch; a.npeaks = num_peaks;
   return launch_zw<32, false>(a, m3d::as_stream(stream));
+}
+
+/* m3d_conv3d_zw_forward_strip FUSED with the prepare step of the layer below - the contract of m3d_prm_strip_dgrad_prepare (fp32 F(2x4,3x3)
+ * kernel), arguments as there plus d_col_bound: d_gn = the prepared gradient strip [cin, in_planes, window, L(window)], d_out = the layer
+ * below's prepared strip [cout, out_planes, window + 2, L(window + 2)] (zero-filled here), d_origin_out = d_origin - 1.  The values are
+ * those of the two launches (strip conv, then m3d_prm_prepare_ex2 with pool = 0, border = 1) bit for bit. */
+M3D_API int m3d_prm_strip_dgrad_prepare_zw(const float* d_gn, const void* d_packed, int cin, int cout, int num_peaks, int window, int in_slab,
+                                           const int32_t* d_origin, const float* d_xnext, const float* d_norm, const float* d_scale,
+                                           const float* d_up_offset, int depth, int height, int width, int out_slab,
+                                           const float* d_col_bound, float* d_out, int32_t* d_origin_out, void* stream) {
+  if (num_peaks < 0 || cin <= 0 || cout <= 0 || window <= 0 || depth <= 0 || height <= 0 || width <= 0) return M3D_EINVAL;
+  if (num_peaks == 0) return M3D_OK;
+  if (!d_gn || !d_packed || !d_origin || !d_xnext || !d_norm || !d_up_offset || !d_out || !d_origin_out || !d_col_bound) return M3D_EINVAL;
+  int pitchA, leadA, pitchB, leadB; long long LA, LB;
+  m3d::strip_geom(window, 2, num_peaks, &pitchA, &leadA, &LA);
+  m3d::strip_geom(window + 2, 2, num_peaks, &pitchB, &leadB, &LB);
+  const int ZA = in_slab ? depth : window, ZB = out_slab ? depth : window + 2;
+  if (!m3d_conv3d_zw_supported(cin, cout, ZA, window, (int)LA, 0) || LA < 24 || (pitchA & 3)) return M3D_EUNSUPPORTED;
+  if ((size_t)cin * ZA * window * LA * sizeof(float) >= 0x7FFFFF00ull || (long long)(window + 2) * LB >= 0x7FFFFFFFll || LA >= (1 << 22))
+    return M3D_EUNSUPPORTED;
+  if ((long long)cout * depth * height * width >= 0x7FFFFFFFll || width < 4) return M3D_EUNSUPPORTED;   // 32-bit map offsets, 16-byte row reads
+  hipStream_t st = m3d::as_stream(stream);
+  const size_t out_bytes = (size_t)cout * ZB * (window + 2) * LB * sizeof(float);
+  if (hipMemsetAsync(d_out, 0, out_bytes, st) != hipSuccess) return M3D_ELAUNCH;
+  ZwArgs a{};
+  a.x = d_gn; a.wp = static_cast<const u32x4*>(d_packed); a.out = d_out;
+  a.in_max = d_col_bound;
+  a.wamax = reinterpret_cast<const float*>(static_cast<const char*>(d_packed) + zw_plane_bytes(cin, cout));
+  a.B = 1; a.cin = cin; a.cout = cout; a.D = ZA; a.H = window; a.W = (int)LA;
+  a.col_bound = d_col_bound; a.pitch = pitchA; a.npeaks = num_peaks;
+  m3d_w24::PrepEpi& pe = a.pe;
+  pe.xnext = d_xnext; pe.norm = d_norm; pe.scale = d_scale; pe.xoff = d_up_offset; pe.origin = d_origin; pe.origin_out = d_origin_out;
+  pe.P = num_peaks; pe.U = window; pe.MD = depth; pe.MH = height; pe.MW = width;
+  pe.pitchA = pitchA; pe.leadA = leadA; pe.slabA = in_slab ? 1 : 0;
+  pe.pitchB = pitchB; pe.leadB = leadB; pe.slabB = out_slab ? 1 : 0;
+  pe.LB = LB; pe.ocs = (long long)ZB * (window + 2) * LB; pe.ozs = (int)((window + 2) * LB);
+  pe.inv_pitchA = 1.0f / (float)pitchA;
+  return launch_zw<32, false, true>(a, st);
 }
 
 M3D_API int m3d_conv3d_zw_forward(const float* d_in, const void* d_packed, float* d_out, int batch, int cin, int cout, int depth, int height,

@@ -19,7 +19,7 @@ SYMBOLS = [
     "m3d_nms3d_workspace_bytes", "m3d_nms3d", "m3d_bbox_overlaps3d", "m3d_bbox_transform3d",
     "m3d_generate_proposals3d_workspace_bytes", "m3d_generate_proposals3d",
     "m3d_conv3d_packed_weight_bytes", "m3d_conv3d_pack_weights", "m3d_conv3d_forward", "m3d_conv3d_forward_dilated", "m3d_conv3d_forward_windowed", "m3d_conv3d_forward_pool2",
-    "m3d_prm_seed", "m3d_prm_seed_ex", "m3d_prm_strip_geometry", "m3d_prm_select_peaks", "m3d_prm_select_peaks_ex", "m3d_prm_prepare", "m3d_prm_stem_prepare_weights", "m3d_prm_stem_dgrad", "m3d_prm_scatter", "m3d_prm_den_pool", "m3d_prm_stem_mfma_prepare_weights", "m3d_prm_stem_dgrad_fused_supported", "m3d_prm_stem_dgrad_fused", "m3d_prm_stem_dgrad_fused_ex", "m3d_prm_prepare_ex", "m3d_prm_stem_dgrad_fused_ex2", "m3d_prm_prepare_ex2", "m3d_prm_prepare_ex3", "m3d_prm_strip_dgrad_prepare", "m3d_conv3d_x3_packed_bytes", "m3d_conv3d_x3f_packed_bytes", "m3d_conv3d_x3f_pack", "m3d_conv3d_x3f_forward_ws", "m3d_reduce_minmax_multi", "m3d_reduce_minmax_multi_workspace_bytes", "m3d_conv3d_x3_supported", "m3d_conv3d_x3_pack", "m3d_conv3d_x3_forward", "m3d_conv3d_x3_workspace_bytes", "m3d_conv3d_x3_forward_ws", "m3d_conv3d_x3_launch_units", "m3d_conv3d_zw_supported", "m3d_conv3d_zw_packed_bytes", "m3d_conv3d_zw_pack", "m3d_conv3d_zw_slots", "m3d_conv3d_zw_bound_of", "m3d_conv3d_zw_forward", "m3d_conv3d_zw_forward_strip", "m3d_prm_strip_absmax", "m3d_prm_small_dgrad_packed_bytes", "m3d_prm_small_dgrad_pack", "m3d_prm_small_dgrad_f16_supported", "m3d_prm_small_dgrad_f16_packed_bytes", "m3d_prm_small_dgrad_f16_pack", "m3d_prm_small_dgrad_f16_workspace_bytes", "m3d_prm_small_dgrad_f16", "m3d_prm_small_dgrad",
+    "m3d_prm_seed", "m3d_prm_seed_ex", "m3d_prm_strip_geometry", "m3d_prm_select_peaks", "m3d_prm_select_peaks_ex", "m3d_prm_prepare", "m3d_prm_stem_prepare_weights", "m3d_prm_stem_dgrad", "m3d_prm_scatter", "m3d_prm_den_pool", "m3d_prm_stem_mfma_prepare_weights", "m3d_prm_stem_dgrad_fused_supported", "m3d_prm_stem_dgrad_fused", "m3d_prm_stem_dgrad_fused_ex", "m3d_prm_prepare_ex", "m3d_prm_stem_dgrad_fused_ex2", "m3d_prm_prepare_ex2", "m3d_prm_prepare_ex3", "m3d_prm_strip_dgrad_prepare", "m3d_conv3d_x3_packed_bytes", "m3d_conv3d_x3f_packed_bytes", "m3d_conv3d_x3f_pack", "m3d_conv3d_x3f_forward_ws", "m3d_reduce_minmax_multi", "m3d_reduce_minmax_multi_workspace_bytes", "m3d_conv3d_x3_supported", "m3d_conv3d_x3_pack", "m3d_conv3d_x3_forward", "m3d_conv3d_x3_workspace_bytes", "m3d_conv3d_x3_forward_ws", "m3d_conv3d_x3_launch_units", "m3d_conv3d_zw_supported", "m3d_conv3d_zw_packed_bytes", "m3d_conv3d_zw_pack", "m3d_conv3d_zw_slots", "m3d_conv3d_zw_bound_of", "m3d_conv3d_zw_forward", "m3d_conv3d_zw_forward_strip", "m3d_prm_strip_dgrad_prepare_zw", "m3d_prm_strip_absmax", "m3d_prm_small_dgrad_packed_bytes", "m3d_prm_small_dgrad_pack", "m3d_prm_small_dgrad_f16_supported", "m3d_prm_small_dgrad_f16_packed_bytes", "m3d_prm_small_dgrad_f16_pack", "m3d_prm_small_dgrad_f16_workspace_bytes", "m3d_prm_small_dgrad_f16", "m3d_prm_small_dgrad",
     "m3d_maxpool3d_2x_forward", "m3d_maxpool3d_2x_backward",
     "m3d_reduce_min_workspace_bytes", "m3d_reduce_min", "m3d_reduce_min_multi_workspace_bytes", "m3d_reduce_min_multi",
     "m3d_otsu2d_workspace_bytes", "m3d_otsu2d_batch", "m3d_prm_quantize_u8", "m3d_roi_normalize", "m3d_prm_quantize_windows_u8", "m3d_prm_quantize_windows_compact_u8", "m3d_roi_normalize_ws", "m3d_roi_normalize_idx",

@@ -1237,15 +1237,43 @@ class ZwConv3d(object):
         cin, D, H, L = (int(v) for v in gn.shape)
         if L < 24 or not self.supports((D, H, L)) or gn.numel() * 4 >= 0x7FFFFF00 or pitch % 4 or L % 4:
             return None
-        if bounds is None:                                  # (the producer did not leave them: one sweep of the strip)
-            bounds = torch.empty((P, 32), dtype=torch.float32, device=gn.device)
-            check(lib().m3d_prm_strip_absmax(_ptr(gn), C.c_longlong(cin * D * H), L, int(pitch), int(P), _ptr(bounds), _stream()), "prm_strip_absmax")
-        assert tuple(bounds.shape) == (P, 32) and bounds.dtype == torch.float32 and bounds.is_contiguous()
+        bounds = self._strip_bounds(gn, pitch, P, bounds)
         if out is None:
             out = torch.empty((self.cout, D, H, L), dtype=torch.float32, device=gn.device)
         check(lib().m3d_conv3d_zw_forward_strip(_ptr(gn), _ptr(self.packed), _ptr(out), cin, self.cout, D, H, L, _ptr(bounds), int(P), int(pitch),
                                                 _stream()), "conv3d_zw_forward_strip")
         return out
+
+    def _strip_bounds(self, gn, pitch, P, bounds):
+        if bounds is None:                                  # (the producer did not leave them: one sweep of the strip)
+            bounds = torch.empty((P, 32), dtype=torch.float32, device=gn.device)
+            check(lib().m3d_prm_strip_absmax(_ptr(gn), C.c_longlong(gn.shape[0] * gn.shape[1] * gn.shape[2]), int(gn.shape[3]), int(pitch), int(P),
+                                             _ptr(bounds), _stream()), "prm_strip_absmax")
+        assert tuple(bounds.shape) == (P, 32) and bounds.dtype == torch.float32 and bounds.is_contiguous()
+        return bounds
+
+    def strip_prepare(self, gn, dims, origin, xnext, scale, norm, up_off, in_slab=False, out_slab=False, bounds=None):
+        """WinoConv3d.strip_prepare on this kernel (m3d_prm_strip_dgrad_prepare_zw): the strip conv fused with the prepare step of the layer
+        below; (strip [cout, planes', U + 2, L(U + 2)], origin - 1), or None where the library has no configuration."""
+        _need_gpu(gn, origin, xnext, norm, up_off)
+        P, cin, U = (int(v) for v in dims)
+        assert cin == self.cin and xnext.shape[0] == self.cout == norm.shape[0] and xnext.shape == norm.shape
+        MD, MH, MW = (int(v) for v in norm.shape[1:])
+        in_slab, out_slab = bool(in_slab), bool(out_slab)
+        pitch, _, L = strip_geometry(U, 2, P)
+        assert tuple(gn.shape) == (cin, MD if in_slab else U, U, L) and gn.is_contiguous()
+        if L < 24 or pitch % 4 or gn.numel() * 4 >= 0x7FFFFF00 or not self.supports((gn.shape[1], U, L)):
+            return None
+        bounds = self._strip_bounds(gn, pitch, P, bounds)
+        out = torch.empty((self.cout, MD if out_slab else U + 2, U + 2, strip_geometry(U + 2, 2, P)[2]), dtype=torch.float32, device=gn.device)
+        oo = torch.empty((P, 3), dtype=torch.int32, device=gn.device)
+        rc = lib().m3d_prm_strip_dgrad_prepare_zw(_ptr(gn), _ptr(self.packed), cin, self.cout, P, U, int(in_slab), _ptr(origin), _ptr(xnext),
+                                                  _ptr(norm), _ptr(scale), _ptr(up_off), MD, MH, MW, int(out_slab), _ptr(bounds), _ptr(out),
+                                                  _ptr(oo), _stream())
+        if rc == -4:                                        # M3D_EUNSUPPORTED
+            return None
+        check(rc, "prm_strip_dgrad_prepare_zw")
+        return out, oo
 
     def units(self, shape):
         """workgroups of a launch on an input [B, cin, D, H, W] (or (D, H, W): one item): (64 channels) x (32 x 4 x 2 or 16 x 8 x 2 voxels)"""

@@ -288,7 +288,17 @@ class PRMEngine:
             between them, that layer's prepare runs in this conv's epilogue"""
             cout = rec["x"].shape[0]
             if strip == 2 and rec.get("dgrad_zw") is not None:
-                y = rec["dgrad_zw"].strip(gn, ops.strip_geometry(Wn, 2, P)[0], P, bounds=getattr(gn, "_m3d_peak_max", None))
+                pb = getattr(gn, "_m3d_peak_max", None)
+                if self.fused_prepare and nxt is not None and nxt["k"] == 3 and not nxt["pool"] and wino(nxt, Wn + 2) == 2:
+                    if nxt.get("ready") is not None:
+                        torch.cuda.current_stream().wait_event(nxt["ready"])
+                    nslab = self.slab_strips and nxt["n"].shape[1] < Wn + 2
+                    r = rec["dgrad_zw"].strip_prepare(gn, (P, gn.shape[0], Wn), origin, nxt["xnext"], nxt["scale"], nxt["n"], rec["off"],
+                                                      in_slab=slab, out_slab=nslab, bounds=pb)
+                    if r is not None:
+                        return dict(t=r[0], strip=2, P=P, C=cout, U=Wn + 2, up_off=None, slab=nslab, prepared=True,
+                                    kernel="strip f16x2 F(2,3)z + fused prepare of " + nxt.get("name", "?"), plan=None), r[1]
+                y = rec["dgrad_zw"].strip(gn, ops.strip_geometry(Wn, 2, P)[0], P, bounds=pb)
                 if y is not None:
                     return dict(t=y, strip=2, P=P, C=cout, U=Wn, up_off=rec["off"], slab=slab, kernel="strip f16x2 F(2,3)z", plan=None), origin
             if self.fused_prepare and strip == 2 and nxt is not None and nxt["k"] == 3 and not nxt["pool"] and wino(nxt, Wn + 2) == 2:
