@@ -158,7 +158,13 @@ class PRMEngine:
                 xn, am = L["conv"].pooled(x, scale=L["scale"], shift=L["shift"], relu=True, return_argmax=True)
             else:
                 wn = det.body_wino[li] if self.wino_forward else None
-                if wn is not None and not L["pool"] and wn.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
+                zw = det.body_zw[li] if (self.wino_forward and det.conv_f16) else None
+                if zw is not None and not L["pool"] and x[0].numel() * 4 < 0x7FFFFFFF and det._zw_ok(zw, x):
+                    # response conv on the f16 matrix cores as in detection mode (csrc/conv3d_zw.hip; the input's bound: left by the
+                    # launch that produced x, else one sweep)
+                    y, ym = zw(x, det._bound(x), scale=L["scale"], shift=L["shift"], relu=True)
+                    y._m3d_bound = (ym, y._version)
+                elif wn is not None and not L["pool"] and wn.supports(x.shape[-1], (x.shape[0],) + tuple(x.shape[2:])):
                     y = wn(x, scale=L["scale"], shift=L["shift"], relu=True)        # response conv: Winograd as in detection mode
                 else:
                     y = L["conv"](x, scale=L["scale"], shift=L["shift"], relu=True)
