@@ -214,13 +214,15 @@ def run_dry(args, rank, world, dist):
 
 
 # ------------------------------------------------------------------------------------------------ PRM workloads
-def cone_limited_gflop_per_peak(stride, in_size=None):
-    """(algorithmic, issued) GFLOP of one peak's back-propagation when every layer only computes its receptive-field window (SURVEY
-    8a-12): window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each un-pool), 2*Cin*Cout*k^3 per
-    voxel of the n^3 window.  Issued = what the kernels put on the matrix cores: every product for the small windows; for the strips
-    the voxels the strip really holds (planes: min(n, depth of the layer's map) - the depth-clipped strips -, rows n, columns the
-    strip's pitch) x 1/3 (F(2x4,3x3), from 16 voxels); the 5^3 stem occupies 32 MFMA rows for
-    its 25 (dy, dx) taps."""
+def cone_limited_gflop_per_peak(stride, in_size=None, strip_zw=True):
+    """(algorithmic GFLOP, matrix-pipe milliseconds at peak, issued GFLOP) of one peak's back-propagation when every layer only computes its
+    receptive-field window: window side per layer from the top (3 -> 5 -> 7 at the RPN stride, x2 + border after each
+    un-pool), 2*Cin*Cout*k^3 per voxel of the n^3 window.  Issued = what the kernels put on the matrix cores: every fp32 product for the
+    small windows (their f16x2 form since round 6: 3 f16 products per product); for the strips the voxels the strip really holds (planes:
+    min(n, depth of the layer's map) - the depth-clipped strips -, rows n, columns the strip's pitch) x 2 f16 products per multiply-add
+    where the strip runs on the f16x2 F(2,3)z kernel (round 6: backward-data convs with >= 64 output channels) or x 1/3 fp32 products
+    (F(2x4,3x3): the 64 -> 32 layer); the 5^3 stem occupies 32 fp32 MFMA rows for its 25 (dy, dx) taps.  Pipe time = issued / the peak of
+    each launch's operand type (fp32 157.3 TF, f16 2500 TF)."""
     if stride == 8:
         L = [(256, 256, 3, 3, 8), (256, 256, 3, 5, 8), (256, 128, 3, 7, 8), (128, 128, 3, 16, 4), (128, 64, 3, 18, 4), (64, 64, 3, 38, 2),
              (64, 32, 3, 40, 2), (32, 1, 5, 84, 1)]
@@ -229,16 +231,26 @@ def cone_limited_gflop_per_peak(stride, in_size=None):
     depth = (in_size[0] if in_size else 64)
     alg = sum(2.0 * a * b * k ** 3 * n ** 3 for a, b, k, n, _ in L) / 1e9
     issued = 0.0
+    pipe_s = 0.0
     for a, b, k, n, down in L:
+        peak = FP32_MFMA_PEAK_TFLOPS
         if k == 5:
             vox, f = n ** 3, 32.0 / 25.0
         elif n >= 16:
             pitch = 4 * ((n + (1 if n % 4 else 0) + 3) // 4) if n % 4 else n + 4      # quad-aligned strip (strip_geom mode 2): 16 -> 20, 18 -> 20, 38 -> 40, 40 -> 44
-            vox, f = min(n, depth // down) * n * pitch, 1.0 / 3.0
+            vox = min(n, depth // down) * n * pitch
+            if strip_zw and b >= 64 and a % 16 == 0:
+                f, peak = 2.0, BF16_MFMA_PEAK_TFLOPS
+            else:
+                f = 1.0 / 3.0
         else:
-            vox, f = n ** 3, 1.0
-        issued += 2.0 * a * b * k ** 3 * vox * f
-    return alg, issued / 1e9
+            vox, f = n ** 3, (3.0 if a % 16 == 0 else 1.0)                          # small-window GEMMs: f16x2 where the forward cout % 16 == 0
+            if a % 16 == 0:
+                peak = BF16_MFMA_PEAK_TFLOPS
+        fl = 2.0 * a * b * k ** 3 * vox * f
+        issued += fl
+        pipe_s += fl / (peak * 1e12)
+    return alg, pipe_s * 1e3, issued / 1e9
 
 
 def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
@@ -331,23 +343,27 @@ def bench_prm(args, rank, world, dist, cpu_budget_s=25.0):
     # cone-limited work of the back-propagation: receptive-field windows per layer, dgrad with relu(W); algorithmic =
     # 2*Cin*Cout*k^3 per window voxel, issued = what the kernels put on the matrix cores (strips: 4/9 or 1/3 of the products of the voxels
     # the strip holds, every product for the small-window GEMMs, 32/25 for the stem whose 25 (dy, dx) taps occupy 32 MFMA rows)
-    cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
+    cone, pipe_ms, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size, strip_zw=eng.strip_zw)
     dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if nuclei else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"     # the largest backward launch
     roof = None
     if back_ms and nlive:
+        frac = nlive * pipe_ms / back_ms
         roof = {"bound": "mfma", "kernel": "peak back-propagation of the tile's %d peaks (%d back-propagated, the rest saturated: map 0 / 0): prm_seed, "
-                                           "prm_prepare*, the strip-Winograd / small-window / stem dgrad kernels, window sums - the backward kernels "
+                                           "prm_prepare*, the strip / small-window / stem dgrad kernels, window sums - the backward kernels "
                                            "ONLY (HIP-event span around them)" % (npeaks, nlive),
-                "achieved": nlive * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": nlive * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                "achieved": frac * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": frac,
                 "frac_algorithmic": nlive * cone / back_ms / FP32_MFMA_PEAK_TFLOPS,
                 "algorithmic_tflops": nlive * cone / back_ms,
-                "cone_limited_gflop_per_peak": cone, "issued_gflop_per_peak": cone_issued, "backward_ms": back_ms,
-                "frac_definition": "frac = fp32 MFMA FLOPs issued by the window convolutions of all peaks / backward_ms / 157.3 TF (round 4: the "
-                                   "issued count follows the kernels - F(2x4) strips issue 1/3, depth-clipped strips hold fewer planes - so it is "
-                                   "lower than the 4/9-of-n^3 count of rounds 2-3 for the same time); frac_algorithmic = the cone-limited direct "
-                                   "count (n^3 windows) over the same time.  backward_ms is a span on the tile's stream and includes the time the "
-                                   "first layers share the chip with the norm convs of the second stream"}
+                "cone_limited_gflop_per_peak": cone, "issued_gflop_per_peak": cone_issued, "pipe_ms_at_peak_per_peak": pipe_ms, "backward_ms": back_ms,
+                "frac_definition": "frac = the window convolutions' matrix-pipe time at peak / backward_ms: per layer, FLOPs issued / the peak of "
+                                   "the layer's operand type - fp32 MFMA 157.3 TF for the stem (32 MFMA rows for 25 taps) and the 64 -> 32 strip "
+                                   "(F(2x4,3x3): 1/3 of the products), f16 MFMA 2 500 TF for the f16x2 launches (round 6: strips with >= 64 "
+                                   "output channels on the F(2,3)z kernel, 2 f16 products per multiply-add of the voxels the strip holds; the "
+                                   "3^3 / 5^3 / 7^3 window GEMMs, 3 per multiply-add).  achieved = frac x the fp32 peak (fp32-equivalent "
+                                   "TFLOP/s).  frac_algorithmic = the cone-limited direct count (n^3 windows) over the same time / the fp32 "
+                                   "peak.  backward_ms is a span on the tile's stream and includes the time the first layers share the chip "
+                                   "with the norm convs of the second stream"}
         t = pmc_traffic(dom, which="largest")
         roof["traffic"] = t.get("traffic")
         roof["traffic_what"] = "HBM bytes per launch of the largest backward kernel (%s), PMC: %s" % (dom, t.get("traffic_source"))
@@ -474,14 +490,14 @@ def bench_volume(args, rank, world, dist, datasets=("nuclei", "soma"), reps=2, c
                                              "device norm1)"},
                    "what": "host uint16 volume -> per-peak LZW TIFFs + dets.npy in a scratch directory (%s), pipelined; best of %d"
                            % ("tmpfs" if base else "tmp", reps)}
-            cone, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size)
+            cone, pipe_ms, cone_issued = cone_limited_gflop_per_peak(cfg.stride, cfg.in_size, strip_zw=eng.strip_zw)
             if back_ms > 0 and live:
                 dom = "prm_stem_dgrad_mfma_kernel<40, 2, 5>" if ds == "nuclei" else "prm_stem_dgrad_mfma_kernel<18, 3, 4>"
                 rec["roofline"] = {"bound": "mfma", "kernel": "peak back-propagation of the volume's %d peaks (%d back-propagated, the rest saturated: map "
                                                               "0 / 0) over %d tiles (backward kernels only, HIP-event spans of one extra untimed pass)"
                                                               % (peaks, live, len(res_)),
-                                   "achieved": live * cone_issued / back_ms, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": live * cone_issued / back_ms / FP32_MFMA_PEAK_TFLOPS,
+                                   "achieved": live * pipe_ms / back_ms * FP32_MFMA_PEAK_TFLOPS, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": live * pipe_ms / back_ms,
                                    "frac_algorithmic": live * cone / back_ms / FP32_MFMA_PEAK_TFLOPS, "kernel_ms": back_ms,
                                    "share_of_volume_time": back_ms * 1e-3 / dt_p, "traffic": pmc_traffic(dom, which="largest").get("traffic")}
             if rank == 0 and not args.no_cpu_baseline and world == 1:
