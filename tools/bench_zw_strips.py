@@ -1,3 +1,5 @@
+"""The f16x2 F(2,3)z conv kernel against the fp32 F(2x4,3x3) kernel on the PRM strips' shapes (windows side by side along x; one global
+bound here - the engine uses one scale per window), with the cost of the bound sweep.  usage: python tools/bench_zw_strips.py"""
 import sys; sys.path.insert(0, "/root/repo"); import __graft_entry__  # noqa
 import torch
 from m3d import ops
