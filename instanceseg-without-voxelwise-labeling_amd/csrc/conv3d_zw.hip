@@ -11,14 +11,20 @@
 //   products per algorithmic multiply-add, at 16 x the fp32 MFMA's rate (the F(2x4,3x3) fp32 kernel of conv3d_wino24.hip issues 1/3 of
 //   the direct products at the fp32 rate: 2.7 x the matrix-pipe time of this form).
 //
-// Decomposition: a workgroup (8 waves) owns 64 output channels x a tile of XB x 4*RY x 2 outputs (XB = 32, RY = 1 or XB = 16, RY = 2);
-// wave = (z point k, 32-channel block): its four accumulator blocks are the tile's four 32-voxel column blocks (XB x RY voxels each) of
-// M_k.  GEMM view per (dy, dx) tap and 16-channel chunk: A = U (32 co x 16 ci, packed fragment-ready in global memory, read straight
-// into registers two taps ahead - every wave has its own (k, block), nothing to share through LDS), B = V_k (16 ci x 32 voxels: one
-// ds_read_b128 per fragment from the channel-contiguous LDS image [hi / lo][k half][point][row][x]).  The halo tile of the next chunk
-// is loaded to registers at the start of a chunk, cut (z transform, scale, hi / lo) and written to the other LDS buffer in its middle:
-// ONE barrier per chunk.  The four M_k meet in an LDS exchange at the end; every wave then finishes one column block (or, with the
-// fused pool, one row pair of half the channels).
+// Decomposition: a UNIT is 64 output channels x a tile of XB x 4*RY x 2 outputs (XB = 32, RY = 1 or XB = 16, RY = 2); workgroups are
+// persistent (one per CU, 8 waves) and walk units; wave = (z point k, 32-channel block): its four accumulator blocks are the unit's four
+// 32-voxel column blocks (XB x RY voxels each) of M_k.  GEMM view per (dy, dx) tap and 16-channel chunk: A = U (32 co x 16 ci, packed
+// fragment-ready in global memory, read straight into registers two taps ahead - every wave has its own (k, block), nothing to share
+// through LDS), B = V_k (16 ci x 32 voxels: one ds_read_b128 per fragment from the channel-contiguous LDS image
+// [hi / lo][k half][point][row][x]).  The halo tile of the next chunk (in a unit's last chunk: of the next unit) is requested plane by
+// plane at taps 0..3, each behind that tap's weight request (loads complete in order), cut point by point (z transform, scale, hi / lo)
+// and written to the other LDS buffer at taps 4..7: ONE barrier per chunk.  The four M_k meet in an LDS exchange at the end; un-pooled, the
+// exchange is transposed so that a lane stores 16 bytes (four x of one channel and row); with the fused pool a wave finishes one row pair
+// of half the channels.
+//
+// Strip mode (PRM back-propagation: the windows of all peaks side by side along x): one operand scale PER WINDOW (col_bound: one float per
+// peak at a stride of 32), looked up by the column of a staged halo item and of an output quad, optionally with the prepare step of the
+// layer below fused into the epilogue (PREP: m3d_w24::PrepEpi, the fp32 strip kernel's contract).
 //
 // Operand scales: the input's largest magnitude comes from the PRODUCER (a 32-slot device array of non-negative floats, the largest is
 // the bound; this kernel's epilogue fills the array for the next layer: `d_out_max`), so no sweep of the activations is ever needed.
