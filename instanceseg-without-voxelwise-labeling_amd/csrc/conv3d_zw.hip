@@ -35,6 +35,15 @@
 #include "m3d_common.h"
 #include "conv3d_wino24.h"      // m3d_w24::PrepEpi: the fused `prepare` epilogue of the PRM strips (same contract as the fp32 kernel's)
 
+// diagnostic build only (make zw_stamps; tools/zw_stamps.py): s_memtime of wave 0 of every workgroup at every tap of its SECOND unit
+#ifdef M3D_ZW_STAMPS
+static unsigned long long* g_zw_stamps = nullptr;
+M3D_API void m3d_debug_set_stamp_buffer_zw(void* p) { g_zw_stamps = (unsigned long long*)p; }
+#define ZW_STAMP(k) do { if (a.stamps && it == 1 && tid == 0 && (k) < 256) a.stamps[(size_t)blockIdx.x * 256 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZW_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -120,6 +129,9 @@ struct ZwArgs {
   // [pitch p, pitch (p + 1)) (pitch a multiple of 4: a 16-byte output quad never straddles two cells); col_bound == null: one scale (in_max)
   const float* col_bound; int pitch, npeaks;
   m3d_w24::PrepEpi pe;     // PREP instantiation only
+#ifdef M3D_ZW_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 __device__ __forceinline__ int zw_xcd_contiguous(int bid, int n) {
@@ -218,7 +230,8 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
   // one z point k of the staged item: V_k of its 8 channels, scaled and cut -> two 16-byte units.  Called point by point from different
   // taps (40 VALU each ride in the MFMAs' shadow; all four at once stalled both waves of a SIMD at the same tap)
   auto commit_point = [&](int buf, float xs_, const int k) __attribute__((always_inline)) {
-    if (!has) return;
+    // branch-free (the tap that carries it must stay one scheduling region): threads without an item write to a dump unit behind the two
+    // staging buffers (inside the exchange area, which nobody reads before the K loop's closing barrier)
     constexpr int PA_[4] = {0, 1, 2, 1}, PB_[4] = {2, 2, 1, 3};               // V_k = d[PA] -+ d[PB]: d0 - d2, d1 + d2, d2 - d1, d1 - d3
     u32x4 ph, pl;
 #pragma unroll
@@ -234,9 +247,10 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       }
       ph[j] = __builtin_bit_cast(unsigned, hh); pl[j] = __builtin_bit_cast(unsigned, ll);
     }
-    u32x4* d = lds + buf * C::BUF_UNITS + st_unit + k * C::PLANE;
+    u32x4* d = lds + (has ? buf * C::BUF_UNITS + st_unit + k * C::PLANE : 2 * C::BUF_UNITS);
     d[0] = ph; d[8 * C::PLANE] = pl;
   };
+  static_assert((2 * C::BUF_UNITS + 8 * C::PLANE + 1) * 16 <= C::XCH_BYTES, "the dump units lie inside the exchange area");
   auto commit_in = [&](int buf, float xs_) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) commit_point(buf, xs_, k);
@@ -290,6 +304,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       float s_;
       m3d::f16_scale_of(2.f * a.col_bound[32 * p], s_, inv_e);
     }
+    ZW_STAMP(0);
     commit_in(0, S.xs);
     float* const aff = reinterpret_cast<float*>(reinterpret_cast<char*>(lds_f) + C::AFF_OFF) + (it & 1) * 128;
     if (tid < 64) {                                      // the unit's 64 channels: scale x the operand scales' inverse, shift
@@ -319,6 +334,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         const int s = c * 9 + t;
         BF& curf = ((par + t) & 1) ? F1 : F0;
         BF& nxtf = ((par + t) & 1) ? F0 : F1;
+        ZW_STAMP(1 + s);
         if (t == 8) __syncthreads();
         {                                                // weight fragments two taps ahead (set (t + 2) % 3 was consumed by tap t - 1)
           const int idx = s + 2;
@@ -335,22 +351,41 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
           for (int j = 0; j < 4; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t % 3][PA[q]], curf.b[j][PB[q]], acc[j], 0, 0, 0);
         }
-        if (t < 4) {                                     // planes 2, 0, 1, 3 at taps 0..3, each behind its tap's weight request (loads complete in order)
-          constexpr int PL[4] = {2, 0, 1, 3};
+        // The next chunk's halo planes, each behind a tap's weight request (loads complete in order): planes 2, 0, 1, 3 at tap 8 of the
+        // PREVIOUS chunk (plane 2's registers are free from tap 7 on) and taps 0, 1, 2 - their points are cut at taps 4..7, and tap 4 used
+        // to wait ~700 cycles for DRAM (tools/zw_stamps.py).  A unit's first chunk has no previous tap 8: it requests two planes at tap 0.
+        auto plane = [&](const int k, int cc, bool nextu) __attribute__((always_inline)) {
           Stage q;
-          q.voff[PL[t]] = last ? SN.voff[PL[t]] : S.voff[PL[t]];
-          q.base = last ? SN.base : S.base; q.okm = 0;
-          fetch_plane(q, last ? 0 : c + 1, PL[t]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          q.voff[k] = nextu ? SN.voff[k] : S.voff[k];
+          q.base = nextu ? SN.base : S.base; q.okm = 0; q.xs = 0.f;
+          fetch_plane(q, cc, k);
+        };
+        if (t == 0 && c == 0) plane(2, last ? 0 : 1, last);
+        if (t == 0) plane(0, last ? 0 : c + 1, last);
+        if (t == 1) plane(1, last ? 0 : c + 1, last);
+        if (t == 2) plane(3, last ? 0 : c + 1, last);
+        if (t == 8 && !last) { const bool nu = c + 2 >= chunks; plane(2, nu ? 0 : c + 2, nu); }
         if (t >= 4 && t <= 7 && !last) {                 // points 0 (planes 0, 2), 2 (2, 1), 1 (1, 2), 3 (1, 3)
           constexpr int PT[4] = {0, 2, 1, 3};
           commit_point(buf ^ 1, S.xs, PT[t - 4]);
+        }
+        if (t >= 4 && t <= 7) {                          // the cut's ~40 VALU between the MFMAs, three per MFMA (an MFMA holds the issue 8 of its 32 cycles)
+#define ZW_MV4 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
+               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
+               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); \
+               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); ZW_MV4
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); ZW_MV4
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); ZW_MV4
+#undef ZW_MV4
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
       }
     };
@@ -360,6 +395,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
       if (c + 1 < chunks) run_chunk(c + 1, 1);
     }
 
+    ZW_STAMP(200);
     // ---- the four M_k meet in LDS
     __syncthreads();
     const int x0 = cur.x0, y0 = cur.y0, z0 = cur.z0;
@@ -556,6 +592,7 @@ __global__ __launch_bounds__(ZW_NT, 2) void conv3d_zw_kernel(ZwArgs a) {
         }
       }
     }
+    ZW_STAMP(202);
     if (!hasn) break;
     u = un_; cur = nxtu; S = SN; wsrc = wsrcN;
   }
@@ -591,6 +628,9 @@ int launch_zw(ZwArgs a, hipStream_t st) {
   }
   const long long rounds = (units + cus - 1) / cus;
   const long long blocks = (units + rounds - 1) / rounds;
+#ifdef M3D_ZW_STAMPS
+  a.stamps = g_zw_stamps;
+#endif
   auto kern = conv3d_zw_kernel<XB, POOL, PREP>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ZW_NT), C::LDS_BYTES, st, a);
