@@ -1060,7 +1060,7 @@ def bench_detect(args, rank, world, dist):
                                  "host-to-host loop that gives `value` carries no probe" % PROBE_STEPS) \
             if rkern else "HIP-event spans of the first %d timed steps" % PROBE_STEPS
     if "conv2b" in roofs:
-        w2 = "conv3d_zw_kernel<32, true>" if "f16x2" in work["conv2b"]["kernel"] else \
+        w2 = "conv3d_zw_kernel<32, true" if "f16x2" in work["conv2b"]["kernel"] else \
             "conv3d_wino24_kernel<4, 16, 2, 1, true" if "F(2x4" in work["conv2b"]["kernel"] else "conv3d_wino2e_kernel<4, 32, 2, 2, true>"
         roofs["conv2b"].update(pmc_traffic({2: w2, 1: "conv3d_wino_kernel<4, 32, 1, 2, 2, 4, 1, true>",
                                             0: "conv3d_mfma_kernel<3, 2, 32, 4, 2, 2, 2, true, 1>"}[wino]))
